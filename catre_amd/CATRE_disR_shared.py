@@ -1,0 +1,185 @@
+"""``CATRE_disR_shared`` - the drop-in model module of the MI355X-native CATRE hot path.
+
+Same module name, class name, constructor, ``forward`` signature, return types, sub-module and
+``state_dict`` names and ``build_model_optimizer(cfg, is_test)`` factory as the reference's
+``core/catre/models/CATRE_disR_shared.py`` (forward ``:40-166``, factory ``:291-350``), so
+``eval(cfg.MODEL.CATRE.NAME).build_model_optimizer(cfg, ...)`` in the reference's
+``main_catre.py:138`` resolves to this file unchanged.
+
+``forward`` launches the hand-written gfx950 kernels of ``libcatre_hip.so`` through the C ABI
+(``catre_refine_iter``).  There is no PyTorch-op or CPU fallback: on a CPU tensor, or without the
+built library, it raises.  ``refine`` is the fused K-iteration entry point (pose-apply + forward
+looped on the device, no Python between iterations).
+"""
+import copy
+import logging
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .model_utils import get_rot_head, get_ts_head
+from .net_factory import PCLNETS
+from .pointnet import _no_grad_only
+from .runtime import HipRuntime, opts_from_cfg
+
+logger = logging.getLogger(__name__)
+
+
+class CATRE_disR_shared(nn.Module):
+    def __init__(self, cfg, pcl_net, rot_head, ts_head):
+        super().__init__()
+        assert cfg.MODEL.CATRE.NAME == "CATRE_disR_shared", cfg.MODEL.CATRE.NAME
+        self.cfg = cfg
+        self.pcl_net = pcl_net
+        self.rot_head = rot_head
+        self.ts_head = ts_head
+        if getattr(pcl_net, "global_feat", False):
+            raise ValueError("CATRE_disR_shared needs per-point features: PCLNET.INIT_CFG.global_feat must be False")
+        self._opts = opts_from_cfg(cfg, feature_transform=pcl_net.feature_transform)
+        if int(ts_head.in_dim) != int(self._opts.ts_in_dim):
+            raise ValueError(
+                f"TS_HEAD.INIT_CFG.in_dim={ts_head.in_dim} does not match the gathered feature width "
+                f"{self._opts.ts_in_dim} implied by WITH_KPS_FEATURE / WITH_INIT_SCALE / WITH_INIT_TRANS"
+            )
+        self._rt = None
+
+    # -- runtime is per-instance state that must never be shared by copies of the module
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_rt"] = None
+        return d
+
+    def _runtime(self):
+        if self._rt is None:
+            num_points = self.rot_head.num_points
+            n = int(self.cfg.INPUT.get("NUM_PCL", num_points // 2))
+            self._rt = HipRuntime(lambda: dict(self.named_parameters()), n, num_points - n, self._opts.ts_in_dim)
+        return self._rt
+
+    def forward(
+        self,
+        x,
+        tfd_kps,
+        init_pose,
+        init_scale,
+        K_zoom=None,
+        obj_class=None,
+        gt_ego_rot=None,
+        gt_trans=None,
+        gt_scale=None,
+        obj_kps=None,
+        mean_scales=None,
+        sym_info=None,
+        do_loss=False,
+        cur_iter=0,
+    ):
+        """x [B,3,N], tfd_kps [B,3,M] (any strides), init_pose [B,3,4], init_scale [B,3], K_zoom [B,3,3]
+        -> ``{"pose_{cur_iter}": [B,3,4], "scale_{cur_iter}": [B,3]}`` (reference ``:122-124``)."""
+        if do_loss:
+            raise NotImplementedError(
+                "do_loss=True (training) needs the backward kernels and the device-side loss (SURVEY.md 8f-1); "
+                "round 1 of catre_amd implements the inference path."
+            )
+        _no_grad_only(self, x, tfd_kps, init_pose, init_scale)
+        pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, self._opts)
+        return {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
+
+    @torch.no_grad()
+    def refine(self, batch, n_iter=None):
+        """The whole test-time loop of ``catre_inference_on_dataset`` (reference
+        ``core/catre/engine/catre_evaluator.py:292-311``) as one stream of kernel launches.
+
+        ``batch`` needs ``pcl [B,N,3]``, ``obj_kps [B,M,3]``, ``obj_pose_est [B,3,4]``, ``obj_scale_est [B,3]``,
+        ``K [B,3,3]`` and (for "mean" scale types) ``obj_mean_scales [B,3]``.  Returns the reference's
+        ``out_dict``: ``pose_0..pose_K`` / ``scale_0..scale_K``.
+        """
+        n_iter = int(self.cfg.MODEL.CATRE.N_ITER_TEST if n_iter is None else n_iter)
+        poses, scales = self._runtime().refine_k(
+            batch["pcl"], batch["obj_kps"], batch["obj_pose_est"], batch["obj_scale_est"], batch.get("K"),
+            batch.get("obj_mean_scales"), self._opts, n_iter,
+        )
+        out = {}
+        for i in range(n_iter + 1):
+            out[f"pose_{i}"], out[f"scale_{i}"] = poses[i], scales[i]
+        return out
+
+
+def _build_optimizer(cfg, params_lr_list):
+    """Stand-in for ``core/utils/solver_utils.build_optimizer_with_params`` (reference ``:75-87``): the
+    Ranger optimiser of the shipped config is host-side Python outside the hot path."""
+    ocfg = dict(cfg.SOLVER.get("OPTIMIZER_CFG", {}) or {})
+    typ = ocfg.pop("type", "Adam")
+    lr = ocfg.pop("lr", float(cfg.SOLVER.BASE_LR))
+    wd = ocfg.pop("weight_decay", float(cfg.SOLVER.get("WEIGHT_DECAY", 0.0)))
+    groups = [dict(params=list(g["params"]), lr=g["lr"]) for g in params_lr_list]
+    if hasattr(torch.optim, typ):
+        return getattr(torch.optim, typ)(groups, lr=lr, weight_decay=wd)
+    logger.warning("optimizer %s is not part of the hot path; using torch.optim.RAdam with the same param groups", typ)
+    return torch.optim.RAdam(groups, lr=lr, weight_decay=wd)
+
+
+def build_model_optimizer(cfg, is_test=False):
+    """reference ``CATRE_disR_shared.py:291-350``: returns ``(model, optimizer-or-None)``; param groups are
+    pcl_net @ BASE_LR, rot_head / ts_head @ BASE_LR x LR_MULT; ends with ``model.to(cfg.MODEL.DEVICE)``."""
+    pcl_net_cfg = cfg.MODEL.CATRE.PCLNET
+    params_lr_list = []
+    init_pcl_net_args = dict(copy.deepcopy(pcl_net_cfg.INIT_CFG))
+    pcl_net_type = init_pcl_net_args.pop("type")
+    pcl_net = PCLNETS[pcl_net_type](**init_pcl_net_args)
+    if pcl_net_cfg.get("FREEZE", False):
+        for param in pcl_net.parameters():  # (the reference calls .parameters() on the cfg dict here: a latent bug)
+            param.requires_grad = False
+    else:
+        params_lr_list.append(
+            {"params": filter(lambda p: p.requires_grad, pcl_net.parameters()), "lr": float(cfg.SOLVER.BASE_LR)}
+        )
+    rot_head, rot_head_params = get_rot_head(cfg)
+    params_lr_list.extend(rot_head_params)
+    ts_head, ts_head_params = get_ts_head(cfg)
+    params_lr_list.extend(ts_head_params)
+
+    model = CATRE_disR_shared(cfg, pcl_net, rot_head, ts_head)
+    optimizer = None if is_test else _build_optimizer(cfg, params_lr_list)
+    if cfg.MODEL.get("WEIGHTS", "") == "":
+        logger.warning("Randomly initialize weights for pcl_net!")
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model, optimizer
+
+
+def expected_state_shapes(cfg):
+    """``{state_dict key: shape}`` of the model ``cfg`` describes (SURVEY.md section 8b listing)."""
+    net = cfg.MODEL.CATRE
+    P = int(net.ROT_HEAD.INIT_CFG.num_points)
+    ts_in = int(net.TS_HEAD.INIT_CFG.in_dim)
+    ft = bool(net.PCLNET.INIT_CFG.get("feature_transform", False))
+    s = {}
+
+    def stn(prefix, k):
+        for name, o, i in (("conv1", 64, k), ("conv2", 128, 64), ("conv3", 1024, 128)):
+            s[f"{prefix}.{name}.weight"], s[f"{prefix}.{name}.bias"] = (o, i, 1), (o,)
+        for name, o, i in (("fc1", 512, 1024), ("fc2", 256, 512), ("fc3", k * k, 256)):
+            s[f"{prefix}.{name}.weight"], s[f"{prefix}.{name}.bias"] = (o, i), (o,)
+
+    stn("pcl_net.stn", 3)
+    for name, o, i in (("conv1", 64, 3), ("conv2", 128, 64), ("conv3", 512, 128), ("conv4", 1024, 512)):
+        s[f"pcl_net.{name}.weight"], s[f"pcl_net.{name}.bias"] = (o, i, 1), (o,)
+    if ft:
+        stn("pcl_net.fstn", 64)
+    for a in ("x", "y"):
+        p = f"rot_head.rot_head_{a}"
+        s[f"{p}.norm.weight"], s[f"{p}.norm.bias"] = (256,), (256,)
+        s[f"{p}.layers.0.weight"], s[f"{p}.layers.0.bias"] = (256, 1088, 1), (256,)
+        s[f"{p}.layers.1.weight"], s[f"{p}.layers.1.bias"] = (256,), (256,)
+        s[f"{p}.layers.3.weight"], s[f"{p}.layers.3.bias"] = (256, 256, 1), (256,)
+        s[f"{p}.layers.4.weight"], s[f"{p}.layers.4.bias"] = (256,), (256,)
+        s[f"{p}.neck.0.weight"], s[f"{p}.neck.0.bias"] = (3, 256, 1), (3,)
+        s[f"{p}.conv_p.weight"], s[f"{p}.conv_p.bias"] = (1, P, 1), (1,)
+    s["ts_head.norm.weight"], s["ts_head.norm.bias"] = (256,), (256,)
+    s["ts_head.linears.0.weight"], s["ts_head.linears.0.bias"] = (256, ts_in), (256,)
+    s["ts_head.linears.1.weight"], s["ts_head.linears.1.bias"] = (256,), (256,)
+    s["ts_head.linears.3.weight"], s["ts_head.linears.3.bias"] = (256, 256), (256,)
+    s["ts_head.linears.4.weight"], s["ts_head.linears.4.bias"] = (256,), (256,)
+    for n in ("fc_t", "fc_s"):
+        s[f"ts_head.{n}.weight"], s[f"ts_head.{n}.bias"] = (3, 256), (3,)
+    return s

@@ -1,0 +1,129 @@
+// catre_device.h - device-side building blocks shared by the CATRE hot-path kernels (gfx950 only).
+//
+// Data layout conventions used by every MFMA kernel in this directory
+// -------------------------------------------------------------------
+// * A workgroup owns one TILE of TP = 64 points of one cloud and carries it through a whole
+//   chain of 1x1-conv layers; activations never leave LDS between layers.
+// * Activations live in LDS point-major: act[point][channel] with a row pitch of C+4 floats.
+//   The +4 (16 B) skew makes the 16-byte fragment reads below conflict-free: the 16-lane
+//   groups of ds_read_b128 hit 16 distinct 4-bank slots (bank = 4*point + k mod 64).
+// * Weights are streamed from L2 straight into registers in "fragment-packed" order
+//   (catre_pack_weights): float4 index ((mblk*(K/8) + kc)*64 + lane) holds
+//       W[mblk*32 + (lane&31)][kc*8 + 4*(lane>>5) + {0,1,2,3}]
+//   so one coalesced 1 KiB global_load_dwordx4 per wave feeds four v_mfma_f32_32x32x2_f32.
+//   The activation fragment uses the same k-slot mapping (lane>>5 selects k-offset 4h+s within
+//   an 8-wide chunk); the k order inside a chunk is permuted identically for both operands,
+//   which only re-associates the fp32 sum.
+// * v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; the
+//   result D[i][j] sits at col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//     "normal"  call mfma(w, x): rows = out-channels, cols = points  (4 consecutive channels per
+//               register quad -> one ds_write_b128 per quad into the next layer's LDS image)
+//     "swapped" call mfma(x, w): rows = points, cols = out-channels  (a lane owns ONE channel and
+//               16 points -> the max-pool over points is in-register)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TP 64  // points per tile
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 v;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 0.f;
+  return v;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  // nn.GELU() default: 0.5 * v * (1 + erf(v / sqrt(2)))
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*nkc.
+//   wp   : fragment-packed weights, already offset to [first m-block][first k-chunk][lane]
+//   wp_mb: float4 stride between consecutive m-blocks  (= (Ktotal/8)*64)
+//   xrow : LDS pointer &act[(lane&31)*ldx + 4*(lane>>5)] of point block 0
+//   x_nb : float stride between point blocks (= 32*ldx)
+template <int MB, int NB, bool SWAP>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
+                                          const float* xrow, int x_nb, int nkc) {
+  f32x4 a_cur[MB], a_nxt[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wp[mb * wp_mb];
+#pragma unroll 2
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int kn = (kc + 1 < nkc) ? kc + 1 : kc;  // last iteration re-loads (harmless, keeps the loop branch-free)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wp[mb * wp_mb + kn * 64];
+    f32x4 b[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(xrow + nb * x_nb + kc * 8);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = SWAP ? mfma32(b[nb][s], a_cur[mb][s], acc[mb][nb]) : mfma32(a_cur[mb][s], b[nb][s], acc[mb][nb]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+  }
+}
+
+// "normal"-orientation epilogue: out[point][ch] = act(acc + bias[ch]) as float4 per register quad.
+template <int MB, int NB, bool RELU>
+__device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MB][NB], float* out, int ldo, int ch0,
+                                               const float* __restrict__ bias, int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = ch0 + mb * 32 + 8 * g + 4 * h;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = acc[mb][nb][4 * g + q] + bv[q];
+          v[q] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f32x4*>(out + (nb * 32 + n) * ldo + ch) = v;
+      }
+    }
+}
+
+// "swapped"-orientation epilogue: channel-wise max over the tile's 64 points, then bias (+ReLU).
+// max_n act(y_n + b) == act(max_n y_n + b) because both are monotone.
+template <int MB, int NB>
+__device__ __forceinline__ void max_tile_store(const f32x16 (&acc)[MB][NB], float* __restrict__ out, int ch0,
+                                               const float* __restrict__ bias, bool relu, int lane) {
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float m = acc[mb][0][0];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mb][nb][r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane < 32) {
+      const int ch = ch0 + mb * 32 + lane;
+      float v = m + bias[ch];
+      out[ch] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}

@@ -1,0 +1,1336 @@
+// catre_kernels.hip - hand-written gfx950 kernels for CATRE's pose-refine hot path + their C ABI.
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see Makefile).
+// Reference citations (file:line) are relative to the CATRE tree; see include/catre_hip.h.
+#include "catre_device.h"
+
+#include "../../include/catre_hip.h"
+
+#define CATRE_VERSION_STR "catre_hip gfx950 r1"
+#define PMW 1088  // row pitch of the tile-partial-max buffer: [1024 conv max | 64 pointfeat max]
+
+// ------------------------------------------------------------------------------------------
+// tile bookkeeping
+// ------------------------------------------------------------------------------------------
+struct TileInfo {
+  int obj;     // object index b
+  int cloud;   // b (observed) or B+b (prior)
+  int is_obs;
+  int p0;      // first point of the tile inside its cloud
+  int valid;   // number of real points in the tile (1..64); the rest are duplicates of the last one
+};
+
+// Tiles are enumerated observed-first: bid in [0, B*TN) -> observed, then B*TM prior tiles.
+__device__ __forceinline__ TileInfo tile_info(int bid, int B, int N, int M) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
+  TileInfo ti;
+  if (bid < B * TN) {
+    ti.obj = bid / TN;
+    ti.cloud = ti.obj;
+    ti.is_obs = 1;
+    ti.p0 = (bid % TN) * TP;
+    ti.valid = min(TP, N - ti.p0);
+  } else {
+    const int r = bid - B * TN;
+    ti.obj = r / TM;
+    ti.cloud = B + ti.obj;
+    ti.is_obs = 0;
+    ti.p0 = (r % TM) * TP;
+    ti.valid = min(TP, M - ti.p0);
+  }
+  return ti;
+}
+
+__device__ __forceinline__ void load_point(const catre_points& P, const TileInfo& ti, int p, float& x, float& y,
+                                           float& z) {
+  const int pi = ti.p0 + min(p, ti.valid - 1);  // clamp: duplicates never change a max-pool
+  const float* base;
+  int64_t sc;
+  if (ti.is_obs) {
+    base = P.obs + ti.obj * P.obs_sb + pi * P.obs_sn;
+    sc = P.obs_sc;
+  } else {
+    base = P.kps + ti.obj * P.kps_sb + pi * P.kps_sn;
+    sc = P.kps_sc;
+  }
+  x = base[0];
+  y = base[sc];
+  z = base[2 * sc];
+}
+
+// out[ch] = relu(W[ch][0..2] . (x,y,z) + b[ch]) for NCH consecutive channels starting at ch0 (wave-uniform)
+template <int NCH>
+__device__ __forceinline__ void conv3_relu_row(float x, float y, float z, const float* __restrict__ W,
+                                               const float* __restrict__ b, int ch0, float* out_row) {
+#pragma unroll
+  for (int c4 = 0; c4 < NCH / 4; ++c4) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = ch0 + c4 * 4 + q;
+      float t = b[ch];
+      t = fmaf(W[ch * 3 + 0], x, t);
+      t = fmaf(W[ch * 3 + 1], y, t);
+      t = fmaf(W[ch * 3 + 2], z, t);
+      v[q] = fmaxf(t, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out_row + ch0 + c4 * 4) = v;
+  }
+}
+
+// x' = x^T T3 : u'[j] = sum_i u[i] * T[i][j]   (pointnet.py:100-102)
+__device__ __forceinline__ void apply_t3(const float* __restrict__ T, float& x, float& y, float& z) {
+  const float nx = fmaf(z, T[6], fmaf(y, T[3], x * T[0]));
+  const float ny = fmaf(z, T[7], fmaf(y, T[4], x * T[1]));
+  const float nz = fmaf(z, T[8], fmaf(y, T[5], x * T[2]));
+  x = nx;
+  y = ny;
+  z = nz;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (layout only, no arithmetic)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_frag(const float* __restrict__ src, int ld, int coloff, int rows, int K, float* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * K) return;
+  const int s = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+  const int nkc = K / 8;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 8 + 4 * (lane >> 5) + s;
+  dst[idx] = src[(size_t)row * ld + coloff + col];
+}
+
+__global__ void k_pack_transpose(const float* __restrict__ src, int J, int K, float* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // dst[k*J + j] = src[j*K + k]
+  if (idx >= J * K) return;
+  const int j = idx % J, k = idx / J;
+  dst[idx] = src[(size_t)j * K + k];
+}
+
+__global__ void k_sum(const float* __restrict__ src, int n, float* __restrict__ dst) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += src[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// a1: pose-apply (engine/batch_test.py:81-97, lib/pysixd/misc.py:1014-1026)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pose_apply(const float* __restrict__ pcl, const float* __restrict__ kps,
+                             const float* __restrict__ pose, const float* __restrict__ scale, float* __restrict__ xo,
+                             float* __restrict__ ko, int B, int N, int M, int zero_center) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total_obs = B * N, total = B * (N + M);
+  if (i >= total) return;
+  if (i < total_obs) {
+    const int b = i / N;
+    const float* p = pose + b * 12;
+    const float* s = pcl + (size_t)i * 3;
+    float x = s[0], y = s[1], z = s[2];
+    if (zero_center) {
+      x -= p[3];
+      y -= p[7];
+      z -= p[11];
+    }
+    float* o = xo + (size_t)i * 3;
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+  } else {
+    const int j = i - total_obs;
+    const int b = j / M;
+    const float* p = pose + b * 12;
+    const float* sc = scale + b * 3;
+    const float* s = kps + (size_t)j * 3;
+    const float x = s[0] * sc[0], y = s[1] * sc[1], z = s[2] * sc[2];  // misc.py:1017
+    float ox = p[0] * x + p[1] * y + p[2] * z;                         // misc.py:1021 (row . column)
+    float oy = p[4] * x + p[5] * y + p[6] * z;
+    float oz = p[8] * x + p[9] * y + p[10] * z;
+    if (!zero_center) {
+      ox += p[3];
+      oy += p[7];
+      oz += p[11];
+    }
+    float* o = ko + (size_t)j * 3;
+    o[0] = ox;
+    o[1] = oy;
+    o[2] = oz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2: STN3d conv stack 3->64->128->1024 (+ReLU) and per-tile max  (pointnet.py:24-28)
+// 256 threads = 4 waves, 2 workgroups per CU.
+// ------------------------------------------------------------------------------------------
+#define LD64 68
+#define LD128 132
+#define LD256 260
+
+__global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* __restrict__ W1,
+                                               const float* __restrict__ b1, const f32x4* __restrict__ wp2,
+                                               const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                               const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
+                                               int M) {
+  __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * LD128];
+  float* a1 = smem;
+  float* a2 = smem + TP * LD64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+
+  {  // conv1 3->64 on the VALU: thread = (point, 16-channel group)
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    conv3_relu_row<16>(x, y, z, W1, b1, wave * 16, a1 + lane * LD64);
+  }
+  __syncthreads();
+  {  // conv2 64->128: wave -> m-block `wave`, both point blocks
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    gemm_tile<1, 2, false>(acc, wp2 + (wave * 8) * 64 + lane, 0, a1 + (lane & 31) * LD64 + 4 * (lane >> 5),
+                           32 * LD64, 8);
+    store_tile_lds<1, 2, true>(acc, a2, LD128, wave * 32, b2, lane);
+  }
+  __syncthreads();
+  // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks
+  float* out = pm + (size_t)blockIdx.x * PMW;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int mblk0 = wave * 8 + pass * 4;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    gemm_tile<4, 2, true>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2 + (lane & 31) * LD128 + 4 * (lane >> 5),
+                          32 * LD128, 16);
+    max_tile_store<4, 2>(acc, out, mblk0 * 32, b3, true, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3+a4: x' = x T3, relu(conv1), STNkd conv stack 64->64->128->1024 (+ReLU), per-tile max
+// (pointnet.py:98-103, 57-61).  256 threads, 2 workgroups per CU.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* __restrict__ trans3,
+                                               const float* __restrict__ Wc1, const float* __restrict__ bc1,
+                                               const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
+                                               const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
+                                               const f32x4* __restrict__ wpf3, const float* __restrict__ bf3,
+                                               float* __restrict__ pm, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + TP * LD128];
+  float* h1 = smem;
+  float* f1 = smem + TP * LD64;
+  float* f2 = smem + 2 * TP * LD64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_row<16>(x, y, z, Wc1, bc1, wave * 16, h1 + lane * LD64);
+  }
+  __syncthreads();
+  {  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks, one per wave
+    const int mblk = wave >> 1, nb = wave & 1;
+    f32x16 acc[1][1] = {{zero16()}};
+    gemm_tile<1, 1, false>(acc, wpf1 + (mblk * 8) * 64 + lane, 0,
+                           h1 + (nb * 32 + (lane & 31)) * LD64 + 4 * (lane >> 5), 0, 8);
+    store_tile_lds<1, 1, true>(acc, f1 + nb * 32 * LD64, LD64, mblk * 32, bf1, lane);
+  }
+  __syncthreads();
+  {  // fstn.conv2 64->128
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    gemm_tile<1, 2, false>(acc, wpf2 + (wave * 8) * 64 + lane, 0, f1 + (lane & 31) * LD64 + 4 * (lane >> 5),
+                           32 * LD64, 8);
+    store_tile_lds<1, 2, true>(acc, f2, LD128, wave * 32, bf2, lane);
+  }
+  __syncthreads();
+  float* out = pm + (size_t)blockIdx.x * PMW;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {  // fstn.conv3 128->1024 + max
+    const int mblk0 = wave * 8 + pass * 4;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    gemm_tile<4, 2, true>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2 + (lane & 31) * LD128 + 4 * (lane >> 5),
+                          32 * LD128, 16);
+    max_tile_store<4, 2>(acc, out, mblk0 * 32, bf3, true, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3+a5: trunk.  x' = x T3 -> relu(conv1) -> pointfeat = h1^T T64 -> relu(conv2) -> relu(conv3)
+// -> conv4 -> max  (pointnet.py:98-116).  512 threads = 8 waves, 1 workgroup per CU.
+// conv3's 512 outputs are produced in two 256-channel chunks so that the LDS image of the
+// conv4 input is 64 KiB; the conv4 accumulators (1024 ch x 64 pts = 128 VGPR per lane over 8
+// waves) stay in registers across both chunks.
+// ------------------------------------------------------------------------------------------
+#define TRUNK_SMEM (TP * LD256 + TP * LD128)
+
+__global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __restrict__ trans3,
+                                               const float* __restrict__ trans64, const float* __restrict__ Wc1,
+                                               const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
+                                               const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                               const float* __restrict__ b3, const f32x4* __restrict__ wp4,
+                                               const float* __restrict__ b4, float* __restrict__ pm,
+                                               float* __restrict__ pointfeat, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
+  // phase-1/2 buffers alias the conv3-chunk image a3 (dead before a3 is first written)
+  float* h1 = smem;                      // [64][68]
+  float* t64 = smem + TP * LD64;         // [64][64]
+  float* pf = smem + TP * LD64 + 4096;   // [64][68]
+  float* a3 = smem;                      // [64][260]
+  float* a2 = smem + TP * LD256;         // [64][132]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const bool ft = trans64 != nullptr;
+
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_row<8>(x, y, z, Wc1, bc1, wave * 8, h1 + lane * LD64);
+    if (ft) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(trans64 + (size_t)ti.cloud * 4096);
+      f32x4* dst = reinterpret_cast<f32x4*>(t64);
+      dst[tid] = src[tid];
+      dst[tid + 512] = src[tid + 512];
+    }
+  }
+  __syncthreads();
+  if (ft) {
+    if (wave < 4) {  // pointfeat[j][n] = sum_i T64[i][j] h1[i][n]  (pointnet.py:107-109); A operand from LDS
+      const int mblk = wave >> 1, nb = wave & 1;
+      const int n = lane & 31, h = lane >> 5;
+      f32x16 acc = zero16();
+      const float* xr = h1 + (nb * 32 + n) * LD64 + 4 * h;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float a = t64[(kc * 8 + 4 * h + s) * 64 + mblk * 32 + n];
+          acc = mfma32(a, bx[s], acc);
+        }
+      }
+      f32x16 accs[1][1] = {{acc}};
+      store_tile_lds<1, 1, false>(accs, pf + nb * 32 * LD64, LD64, mblk * 32, nullptr, lane);
+    }
+    __syncthreads();
+  } else {
+    pf = h1;
+  }
+  {
+    // pointfeat tile -> HBM, point-major [cloud points][64], fully coalesced 16 KiB
+    float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
+                                            : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
+    const int row = tid >> 3, c4 = tid & 7;
+    if (row < ti.valid) {
+      f32x4* d = reinterpret_cast<f32x4*>(dstbase + row * 64);
+      const f32x4* s = reinterpret_cast<const f32x4*>(pf + row * LD64);
+      d[c4] = s[c4];
+      d[c4 + 8] = s[c4 + 8];
+    }
+    if (tid < 64) {  // max_n pointfeat (second half of flat_pcl_feat, CATRE_disR_shared.py:69)
+      float m = pf[tid];
+#pragma unroll 8
+      for (int p = 1; p < TP; ++p) m = fmaxf(m, pf[p * LD64 + tid]);
+      pm[(size_t)blockIdx.x * PMW + 1024 + tid] = m;
+    }
+    // conv2 64->128: 4 m-blocks x 2 point blocks over 8 waves
+    const int mblk = wave >> 1, nb = wave & 1;
+    f32x16 acc[1][1] = {{zero16()}};
+    gemm_tile<1, 1, false>(acc, wp2 + (mblk * 8) * 64 + lane, 0,
+                           pf + (nb * 32 + (lane & 31)) * LD64 + 4 * (lane >> 5), 0, 8);
+    store_tile_lds<1, 1, true>(acc, a2 + nb * 32 * LD128, LD128, mblk * 32, b2, lane);
+  }
+  __syncthreads();
+
+  f32x16 acc4[4][2];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    {  // conv3 chunk: out channels [hh*256, +256): 8 m-blocks, one per wave, K = 128
+      const int mblk = hh * 8 + wave;
+      f32x16 acc3[1][2] = {{zero16(), zero16()}};
+      gemm_tile<1, 2, false>(acc3, wp3 + (mblk * 16) * 64 + lane, 0, a2 + (lane & 31) * LD128 + 4 * (lane >> 5),
+                             32 * LD128, 16);
+      store_tile_lds<1, 2, true>(acc3, a3, LD256, wave * 32, b3 + hh * 256, lane);
+    }
+    __syncthreads();
+    // conv4 partial sum over k in [hh*256, +256): wave owns out channels [wave*128, +128)
+    gemm_tile<4, 2, true>(acc4, wp4 + ((wave * 4) * 64 + hh * 32) * 64 + lane, 64 * 64,
+                          a3 + (lane & 31) * LD256 + 4 * (lane >> 5), 32 * LD256, 32);
+    if (hh == 0) __syncthreads();  // a3 is rewritten by the second chunk
+  }
+  max_tile_store<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, b4, false, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// tile partial maxima -> per-cloud max:  out[cloud][c] = max_t pm[row(cloud,t)][c]
+// ------------------------------------------------------------------------------------------
+__global__ void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ out, int ldo, int C, int B, int N,
+                            int M) {
+  const int cloud = blockIdx.x;
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
+  const int nt = cloud < B ? TN : TM;
+  const size_t row0 = cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = pm[row0 * PMW + c];
+    for (int t = 1; t < nt; ++t) m = fmaxf(m, pm[(row0 + t) * PMW + c]);
+    out[(size_t)cloud * ldo + c] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic y = act(x W^T + b) (+ I_k): one wave per 32x32 output block, operands straight from
+// L2 (F.linear in pointnet.py:31-33,64-66 and the global-feature half of RotHead layer 0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_linear(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                               int ldw, const float* __restrict__ bias, float* __restrict__ Y,
+                                               int ldy, int R, int J, int K, int relu, int iden_k) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int r = min((int)blockIdx.x * 32 + i, R - 1), j = min((int)blockIdx.y * 32 + i, J - 1);
+  const f32x4* xa = reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + 4 * h);
+  const f32x4* wb = reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + 4 * h);
+  f32x16 acc = zero16();
+  const int nkc = K / 8;
+#pragma unroll 4
+  for (int kc = 0; kc < nkc; ++kc) {
+    const f32x4 a = xa[kc * 2], b = wb[kc * 2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);  // D[row r][col j]
+  }
+  const int col = blockIdx.y * 32 + i;
+  if (col >= J) return;
+  const float bv = bias ? bias[col] : 0.f;
+  const float idv = (iden_k > 0 && col < iden_k * iden_k && (col % (iden_k + 1)) == 0) ? 1.f : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (row < R) {
+      float v = acc[reg] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      Y[(size_t)row * ldy + col] = v + idv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7+a8: ts head (heads/fc_trans_size_head.py:61-70) on
+// ts_feat = [flat_pcl_feat | (flat_kps_feat) | (init_scale) | (init_trans)] (CATRE_disR_shared.py:69-82)
+// 4 objects per workgroup, thread = output channel; weights pre-transposed to [in][256].
+// ------------------------------------------------------------------------------------------
+#define TS_OB 4
+
+__device__ __forceinline__ float group8_norm_gelu(float v, float gamma, float beta) {
+  // GroupNorm(32,256) on a [B,256] row: statistics over 8 consecutive channels = 8 consecutive lanes
+  float s = v;
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  const float mean = s * 0.125f;
+  const float d = v - mean;
+  float q = d * d;
+  q += __shfl_xor(q, 1);
+  q += __shfl_xor(q, 2);
+  q += __shfl_xor(q, 4);
+  const float rstd = 1.0f / sqrtf(q * 0.125f + 1e-5f);
+  const float sc = rstd * gamma;
+  return gelu_erf(fmaf(v, sc, beta - mean * sc));
+}
+
+__global__ __launch_bounds__(256) void k_ts_head(const float* __restrict__ gfeat, const float* __restrict__ pose,
+                                                 const float* __restrict__ scale, const float* __restrict__ W0T,
+                                                 const float* __restrict__ b0, const float* __restrict__ g0,
+                                                 const float* __restrict__ be0, const float* __restrict__ W1T,
+                                                 const float* __restrict__ b1, const float* __restrict__ g1,
+                                                 const float* __restrict__ be1, const float* __restrict__ Wt,
+                                                 const float* __restrict__ bt, const float* __restrict__ Ws,
+                                                 const float* __restrict__ bs, float* __restrict__ dt,
+                                                 float* __restrict__ ds, int B, int in_dim, int with_kps,
+                                                 int with_scale, int with_trans) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* feat = sm;                    // [TS_OB][in_dim]
+  float* hbuf = sm + TS_OB * in_dim;   // [TS_OB][256]
+  const int tid = threadIdx.x;
+  const int b0i = blockIdx.x * TS_OB;
+  for (int o = 0; o < TS_OB; ++o) {
+    const int b = min(b0i + o, B - 1);
+    for (int k = tid; k < in_dim; k += 256) {
+      int kk = k;
+      float v;
+      if (kk < PMW) {
+        v = gfeat[(size_t)b * PMW + kk];
+      } else {
+        kk -= PMW;
+        if (with_kps && kk < PMW) {
+          v = gfeat[(size_t)(B + b) * PMW + kk];
+        } else {
+          if (with_kps) kk -= PMW;
+          if (with_scale && kk < 3) {
+            v = scale[b * 3 + kk];
+          } else {
+            if (with_scale) kk -= 3;
+            v = pose[b * 12 + kk * 4 + 3];  // init_trans (with_trans)
+          }
+        }
+      }
+      feat[o * in_dim + k] = v;
+    }
+  }
+  __syncthreads();
+  float acc[TS_OB];
+#pragma unroll
+  for (int o = 0; o < TS_OB; ++o) acc[o] = b0[tid];
+#pragma unroll 4
+  for (int k = 0; k < in_dim; ++k) {
+    const float w = W0T[(size_t)k * 256 + tid];
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * in_dim + k], w, acc[o]);
+  }
+  {
+    const float ga = g0[tid], be = be0[tid];
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) hbuf[o * 256 + tid] = group8_norm_gelu(acc[o], ga, be);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < TS_OB; ++o) acc[o] = b1[tid];
+#pragma unroll 4
+  for (int k = 0; k < 256; ++k) {
+    const float w = W1T[k * 256 + tid];
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(hbuf[o * 256 + k], w, acc[o]);
+  }
+  __syncthreads();
+  {
+    const float ga = g1[tid], be = be1[tid];
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) hbuf[o * 256 + tid] = group8_norm_gelu(acc[o], ga, be);
+  }
+  __syncthreads();
+  if (tid < TS_OB * 6) {
+    const int o = tid / 6, c = tid % 6;
+    const int b = b0i + o;
+    if (b < B) {
+      const float* w = c < 3 ? Wt + c * 256 : Ws + (c - 3) * 256;
+      float s = c < 3 ? bt[c] : bs[c - 3];
+      for (int k = 0; k < 256; ++k) s = fmaf(hbuf[o * 256 + k], w[k], s);
+      if (c < 3)
+        dt[b * 3 + c] = s;
+      else
+        ds[b * 3 + c - 3] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a9: rotation heads (heads/conv_out_per_rot_head.py:126-140) over the concatenated point
+// sequence [observed N | prior M] (CATRE_disR_shared.py:86), never materialised.
+//   layer 0 : y0 = W0[:,1024:] . pointfeat + (W0[:,:1024] . g_cloud + b0)      (bias0 from k_linear)
+//   GN(32,256) couples all N+M points of an object: statistics are accumulated as per-tile
+//   (mean, M2) and merged with Chan's formula in tile order (deterministic).
+// Tiles never straddle the observed/prior boundary: T = ceil(N/64) + ceil(M/64) per object.
+// ------------------------------------------------------------------------------------------
+struct RotTile {
+  int obj, t, is_obs, cloud, p0, valid, gp0;  // gp0 = index in the concatenated sequence
+  size_t pf_off;                              // float offset of the tile inside the pointfeat buffer
+};
+
+__device__ __forceinline__ RotTile rot_tile(int bid, int B, int N, int M) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM;
+  RotTile r;
+  r.obj = bid / T;
+  r.t = bid % T;
+  r.is_obs = r.t < TN;
+  r.cloud = r.is_obs ? r.obj : B + r.obj;
+  r.p0 = (r.is_obs ? r.t : r.t - TN) * TP;
+  r.valid = min(TP, (r.is_obs ? N : M) - r.p0);
+  r.gp0 = r.is_obs ? r.p0 : N + r.p0;
+  r.pf_off = r.is_obs ? ((size_t)r.obj * N + r.p0) * 64 : ((size_t)B * N + (size_t)r.obj * M + r.p0) * 64;
+  return r;
+}
+
+__device__ __forceinline__ void load_pf_tile(const float* __restrict__ pointfeat, const RotTile& rt, float* pf,
+                                             int tid) {
+  const int row = tid >> 3, c4 = tid & 7;  // 512 threads: 64 rows x 8 lanes x 2 float4
+  const int srow = min(row, rt.valid - 1);
+  const f32x4* s = reinterpret_cast<const f32x4*>(pointfeat + rt.pf_off + (size_t)srow * 64);
+  f32x4* d = reinterpret_cast<f32x4*>(pf + row * LD64);
+  d[c4] = s[c4];
+  d[c4 + 8] = s[c4 + 8];
+}
+
+// Merge per-tile (mean, M2) partials of one (object, head, group) in tile order -> (mean, rstd)
+__device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64]*/, int group, int T, int TN, int N,
+                                         int M, float& mean_out, float& rstd_out) {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int p0 = (t < TN ? t : t - TN) * TP;
+    const float nb = 8.f * (float)min(TP, (t < TN ? N : M) - p0);
+    const float mb = part[t * 64 + group * 2], m2b = part[t * 64 + group * 2 + 1];
+    const float nn = n + nb, delta = mb - mean;
+    mean += delta * (nb / nn);
+    m2 += m2b + delta * delta * (n * nb / nn);
+    n = nn;
+  }
+  mean_out = mean;
+  rstd_out = 1.0f / sqrtf(m2 / n + 1e-5f);
+}
+
+// y0 of one head for this wave's 32 channels x 64 points ("normal" orientation), incl. bias0
+__device__ __forceinline__ void rot_layer0(f32x16 (&acc)[1][2], const f32x4* __restrict__ wpl0, const float* pf,
+                                           int wave, int lane) {
+  acc[0][0] = acc[0][1] = zero16();
+  gemm_tile<1, 2, false>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf + (lane & 31) * LD64 + 4 * (lane >> 5), 32 * LD64,
+                         8);
+}
+
+__global__ __launch_bounds__(512) void k_rot_l0_stats(const float* __restrict__ pointfeat,
+                                                      const f32x4* __restrict__ wpl0x,
+                                                      const f32x4* __restrict__ wpl0y,
+                                                      const float* __restrict__ bias0 /*[2][2B][256]*/,
+                                                      float* __restrict__ gn0 /*[B][2][T][64]*/, int B, int N,
+                                                      int M) {
+  __shared__ __attribute__((aligned(16))) float pf[TP * LD64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  load_pf_tile(pointfeat, rt, pf, tid);
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+  const float cnt = 8.f * (float)rt.valid;
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    f32x16 acc[1][2];
+    rot_layer0(acc, hd ? wpl0y : wpl0x, pf, wave, lane);
+    const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
+    float* out = gn0 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + 8 * g + 4 * h);
+      float v[2][4];
+      float s = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bool ok = nb * 32 + n < rt.valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[nb][q] = acc[0][nb][4 * g + q] + bv[q];
+          s += ok ? v[nb][q] : 0.f;
+        }
+      }
+      const float mean = wave_sum(s) / cnt;
+      float m2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bool ok = nb * 32 + n < rt.valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = v[nb][q] - mean;
+          m2 += ok ? d * d : 0.f;
+        }
+      }
+      m2 = wave_sum(m2);
+      if (lane == 0) {
+        out[(wave * 4 + g) * 2] = mean;
+        out[(wave * 4 + g) * 2 + 1] = m2;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
+                                                const f32x4* __restrict__ wpl0y, const float* __restrict__ bias0,
+                                                const float* __restrict__ gn0, const float* __restrict__ gam0x,
+                                                const float* __restrict__ bet0x, const float* __restrict__ gam0y,
+                                                const float* __restrict__ bet0y, const f32x4* __restrict__ wpl1x,
+                                                const f32x4* __restrict__ wpl1y, const float* __restrict__ b1x,
+                                                const float* __restrict__ b1y, float* __restrict__ y1,
+                                                float* __restrict__ gn1, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * LD256 + 128];
+  float* pf = smem;
+  float* a0 = smem + TP * LD64;
+  float* stat = smem + TP * LD64 + TP * LD256;  // [2][32][2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
+  const int P = N + M;
+  if (tid < 64) {
+    const int hd = tid >> 5, grp = tid & 31;
+    float mean, rstd;
+    merge_gn(gn0 + ((size_t)rt.obj * 2 + hd) * T * 64, grp, T, TN, N, M, mean, rstd);
+    stat[(hd * 32 + grp) * 2] = mean;
+    stat[(hd * 32 + grp) * 2 + 1] = rstd;
+  }
+  load_pf_tile(pointfeat, rt, pf, tid);
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    {
+      f32x16 acc[1][2];
+      rot_layer0(acc, hd ? wpl0y : wpl0x, pf, wave, lane);
+      const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
+      const float* gam = (hd ? gam0y : gam0x) + wave * 32;
+      const float* bet = (hd ? bet0y : bet0x) + wave * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gam + c);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(bet + c);
+        const float mean = stat[(hd * 32 + wave * 4 + g) * 2], rstd = stat[(hd * 32 + wave * 4 + g) * 2 + 1];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x4 z;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float sc = rstd * gv[q];
+            z[q] = gelu_erf(fmaf(acc[0][nb][4 * g + q] + bv[q], sc, ev[q] - mean * sc));
+          }
+          *reinterpret_cast<f32x4*>(a0 + (nb * 32 + n) * LD256 + wave * 32 + c) = z;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // layer 1 (256->256), "swapped": lane owns channel wave*32+n and 32 of the tile's points
+      f32x16 acc[1][2] = {{zero16(), zero16()}};
+      gemm_tile<1, 2, true>(acc, (hd ? wpl1y : wpl1x) + (wave * 32) * 64 + lane, 0,
+                            a0 + (lane & 31) * LD256 + 4 * (lane >> 5), 32 * LD256, 32);
+      const int ch = wave * 32 + n;
+      const float bb = (hd ? b1y : b1x)[ch];
+      float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+      float s = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[0][nb][r] + bb;
+          acc[0][nb][r] = v;
+          if (pt < rt.valid) {
+            dst[(size_t)pt * 256] = v;
+            s += v;
+          }
+        }
+      // group = 8 consecutive channels = 8 consecutive lanes, both half-waves
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 32);
+      const float mean = s / (8.f * (float)rt.valid);
+      float m2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float d = acc[0][nb][r] - mean;
+          m2 += pt < rt.valid ? d * d : 0.f;
+        }
+      m2 += __shfl_xor(m2, 1);
+      m2 += __shfl_xor(m2, 2);
+      m2 += __shfl_xor(m2, 4);
+      m2 += __shfl_xor(m2, 32);
+      if ((lane & 7) == 0 && h == 0) {
+        float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (wave * 4 + (n >> 3)) * 2;
+        out[0] = mean;
+        out[1] = m2;
+      }
+    }
+    __syncthreads();  // a0 is rewritten for the second head
+  }
+}
+
+// GN -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; memory-bound read of y1.
+__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1,
+                                                 const float* __restrict__ gam1x, const float* __restrict__ bet1x,
+                                                 const float* __restrict__ gam1y, const float* __restrict__ bet1y,
+                                                 const float* __restrict__ neckx, const float* __restrict__ necky,
+                                                 const float* __restrict__ wpx, const float* __restrict__ wpy,
+                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M) {
+  __shared__ float stat[64];
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP, P = N + M;
+  const int hd = blockIdx.y;
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  if (tid < 32) {
+    float mean, rstd;
+    merge_gn(gn1 + ((size_t)rt.obj * 2 + hd) * T * 64, tid, T, TN, N, M, mean, rstd);
+    stat[tid * 2] = mean;
+    stat[tid * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  const int c0 = lane * 4;  // this lane's 4 channels
+  const float* gam = hd ? gam1y : gam1x;
+  const float* bet = hd ? bet1y : bet1x;
+  const float* neck = hd ? necky : neckx;
+  const float* wp = hd ? wpy : wpx;
+  const float mean = stat[(c0 >> 3) * 2], rstd = stat[(c0 >> 3) * 2 + 1];
+  float sc[4], sh[4], nk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * gam[c0 + q];
+    sh[q] = bet[c0 + q] - mean * sc[q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
+  }
+  const float* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
+  float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int p = wave; p < rt.valid; p += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * 256);
+    const float w = wp[rt.gp0 + p];
+    float z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = nk[c][0] * z[0];
+      t = fmaf(nk[c][1], z[1], t);
+      t = fmaf(nk[c][2], z[2], t);
+      t = fmaf(nk[c][3], z[3], t);
+      a3[c] = fmaf(w, t, a3[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a3[c] = wave_sum(a3[c]);
+  if (lane == 0) {
+    red[wave][0] = a3[0];
+    red[wave][1] = a3[1];
+    red[wave][2] = a3[2];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    rpart[(((size_t)rt.obj * 2 + hd) * T + rt.t) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}
+
+// rot6d[b][hd*3+c] = sum_tiles rpart + neck_b[c] * sum_p w_p + conv_p.bias
+__global__ void k_rot_finish(const float* __restrict__ rpart, const float* __restrict__ neckbx,
+                             const float* __restrict__ neckby, const float* __restrict__ sumwp /*[2]*/,
+                             const float* __restrict__ cpbx, const float* __restrict__ cpby, float* __restrict__ rot6d,
+                             int B, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 6) return;
+  const int b = i / 6, hd = (i % 6) / 3, c = i % 3;
+  const float* rp = rpart + ((size_t)b * 2 + hd) * T * 4 + c;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += rp[t * 4];
+  const float nb = (hd ? neckby : neckbx)[c];
+  const float* cpb = hd ? cpby : cpbx;
+  s = fmaf(nb, sumwp[hd], s);
+  if (cpb) s += cpb[0];
+  rot6d[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// a10-a12: rot6d -> R (rot_reps.py:46-55), pose/scale update (pose_scale_from_delta_init.py:48-93)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ void normalize3(float* v) {  // F.normalize(p=2, eps=1e-12)
+  const float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+  v[0] /= nrm;
+  v[1] /= nrm;
+  v[2] /= nrm;
+}
+
+__global__ void k_pose_update(const float* __restrict__ rot6d, const float* __restrict__ dtr,
+                              const float* __restrict__ dsr, const float* __restrict__ pose0,
+                              const float* __restrict__ scale0, const float* __restrict__ mean_scales,
+                              const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
+                              float* __restrict__ scale_out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float dR[9];
+  if (o.rot_input_is_matrix) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dR[i] = rot6d[b * 9 + i];
+  } else {
+    float x[3] = {rot6d[b * 6 + 0], rot6d[b * 6 + 1], rot6d[b * 6 + 2]};
+    const float yr[3] = {rot6d[b * 6 + 3], rot6d[b * 6 + 4], rot6d[b * 6 + 5]};
+    float z[3], y[3];
+    normalize3(x);
+    cross3(x, yr, z);
+    normalize3(z);
+    cross3(z, x, y);
+    // columns (x, y, z): torch.stack((x, y, z), dim=-1)
+    dR[0] = x[0]; dR[1] = y[0]; dR[2] = z[0];
+    dR[3] = x[1]; dR[4] = y[1]; dR[5] = z[1];
+    dR[6] = x[2]; dR[7] = y[2]; dR[8] = z[2];
+  }
+
+  const float* p0 = pose0 + b * 12;
+  const float t0[3] = {p0[3], p0[7], p0[11]};
+  float d[3] = {dtr[b * 3] * o.delta_t_weight, dtr[b * 3 + 1] * o.delta_t_weight, dtr[b * 3 + 2] * o.delta_t_weight};
+  float t[3];
+  if (!o.delta_t_space_3d) {
+    const float zsrc = t0[2];
+    const float ztgt = o.delta_z_deepim ? zsrc / expf(d[2]) : d[2] * zsrc;
+    const float fx = o.k_aware ? Ks[b * 9 + 0] : 1.f, fy = o.k_aware ? Ks[b * 9 + 4] : 1.f;
+    t[0] = ztgt * (d[0] / fx + t0[0] / zsrc);
+    t[1] = ztgt * (d[1] / fy + t0[1] / zsrc);
+    t[2] = ztgt;
+  } else {
+    t[0] = t0[0] + d[0];
+    t[1] = t0[1] + d[1];
+    t[2] = t0[2] + d[2];
+  }
+  const float* sb = o.scale_base_mean ? mean_scales + b * 3 : scale0 + b * 3;
+  float s[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s[i] = o.scale_mul ? sb[i] * expf(dsr[b * 3 + i]) : sb[i] + dsr[b * 3 + i];
+
+  if (o.is_allo) {  // allo_to_ego_mat_torch, core/utils/utils.py:200-231
+    const float nrm = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + o.allo_eps;
+    const float ray[3] = {t[0] / nrm, t[1] / nrm, t[2] / nrm};
+    const float angle = acosf(ray[2]);
+    float ax[3] = {-ray[1], ray[0], 0.f};  // (0,0,1) x ray
+    const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1]) + o.allo_eps;
+    ax[0] /= an;
+    ax[1] /= an;
+    const float sh = sinf(angle * 0.5f);
+    float q[4] = {cosf(angle * 0.5f), ax[0] * sh, ax[1] * sh, 0.f * sh};
+    const float qn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] /= qn;  // quat2mat_torch, core/utils/pose_utils.py:349-412
+    const float X = q[1] * 2.f, Y = q[2] * 2.f, Z = q[3] * 2.f;
+    const float wX = q[0] * X, wY = q[0] * Y, wZ = q[0] * Z, xX = q[1] * X, xY = q[1] * Y, xZ = q[1] * Z;
+    const float yY = q[2] * Y, yZ = q[2] * Z, zZ = q[3] * Z;
+    const float A[9] = {1.f - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, 1.f - (xX + zZ), yZ - wX,
+                        xZ - wY,         yZ + wX, 1.f - (xX + yY)};
+    float E[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) E[i * 3 + j] = A[i * 3] * dR[j] + A[i * 3 + 1] * dR[3 + j] + A[i * 3 + 2] * dR[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dR[i] = E[i];
+  }
+  float* po = pose_out + b * 12;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      po[i * 4 + j] = dR[i * 3] * p0[j] + dR[i * 3 + 1] * p0[4 + j] + dR[i * 3 + 2] * p0[8 + j];  // dR @ R0
+    po[i * 4 + 3] = t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) scale_out[b * 3 + i] = o.refine_scale ? s[i] : scale0[b * 3 + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone channel-wise max-pool [B,C,N] -> [B,C]: one wave per row, float4 streaming loads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                int N) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int nwaves = gridDim.x * wpb;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const float* r = x + (size_t)row * N;
+    float m = -INFINITY;
+    if ((N & 3) == 0) {
+      const f32x4* r4 = reinterpret_cast<const f32x4*>(r);
+      const int n4 = N >> 2;
+#pragma unroll 4
+      for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = __builtin_nontemporal_load(r4 + i);
+        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+      }
+    } else {
+      for (int i = lane; i < N; i += 64) m = fmaxf(m, r[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) out[row] = m;
+  }
+}
+
+// ==========================================================================================
+// host side: packed-weight and workspace layouts, launchers, C ABI
+// ==========================================================================================
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PackLayout {
+  size_t stn_c2, stn_c3, fstn_c1, fstn_c2, fstn_c3, c2, c3, c4, rot_l0[2], rot_l1[2], ts_w0t, ts_w1t, sumwp, total;
+};
+
+PackLayout pack_layout(int ts_in) {
+  PackLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += align_up(n, 64);
+    return r;
+  };
+  L.stn_c2 = take(128 * 64);
+  L.stn_c3 = take(1024 * 128);
+  L.fstn_c1 = take(64 * 64);
+  L.fstn_c2 = take(128 * 64);
+  L.fstn_c3 = take(1024 * 128);
+  L.c2 = take(128 * 64);
+  L.c3 = take(512 * 128);
+  L.c4 = take(1024 * 512);
+  for (int h = 0; h < 2; ++h) {
+    L.rot_l0[h] = take(256 * 64);
+    L.rot_l1[h] = take(256 * 256);
+  }
+  L.sumwp = take(64);
+  // everything above is independent of ts_in (the stage entry points rely on that)
+  L.ts_w0t = take((size_t)ts_in * 256);
+  L.ts_w1t = take(256 * 256);
+  L.total = o;
+  return L;
+}
+
+struct WsLayout {
+  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, y1, rpart,
+      total;  // offsets in floats
+};
+
+WsLayout ws_layout(int B, int N, int M) {
+  const size_t TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM;
+  const size_t b = B, P = (size_t)N + M;
+  WsLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += align_up(n, 64);
+    return r;
+  };
+  L.xbuf = take(b * N * 3);
+  L.kbuf = take(b * M * 3);
+  L.pm = take(b * T * PMW);
+  L.pool = take(2 * b * 1024);
+  L.h1 = take(2 * b * 512);
+  L.h2 = take(2 * b * 256);
+  L.trans3 = take(2 * b * 9);
+  L.trans64 = take(2 * b * 4096);
+  L.gfeat = take(2 * b * PMW);
+  L.pointfeat = take(b * P * 64);
+  L.dt = take(b * 3);
+  L.ds = take(b * 3);
+  L.rot6d = take(b * 6);
+  L.bias0 = take(2 * 2 * b * 256);
+  L.gn0 = take(b * 2 * T * 64);
+  L.gn1 = take(b * 2 * T * 64);
+  L.y1 = take(b * 2 * P * 256);
+  L.rpart = take(b * 2 * T * 4);
+  L.total = o;
+  return L;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? CATRE_OK : CATRE_ERR_LAUNCH; }
+
+inline bool dims_ok(int B, int N, int M) { return B > 0 && N > 0 && M > 0; }
+// the PointNet stages also run on a single cloud per object (M == 0: PointNetfeat.forward on its own)
+inline bool dims_ok1(int B, int N, int M) { return B > 0 && N > 0 && M >= 0; }
+inline int n_clouds(int B, int M) { return M > 0 ? 2 * B : B; }
+
+#define REQUIRE(cond) \
+  do {                \
+    if (!(cond)) return CATRE_ERR_BAD_ARG; \
+  } while (0)
+
+inline const f32x4* pk4(const float* packed, size_t off) { return reinterpret_cast<const f32x4*>(packed + off); }
+
+int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
+                float* out, int k, int R, hipStream_t st) {
+  // relu(fc1) -> relu(fc2) -> fc3 + I_k   (pointnet.py:31-40 / 64-77)
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(64), 0, st, pooled, 1024, prm[base], 1024,
+                     prm[base + 1], h1, 512, R, 512, 1024, 1, 0);
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(64), 0, st, h1, 512, prm[base + 2], 512,
+                     prm[base + 3], h2, 256, R, 256, 512, 1, 0);
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(64), 0, st, h2, 256, prm[base + 4], 256,
+                     prm[base + 5], out, k * k, R, k * k, 256, 0, k);
+  return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* catre_version(void) { return CATRE_VERSION_STR; }
+
+const char* catre_status_string(int s) {
+  switch (s) {
+    case CATRE_OK: return "ok";
+    case CATRE_ERR_BAD_ARG: return "bad argument";
+    case CATRE_ERR_WORKSPACE: return "workspace or packed-weight buffer too small";
+    case CATRE_ERR_LAUNCH: return "kernel launch failed";
+    case CATRE_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+size_t catre_workspace_bytes(int B, int N, int M) {
+  if (!dims_ok1(B, N, M)) return 0;
+  return ws_layout(B, N, M).total * sizeof(float);
+}
+
+size_t catre_packed_floats(int N, int M, int ts_in_dim) {
+  if (N <= 0 || M <= 0 || ts_in_dim <= 0) return 0;
+  return pack_layout(ts_in_dim).total;
+}
+
+int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* packed, size_t packed_floats,
+                       void* stream) {
+  REQUIRE(prm && packed && N > 0 && M > 0 && ts_in > 0);
+  const PackLayout L = pack_layout(ts_in);
+  if (packed_floats < L.total) return CATRE_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  // a NULL source is skipped, so a sub-module (e.g. PointNetfeat alone) can pack just its own layers
+  auto frag = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
+    if (!src) return;
+    const int n = rows * K;
+    hipLaunchKernelGGL(k_pack_frag, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K, packed + off);
+  };
+  frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);
+  frag(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.stn_c3);
+  frag(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.fstn_c1);
+  frag(prm[CATRE_P_FSTN_CONV2_W], 64, 0, 128, 64, L.fstn_c2);
+  frag(prm[CATRE_P_FSTN_CONV3_W], 128, 0, 1024, 128, L.fstn_c3);
+  frag(prm[CATRE_P_CONV2_W], 64, 0, 128, 64, L.c2);
+  frag(prm[CATRE_P_CONV3_W], 128, 0, 512, 128, L.c3);
+  frag(prm[CATRE_P_CONV4_W], 512, 0, 1024, 512, L.c4);
+  for (int h = 0; h < 2; ++h) {
+    const int base = h ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
+    frag(prm[base], PMW, 1024, 256, 64, L.rot_l0[h]);  // W0[:, 1024:1088]
+    frag(prm[base + 4], 256, 0, 256, 256, L.rot_l1[h]);
+    if (prm[base + 10])
+      hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, prm[base + 10], N + M, packed + L.sumwp + h);
+  }
+  if (prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
+    int n = ts_in * 256;
+    hipLaunchKernelGGL(k_pack_transpose, dim3((n + 255) / 256), dim3(256), 0, st, prm[CATRE_P_TS_L0_W], 256, ts_in,
+                       packed + L.ts_w0t);
+    n = 256 * 256;
+    hipLaunchKernelGGL(k_pack_transpose, dim3((n + 255) / 256), dim3(256), 0, st, prm[CATRE_P_TS_L1_W], 256, 256,
+                       packed + L.ts_w1t);
+  }
+  return check_launch();
+}
+
+int catre_pose_apply(const float* pcl, const float* kps, const float* pose, const float* scale, float* x_out,
+                     float* kps_out, int B, int N, int M, int zero_center, void* stream) {
+  REQUIRE(pcl && kps && pose && scale && x_out && kps_out && dims_ok(B, N, M));
+  const int total = B * (N + M);
+  hipLaunchKernelGGL(k_pose_apply, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcl, kps, pose, scale,
+                     x_out, kps_out, B, N, M, zero_center);
+  return check_launch();
+}
+
+int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const float* packed, float* pooled,
+                     void* workspace, size_t ws_bytes, int B, int N, int M, void* stream) {
+  REQUIRE(pts && prm && packed && pooled && workspace && dims_ok1(B, N, M));
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  const PackLayout L = pack_layout(1);  // conv offsets do not depend on ts_in
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  hipLaunchKernelGGL(k_stn3d, dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
+                     pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
+                     ws + W.pm, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
+  return check_launch();
+}
+
+int catre_linear(const float* x, int ldx, const float* Wt, int ldw, const float* bias, float* y, int ldy, int R, int J,
+                 int K, int relu, int add_identity_k, void* stream) {
+  REQUIRE(x && Wt && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0);
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(64), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
+                     bias, y, ldy, R, J, K, relu, add_identity_k);
+  return check_launch();
+}
+
+int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* const* prm, const float* packed,
+                     float* pooled, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream) {
+  REQUIRE(pts && trans3 && prm && packed && pooled && workspace && dims_ok1(B, N, M));
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  const PackLayout L = pack_layout(1);
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  hipLaunchKernelGGL(k_stnkd, dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
+                     pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),
+                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
+  return check_launch();
+}
+
+int catre_trunk(const catre_points* pts, const float* trans3, const float* trans64, const float* const* prm,
+                const float* packed, float* gfeat, float* pointfeat, void* workspace, size_t ws_bytes, int B, int N,
+                int M, void* stream) {
+  REQUIRE(pts && trans3 && prm && packed && gfeat && pointfeat && workspace && dims_ok1(B, N, M));
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  const PackLayout L = pack_layout(1);
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  hipLaunchKernelGGL(k_trunk, dim3(tiles), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W],
+                     prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),
+                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
+  return check_launch();
+}
+
+int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_scale, const float* const* prm,
+                  const float* packed, const catre_opts* o, float* trans_deltas, float* scale_deltas, int B,
+                  void* stream) {
+  REQUIRE(gfeat && init_pose && init_scale && prm && packed && o && trans_deltas && scale_deltas && B > 0);
+  const int expect = PMW * (o->with_kps_feature ? 2 : 1) + (o->with_init_scale ? 3 : 0) + (o->with_init_trans ? 3 : 0);
+  if (o->ts_in_dim != expect) return CATRE_ERR_BAD_ARG;
+  const PackLayout L = pack_layout(o->ts_in_dim);
+  const size_t smem = (size_t)TS_OB * (o->ts_in_dim + 256) * sizeof(float);
+  if (smem > 64 * 1024) return CATRE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_ts_head, dim3((B + TS_OB - 1) / TS_OB), dim3(256), smem, (hipStream_t)stream, gfeat, init_pose,
+                     init_scale, packed + L.ts_w0t, prm[CATRE_P_TS_L0_B], prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B],
+                     packed + L.ts_w1t, prm[CATRE_P_TS_L1_B], prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B],
+                     prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B], prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B],
+                     trans_deltas, scale_deltas, B, o->ts_in_dim, o->with_kps_feature, o->with_init_scale,
+                     o->with_init_trans);
+  return check_launch();
+}
+
+static int rot_head_impl(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
+                         float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st) {
+  const PackLayout L = pack_layout(1);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  float* bias0 = ws + W.bias0;
+  // global-feature half of layer 0 for every cloud: bias0[hd][cloud][:] = W0[:, :1024] g_cloud + b0
+  for (int hd = 0; hd < 2; ++hd) {
+    const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
+    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64), 0, st, gfeat, PMW, prm[base], PMW,
+                       prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
+  }
+  hipLaunchKernelGGL(k_rot_l0_stats, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                     pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, B, N, M);
+  hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                     pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
+                     prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], pk4(packed, L.rot_l1[0]),
+                     pk4(packed, L.rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B,
+                     N, M);
+  hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1, prm[CATRE_P_ROTX_GN1_W],
+                     prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
+                     prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
+                     prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
+                     rot6d, B, T);
+  return check_launch();
+}
+
+int catre_rot_head(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
+                   float* rot6d, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream) {
+  REQUIRE(gfeat && pointfeat && prm && packed && rot6d && workspace && dims_ok(B, N, M));
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  return rot_head_impl(gfeat, pointfeat, prm, packed, rot6d, (float*)workspace, W, B, N, M, (hipStream_t)stream);
+}
+
+int catre_pose_update(const float* rot6d, const float* trans_deltas, const float* scale_deltas, const float* init_pose,
+                      const float* init_scale, const float* mean_scales, const float* Ks, const catre_opts* o,
+                      float* pose_out, float* scale_out, int B, void* stream) {
+  REQUIRE(rot6d && trans_deltas && scale_deltas && init_pose && init_scale && o && pose_out && scale_out && B > 0);
+  if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
+  if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, trans_deltas,
+                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
+  return check_launch();
+}
+
+int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
+                      const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                      const catre_opts* o, float* pose_out, float* scale_out, void* workspace, size_t ws_bytes, int B,
+                      int N, int M, void* stream) {
+  REQUIRE(pts && pts->obs && pts->kps && init_pose && init_scale && prm && packed && o && pose_out && scale_out &&
+          workspace && dims_ok(B, N, M));
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  // STN3d (pointnet.py:98) on both clouds
+  if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) return rc;
+  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
+    return rc;
+  const float* t64 = nullptr;
+  if (o->feature_transform) {  // STNkd (pointnet.py:105-106)
+    if ((rc = catre_stnkd_pool(pts, ws + W.trans3, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream)))
+      return rc;
+    if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
+      return rc;
+    t64 = ws + W.trans64;
+  }
+  if ((rc = catre_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.gfeat, ws + W.pointfeat, workspace, ws_bytes, B, N,
+                        M, stream)))
+    return rc;
+  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, stream)))
+    return rc;
+  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st))) return rc;
+  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                           scale_out, B, stream);
+}
+
+int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,
+                   const float* const* prm, const float* packed, const catre_opts* o, float* poses, float* scales,
+                   void* workspace, size_t ws_bytes, int B, int N, int M, int n_iter, void* stream) {
+  REQUIRE(pcl && kps && prm && packed && o && poses && scales && workspace && dims_ok(B, N, M) && n_iter >= 0);
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  catre_points pts;
+  pts.obs = ws + W.xbuf;
+  pts.obs_sb = (int64_t)N * 3;
+  pts.obs_sn = 3;
+  pts.obs_sc = 1;
+  pts.kps = ws + W.kbuf;
+  pts.kps_sb = (int64_t)M * 3;
+  pts.kps_sn = 3;
+  pts.kps_sc = 1;
+  for (int i = 1; i <= n_iter; ++i) {
+    const float* pose_in = poses + (size_t)(i - 1) * B * 12;
+    // batch_test.py:74-75: the scale estimate is only fed back when REFINE_SCLAE
+    const float* scale_in = scales + (size_t)(o->refine_scale ? i - 1 : 0) * B * 3;
+    int rc = catre_pose_apply(pcl, kps, pose_in, scale_in, ws + W.xbuf, ws + W.kbuf, B, N, M, o->zero_center, stream);
+    if (rc) return rc;
+    rc = catre_refine_iter(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
+                           scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream);
+    if (rc) return rc;
+  }
+  return CATRE_OK;
+}
+
+
+int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream) {
+  REQUIRE(x && out && B > 0 && C > 0 && N > 0);
+  const int rows = B * C;
+  const int grid = rows / 4 < 8192 ? (rows + 3) / 4 : 8192;
+  hipLaunchKernelGGL(k_colmax, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, rows, N);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Residual heads of the CATRE hot path - parameter containers (HIP forward lives in the fused driver).
+
+Mirrors ``core/catre/models/heads/conv_out_per_rot_head.py`` and ``fc_trans_size_head.py``:
+same class names, constructor kwargs, ModuleList indices (``layers.0/1/3/4``, ``linears.0/1/3/4``),
+never-used ``norm`` GroupNorm, and initialisation (N(0, 0.001^2) conv/linear weights, zero bias,
+GN weight 1; ``fc_t``/``fc_s`` N(0, 0.01^2)), so reference checkpoints load ``strict=True``.
+"""
+import torch.nn as nn
+
+_FUSED_ONLY = (
+    "{cls}.forward on its own takes the materialised feature tensor ({what}) that the fused MI355X path never "
+    "builds (SURVEY.md a6/a7: the repeated global feature is folded into a per-cloud bias).  It is evaluated "
+    "inside CATRE_disR_shared.forward / catre_rot_head / catre_ts_head."
+)
+
+
+def _normal_init(m, std):
+    nn.init.normal_(m.weight, 0.0, std)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, 0.0)
+
+
+def _get_norm(norm, channels, num_gn_groups):
+    if norm is None or (isinstance(norm, str) and norm.lower() in ("", "none")):
+        return nn.Identity()
+    if norm == "GN":
+        return nn.GroupNorm(num_gn_groups, channels)
+    raise NotImplementedError(f"norm={norm!r}: the HIP heads implement GroupNorm ('GN'), as in every shipped config")
+
+
+def _get_act(act):
+    if act is not None and act.lower() == "gelu":
+        return nn.GELU()
+    raise NotImplementedError(f"act={act!r}: the HIP heads implement exact-erf GELU, as in every shipped config")
+
+
+class RotHead(nn.Module):
+    """reference conv_out_per_rot_head.py:74-140."""
+
+    def __init__(self, in_dim=1024, feat_dim=256, num_layers=2, rot_dim=4, norm="none", num_gn_groups=32,
+                 act="leaky_relu", num_classes=1, kernel_size=1, num_points=1, norm_input=False, dropout=False,
+                 point_bias=True):
+        super().__init__()
+        if (in_dim, feat_dim, num_layers, rot_dim, num_classes, kernel_size, num_gn_groups) != (1088, 256, 2, 3, 1, 1, 32):
+            raise NotImplementedError(
+                "HIP rot head is built for in_dim=1088, feat_dim=256, num_layers=2, rot_dim=3, kernel_size=1, "
+                f"num_gn_groups=32, num_classes=1; got {(in_dim, feat_dim, num_layers, rot_dim, num_classes, kernel_size, num_gn_groups)}"
+            )
+        if norm_input or dropout:
+            raise NotImplementedError("norm_input / dropout are not used by the shipped configs")
+        self.norm = _get_norm(norm, feat_dim, num_gn_groups)  # never used in forward (reference :92)
+        self.act_func = act_func = _get_act(act)
+        self.num_classes = num_classes
+        self.rot_dim = rot_dim
+        self.layers = nn.ModuleList()
+        for i in range(num_layers):
+            self.layers.append(nn.Conv1d(in_dim if i == 0 else feat_dim, feat_dim, kernel_size))
+            self.layers.append(_get_norm(norm, feat_dim, num_gn_groups))
+            self.layers.append(act_func)
+        self.neck = nn.ModuleList([nn.Conv1d(feat_dim, rot_dim * num_classes, 1)])
+        self.conv_p = nn.Conv1d(num_points, 1, 1, bias=point_bias)
+        self._init_weights()
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Linear)):
+                _normal_init(m, 0.001)
+            elif isinstance(m, nn.GroupNorm):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+
+    def forward(self, x):
+        raise NotImplementedError(_FUSED_ONLY.format(cls="RotHead", what="[B,1088,N+M]"))
+
+
+class ConvOutPerRotHead(nn.Module):
+    """reference conv_out_per_rot_head.py:10-71: two independent RotHeads (x axis, y axis) -> rot6d."""
+
+    def __init__(self, in_dim=1024, feat_dim=256, num_layers=2, rot_dim=3, norm="GN", num_gn_groups=32, act="gelu",
+                 num_classes=1, kernel_size=1, num_points=1, per_rot_sup=False, norm_input=False, dropout=False,
+                 point_bias=True, **args):
+        super().__init__()
+        if per_rot_sup:
+            raise NotImplementedError("per_rot_sup=True is not used by the shipped configs")
+        self.per_rot_sup = per_rot_sup
+        mk = lambda: RotHead(in_dim, feat_dim, num_layers, rot_dim, norm, num_gn_groups, act, num_classes, kernel_size,
+                             num_points, norm_input, dropout, point_bias)
+        self.rot_head_x = mk()
+        self.rot_head_y = mk()
+        self.num_points = num_points
+
+    def forward(self, x):
+        raise NotImplementedError(_FUSED_ONLY.format(cls="ConvOutPerRotHead", what="[B,1088,N+M]"))
+
+
+class FC_TransSizeHead(nn.Module):
+    """reference fc_trans_size_head.py:9-70."""
+
+    def __init__(self, in_dim=1024, feat_dim=256, num_layers=2, rot_dim=4, norm="none", num_gn_groups=32,
+                 act="leaky_relu", num_classes=1, norm_input=False, dropout=False):
+        super().__init__()
+        if (feat_dim, num_layers, num_classes, num_gn_groups) != (256, 2, 1, 32):
+            raise NotImplementedError("HIP ts head is built for feat_dim=256, num_layers=2, num_gn_groups=32, num_classes=1")
+        if norm_input or dropout:
+            raise NotImplementedError("norm_input / dropout are not used by the shipped configs")
+        self.norm = _get_norm(norm, feat_dim, num_gn_groups)  # never used in forward (reference :28)
+        self.act_func = act_func = _get_act(act)
+        self.num_classes = num_classes
+        self.rot_dim = rot_dim
+        self.in_dim = in_dim
+        self.linears = nn.ModuleList()
+        for i in range(num_layers):
+            self.linears.append(nn.Linear(in_dim if i == 0 else feat_dim, feat_dim))
+            self.linears.append(_get_norm(norm, feat_dim, num_gn_groups))
+            self.linears.append(act_func)
+        self.fc_t = nn.Linear(feat_dim, 3 * num_classes)
+        self.fc_s = nn.Linear(feat_dim, 3 * num_classes)
+        self._init_weights()
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Linear)):
+                _normal_init(m, 0.001)
+            elif isinstance(m, nn.GroupNorm):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+        _normal_init(self.fc_t, 0.01)
+        _normal_init(self.fc_s, 0.01)
+
+    def forward(self, x):
+        raise NotImplementedError(_FUSED_ONLY.format(cls="FC_TransSizeHead", what="[B,1091]"))

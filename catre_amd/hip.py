@@ -1,0 +1,165 @@
+"""ctypes binding of ``libcatre_hip.so`` (C ABI declared in ``include/catre_hip.h``).
+
+PyTorch is only plumbing here: device memory (``tensor.data_ptr()``), the current HIP stream
+and, elsewhere, ``torch.distributed``.  There is NO fallback: if the library is missing or a
+tensor is not on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcatre_hip.so")
+
+# state_dict keys in the order of `enum catre_param` (include/catre_hip.h)
+PARAM_KEYS = (
+    [f"pcl_net.stn.{l}.{p}" for l in ("conv1", "conv2", "conv3", "fc1", "fc2", "fc3") for p in ("weight", "bias")]
+    + [f"pcl_net.{l}.{p}" for l in ("conv1", "conv2", "conv3", "conv4") for p in ("weight", "bias")]
+    + [f"pcl_net.fstn.{l}.{p}" for l in ("conv1", "conv2", "conv3", "fc1", "fc2", "fc3") for p in ("weight", "bias")]
+    + [
+        f"rot_head.rot_head_{a}.{l}.{p}"
+        for a in ("x", "y")
+        for l in ("layers.0", "layers.1", "layers.3", "layers.4", "neck.0", "conv_p")
+        for p in ("weight", "bias")
+    ]
+    + [
+        f"ts_head.{l}.{p}"
+        for l in ("linears.0", "linears.1", "linears.3", "linears.4", "fc_t", "fc_s")
+        for p in ("weight", "bias")
+    ]
+)
+CATRE_P_COUNT = len(PARAM_KEYS)
+assert CATRE_P_COUNT == 68, CATRE_P_COUNT
+
+
+class CatreOpts(ctypes.Structure):
+    _fields_ = [
+        ("feature_transform", ctypes.c_int32),
+        ("with_kps_feature", ctypes.c_int32),
+        ("with_init_scale", ctypes.c_int32),
+        ("with_init_trans", ctypes.c_int32),
+        ("delta_t_space_3d", ctypes.c_int32),
+        ("delta_z_deepim", ctypes.c_int32),
+        ("k_aware", ctypes.c_int32),
+        ("scale_mul", ctypes.c_int32),
+        ("scale_base_mean", ctypes.c_int32),
+        ("is_allo", ctypes.c_int32),
+        ("refine_scale", ctypes.c_int32),
+        ("zero_center", ctypes.c_int32),
+        ("delta_t_weight", ctypes.c_float),
+        ("allo_eps", ctypes.c_float),
+        ("ts_in_dim", ctypes.c_int32),
+        ("rot_input_is_matrix", ctypes.c_int32),
+    ]
+
+
+class CatrePoints(ctypes.Structure):
+    _fields_ = [
+        ("obs", ctypes.c_void_p), ("obs_sb", ctypes.c_int64), ("obs_sn", ctypes.c_int64), ("obs_sc", ctypes.c_int64),
+        ("kps", ctypes.c_void_p), ("kps_sb", ctypes.c_int64), ("kps_sn", ctypes.c_int64), ("kps_sc", ctypes.c_int64),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_SZ = ctypes.c_size_t
+_SIGS = {
+    "catre_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "catre_packed_floats": (_SZ, [_I, _I, _I]),
+    "catre_pack_weights": (_I, [_P, _I, _I, _I, _P, _SZ, _P]),
+    "catre_pose_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "catre_stn3d_pool": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_linear": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_stnkd_pool": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_trunk": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_ts_head": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "catre_rot_head": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_pose_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_colmax": (_I, [_P, _P, _I, _I, _I, _P]),
+    "catre_status_string": (ctypes.c_char_p, [_I]),
+    "catre_version": (ctypes.c_char_p, []),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+class CatreHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises ``CatreHipError`` if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CatreHipError(
+            f"{LIB_PATH} not found - build it with `make -C catre_amd/csrc` (or `python -c "
+            "'import __graft_entry__ as g; g.build()'`).  catre_amd has no CPU or PyTorch fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().catre_status_string(status).decode()
+        raise CatreHipError(f"{what} failed: {msg} (status {status})")
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_dev_f32(t, name, shape=None, contiguous=True):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise CatreHipError(
+            f"{name} is on {t.device}; catre_amd runs on HIP devices only (no CPU fallback - the CPU "
+            "restatement lives in oracle/ and is test infrastructure)"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if shape is not None:
+        if t.dim() != len(shape) or any(e is not None and int(a) != int(e) for a, e in zip(t.shape, shape)):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def points_desc(x, tfd_kps):
+    """Describe the reference's ``x [B,3,N]`` / ``tfd_kps [B,3,M]`` inputs (arbitrary strides, e.g. the
+    permuted views produced by ``engine/batch_test.py:91-94``) for the kernels - no copy."""
+    require_dev_f32(x, "x", (None, 3, None), contiguous=False)
+    require_dev_f32(tfd_kps, "tfd_kps", (x.shape[0], 3, None), contiguous=False)
+    d = CatrePoints()
+    d.obs, d.obs_sb, d.obs_sc, d.obs_sn = x.data_ptr(), x.stride(0), x.stride(1), x.stride(2)
+    d.kps, d.kps_sb, d.kps_sc, d.kps_sn = tfd_kps.data_ptr(), tfd_kps.stride(0), tfd_kps.stride(1), tfd_kps.stride(2)
+    return d
+
+
+def param_array(tensors):
+    """``tensors``: list in ``PARAM_KEYS`` order (``None`` allowed only for conv_p.bias)."""
+    arr = (ctypes.c_void_p * CATRE_P_COUNT)()
+    for i, t in enumerate(tensors):
+        if t is None:
+            arr[i] = None
+        else:
+            require_dev_f32(t, PARAM_KEYS[i])
+            arr[i] = t.data_ptr()
+    return arr

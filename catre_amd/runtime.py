@@ -1,0 +1,289 @@
+"""Host-side runtime: binds a set of parameter tensors to the C ABI.
+
+* keeps the ``const float* const* params`` array alive and in ``catre_param`` order,
+* re-packs the MFMA weight image (``catre_pack_weights``) only when a parameter changed
+  (``tensor._version`` / ``data_ptr`` fingerprint), stream-ordered with the forward that needs it,
+* owns a grow-only workspace per device (sized by ``catre_workspace_bytes``; 288 GB of HBM3E per
+  MI355X means B=256, N=M=1024 needs ~1.4 GB and is simply kept resident).
+
+No torch op is on the hot path: the only torch calls are ``torch.empty`` for outputs/workspace.
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+
+def opts_from_cfg(cfg, feature_transform=True):
+    """Translate the cfg flags read by ``CATRE_disR_shared.forward`` (reference
+    ``core/catre/models/CATRE_disR_shared.py:57-120``) into ``catre_opts``."""
+    net = cfg.MODEL.CATRE
+    rh, th = net.ROT_HEAD, net.TS_HEAD
+    if rh.ROT_TYPE not in ("ego_rot6d", "allo_rot6d"):
+        raise NotImplementedError(
+            f"ROT_TYPE={rh.ROT_TYPE!r}: the HIP path implements the rot6d heads of the shipped configs "
+            "(ConvOutPerRotHead emits 3+3 values, reference heads/conv_out_per_rot_head.py:62-66)"
+        )
+    if rh.get("CLASS_AWARE", False):
+        # the reference branch itself is unreachable: it dereferences the non-existent self.pose_head
+        # (CATRE_disR_shared.py:90-95)
+        raise NotImplementedError("ROT_HEAD.CLASS_AWARE=True is not supported (latent bug in the reference too)")
+    if rh.DELTA_T_SPACE not in ("image", "3D"):
+        raise ValueError("Unknown delta_T_space: {}".format(rh.DELTA_T_SPACE))  # pose_scale_from_delta_init.py:76
+    o = hip.CatreOpts()
+    o.feature_transform = int(bool(feature_transform))
+    o.with_kps_feature = int(bool(th.WITH_KPS_FEATURE))
+    o.with_init_scale = int(bool(th.WITH_INIT_SCALE))
+    o.with_init_trans = int(bool(th.get("WITH_INIT_TRANS", False)))
+    o.delta_t_space_3d = int(rh.DELTA_T_SPACE == "3D")
+    o.delta_z_deepim = int(rh.DELTA_Z_STYLE != "cosypose")
+    o.k_aware = int(bool(rh.T_TRANSFORM_K_AWARE))
+    o.scale_mul = int("add" not in rh.SCLAE_TYPE)
+    o.scale_base_mean = int("iter" not in rh.SCLAE_TYPE)
+    o.is_allo = int("allo" in rh.ROT_TYPE)
+    o.refine_scale = int(bool(cfg.MODEL.REFINE_SCLAE))
+    o.zero_center = int(bool(cfg.INPUT.ZERO_CENTER_INPUT))
+    o.delta_t_weight = float(rh.DELTA_T_WEIGHT)
+    o.allo_eps = 1e-4  # CATRE_disR_shared.py:112
+    o.ts_in_dim = 1088 * (2 if o.with_kps_feature else 1) + 3 * o.with_init_scale + 3 * o.with_init_trans
+    return o
+
+
+class HipRuntime:
+    """One per model instance (and device)."""
+
+    def __init__(self, named_params, N, M, ts_in_dim):
+        """``named_params``: callable returning ``{state_dict key: tensor}`` of the LIVE parameters."""
+        self._named_params = named_params
+        self.N, self.M, self.ts_in_dim = int(N), int(M), int(ts_in_dim)
+        self._fingerprint = None
+        self._param_arr = None
+        self._param_keep = None
+        self._packed = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ weights
+    def _live_params(self):
+        named = self._named_params()
+        return [named.get(k) for k in hip.PARAM_KEYS]
+
+    def params(self, device):
+        """(param pointer array, packed weights) - re-packed on the current stream if stale."""
+        lib = hip.load()
+        tensors = self._live_params()
+        fp = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        if fp != self._fingerprint or self._packed is None or self._packed.device != device:
+            for k, t in zip(hip.PARAM_KEYS, tensors):
+                if t is not None and t.device != device:
+                    raise hip.CatreHipError(f"parameter {k} is on {t.device}, inputs are on {device}")
+            tensors = [t.detach().contiguous() if t is not None else None for t in tensors]
+            self._param_keep = tensors
+            self._param_arr = hip.param_array(tensors)
+            n = lib.catre_packed_floats(self.N, self.M, self.ts_in_dim)
+            if self._packed is None or self._packed.numel() < n or self._packed.device != device:
+                self._packed = torch.empty(n, dtype=torch.float32, device=device)
+            hip.check(
+                lib.catre_pack_weights(self._param_arr, self.N, self.M, self.ts_in_dim, hip.ptr(self._packed),
+                                       self._packed.numel(), hip.stream_ptr(device)),
+                "catre_pack_weights",
+            )
+            self._fingerprint = fp
+        return self._param_arr, self._packed
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B, N, M, device):
+        lib = hip.load()
+        need = lib.catre_workspace_bytes(B, N, M)
+        if need == 0:
+            raise ValueError(f"bad sizes B={B} N={N} M={M}")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ drivers
+    def refine_iter(self, x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, opts):
+        """One ``CATRE_disR_shared.forward`` (test path) -> (pose [B,3,4], scale [B,3])."""
+        lib = hip.load()
+        pts = hip.points_desc(x, tfd_kps)
+        B, N, M = x.shape[0], x.shape[2], tfd_kps.shape[2]
+        dev = x.device
+        self._check_nm(N, M)
+        init_pose = hip.require_dev_f32(init_pose.contiguous(), "init_pose", (B, 3, 4))
+        init_scale = hip.require_dev_f32(init_scale.contiguous(), "init_scale", (B, 3))
+        Ks = hip.require_dev_f32(K_zoom.contiguous(), "K_zoom", (B, 3, 3)) if K_zoom is not None else None
+        ms = hip.require_dev_f32(mean_scales.contiguous(), "mean_scales", (B, 3)) if mean_scales is not None else None
+        if opts.k_aware and not opts.delta_t_space_3d:
+            assert Ks is not None and Ks.shape == (B, 3, 3)  # pose_scale_from_delta_init.py:64
+        if opts.scale_base_mean and ms is None:
+            raise ValueError("SCLAE_TYPE without 'iter' needs mean_scales")
+        prm, packed = self.params(dev)
+        ws = self.workspace(B, N, M, dev)
+        pose_out = torch.empty(B, 3, 4, dtype=torch.float32, device=dev)
+        scale_out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        hip.check(
+            lib.catre_refine_iter(ctypes.byref(pts), hip.ptr(init_pose), hip.ptr(init_scale), hip.ptr(ms), hip.ptr(Ks),
+                                  prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(pose_out), hip.ptr(scale_out),
+                                  hip.ptr(ws), ws.numel(), B, N, M, hip.stream_ptr(dev)),
+            "catre_refine_iter",
+        )
+        return pose_out, scale_out
+
+    def refine_k(self, pcl, obj_kps, init_pose, init_scale, K, mean_scales, opts, n_iter):
+        """Fused K-loop -> poses [n_iter+1,B,3,4], scales [n_iter+1,B,3] (slot 0 = initial estimate)."""
+        lib = hip.load()
+        B, N, M = pcl.shape[0], pcl.shape[1], obj_kps.shape[1]
+        dev = pcl.device
+        self._check_nm(N, M)
+        pcl = hip.require_dev_f32(pcl.contiguous(), "pcl", (B, N, 3))
+        obj_kps = hip.require_dev_f32(obj_kps.contiguous(), "obj_kps", (B, M, 3))
+        hip.require_dev_f32(init_pose, "init_pose", (B, 3, 4), contiguous=False)
+        hip.require_dev_f32(init_scale, "init_scale", (B, 3), contiguous=False)
+        Ks = hip.require_dev_f32(K.contiguous(), "K", (B, 3, 3)) if K is not None else None
+        ms = hip.require_dev_f32(mean_scales.contiguous(), "mean_scales", (B, 3)) if mean_scales is not None else None
+        if opts.k_aware and not opts.delta_t_space_3d and Ks is None:
+            raise ValueError("T_TRANSFORM_K_AWARE needs K")
+        if opts.scale_base_mean and ms is None:
+            raise ValueError("SCLAE_TYPE without 'iter' needs mean_scales")
+        prm, packed = self.params(dev)
+        ws = self.workspace(B, N, M, dev)
+        poses = torch.empty(n_iter + 1, B, 3, 4, dtype=torch.float32, device=dev)
+        scales = torch.empty(n_iter + 1, B, 3, dtype=torch.float32, device=dev)
+        poses[0].copy_(init_pose)
+        scales[0].copy_(init_scale)
+        hip.check(
+            lib.catre_refine_k(hip.ptr(pcl), hip.ptr(obj_kps), hip.ptr(ms), hip.ptr(Ks), prm, hip.ptr(packed),
+                               ctypes.byref(opts), hip.ptr(poses), hip.ptr(scales), hip.ptr(ws), ws.numel(),
+                               B, N, M, n_iter, hip.stream_ptr(dev)),
+            "catre_refine_k",
+        )
+        return poses, scales
+
+    def _check_nm(self, N, M):
+        if N + M != self.N + self.M:
+            # conv_p bakes the number of points into the weights (conv_out_per_rot_head.py:112)
+            raise ValueError(
+                f"got N+M={N + M} points but the rotation head was built for num_points={self.N + self.M}"
+            )
+
+    # ------------------------------------------------------------------ single stages (tests, sub-modules)
+    def stage_linear(self, x, W, bias, relu=False, add_identity_k=0):
+        """y = act(x W^T + b) (+ I_k) through ``catre_linear`` (F.linear as used by pointnet.py:31-40)."""
+        lib = hip.load()
+        R, K = x.shape
+        J = W.shape[0]
+        y = torch.empty(R, J, dtype=torch.float32, device=x.device)
+        hip.check(
+            lib.catre_linear(hip.ptr(x), x.stride(0), hip.ptr(W), W.stride(0), hip.ptr(bias), hip.ptr(y), J, R, J, K,
+                             int(relu), int(add_identity_k), hip.stream_ptr(x.device)),
+            "catre_linear",
+        )
+        return y
+
+    def _stn_tail(self, pooled, named, prefix, k):
+        h = self.stage_linear(pooled, named[f"{prefix}.fc1.weight"], named[f"{prefix}.fc1.bias"], relu=True)
+        h = self.stage_linear(h, named[f"{prefix}.fc2.weight"], named[f"{prefix}.fc2.bias"], relu=True)
+        return self.stage_linear(h, named[f"{prefix}.fc3.weight"], named[f"{prefix}.fc3.bias"], add_identity_k=k)
+
+    def stage_pointnet(self, x, tfd_kps=None, feature_transform=True):
+        """PointNetfeat stages on x [B,3,N] (and optionally tfd_kps [B,3,M]) -> dict with
+        ``trans [C,3,3]``, ``trans_feat [C,64,64]``, ``stn_pool``/``fstn_pool [C,1024]``,
+        ``gfeat [C,1088]``, ``pointfeat`` (flat [B*(N+M),64], observed clouds first); C = B or 2B."""
+        lib = hip.load()
+        dev = x.device
+        B, N = x.shape[0], x.shape[2]
+        if tfd_kps is None:
+            M = 0
+            pts = hip.points_desc(x, x)
+        else:
+            M = tfd_kps.shape[2]
+            pts = hip.points_desc(x, tfd_kps)
+        C = 2 * B if M > 0 else B
+        prm, packed = self.params(dev)
+        named = {k: t for k, t in zip(hip.PARAM_KEYS, self._param_keep)}
+        ws = self.workspace(B, N, M, dev)
+        st = hip.stream_ptr(dev)
+        out = {}
+        pool = torch.empty(C, 1024, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_stn3d_pool(ctypes.byref(pts), prm, hip.ptr(packed), hip.ptr(pool), hip.ptr(ws), ws.numel(),
+                                       B, N, M, st), "catre_stn3d_pool")
+        out["stn_pool"] = pool
+        trans = self._stn_tail(pool, named, "pcl_net.stn", 3)
+        out["trans"] = trans.view(C, 3, 3)
+        t64 = None
+        if feature_transform:
+            pool2 = torch.empty(C, 1024, dtype=torch.float32, device=dev)
+            hip.check(lib.catre_stnkd_pool(ctypes.byref(pts), hip.ptr(trans), prm, hip.ptr(packed), hip.ptr(pool2),
+                                           hip.ptr(ws), ws.numel(), B, N, M, st), "catre_stnkd_pool")
+            out["fstn_pool"] = pool2
+            t64 = self._stn_tail(pool2, named, "pcl_net.fstn", 64)
+            out["trans_feat"] = t64.view(C, 64, 64)
+        gfeat = torch.empty(C, 1088, dtype=torch.float32, device=dev)
+        pointfeat = torch.empty(B * (N + M), 64, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_trunk(ctypes.byref(pts), hip.ptr(trans), hip.ptr(t64), prm, hip.ptr(packed), hip.ptr(gfeat),
+                                  hip.ptr(pointfeat), hip.ptr(ws), ws.numel(), B, N, M, st), "catre_trunk")
+        out["gfeat"], out["pointfeat"] = gfeat, pointfeat
+        return out
+
+    def stage_ts_head(self, gfeat, init_pose, init_scale, opts):
+        lib = hip.load()
+        dev = gfeat.device
+        B = init_scale.shape[0]
+        prm, packed = self.params(dev)
+        dt = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        ds = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_ts_head(hip.ptr(gfeat), hip.ptr(init_pose.contiguous()), hip.ptr(init_scale.contiguous()),
+                                    prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(dt), hip.ptr(ds), B,
+                                    hip.stream_ptr(dev)), "catre_ts_head")
+        return dt, ds
+
+    def stage_rot_head(self, gfeat, pointfeat, B, N, M):
+        lib = hip.load()
+        dev = gfeat.device
+        prm, packed = self.params(dev)
+        ws = self.workspace(B, N, M, dev)
+        rot6d = torch.empty(B, 6, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_rot_head(hip.ptr(gfeat), hip.ptr(pointfeat), prm, hip.ptr(packed), hip.ptr(rot6d),
+                                     hip.ptr(ws), ws.numel(), B, N, M, hip.stream_ptr(dev)), "catre_rot_head")
+        return rot6d
+
+
+def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
+    """``batch_updater_test`` core (engine/batch_test.py:81-97) -> x [B,3,N], tfd_kps [B,3,M] as permuted
+    views of point-major buffers, exactly the layout the reference hands to the model."""
+    lib = hip.load()
+    B, N, M = pcl.shape[0], pcl.shape[1], obj_kps.shape[1]
+    dev = pcl.device
+    pcl = hip.require_dev_f32(pcl.contiguous(), "pcl", (B, N, 3))
+    obj_kps = hip.require_dev_f32(obj_kps.contiguous(), "obj_kps", (B, M, 3))
+    pose = hip.require_dev_f32(pose.contiguous(), "pose", (B, 3, 4))
+    scale = hip.require_dev_f32(scale.contiguous(), "scale", (B, 3))
+    xo = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+    ko = torch.empty(B, M, 3, dtype=torch.float32, device=dev)
+    hip.check(lib.catre_pose_apply(hip.ptr(pcl), hip.ptr(obj_kps), hip.ptr(pose), hip.ptr(scale), hip.ptr(xo),
+                                   hip.ptr(ko), B, N, M, int(zero_center), hip.stream_ptr(dev)), "catre_pose_apply")
+    return xo.permute(0, 2, 1), ko.permute(0, 2, 1)
+
+
+def pose_update(rot6d, trans_deltas, scale_deltas, init_pose, init_scale, mean_scales, Ks, opts):
+    lib = hip.load()
+    B = rot6d.shape[0]
+    dev = rot6d.device
+    pose_out = torch.empty(B, 3, 4, dtype=torch.float32, device=dev)
+    scale_out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    c = lambda t: t.contiguous() if t is not None else None
+    hip.check(lib.catre_pose_update(hip.ptr(c(rot6d)), hip.ptr(c(trans_deltas)), hip.ptr(c(scale_deltas)),
+                                    hip.ptr(c(init_pose)), hip.ptr(c(init_scale)), hip.ptr(c(mean_scales)),
+                                    hip.ptr(c(Ks)), ctypes.byref(opts), hip.ptr(pose_out), hip.ptr(scale_out), B,
+                                    hip.stream_ptr(dev)), "catre_pose_update")
+    return pose_out, scale_out
+
+
+def colmax(x):
+    """``torch.max(x, 2)[0]`` for x [B,C,N] on the HIP device (stand-alone max-pool kernel)."""
+    lib = hip.load()
+    x = hip.require_dev_f32(x, "x", (None, None, None))
+    B, C, N = x.shape
+    out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    hip.check(lib.catre_colmax(hip.ptr(x), hip.ptr(out), B, C, N, hip.stream_ptr(x.device)), "catre_colmax")
+    return out

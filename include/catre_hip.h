@@ -1,0 +1,203 @@
+/*
+ * catre_hip.h - C ABI of the MI355X (gfx950) implementation of CATRE's pose-refine hot path.
+ *
+ * The reference (THU-DA-6D-Pose-Group/CATRE) is 100 % Python on stock torch ops and has no FFI
+ * of its own; each entry point below names the reference Python function (file:line, relative
+ * to the reference root) whose arithmetic it replaces.  Host code binds these with ctypes
+ * (catre_amd/hip.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless noted; tensors are dense row-major
+ *     unless strides are passed explicitly (strides are in ELEMENTS);
+ *   - B objects, N observed points, M shape-prior points per object; "cloud" c in [0,2B):
+ *     c <  B -> observed cloud of object c      (N points)
+ *     c >= B -> transformed prior of object c-B (M points)
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); nothing
+ *     allocates, frees or synchronises; scratch comes from the caller's `workspace`;
+ *   - return value: CATRE_OK (0) or a negative catre_status; kernels never abort.
+ */
+#ifndef CATRE_HIP_H
+#define CATRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum catre_status {
+  CATRE_OK = 0,
+  CATRE_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, unsupported option */
+  CATRE_ERR_WORKSPACE = -2,    /* workspace / packed buffer too small */
+  CATRE_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after a launch */
+  CATRE_ERR_UNSUPPORTED = -4   /* configuration outside what the kernels implement */
+} catre_status;
+
+/* Parameter tensors, in the reference's state_dict layout.  Conv1d weights
+ * are [out,in,1] == [out,in] row-major.  `params[CATRE_P_xxx]` is the device pointer. */
+typedef enum catre_param {
+  CATRE_P_STN_CONV1_W = 0, CATRE_P_STN_CONV1_B,   /* pcl_net.stn.conv1   [64,3]      */
+  CATRE_P_STN_CONV2_W, CATRE_P_STN_CONV2_B,       /* pcl_net.stn.conv2   [128,64]    */
+  CATRE_P_STN_CONV3_W, CATRE_P_STN_CONV3_B,       /* pcl_net.stn.conv3   [1024,128]  */
+  CATRE_P_STN_FC1_W, CATRE_P_STN_FC1_B,           /* pcl_net.stn.fc1     [512,1024]  */
+  CATRE_P_STN_FC2_W, CATRE_P_STN_FC2_B,           /* pcl_net.stn.fc2     [256,512]   */
+  CATRE_P_STN_FC3_W, CATRE_P_STN_FC3_B,           /* pcl_net.stn.fc3     [9,256]     */
+  CATRE_P_CONV1_W, CATRE_P_CONV1_B,               /* pcl_net.conv1       [64,3]      */
+  CATRE_P_CONV2_W, CATRE_P_CONV2_B,               /* pcl_net.conv2       [128,64]    */
+  CATRE_P_CONV3_W, CATRE_P_CONV3_B,               /* pcl_net.conv3       [512,128]   */
+  CATRE_P_CONV4_W, CATRE_P_CONV4_B,               /* pcl_net.conv4       [1024,512]  */
+  CATRE_P_FSTN_CONV1_W, CATRE_P_FSTN_CONV1_B,     /* pcl_net.fstn.conv1  [64,64]     */
+  CATRE_P_FSTN_CONV2_W, CATRE_P_FSTN_CONV2_B,     /* pcl_net.fstn.conv2  [128,64]    */
+  CATRE_P_FSTN_CONV3_W, CATRE_P_FSTN_CONV3_B,     /* pcl_net.fstn.conv3  [1024,128]  */
+  CATRE_P_FSTN_FC1_W, CATRE_P_FSTN_FC1_B,         /* pcl_net.fstn.fc1    [512,1024]  */
+  CATRE_P_FSTN_FC2_W, CATRE_P_FSTN_FC2_B,         /* pcl_net.fstn.fc2    [256,512]   */
+  CATRE_P_FSTN_FC3_W, CATRE_P_FSTN_FC3_B,         /* pcl_net.fstn.fc3    [4096,256]  */
+  /* rot_head.rot_head_x.* then rot_head.rot_head_y.* (12 tensors each) */
+  CATRE_P_ROTX_L0_W, CATRE_P_ROTX_L0_B,           /* layers.0  [256,1088]            */
+  CATRE_P_ROTX_GN0_W, CATRE_P_ROTX_GN0_B,         /* layers.1  [256]                 */
+  CATRE_P_ROTX_L1_W, CATRE_P_ROTX_L1_B,           /* layers.3  [256,256]             */
+  CATRE_P_ROTX_GN1_W, CATRE_P_ROTX_GN1_B,         /* layers.4  [256]                 */
+  CATRE_P_ROTX_NECK_W, CATRE_P_ROTX_NECK_B,       /* neck.0    [3,256]               */
+  CATRE_P_ROTX_CONVP_W, CATRE_P_ROTX_CONVP_B,     /* conv_p    [1,N+M] , [1] (bias may be NULL) */
+  CATRE_P_ROTY_L0_W, CATRE_P_ROTY_L0_B,
+  CATRE_P_ROTY_GN0_W, CATRE_P_ROTY_GN0_B,
+  CATRE_P_ROTY_L1_W, CATRE_P_ROTY_L1_B,
+  CATRE_P_ROTY_GN1_W, CATRE_P_ROTY_GN1_B,
+  CATRE_P_ROTY_NECK_W, CATRE_P_ROTY_NECK_B,
+  CATRE_P_ROTY_CONVP_W, CATRE_P_ROTY_CONVP_B,
+  CATRE_P_TS_L0_W, CATRE_P_TS_L0_B,               /* ts_head.linears.0 [256,ts_in]   */
+  CATRE_P_TS_GN0_W, CATRE_P_TS_GN0_B,             /* ts_head.linears.1 [256]         */
+  CATRE_P_TS_L1_W, CATRE_P_TS_L1_B,               /* ts_head.linears.3 [256,256]     */
+  CATRE_P_TS_GN1_W, CATRE_P_TS_GN1_B,             /* ts_head.linears.4 [256]         */
+  CATRE_P_TS_FCT_W, CATRE_P_TS_FCT_B,             /* ts_head.fc_t      [3,256]       */
+  CATRE_P_TS_FCS_W, CATRE_P_TS_FCS_B,             /* ts_head.fc_s      [3,256]       */
+  CATRE_P_COUNT
+} catre_param;
+
+/* Options of one refine iteration: the flags `CATRE_disR_shared.forward` reads from
+ * cfg.MODEL.CATRE.{ROT_HEAD,TS_HEAD} and cfg.INPUT (core/catre/models/CATRE_disR_shared.py:57-120). */
+typedef struct catre_opts {
+  int32_t feature_transform;   /* PCLNET.INIT_CFG.feature_transform (pointnet.py:105)            */
+  int32_t with_kps_feature;    /* TS_HEAD.WITH_KPS_FEATURE  (CATRE_disR_shared.py:71-75)         */
+  int32_t with_init_scale;     /* TS_HEAD.WITH_INIT_SCALE   (:78-79)                             */
+  int32_t with_init_trans;     /* TS_HEAD.WITH_INIT_TRANS   (:80-82)                             */
+  int32_t delta_t_space_3d;    /* 0: "image", 1: "3D"  (pose_scale_from_delta_init.py:51,72)     */
+  int32_t delta_z_deepim;      /* 0: "cosypose", 1: "deepim" (:55-61)                            */
+  int32_t k_aware;             /* T_TRANSFORM_K_AWARE (:63-69)                                   */
+  int32_t scale_mul;           /* 0: "add" in SCLAE_TYPE, 1: multiplicative exp (:79-84)          */
+  int32_t scale_base_mean;     /* 0: "iter" in SCLAE_TYPE (base = current scale), 1: mean_scales  */
+  int32_t is_allo;             /* "allo" in ROT_TYPE (:87-90)                                    */
+  int32_t refine_scale;        /* cfg.MODEL.REFINE_SCLAE (CATRE_disR_shared.py:119-120)          */
+  int32_t zero_center;         /* cfg.INPUT.ZERO_CENTER_INPUT (engine/batch_test.py:84-97)       */
+  float   delta_t_weight;      /* DELTA_T_WEIGHT (:48)                                           */
+  float   allo_eps;            /* eps of allo_to_ego_mat_torch, 1e-4 (CATRE_disR_shared.py:112)  */
+  int32_t ts_in_dim;           /* TS_HEAD.INIT_CFG.in_dim; must equal the gathered feature width */
+  int32_t rot_input_is_matrix; /* catre_pose_update only: `rot6d` holds [B,3,3] matrices (get_rot_mat already applied) */
+} catre_opts;
+
+/* ---- sizes ---------------------------------------------------------------------------- */
+
+/* Bytes of scratch one refine iteration needs for (B,N,M).  0 on bad arguments. */
+size_t catre_workspace_bytes(int B, int N, int M);
+
+/* Floats of the fragment-packed weight image produced by catre_pack_weights. */
+size_t catre_packed_floats(int N, int M, int ts_in_dim);
+
+/* Re-lay the weights the MFMA kernels stream (conv / head GEMM operands) into wave-fragment
+ * order, transpose the ts-head matrices and pre-reduce conv_p.  Must be re-run whenever the
+ * parameters change (e.g. after an optimizer step).  No reference counterpart (layout only). */
+int catre_pack_weights(const float* const* params, int N, int M, int ts_in_dim,
+                       float* packed, size_t packed_floats, void* stream);
+
+/* ---- single stages (each also usable on its own; tests check them one by one) ---------- */
+
+/* a1: batch_updater_test core (core/catre/engine/batch_test.py:81-97) with
+ * transform_normed_pts_batch (lib/pysixd/misc.py:1001-1026).
+ * x_out [B,N,3] point-major = pcl - t (or pcl if !zero_center); kps_out [B,M,3] = R (kps*s) (+t). */
+int catre_pose_apply(const float* pcl, const float* kps, const float* pose /*[B,3,4]*/,
+                     const float* scale /*[B,3]*/, float* x_out, float* kps_out,
+                     int B, int N, int M, int zero_center, void* stream);
+
+/* Point arrays are described by a base pointer and element strides (batch, point, coord), so the
+ * permuted [B,3,N] views the reference passes (SURVEY.md 8b "forward") are consumed in place. */
+typedef struct catre_points {
+  const float* obs;  int64_t obs_sb, obs_sn, obs_sc;   /* observed cloud  x        [B,N,3] */
+  const float* kps;  int64_t kps_sb, kps_sn, kps_sc;   /* transformed prior tfd_kps [B,M,3] */
+} catre_points;
+
+/* a2: STN3d conv stack + max-pool (core/catre/models/pointnets/pointnet.py:24-29).
+ * pooled [2B,1024]. */
+int catre_stn3d_pool(const catre_points* pts, const float* const* params, const float* packed,
+                     float* pooled, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+
+/* a2/a4 tails: y = act(x W^T + b) (+ I_k flattened), torch.nn.functional.linear as used by
+ * pointnet.py:31-40,64-77.  x [R,K] (ldx), W [J,K] (ldw), y [R,J] (ldy). K % 8 == 0. */
+int catre_linear(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy,
+                 int R, int J, int K, int relu, int add_identity_k, void* stream);
+
+/* a3+a4: x' = x T3, relu(conv1), STNkd conv stack + max-pool (pointnet.py:98-103,57-62).
+ * trans3 [2B,3,3] -> pooled [2B,1024]. */
+int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* const* params,
+                     const float* packed, float* pooled, void* workspace, size_t ws_bytes,
+                     int B, int N, int M, void* stream);
+
+/* a3+a5: point feature transform, conv2..conv4, max-pool (pointnet.py:98-116).
+ * trans64 [2B,64,64] (NULL when !feature_transform) -> gfeat [2B,1088] = [max_n conv4 | max_n pointfeat],
+ * pointfeat written point-major: obs [B,N,64] then prior [B,M,64] (one buffer of B*(N+M)*64 floats). */
+int catre_trunk(const catre_points* pts, const float* trans3, const float* trans64,
+                const float* const* params, const float* packed, float* gfeat, float* pointfeat,
+                void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+
+/* a7+a8: feature gather + FC_TransSizeHead.forward (CATRE_disR_shared.py:69-84,
+ * heads/fc_trans_size_head.py:61-70).  -> trans_deltas [B,3], scale_deltas [B,3]. */
+int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_scale,
+                  const float* const* params, const float* packed, const catre_opts* opts,
+                  float* trans_deltas, float* scale_deltas, int B, void* stream);
+
+/* a7+a9: ConvOutPerRotHead.forward on cat(pcl_feat,kps_feat,dim=2) without materialising it
+ * (CATRE_disR_shared.py:86-88, heads/conv_out_per_rot_head.py:62-71,126-140). -> rot6d [B,6]. */
+int catre_rot_head(const float* gfeat, const float* pointfeat, const float* const* params,
+                   const float* packed, float* rot6d, void* workspace, size_t ws_bytes,
+                   int B, int N, int M, void* stream);
+
+/* a10+a11+a12: rot6d_to_mat_batch (core/utils/rot_reps.py:34-55) and pose_scale_from_delta_init
+ * (core/catre/models/pose_scale_from_delta_init.py:8-95).  Ks / mean_scales may be NULL when unused.
+ * rot6d is [B,6], or [B,3,3] rotation matrices when opts->rot_input_is_matrix.
+ * -> pose_out [B,3,4], scale_out [B,3]. */
+int catre_pose_update(const float* rot6d, const float* trans_deltas, const float* scale_deltas,
+                      const float* init_pose, const float* init_scale, const float* mean_scales,
+                      const float* Ks, const catre_opts* opts, float* pose_out, float* scale_out,
+                      int B, void* stream);
+
+/* ---- fused drivers ------------------------------------------------------------------------ */
+
+/* One CATRE_disR_shared.forward (test path, CATRE_disR_shared.py:57-124) on given x / tfd_kps. */
+int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
+                      const float* mean_scales, const float* Ks, const float* const* params,
+                      const float* packed, const catre_opts* opts, float* pose_out, float* scale_out,
+                      void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+
+/* The K-loop of catre_inference_on_dataset (core/catre/engine/catre_evaluator.py:292-311):
+ * for i in 1..n_iter: pose-apply (batch_test.py:63-99) -> forward -> feed back.
+ * poses [n_iter+1,B,3,4] / scales [n_iter+1,B,3]: slot 0 holds the initial estimate on entry,
+ * slots 1..n_iter are written.  pcl [B,N,3], kps [B,M,3] point-major contiguous. */
+int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,
+                   const float* const* params, const float* packed, const catre_opts* opts,
+                   float* poses, float* scales, void* workspace, size_t ws_bytes,
+                   int B, int N, int M, int n_iter, void* stream);
+
+/* ---- stand-alone memory-bound kernels (HBM roofline figures of SURVEY.md 8d) --------------- */
+
+/* torch.max(x, 2)[0] for x [B,C,N] contiguous -> out [B,C]  (pointnet.py:28,61,115). */
+int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream);
+
+const char* catre_status_string(int status);
+
+/* Build identification: "catre_hip gfx950 <version>" */
+const char* catre_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATRE_HIP_H */

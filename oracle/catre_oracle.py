@@ -1,0 +1,307 @@
+"""ORACLE - CPU restatement of CATRE's refine hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file.  The product (``catre_amd``) never does: its forward is the HIP library
+and it raises when that library is missing.
+
+What this is: a literal, as-written restatement (plain ``torch`` CPU ops, fp32 by default,
+fp64 on request) of the reference functions on the path, each citing the reference
+``file:line`` it follows (paths relative to ``/root/reference``).  It materialises every
+intermediate exactly like the reference does (``repeat``/``cat`` of the global feature
+included), so it is slow and only meant for small batches.
+
+Parity pin: the reference holds no tests or golden vectors for this path (SURVEY.md
+section 4), so the oracle is pinned against outputs of the reference itself, imported in
+the build container by ``oracle/make_golden.py`` and committed as ``tests/golden/*.npz``
+(``tests/test_oracle_golden.py`` checks oracle == reference outputs).
+
+All functions take ``sd``: a ``state_dict``-style mapping with the reference's parameter
+names (``pcl_net.stn.conv1.weight`` ... see SURVEY.md section 8b).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- a1
+def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
+    """``batch_updater_test`` core, ``core/catre/engine/batch_test.py:81-97`` with
+    ``transform_normed_pts_batch`` ``lib/pysixd/misc.py:1001-1026``.
+
+    pcl [B,N,3], obj_kps [B,M,3], pose [B,3,4], scale [B,3] -> x [B,3,N], tfd_kps [B,3,M]
+    """
+    B, M = obj_kps.shape[0], obj_kps.shape[1]
+    r_est = pose[:, :3, :3]
+    t_est = pose[:, :3, 3:4]
+    pts = obj_kps * scale.unsqueeze(1)  # misc.py:1017
+    pts = r_est.reshape(B, 1, 3, 3) @ pts.reshape(B, M, 3, 1)  # misc.py:1021
+    if not zero_center:
+        pts = pts + t_est.reshape(B, 1, 3, 1)  # misc.py:1023-1025
+    tfd_kps = pts.squeeze(-1).permute(0, 2, 1)  # batch_test.py:91
+    if zero_center:
+        x = pcl.permute(0, 2, 1) - t_est.reshape(B, 3, 1)  # batch_test.py:94
+    else:
+        x = pcl.permute(0, 2, 1)
+    return x, tfd_kps
+
+
+# ----------------------------------------------------------------------------- a2 / a4
+def stn(x, sd, prefix, k):
+    """``STN3d.forward`` / ``STNkd.forward``, ``core/catre/models/pointnets/pointnet.py:24-41,57-78``."""
+    w = lambda n: sd[f"{prefix}.{n}"]
+    h = F.relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")))
+    h = F.relu(F.conv1d(h, w("conv2.weight"), w("conv2.bias")))
+    h = F.relu(F.conv1d(h, w("conv3.weight"), w("conv3.bias")))
+    h = torch.max(h, 2)[0]  # [B,1024]
+    pooled = h
+    h = F.relu(F.linear(h, w("fc1.weight"), w("fc1.bias")))
+    h = F.relu(F.linear(h, w("fc2.weight"), w("fc2.bias")))
+    h = F.linear(h, w("fc3.weight"), w("fc3.bias"))
+    h = h + torch.eye(k, dtype=h.dtype).reshape(1, k * k)
+    return h.reshape(-1, k, k), pooled
+
+
+# ----------------------------------------------------------------------------- a3 / a5 / a6
+def pointnet_feat(x, sd, prefix="pcl_net", feature_transform=True, global_feat=False, detail=False):
+    """``PointNetfeat.forward``, ``pointnet.py:97-121``.  x [B,3,n] -> [B,1088,n]."""
+    w = lambda n: sd[f"{prefix}.{n}"]
+    n_pts = x.shape[2]
+    trans, pool3 = stn(x, sd, f"{prefix}.stn", 3)
+    h = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)  # :100-102
+    h = F.relu(F.conv1d(h, w("conv1.weight"), w("conv1.bias")))  # :103
+    trans_feat, pool64 = None, None
+    if feature_transform:
+        trans_feat, pool64 = stn(h, sd, f"{prefix}.fstn", 64)  # :106
+        h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)  # :107-109
+    pointfeat = h  # :111
+    h = F.relu(F.conv1d(h, w("conv2.weight"), w("conv2.bias")))
+    h = F.relu(F.conv1d(h, w("conv3.weight"), w("conv3.bias")))
+    h = F.conv1d(h, w("conv4.weight"), w("conv4.bias"))  # no ReLU, :114
+    g = torch.max(h, 2)[0]  # :115-116
+    if global_feat:
+        out = g
+    else:
+        out = torch.cat([g.unsqueeze(-1).repeat(1, 1, n_pts), pointfeat], 1)  # :120-121
+    if detail:
+        return out, dict(trans=trans, trans_feat=trans_feat, pointfeat=pointfeat, g=g,
+                         stn_pool=pool3, fstn_pool=pool64)
+    return out
+
+
+# ----------------------------------------------------------------------------- a8
+def gelu_exact(v):
+    """``nn.GELU()`` default = exact erf form (``layer_utils.py:83-84``)."""
+    return F.gelu(v)
+
+
+def ts_head(feat, sd, prefix="ts_head", num_gn_groups=32):
+    """``FC_TransSizeHead.forward``, ``heads/fc_trans_size_head.py:61-70`` (layers built ``:33-45``)."""
+    w = lambda n: sd[f"{prefix}.{n}"]
+    h = F.linear(feat, w("linears.0.weight"), w("linears.0.bias"))
+    h = F.group_norm(h, num_gn_groups, w("linears.1.weight"), w("linears.1.bias"), 1e-5)
+    h = gelu_exact(h)
+    h = F.linear(h, w("linears.3.weight"), w("linears.3.bias"))
+    h = F.group_norm(h, num_gn_groups, w("linears.4.weight"), w("linears.4.bias"), 1e-5)
+    h = gelu_exact(h)
+    return F.linear(h, w("fc_t.weight"), w("fc_t.bias")), F.linear(h, w("fc_s.weight"), w("fc_s.bias"))
+
+
+# ----------------------------------------------------------------------------- a9
+def rot_head_single(feat, sd, prefix, num_gn_groups=32):
+    """``RotHead.forward``, ``heads/conv_out_per_rot_head.py:126-140``.  feat [B,1088,P] -> [B,3]."""
+    w = lambda n: sd[f"{prefix}.{n}"]
+    h = F.conv1d(feat, w("layers.0.weight"), w("layers.0.bias"))
+    h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+    h = gelu_exact(h)
+    h = F.conv1d(h, w("layers.3.weight"), w("layers.3.bias"))
+    h = F.group_norm(h, num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
+    h = gelu_exact(h)
+    h = F.conv1d(h, w("neck.0.weight"), w("neck.0.bias"))  # [B,3,P]
+    h = h.permute(0, 2, 1)  # [B,P,3]
+    h = F.conv1d(h, w("conv_p.weight"), sd.get(f"{prefix}.conv_p.bias"))  # [B,1,3]
+    return h.squeeze(1).contiguous()
+
+
+def rot_head(feat, sd, prefix="rot_head"):
+    """``ConvOutPerRotHead.forward``, ``conv_out_per_rot_head.py:62-71`` (``per_rot_sup=False``)."""
+    rx = rot_head_single(feat, sd, f"{prefix}.rot_head_x")
+    ry = rot_head_single(feat, sd, f"{prefix}.rot_head_y")
+    return torch.cat((rx, ry), dim=1)
+
+
+# ----------------------------------------------------------------------------- a10
+def rot6d_to_mat_batch(d6):
+    """``core/utils/rot_reps.py:34-55``."""
+    x_raw, y_raw = d6[..., 0:3], d6[..., 3:6]
+    x = F.normalize(x_raw, p=2, dim=-1)
+    z = torch.cross(x, y_raw, dim=-1)
+    z = F.normalize(z, p=2, dim=-1)
+    y = torch.cross(z, x, dim=-1)
+    return torch.stack((x, y, z), dim=-1)
+
+
+def quat2mat_torch(quat, eps=0.0):
+    """``core/utils/pose_utils.py:349-412`` (w,x,y,z; normalised by ``norm + eps``)."""
+    assert quat.ndim == 2 and quat.shape[1] == 4, quat.shape
+    norm_quat = quat.norm(p=2, dim=1, keepdim=True)
+    norm_quat = quat / (norm_quat + eps)
+    qw, qx, qy, qz = norm_quat[:, 0], norm_quat[:, 1], norm_quat[:, 2], norm_quat[:, 3]
+    B = quat.size(0)
+    s = 2.0
+    X, Y, Z = qx * s, qy * s, qz * s
+    wX, wY, wZ = qw * X, qw * Y, qw * Z
+    xX, xY, xZ = qx * X, qx * Y, qx * Z
+    yY, yZ, zZ = qy * Y, qy * Z, qz * Z
+    return torch.stack(
+        [1.0 - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, 1.0 - (xX + zZ), yZ - wX, xZ - wY, yZ + wX, 1.0 - (xX + yY)],
+        dim=1,
+    ).reshape(B, 3, 3)
+
+
+def allo_to_ego_mat_torch(translation, rot_allo, eps=1e-4):
+    """``core/utils/utils.py:200-231``."""
+    cam_ray = torch.tensor([0, 0, 1.0], dtype=translation.dtype)
+    obj_ray = translation / (torch.norm(translation, dim=1, keepdim=True) + eps)
+    angle = obj_ray[:, 2:3].acos()
+    axis = torch.cross(cam_ray.expand_as(obj_ray), obj_ray, dim=-1)
+    axis = axis / (torch.norm(axis, dim=1, keepdim=True) + eps)
+    q = torch.cat(
+        [
+            torch.cos(angle / 2.0),
+            axis[:, 0:1] * torch.sin(angle / 2.0),
+            axis[:, 1:2] * torch.sin(angle / 2.0),
+            axis[:, 2:3] * torch.sin(angle / 2.0),
+        ],
+        dim=1,
+    )
+    return torch.matmul(quat2mat_torch(q), rot_allo)
+
+
+def get_rot_mat(rot, rot_type):
+    """``core/catre/models/model_utils.py:28-40`` (rot6d and quat branches)."""
+    if rot_type in ["ego_quat", "allo_quat"]:
+        return quat2mat_torch(rot)
+    if rot_type in ["ego_rot6d", "allo_rot6d"]:
+        return rot6d_to_mat_batch(rot)
+    raise ValueError(f"Wrong pred_rot type: {rot_type}")
+
+
+# ----------------------------------------------------------------------------- a11
+def pose_scale_from_delta_init(
+    rot_deltas, trans_deltas, scale_deltas, rot_inits, trans_inits, scale_inits, Ks=None,
+    K_aware=False, delta_T_space="3D", delta_T_weight=1.0, delta_z_style="cosypose",
+    eps=1e-4, is_allo=False, scale_type="add_iter",
+):
+    """``core/catre/models/pose_scale_from_delta_init.py:8-95``."""
+    bs = rot_deltas.shape[0]
+    assert rot_deltas.shape == (bs, 3, 3) and rot_inits.shape == (bs, 3, 3)
+    assert trans_deltas.shape == (bs, 3) and trans_inits.shape == (bs, 3)
+    trans_deltas = trans_deltas * delta_T_weight
+    if delta_T_space == "image":
+        zsrc = trans_inits[:, [2]]
+        vz = trans_deltas[:, [2]]
+        if delta_z_style == "cosypose":
+            ztgt = vz * zsrc
+        else:
+            ztgt = torch.div(zsrc, torch.exp(vz))
+        vxvy = trans_deltas[:, :2]
+        if K_aware:
+            assert Ks is not None and Ks.shape == (bs, 3, 3)
+            fxfy = Ks[:, [0, 1], [0, 1]]
+        else:
+            fxfy = torch.ones_like(vxvy)
+        xy_src = trans_inits[:, :2]
+        xy_tgt = ztgt * (vxvy / fxfy + xy_src / zsrc)
+        trans_tgts = torch.cat([xy_tgt, ztgt], dim=-1)
+    elif delta_T_space == "3D":
+        trans_tgts = trans_inits + trans_deltas
+    else:
+        raise ValueError("Unknown delta_T_space: {}".format(delta_T_space))
+    if "add" in scale_type:
+        scale_tgts = scale_inits + scale_deltas
+    else:
+        scale_tgts = scale_inits * torch.exp(scale_deltas)
+    ego_rot_deltas = allo_to_ego_mat_torch(trans_tgts, rot_deltas, eps=eps) if is_allo else rot_deltas
+    rot_tgts = ego_rot_deltas @ rot_inits
+    return rot_tgts, trans_tgts, scale_tgts
+
+
+# ----------------------------------------------------------------------------- a7 / a12
+def model_forward(x, tfd_kps, init_pose, init_scale, sd, cfg, K_zoom=None, mean_scales=None, detail=False):
+    """``CATRE_disR_shared.forward`` test path, ``core/catre/models/CATRE_disR_shared.py:57-124``."""
+    net_cfg = cfg.MODEL.CATRE
+    rh, th = net_cfg.ROT_HEAD, net_cfg.TS_HEAD
+    pn = net_cfg.PCLNET.INIT_CFG
+    ft = pn.get("feature_transform", False)
+    pcl_feat, dx = pointnet_feat(x, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True)  # :66
+    kps_feat, dk = pointnet_feat(tfd_kps, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True)  # :67
+    flat_pcl_feat = torch.max(pcl_feat, 2)[0]  # :69
+    if th.WITH_KPS_FEATURE:
+        ts_feat = torch.cat((flat_pcl_feat, torch.max(kps_feat, 2)[0]), dim=1)  # :71-73
+    else:
+        ts_feat = flat_pcl_feat
+    if th.WITH_INIT_SCALE:
+        ts_feat = torch.cat((ts_feat, init_scale), dim=1)  # :78-79
+    if th.get("WITH_INIT_TRANS", False):
+        ts_feat = torch.cat((ts_feat, init_pose[:, :3, 3]), dim=1)  # :80-82
+    trans_deltas, scale_deltas = ts_head(ts_feat, sd, "ts_head", th.INIT_CFG.get("num_gn_groups", 32))  # :84
+    rot_feat = torch.cat((pcl_feat, kps_feat), dim=2)  # :86
+    rot_deltas = rot_head(rot_feat, sd, "rot_head")  # :88
+    rot_m = get_rot_mat(rot_deltas, rh.ROT_TYPE)  # :98
+    R, t, s = pose_scale_from_delta_init(  # :100-115
+        rot_m, trans_deltas, scale_deltas, init_pose[:, :3, :3], init_pose[:, :3, 3],
+        init_scale if "iter" in rh.SCLAE_TYPE else mean_scales, Ks=K_zoom,
+        K_aware=rh.T_TRANSFORM_K_AWARE, delta_T_space=rh.DELTA_T_SPACE, delta_T_weight=rh.DELTA_T_WEIGHT,
+        delta_z_style=rh.DELTA_Z_STYLE, eps=1e-4, is_allo="allo" in rh.ROT_TYPE, scale_type=rh.SCLAE_TYPE,
+    )
+    pose = torch.cat([R, t.reshape(-1, 3, 1)], dim=-1)  # :116
+    if not cfg.MODEL.REFINE_SCLAE:
+        s = init_scale  # :119-120
+    if detail:
+        d = dict(
+            trans_x=dx["trans"], transfeat_x=dx["trans_feat"], g_x=dx["g"], pointfeat_x=dx["pointfeat"],
+            trans_k=dk["trans"], transfeat_k=dk["trans_feat"], g_k=dk["g"], pointfeat_k=dk["pointfeat"],
+            stn_pool_x=dx["stn_pool"], fstn_pool_x=dx["fstn_pool"],
+            stn_pool_k=dk["stn_pool"], fstn_pool_k=dk["fstn_pool"],
+            flat_pcl_feat=flat_pcl_feat, trans_deltas=trans_deltas, scale_deltas=scale_deltas,
+            rot_deltas=rot_deltas, rot_m=rot_m,
+        )
+        return pose, s, d
+    return pose, s
+
+
+# ----------------------------------------------------------------------------- a13
+def refine_k(batch, sd, cfg, n_iter=None, detail_iter=None):
+    """The K-loop of ``catre_inference_on_dataset``, ``core/catre/engine/catre_evaluator.py:292-311``.
+
+    ``batch``: dict with ``pcl, obj_kps, obj_pose_est, obj_scale_est, K, obj_mean_scales``.
+    Returns ``out_dict`` with ``pose_0..K`` / ``scale_0..K`` (+ ``detail`` of iteration ``detail_iter``).
+    """
+    n_iter = cfg.MODEL.CATRE.N_ITER_TEST if n_iter is None else n_iter
+    pose, scale = batch["obj_pose_est"], batch["obj_scale_est"]
+    out = {"pose_0": pose, "scale_0": scale}
+    for i in range(1, n_iter + 1):
+        x, tfd = pose_apply(batch["pcl"], batch["obj_kps"], pose, scale, cfg.INPUT.ZERO_CENTER_INPUT)
+        r = model_forward(x, tfd, pose, scale, sd, cfg, K_zoom=batch["K"],
+                          mean_scales=batch.get("obj_mean_scales"), detail=(detail_iter == i))
+        if detail_iter == i:
+            out["detail"] = r[2]
+        new_pose, new_scale = r[0], r[1]
+        pose = new_pose
+        if cfg.MODEL.REFINE_SCLAE:  # batch_test.py:74-75
+            scale = new_scale
+        out[f"pose_{i}"], out[f"scale_{i}"] = new_pose, new_scale
+    return out
+
+
+def cast_sd(sd, dtype):
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def colmax(x):
+    """Stand-alone channel-wise max-pool ``torch.max(x, 2)[0]`` (``pointnet.py:28,61,115``)."""
+    return torch.max(x, 2)[0]
+
+
+GELU_C = 1.0 / math.sqrt(2.0)

@@ -1,0 +1,170 @@
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE ITSELF (imported from
+``/root/reference`` through ``oracle/ref_shim.py``) on seeded synthetic inputs.
+
+Runs only in the build container (the reference does not exist on the GPU box):
+
+    python -m oracle.make_golden            # rewrites tests/golden/*.npz
+
+Each fixture stores the inputs (so nothing depends on RNG reproducibility), the name of the
+weight recipe (``catre_amd.synth.recipe_state_dict`` - regenerated, not stored: 17 MB) and the
+reference outputs: ``pose_i`` / ``scale_i`` for every refine iteration plus per-stage
+intermediates of iteration 1 captured with forward hooks on the reference sub-modules.
+
+ORACLE TOOLING - never imported by the product.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from catre_amd import synth  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def reference_cfg(N, M, overrides=None):
+    cfg = ref_shim.load_reference_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.INPUT.NUM_PCL, cfg.INPUT.NUM_KPS = N, M
+    cfg.MODEL.CATRE.PCLNET.INIT_CFG.num_points = N
+    cfg.MODEL.CATRE.ROT_HEAD.INIT_CFG.num_points = N + M
+    for path, v in (overrides or {}).items():
+        node = cfg
+        keys = path.split(".")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = v
+    return cfg
+
+
+def run_reference(cfg, batch, n_iter, salt=0):
+    """The loop of catre_evaluator.py:292-311 with the reference's own batch_updater_test + model."""
+    ref_shim.install()
+    from core.catre.engine.batch_test import batch_updater_test
+
+    model = ref_shim.build_reference_model(cfg).eval()
+    sd = synth.recipe_state_dict({k: v.shape for k, v in model.state_dict().items()}, salt)
+    model.load_state_dict(sd, strict=True)
+
+    cap = {}
+    calls = {"pcl": 0}
+
+    def hook_pcl(mod, inp, out):
+        tag = "x" if calls["pcl"] % 2 == 0 else "k"
+        if calls["pcl"] < 2:
+            cap[f"g_{tag}"] = _np(out[:, :1024, 0])
+            cap[f"pointfeat_{tag}"] = _np(out[:, 1024:, :64])  # first 64 points
+            cap[f"pointfeat_max_{tag}"] = _np(out[:, 1024:, :].max(2)[0])
+        calls["pcl"] += 1
+
+    def mk(name, counter):
+        def hook(mod, inp, out):
+            i = counter.setdefault(name, 0)
+            if i < 2:
+                cap[f"{name}_{'x' if i == 0 else 'k'}"] = _np(out)
+            counter[name] = i + 1
+        return hook
+
+    def hook_rot(mod, inp, out):  # hooks must return None (a value would replace the output)
+        cap.setdefault("rot_deltas", _np(out))
+
+    def hook_ts(mod, inp, out):
+        cap.setdefault("trans_deltas", _np(out[0]))
+        cap.setdefault("scale_deltas", _np(out[1]))
+
+    ctr = {}
+    hs = [
+        model.pcl_net.register_forward_hook(hook_pcl),
+        model.pcl_net.stn.register_forward_hook(mk("trans", ctr)),
+        model.rot_head.register_forward_hook(hook_rot),
+        model.ts_head.register_forward_hook(hook_ts),
+    ]
+    if hasattr(model.pcl_net, "fstn"):
+        hs.append(model.pcl_net.fstn.register_forward_hook(mk("transfeat", ctr)))
+
+    b = {k: (v.clone() if isinstance(v, torch.Tensor) else copy.deepcopy(v)) for k, v in batch.items()}
+    out = {"pose_0": _np(b["obj_pose_est"]), "scale_0": _np(b["obj_scale_est"])}
+    poses_est, scales_est = None, None
+    with torch.no_grad():
+        for i in range(1, n_iter + 1):
+            batch_updater_test(cfg, b, poses_est=poses_est, scales_est=scales_est, device="cpu")
+            if i == 1:
+                cap["x_in"] = _np(b["x"][:, :, :64])
+                cap["tfd_kps_in"] = _np(b["tfd_kps"][:, :, :64])
+            o = model(
+                b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"],
+                K_zoom=b["K"], obj_class=b["obj_cls"], mean_scales=b["obj_mean_scales"],
+                do_loss=False, cur_iter=i,
+            )
+            poses_est, scales_est = o[f"pose_{i}"], o[f"scale_{i}"]
+            out[f"pose_{i}"], out[f"scale_{i}"] = _np(poses_est), _np(scales_est)
+    for h in hs:
+        h.remove()
+    out.update({f"stage_{k}": v for k, v in cap.items()})
+    return out
+
+
+CASES = {
+    # name: (B, N, M, K, seed, salt, prior, cfg overrides)
+    "refine_b2_n1024": (2, 1024, 1024, 4, 0, 0, None, {}),
+    "refine_b3_ragged": (3, 1000, 500, 2, 1, 1, None, {}),
+    "refine_b1_bottle": (1, 1024, 1024, 4, 2, 0, "bottle", {}),
+    "refine_b2_small": (2, 100, 37, 2, 3, 2, None, {}),
+    "refine_b2_3d_mul": (2, 256, 256, 2, 4, 0, None, {
+        "MODEL.CATRE.ROT_HEAD.DELTA_T_SPACE": "3D", "MODEL.CATRE.ROT_HEAD.SCLAE_TYPE": "mean_mul"}),
+    "refine_b2_deepim_noK": (2, 256, 256, 2, 5, 0, None, {
+        "MODEL.CATRE.ROT_HEAD.DELTA_Z_STYLE": "deepim", "MODEL.CATRE.ROT_HEAD.T_TRANSFORM_K_AWARE": False,
+        "MODEL.CATRE.ROT_HEAD.DELTA_T_WEIGHT": 0.1}),
+    "refine_b2_allo": (2, 256, 256, 2, 6, 0, None, {"MODEL.CATRE.ROT_HEAD.ROT_TYPE": "allo_rot6d"}),
+    "refine_b2_norefscale_nozc": (2, 256, 256, 2, 7, 0, None, {
+        "MODEL.REFINE_SCLAE": False, "INPUT.ZERO_CENTER_INPUT": False}),
+    "refine_b2_kpsfeat_trans": (2, 256, 256, 2, 8, 0, None, {
+        "MODEL.CATRE.TS_HEAD.WITH_KPS_FEATURE": True, "MODEL.CATRE.TS_HEAD.WITH_INIT_TRANS": True,
+        "MODEL.CATRE.TS_HEAD.INIT_CFG.in_dim": 1088 * 2 + 3 + 3}),
+}
+
+
+def bottle_prior():
+    """The reference's data file for category 'bottle' (config 1 of BASELINE.json)."""
+    import pickle
+
+    p = os.path.join(ref_shim.REFERENCE_ROOT, "datasets/NOCS/obj_models/cr_normed_mean_model_points_spd.pkl")
+    with open(p, "rb") as f:
+        return np.asarray(pickle.load(f)["bottle"], dtype=np.float32)
+
+
+def main(argv=None):
+    names = (argv or sys.argv[1:]) or list(CASES)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(8)
+    for name in names:
+        B, N, M, K, seed, salt, prior, ov = CASES[name]
+        pr = bottle_prior() if prior == "bottle" else None
+        batch = synth.make_inputs(B, N, M, seed=seed, prior=pr)
+        cfg = reference_cfg(N, M, ov)
+        out = run_reference(cfg, batch, K, salt)
+        arrays = {f"in_{k}": _np(v) for k, v in batch.items()}
+        arrays.update(out)
+        arrays["meta_overrides"] = np.array(repr(sorted(ov.items())))
+        arrays["meta"] = np.array([B, N, M, K, seed, salt], dtype=np.int64)
+        path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+        print("   pose_K[0] =", np.array2string(out[f"pose_{K}"][0], precision=4).replace("\n", " "))
+        print("   scale_K[0]=", out[f"scale_{K}"][0], " rot6d=", out["stage_rot_deltas"][0],
+              " dt=", out["stage_trans_deltas"][0], " ds=", out["stage_scale_deltas"][0])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""Shared helpers for the tests: golden loading, cfg reconstruction, recipe weights."""
+import ast
+import glob
+import os
+
+import numpy as np
+import torch
+
+from catre_amd import synth
+from catre_amd.config import default_cfg
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "refine_*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False)
+    B, N, M, K, seed, salt = (int(v) for v in z["meta"])
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=K, device="cpu")
+    for path, v in ast.literal_eval(str(z["meta_overrides"])):
+        node = cfg
+        keys = path.split(".")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = v
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    ref = {k: z[k] for k in z.files if k.startswith(("pose_", "scale_", "stage_"))}
+    return dict(B=B, N=N, M=M, K=K, seed=seed, salt=salt, cfg=cfg, batch=batch, ref=ref)
+
+
+def state_shapes(cfg):
+    """Parameter names/shapes of the model the cfg describes, derived
+    without instantiating anything."""
+    from catre_amd.CATRE_disR_shared import expected_state_shapes
+
+    return expected_state_shapes(cfg)
+
+
+def recipe_sd(cfg, salt=0):
+    return synth.recipe_state_dict(state_shapes(cfg), salt)
