@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py - pose-refine throughput of the MI355X-native CATRE hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch = a K_ITER=4 refine (pose-apply -> shared PointNet
+on observed cloud + transformed prior -> t/s head + rotation heads -> SO(3)/scale update, looped 4x on
+the device) of B=256 objects with N=M=1024 points per rank: 1024 object-iterations per rank-step
+(BASELINE.json metric "pose-refine iters/sec (B=256, N=1024, K=4)").  Inputs are synthetic (seeded,
+reference shapes), weights are the seeded recipe; both are resident in HBM before the timed region.
+
+Multi-GPU: objects are independent, so ranks hold disjoint batches and the data path
+has no collective ("weak" scaling: 256 objects per GPU).  Timing: barrier + synchronize, K steps,
+synchronize + barrier, MAX over ranks.
+
+The JSON line also carries
+  roofline     - the dominant kernel (k_trunk: feature transform + conv2..conv4 + max-pool, 57 % of the
+                 FLOPs) measured live with HIP events recorded on its launch stream inside the timed
+                 region, against the dense fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline - the oracle (torch CPU port of the reference path) timed on this box's host cores on a
+                 bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_PER_GPU, N_PTS, M_PTS, K_ITER = 256, 1024, 1024, 4
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+# algorithmic FLOPs: per point of one cloud through k_trunk
+#   pointfeat = h1^T T64 (2*64*64) + conv2 (2*64*128) + conv3 (2*128*512) + conv4 (2*512*1024) + conv1/T3 (2*3*64 + 18)
+TRUNK_FLOPS_PER_POINT = 2 * (64 * 64 + 64 * 128 + 128 * 512 + 512 * 1024) + 2 * 3 * 64 + 18
+
+
+def flops_per_object_iteration(N, M):
+    """SURVEY.md 8d general form (rot-head layer 0 counted in its restructured form)."""
+    return 1770258 * (N + M) + 9446400 + 2 * ((2 * 64 * 256 + 2 * 256 * 256 + 2 * 256 * 3 + 6) * (N + M) + 4 * 1024 * 256) + 692736
+
+
+def cpu_baseline(cfg_fn, sd):
+    """Oracle (port of the reference's CPU path) on the host cores, bounded sample."""
+    from catre_amd import synth
+    from oracle import catre_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bs, Ks = 16, 2
+    cfg = cfg_fn("cpu")
+    batch = synth.make_inputs(Bs, N_PTS, M_PTS, seed=123)
+    with torch.no_grad():
+        O.refine_k({k: v[:2] for k, v in batch.items()}, sd, cfg, n_iter=1)  # warm-up
+        t0 = time.perf_counter()
+        O.refine_k(batch, sd, cfg, n_iter=Ks)
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(Bs * Ks / dt, 3),
+        "unit": "object-iterations/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle/catre_oracle.refine_k (torch CPU fp32), B={Bs}, N=M={N_PTS}, K={Ks}, 1 run, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm; used for barrier / max only
+
+    from catre_amd import hip, synth
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+
+    hip.load()  # fail loudly if the HIP library is missing
+
+    def cfg_fn(device):
+        return default_cfg(num_pcl=N_PTS, num_kps=M_PTS, n_iter=K_ITER, device=device)
+
+    cfg = cfg_fn(str(dev))
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    sd = synth.recipe_state_dict(expected_state_shapes(cfg))
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    model.eval()
+    # each rank refines its own shard of the global batch (disjoint seeds)
+    batch = {k: v.to(dev) for k, v in synth.make_inputs(B_PER_GPU, N_PTS, M_PTS, seed=1000 + rank).items()}
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model.refine(batch, n_iter=K_ITER)
+    nrec = args.steps * K_ITER
+    hip.profile_kernel("trunk", nrec)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.refine(batch, n_iter=K_ITER)
+    barrier()
+    dt = time.perf_counter() - t0
+    trunk_ms = hip.profile_collect(nrec)
+    hip.profile_kernel(None, 0)
+    assert torch.isfinite(out[f"pose_{K_ITER}"]).all()
+
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        obj_iters = world * B_PER_GPU * K_ITER * args.steps
+        value = obj_iters / dt
+        trunk_avg_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
+        trunk_flops = 2 * B_PER_GPU * N_PTS * TRUNK_FLOPS_PER_POINT  # N == M: 2B clouds of N points per launch
+        achieved = trunk_flops / (trunk_avg_ms * 1e-3) / 1e12 if trunk_ms else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_trunk_hbm_bytes.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        path_flops = flops_per_object_iteration(N_PTS, M_PTS)
+        line = {
+            "metric": "pose-refine iters/sec (B=256, N=1024, K=4)",
+            "value": round(value, 1),
+            "unit": "object-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "B=256 objects/GPU, N=1024 observed + M=1024 prior points, K=4 refine iterations, "
+                            "forward-only (eval loop of catre_evaluator.py:292-311), fp32 MFMA",
+                "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER,
+                "parallelism": f"batch-sharded x{world} (no data-path collective)",
+            },
+            "path_tflops": round(value * path_flops / 1e12, 2),
+            "path_frac_of_fp32_mfma_peak": round(value * path_flops / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "roofline": {
+                "kernel": "k_trunk",
+                "bound": "mfma",
+                "achieved": round(achieved, 2) if achieved else None,
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                "traffic": traffic,
+                "avg_launch_ms": round(trunk_avg_ms, 4),
+                "launches_timed": len(trunk_ms),
+                "flops_per_launch": trunk_flops,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg_fn, sd)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

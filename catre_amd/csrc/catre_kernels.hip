@@ -1066,6 +1066,31 @@ int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P
   return check_launch();
 }
 
+
+// ---- opt-in per-kernel timing with HIP events recorded on the launch stream -----------------
+// bench.py uses this to measure the dominant kernel's average launch duration inside its timed
+// region.  Process-global and not re-entrant by design (a measurement aid, off by default).
+struct ProfState {
+  int kernel = -1;
+  int cap = 0, n = 0;
+  hipEvent_t* ev = nullptr;  // 2 per record
+};
+ProfState g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  int slot = -1;
+  ProfScope(int kernel_id, hipStream_t s) : st(s) {
+    if (g_prof.kernel == kernel_id && g_prof.n < g_prof.cap) {
+      slot = g_prof.n++;
+      (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    }
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1149,9 +1174,12 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
   const PackLayout L = pack_layout(1);  // conv offsets do not depend on ts_in
   hipStream_t st = (hipStream_t)stream;
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  {
+    ProfScope ps(CATRE_K_STN3D, st);
   hipLaunchKernelGGL(k_stn3d, dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
                      pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
                      ws + W.pm, B, N, M);
+  }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
@@ -1173,9 +1201,12 @@ int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* 
   const PackLayout L = pack_layout(1);
   hipStream_t st = (hipStream_t)stream;
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  {
+    ProfScope ps(CATRE_K_STNKD, st);
   hipLaunchKernelGGL(k_stnkd, dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
                      pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),
                      prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+  }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
@@ -1190,9 +1221,12 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
   const PackLayout L = pack_layout(1);
   hipStream_t st = (hipStream_t)stream;
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  {
+    ProfScope ps(CATRE_K_TRUNK, st);
   hipLaunchKernelGGL(k_trunk, dim3(tiles), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W],
                      prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),
                      prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M);
+  }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
   return check_launch();
 }
@@ -1206,12 +1240,15 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
   const PackLayout L = pack_layout(o->ts_in_dim);
   const size_t smem = (size_t)TS_OB * (o->ts_in_dim + 256) * sizeof(float);
   if (smem > 64 * 1024) return CATRE_ERR_UNSUPPORTED;
+  {
+    ProfScope ps(CATRE_K_TS_HEAD, (hipStream_t)stream);
   hipLaunchKernelGGL(k_ts_head, dim3((B + TS_OB - 1) / TS_OB), dim3(256), smem, (hipStream_t)stream, gfeat, init_pose,
                      init_scale, packed + L.ts_w0t, prm[CATRE_P_TS_L0_B], prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B],
                      packed + L.ts_w1t, prm[CATRE_P_TS_L1_B], prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B],
                      prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B], prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B],
                      trans_deltas, scale_deltas, B, o->ts_in_dim, o->with_kps_feature, o->with_init_scale,
                      o->with_init_trans);
+  }
   return check_launch();
 }
 
@@ -1226,17 +1263,26 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
     hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64), 0, st, gfeat, PMW, prm[base], PMW,
                        prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
   }
+  {
+    ProfScope ps(CATRE_K_ROT_L0_STATS, st);
   hipLaunchKernelGGL(k_rot_l0_stats, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
                      pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, B, N, M);
+  }
+  {
+    ProfScope ps(CATRE_K_ROT_L1, st);
   hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
                      pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
                      prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], pk4(packed, L.rot_l1[0]),
                      pk4(packed, L.rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B,
                      N, M);
+  }
+  {
+    ProfScope ps(CATRE_K_ROT_OUT, st);
   hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1, prm[CATRE_P_ROTX_GN1_W],
                      prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
                      prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
                      prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+  }
   hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
                      rot6d, B, T);
@@ -1325,11 +1371,40 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
 }
 
 
+int catre_profile_enable(int kernel_id, int max_records) {
+  for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+  delete[] g_prof.ev;
+  g_prof = ProfState();
+  if (kernel_id < 0 || max_records <= 0) return CATRE_OK;
+  if (kernel_id >= CATRE_K_COUNT) return CATRE_ERR_BAD_ARG;
+  g_prof.ev = new hipEvent_t[2 * max_records];
+  for (int i = 0; i < 2 * max_records; ++i)
+    if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return CATRE_ERR_LAUNCH;
+  g_prof.kernel = kernel_id;
+  g_prof.cap = max_records;
+  return CATRE_OK;
+}
+
+int catre_profile_collect(float* ms_out, int max_out, int* n_out) {
+  REQUIRE(n_out && (ms_out || max_out == 0));
+  int n = g_prof.n < max_out ? g_prof.n : max_out;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return CATRE_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms_out[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return CATRE_ERR_LAUNCH;
+  }
+  *n_out = n;
+  g_prof.n = 0;
+  return CATRE_OK;
+}
+
 int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream) {
   REQUIRE(x && out && B > 0 && C > 0 && N > 0);
   const int rows = B * C;
   const int grid = rows / 4 < 8192 ? (rows + 3) / 4 : 8192;
-  hipLaunchKernelGGL(k_colmax, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, rows, N);
+  {
+    ProfScope ps(CATRE_K_COLMAX, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_colmax, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, rows, N);
+  }
   return check_launch();
 }
 

@@ -79,10 +79,14 @@ _SIGS = {
     "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_colmax": (_I, [_P, _P, _I, _I, _I, _P]),
+    "catre_profile_enable": (_I, [_I, _I]),
+    "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_status_string": (ctypes.c_char_p, [_I]),
     "catre_version": (ctypes.c_char_p, []),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
+
+KERNEL_IDS = {"stn3d": 0, "stnkd": 1, "trunk": 2, "ts_head": 3, "rot_l0_stats": 4, "rot_l1": 5, "rot_out": 6, "colmax": 7}
 
 _lib = None
 
@@ -163,3 +167,16 @@ def param_array(tensors):
             require_dev_f32(t, PARAM_KEYS[i])
             arr[i] = t.data_ptr()
     return arr
+
+
+def profile_kernel(name, max_records):
+    """Start recording HIP-event pairs around every launch of kernel ``name`` (``None`` disables)."""
+    check(load().catre_profile_enable(-1 if name is None else KERNEL_IDS[name], int(max_records)), "catre_profile_enable")
+
+
+def profile_collect(max_records):
+    """-> list of per-launch durations in ms (synchronises on the recorded events)."""
+    buf = (ctypes.c_float * max_records)()
+    n = ctypes.c_int(0)
+    check(load().catre_profile_collect(buf, max_records, ctypes.byref(n)), "catre_profile_collect")
+    return [buf[i] for i in range(n.value)]

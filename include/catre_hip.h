@@ -192,6 +192,18 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
 /* torch.max(x, 2)[0] for x [B,C,N] contiguous -> out [B,C]  (pointnet.py:28,61,115). */
 int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream);
 
+/* ---- opt-in kernel timing (measurement aid for bench.py; process-global, not re-entrant) -------- */
+typedef enum catre_kernel_id {
+  CATRE_K_STN3D = 0, CATRE_K_STNKD, CATRE_K_TRUNK, CATRE_K_TS_HEAD, CATRE_K_ROT_L0_STATS, CATRE_K_ROT_L1,
+  CATRE_K_ROT_OUT, CATRE_K_COLMAX, CATRE_K_COUNT
+} catre_kernel_id;
+
+/* Record a HIP event pair around every launch of `kernel_id` on its launch stream (up to max_records).
+ * kernel_id < 0 or max_records <= 0 disables and frees the events. */
+int catre_profile_enable(int kernel_id, int max_records);
+/* Wait for the recorded events, write per-launch durations (ms) and reset the record counter. */
+int catre_profile_collect(float* ms_out, int max_out, int* n_out);
+
 const char* catre_status_string(int status);
 
 /* Build identification: "catre_hip gfx950 <version>" */

@@ -1,0 +1,174 @@
+"""CPU-side checks: drop-in surface (names, state_dict, factory), config handling, the C-ABI library loads and
+exports every symbol the header declares, and the product refuses to run without a HIP device."""
+import copy
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from catre_amd import hip
+from catre_amd.config import CfgNode, default_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "catre_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(catre_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    declared = _header_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/catre_hip.h but not exported"
+    assert set(declared) == set(hip.EXPORTED_SYMBOLS), set(declared) ^ set(hip.EXPORTED_SYMBOLS)
+    lib.catre_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.catre_version()
+
+
+def test_size_queries_without_gpu():
+    lib = hip.load()
+    assert lib.catre_workspace_bytes(0, 1024, 1024) == 0
+    assert lib.catre_workspace_bytes(256, 1024, 1024) > 1 << 30
+    small, big = lib.catre_workspace_bytes(1, 64, 64), lib.catre_workspace_bytes(2, 64, 64)
+    assert 0 < small < big
+    assert lib.catre_packed_floats(1024, 1024, 1091) > 1024 * 512
+    assert lib.catre_status_string(-2).decode().startswith("workspace")
+    assert ctypes.sizeof(hip.CatreOpts) == 64 and ctypes.sizeof(hip.CatrePoints) == 64
+
+
+def test_param_enum_matches_header():
+    src = open(os.path.join(ROOT, "include", "catre_hip.h")).read()
+    body = src[src.index("typedef enum catre_param {"):src.index("} catre_param;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"CATRE_P_[A-Z0-9_]+", body)
+    assert names[-1] == "CATRE_P_COUNT" and len(names) - 1 == hip.CATRE_P_COUNT == len(hip.PARAM_KEYS)
+
+
+def test_state_dict_surface_matches_reference_listing():
+    """Keys / shapes of SURVEY.md section 8b (probe listing of the reference model)."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+
+    cfg = default_cfg(device="cpu")
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    sd = model.state_dict()
+    exp = expected_state_shapes(cfg)
+    assert list(sd) and set(sd) == set(exp)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(exp[k]), k
+    assert len(sd) == 74 and sum(v.numel() for v in sd.values()) == 4298711
+    # every tensor the kernels read is a state_dict entry; the 6 never-used `norm` tensors are not read
+    assert set(hip.PARAM_KEYS) <= set(sd)
+    assert sorted(set(sd) - set(hip.PARAM_KEYS)) == sorted(
+        f"{p}.norm.{w}" for p in ("rot_head.rot_head_x", "rot_head.rot_head_y", "ts_head") for w in ("weight", "bias"))
+    # param groups: pcl_net @ BASE_LR, rot_head / ts_head @ BASE_LR * LR_MULT  (reference :306-315)
+    assert [len(g["params"]) for g in opt.param_groups] == [32, 28, 14]
+    assert all(abs(g["lr"] - 1e-4) < 1e-12 for g in opt.param_groups)
+    # init recipe of the heads (conv_out_per_rot_head.py:117-124, fc_trans_size_head.py:50-59)
+    assert float(sd["rot_head.rot_head_x.layers.0.weight"].std()) < 2e-3
+    assert float(sd["rot_head.rot_head_x.layers.0.bias"].abs().max()) == 0.0
+    assert 5e-3 < float(sd["ts_head.fc_t.weight"].std()) < 2e-2
+    assert torch.equal(sd["ts_head.linears.1.weight"], torch.ones(256))
+    _, none_opt = build_model_optimizer(cfg, is_test=True)
+    assert none_opt is None
+
+
+def test_registries_and_names():
+    import catre_amd.CATRE_disR_shared as mod
+    from catre_amd.net_factory import HEADS, PCLNETS
+
+    assert set(PCLNETS) == {"point_net"} and set(HEADS) == {"FC_TransSizeHead", "ConvOutPerRotHead"}
+    assert hasattr(mod, "build_model_optimizer") and hasattr(mod, "CATRE_disR_shared")
+    cfg = default_cfg(device="cpu")
+    cfg.MODEL.CATRE.NAME = "something_else"
+    with pytest.raises(AssertionError):
+        mod.build_model_optimizer(cfg, is_test=True)
+
+
+def test_opts_from_cfg_flag_mapping():
+    from catre_amd.runtime import opts_from_cfg
+
+    cfg = default_cfg(device="cpu")
+    o = opts_from_cfg(cfg)
+    assert (o.delta_t_space_3d, o.delta_z_deepim, o.k_aware, o.scale_mul, o.scale_base_mean, o.is_allo) == (0, 0, 1, 0, 0, 0)
+    assert (o.with_kps_feature, o.with_init_scale, o.with_init_trans, o.ts_in_dim) == (0, 1, 0, 1091)
+    assert o.zero_center == 1 and o.refine_scale == 1 and abs(o.delta_t_weight - 1.0) < 1e-12
+    cfg.MODEL.CATRE.ROT_HEAD.SCLAE_TYPE = "mean_mul"
+    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "allo_rot6d"
+    cfg.MODEL.CATRE.ROT_HEAD.DELTA_T_SPACE = "3D"
+    cfg.MODEL.CATRE.TS_HEAD.WITH_KPS_FEATURE = True
+    o = opts_from_cfg(cfg)
+    assert (o.scale_mul, o.scale_base_mean, o.is_allo, o.delta_t_space_3d, o.ts_in_dim) == (1, 1, 1, 1, 2179)
+    cfg.MODEL.CATRE.ROT_HEAD.DELTA_T_SPACE = "nope"
+    with pytest.raises(ValueError):
+        opts_from_cfg(cfg)
+    cfg = default_cfg(device="cpu")
+    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_quat"
+    with pytest.raises(NotImplementedError):
+        opts_from_cfg(cfg)
+    # in_dim inconsistent with the gathered features is caught at construction
+    cfg = default_cfg(device="cpu")
+    cfg.MODEL.CATRE.TS_HEAD.WITH_INIT_SCALE = False
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+    with pytest.raises(ValueError):
+        build_model_optimizer(cfg, is_test=True)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a HIP device - never route to the oracle or to torch ops."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    cfg = default_cfg(num_pcl=8, num_kps=8, device="cpu")
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    x = torch.zeros(1, 3, 8)
+    with torch.no_grad():
+        with pytest.raises(hip.CatreHipError):
+            model(x, x, torch.zeros(1, 3, 4), torch.zeros(1, 3))
+        with pytest.raises(hip.CatreHipError):
+            model.pcl_net(x)
+    with pytest.raises(NotImplementedError):  # grad-enabled call: no autograd fallback either
+        model(x, x, torch.zeros(1, 3, 4), torch.zeros(1, 3))
+    src = "".join(open(os.path.join(ROOT, "catre_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "catre_amd"))
+                  if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src, "product code must not import the oracle"
+
+
+def test_model_copies_do_not_share_runtime():
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    model, _ = build_model_optimizer(default_cfg(device="cpu"), is_test=True)
+    model._rt = object()
+    clone = copy.deepcopy(model)
+    assert clone._rt is None and clone._opts.ts_in_dim == 1091
+    assert clone.pcl_net.conv4.weight.data_ptr() != model.pcl_net.conv4.weight.data_ptr()
+
+
+def test_cfgnode_merge_semantics():
+    base = CfgNode(A=dict(x=1, y=dict(z=2)), B=3)
+    base.merge(dict(A=dict(y=dict(w=5)), C=7))
+    assert base.A.x == 1 and base.A.y.z == 2 and base.A.y.w == 5 and base.C == 7
+    base.merge(dict(A=dict(_delete_=True, q=1)))
+    assert dict(base.A) == {"q": 1}
+    assert base.get("missing", 9) == 9 and "B" in base
+
+
+def test_recipe_is_deterministic():
+    from catre_amd import synth
+    from catre_amd.CATRE_disR_shared import expected_state_shapes
+
+    shapes = expected_state_shapes(default_cfg(device="cpu"))
+    a = synth.recipe_state_dict(shapes)
+    b = synth.recipe_state_dict(shapes)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = synth.make_inputs(3, 64, 32, seed=4)
+    d = synth.make_inputs(3, 64, 32, seed=4)
+    assert all(torch.equal(c[k], d[k]) for k in c)
+    assert c["pcl"].shape == (3, 64, 3) and c["obj_kps"].shape == (3, 32, 3) and c["obj_pose_est"].shape == (3, 3, 4)
