@@ -1,0 +1,62 @@
+"""Multi-GPU sharding of the refine path: one process per GPU, objects split across ranks.
+
+Every object (batch row) is independent through the whole path (no BatchNorm; GroupNorm is per
+sample - SURVEY.md section 8e), so inference shards with NO data-path collective: each rank refines
+its contiguous slice of the global batch.  The only exchange is the optional all-gather of the
+results at the end, the counterpart of the reference's prediction all-gather
+(``core/catre/engine/catre_custom_evaluator.py:203``).  ``torch.distributed`` backend ``"nccl"`` is
+RCCL over xGMI on MI355X; ``"gloo"`` is used by the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous [lo, hi) slice of ``total`` objects owned by ``rank``; sizes differ by at most one
+    (the reference hands each rank ``IMS_PER_BATCH / world`` images, ``core/utils/dataset_utils.py:411-416``)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(batch, rank, world):
+    """Slice every per-object tensor / list of a reference-style batch dict."""
+    B = batch["pcl"].shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == B:
+            out[k] = v[lo:hi].contiguous()
+        elif isinstance(v, (list, tuple)) and len(v) == B:
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
+    return out
+
+
+def gather_outputs(local_out, total, group=None):
+    """All-gather an ``out_dict`` (``pose_i`` / ``scale_i`` tensors with the local objects first) so that
+    every rank holds the full-batch result in the original object order.  Ragged shards are padded to
+    the largest shard for the collective."""
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(total, r, world) for r in range(world)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    full = {}
+    for k, v in local_out.items():
+        pad = torch.zeros((maxn,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[: v.shape[0]] = v
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        full[k] = torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+    return full
+
+
+def refine_sharded(refine_fn, batch, n_iter, group=None, gather=True):
+    """Run ``refine_fn(local_batch, n_iter) -> out_dict`` on this rank's shard of ``batch``."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local = refine_fn(shard_batch(batch, rank, world), n_iter)
+    if not gather:
+        return local
+    return gather_outputs(local, batch["pcl"].shape[0], group)
