@@ -82,6 +82,42 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const f32x4* __
   }
 }
 
+// XOR-swizzled LDS images (no row padding): the 16-byte chunk c of row r lives at chunk c ^ (r & 15).
+// For row pitches that are multiples of 64 floats this spreads the 16 rows of a ds_read_b128 lane
+// group over 16 distinct 4-bank slots exactly like the +4 skew does, but costs no LDS bytes - which
+// is what lets two 80 KiB workgroups share one CU in the rotation head.
+__device__ __forceinline__ int swz_off(int row, int chunk, int ld) { return row * ld + ((chunk ^ (row & 15)) << 2); }
+
+// gemm_tile over a swizzled activation image `x` ([64 points][ld floats], ld % 64 == 0).
+template <int MB, int NB, bool SWAP>
+__device__ __forceinline__ void gemm_tile_swz(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
+                                              const float* x, int ld, int lane, int nkc) {
+  const int n = lane & 31, h = lane >> 5, sw = lane & 15;
+  const float* xrow = x + n * ld;
+  f32x4 a_cur[MB], a_nxt[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wp[mb * wp_mb];
+#pragma unroll 2
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wp[mb * wp_mb + kn * 64];
+    const int coff = ((2 * kc + h) ^ sw) << 2;
+    f32x4 b[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = SWAP ? mfma32(b[nb][s], a_cur[mb][s], acc[mb][nb]) : mfma32(a_cur[mb][s], b[nb][s], acc[mb][nb]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+  }
+}
+
 // "normal"-orientation epilogue: out[point][ch] = act(acc + bias[ch]) as float4 per register quad.
 template <int MB, int NB, bool RELU>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MB][NB], float* out, int ldo, int ch0,

@@ -648,175 +648,7 @@ __global__ __launch_bounds__(512) void k_rot_l0_stats(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(512) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
-                                                const f32x4* __restrict__ wpl0y, const float* __restrict__ bias0,
-                                                const float* __restrict__ gn0, const float* __restrict__ gam0x,
-                                                const float* __restrict__ bet0x, const float* __restrict__ gam0y,
-                                                const float* __restrict__ bet0y, const f32x4* __restrict__ wpl1x,
-                                                const f32x4* __restrict__ wpl1y, const float* __restrict__ b1x,
-                                                const float* __restrict__ b1y, float* __restrict__ y1,
-                                                float* __restrict__ gn1, int B, int N, int M) {
-  __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * LD256 + 128];
-  float* pf = smem;
-  float* a0 = smem + TP * LD64;
-  float* stat = smem + TP * LD64 + TP * LD256;  // [2][32][2]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
-  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
-  const int P = N + M;
-  if (tid < 64) {
-    const int hd = tid >> 5, grp = tid & 31;
-    float mean, rstd;
-    merge_gn(gn0 + ((size_t)rt.obj * 2 + hd) * T * 64, grp, T, TN, N, M, mean, rstd);
-    stat[(hd * 32 + grp) * 2] = mean;
-    stat[(hd * 32 + grp) * 2 + 1] = rstd;
-  }
-  load_pf_tile(pointfeat, rt, pf, tid);
-  __syncthreads();
-  const int n = lane & 31, h = lane >> 5;
-#pragma unroll 1
-  for (int hd = 0; hd < 2; ++hd) {
-    {
-      f32x16 acc[1][2];
-      rot_layer0(acc, hd ? wpl0y : wpl0x, pf, wave, lane);
-      const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
-      const float* gam = (hd ? gam0y : gam0x) + wave * 32;
-      const float* bet = (hd ? bet0y : bet0x) + wave * 32;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = 8 * g + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + c);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(gam + c);
-        const f32x4 ev = *reinterpret_cast<const f32x4*>(bet + c);
-        const float mean = stat[(hd * 32 + wave * 4 + g) * 2], rstd = stat[(hd * 32 + wave * 4 + g) * 2 + 1];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          f32x4 z;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float sc = rstd * gv[q];
-            z[q] = gelu_erf(fmaf(acc[0][nb][4 * g + q] + bv[q], sc, ev[q] - mean * sc));
-          }
-          *reinterpret_cast<f32x4*>(a0 + (nb * 32 + n) * LD256 + wave * 32 + c) = z;
-        }
-      }
-    }
-    __syncthreads();
-    {
-      // layer 1 (256->256), "swapped": lane owns channel wave*32+n and 32 of the tile's points
-      f32x16 acc[1][2] = {{zero16(), zero16()}};
-      gemm_tile<1, 2, true>(acc, (hd ? wpl1y : wpl1x) + (wave * 32) * 64 + lane, 0,
-                            a0 + (lane & 31) * LD256 + 4 * (lane >> 5), 32 * LD256, 32);
-      const int ch = wave * 32 + n;
-      const float bb = (hd ? b1y : b1x)[ch];
-      float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
-      float s = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float v = acc[0][nb][r] + bb;
-          acc[0][nb][r] = v;
-          if (pt < rt.valid) {
-            dst[(size_t)pt * 256] = v;
-            s += v;
-          }
-        }
-      // group = 8 consecutive channels = 8 consecutive lanes, both half-waves
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      s += __shfl_xor(s, 32);
-      const float mean = s / (8.f * (float)rt.valid);
-      float m2 = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float d = acc[0][nb][r] - mean;
-          m2 += pt < rt.valid ? d * d : 0.f;
-        }
-      m2 += __shfl_xor(m2, 1);
-      m2 += __shfl_xor(m2, 2);
-      m2 += __shfl_xor(m2, 4);
-      m2 += __shfl_xor(m2, 32);
-      if ((lane & 7) == 0 && h == 0) {
-        float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (wave * 4 + (n >> 3)) * 2;
-        out[0] = mean;
-        out[1] = m2;
-      }
-    }
-    __syncthreads();  // a0 is rewritten for the second head
-  }
-}
-
-// GN -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; memory-bound read of y1.
-__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1,
-                                                 const float* __restrict__ gam1x, const float* __restrict__ bet1x,
-                                                 const float* __restrict__ gam1y, const float* __restrict__ bet1y,
-                                                 const float* __restrict__ neckx, const float* __restrict__ necky,
-                                                 const float* __restrict__ wpx, const float* __restrict__ wpy,
-                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M) {
-  __shared__ float stat[64];
-  __shared__ float red[4][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP, P = N + M;
-  const int hd = blockIdx.y;
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
-  if (tid < 32) {
-    float mean, rstd;
-    merge_gn(gn1 + ((size_t)rt.obj * 2 + hd) * T * 64, tid, T, TN, N, M, mean, rstd);
-    stat[tid * 2] = mean;
-    stat[tid * 2 + 1] = rstd;
-  }
-  __syncthreads();
-  const int c0 = lane * 4;  // this lane's 4 channels
-  const float* gam = hd ? gam1y : gam1x;
-  const float* bet = hd ? bet1y : bet1x;
-  const float* neck = hd ? necky : neckx;
-  const float* wp = hd ? wpy : wpx;
-  const float mean = stat[(c0 >> 3) * 2], rstd = stat[(c0 >> 3) * 2 + 1];
-  float sc[4], sh[4], nk[3][4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    sc[q] = rstd * gam[c0 + q];
-    sh[q] = bet[c0 + q] - mean * sc[q];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
-  }
-  const float* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
-  float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int p = wave; p < rt.valid; p += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * 256);
-    const float w = wp[rt.gp0 + p];
-    float z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float t = nk[c][0] * z[0];
-      t = fmaf(nk[c][1], z[1], t);
-      t = fmaf(nk[c][2], z[2], t);
-      t = fmaf(nk[c][3], z[3], t);
-      a3[c] = fmaf(w, t, a3[c]);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) a3[c] = wave_sum(a3[c]);
-  if (lane == 0) {
-    red[wave][0] = a3[0];
-    red[wave][1] = a3[1];
-    red[wave][2] = a3[2];
-  }
-  __syncthreads();
-  if (tid < 3) {
-    rpart[(((size_t)rt.obj * 2 + hd) * T + rt.t) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-  }
-}
+#include "catre_rot.h"
 
 // rot6d[b][hd*3+c] = sum_tiles rpart + neck_b[c] * sum_p w_p + conv_p.bias
 __global__ void k_rot_finish(const float* __restrict__ rpart, const float* __restrict__ neckbx,
@@ -1004,7 +836,7 @@ PackLayout pack_layout(int ts_in) {
 }
 
 struct WsLayout {
-  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, y1, rpart,
+  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, gn0stat, gn1stat, y1, rpart,
       total;  // offsets in floats
 };
 
@@ -1034,6 +866,8 @@ WsLayout ws_layout(int B, int N, int M) {
   L.bias0 = take(2 * 2 * b * 256);
   L.gn0 = take(b * 2 * T * 64);
   L.gn1 = take(b * 2 * T * 64);
+  L.gn0stat = take(b * 2 * 64);
+  L.gn1stat = take(b * 2 * 64);
   L.y1 = take(b * 2 * P * 256);
   L.rpart = take(b * 2 * T * 4);
   L.total = o;
@@ -1268,20 +1102,22 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   hipLaunchKernelGGL(k_rot_l0_stats, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
                      pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, B, N, M);
   }
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn0, ws + W.gn0stat, N, M);
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
-  hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                     pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
-                     prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], pk4(packed, L.rot_l1[0]),
-                     pk4(packed, L.rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B,
-                     N, M);
+    hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                       pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0stat, prm[CATRE_P_ROTX_GN0_W],
+                       prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B],
+                       pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]), prm[CATRE_P_ROTX_L1_B],
+                       prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M);
   }
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
   {
     ProfScope ps(CATRE_K_ROT_OUT, st);
-  hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1, prm[CATRE_P_ROTX_GN1_W],
-                     prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
-                     prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
-                     prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+    hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1stat,
+                       prm[CATRE_P_ROTX_GN1_W], prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W],
+                       prm[CATRE_P_ROTY_GN1_B], prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W],
+                       prm[CATRE_P_ROTX_CONVP_W], prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
   }
   hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],

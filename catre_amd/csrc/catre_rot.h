@@ -1,0 +1,204 @@
+// catre_rot.h - rotation-head kernels after the layer-0 statistics pass (included by catre_kernels.hip).
+//
+// a9 (heads/conv_out_per_rot_head.py:126-140) per (object, head), over the P = N+M concatenated points:
+//   y0 = W0[:,1024:] pointfeat + bias0(cloud)       -> GN0 statistics         (k_rot_l0_stats)
+//   k_gn_finalize: merge per-tile (mean, M2) partials in tile order (Chan) -> (mean, rstd) per group
+//   a0 = gelu(GN0(y0));  y1 = W1 a0 + b1             -> y1 to HBM, GN1 partials (k_rot_l1)
+//   k_gn_finalize
+//   out[c] = sum_p w_p * (neck gelu(GN1(y1)))[c,p]                             (k_rot_out, HBM-bound)
+//
+// k_rot_l1 is sized for TWO workgroups per CU: 256 threads, 64 accumulator VGPRs per layer, and exactly
+// 80 KiB of LDS (pointfeat tile 16 KiB + a0 image 64 KiB, both XOR-swizzled instead of padded).
+#pragma once
+
+// (mean, M2) partials [rows][T][32][2] -> (mean, rstd) [rows][32][2]; one wave per row (row = object*2+head)
+__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ part, float* __restrict__ stat, int N,
+                                                    int M) {
+  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
+  const int g = threadIdx.x;
+  if (g >= 32) return;
+  float mean, rstd;
+  merge_gn(part + (size_t)blockIdx.x * T * 64, g, T, TN, N, M, mean, rstd);
+  stat[((size_t)blockIdx.x * 32 + g) * 2] = mean;
+  stat[((size_t)blockIdx.x * 32 + g) * 2 + 1] = rstd;
+}
+
+__device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ pointfeat, const RotTile& rt, float* pf,
+                                                 int tid) {
+  // 256 threads: 64 rows x 4 lanes x 4 float4 (16 chunks per row)
+  const int row = tid >> 2, c0 = tid & 3;
+  const int srow = min(row, rt.valid - 1);
+  const f32x4* s = reinterpret_cast<const f32x4*>(pointfeat + rt.pf_off + (size_t)srow * 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + 4 * i;
+    *reinterpret_cast<f32x4*>(pf + swz_off(row, c, 64)) = s[c];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
+                                                   const f32x4* __restrict__ wpl0y, const float* __restrict__ bias0,
+                                                   const float* __restrict__ gn0stat /*[B][2][32][2]*/,
+                                                   const float* __restrict__ gam0x, const float* __restrict__ bet0x,
+                                                   const float* __restrict__ gam0y, const float* __restrict__ bet0y,
+                                                   const f32x4* __restrict__ wpl1x, const f32x4* __restrict__ wpl1y,
+                                                   const float* __restrict__ b1x, const float* __restrict__ b1y,
+                                                   float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
+                                                   int M) {
+  __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
+  float* pf = smem;            // [64][64]  swizzled
+  float* a0 = smem + TP * 64;  // [64][256] swizzled
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  const int P = N + M;
+  load_pf_tile_swz(pointfeat, rt, pf, tid);
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    {
+      // layer 0 recompute: wave -> channels [wave*64, +64), "normal" orientation
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      gemm_tile_swz<2, 2, false>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane, 8);
+      const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256;
+      const float* gam = hd ? gam0y : gam0x;
+      const float* bet = hd ? bet0y : bet0x;
+      const float* st = gn0stat + ((size_t)rt.obj * 2 + hd) * 64;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + c);
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(gam + c);
+          const f32x4 ev = *reinterpret_cast<const f32x4*>(bet + c);
+          const float mean = st[(c >> 3) * 2], rstd = st[(c >> 3) * 2 + 1];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x4 z;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float sc = rstd * gv[q];
+              z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q] + bv[q], sc, ev[q] - mean * sc));
+            }
+            *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
+          }
+        }
+    }
+    __syncthreads();
+    {
+      // layer 1 (256->256), "swapped": lane owns channels wave*64 + mb*32 + n and 32 of the tile's points
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      gemm_tile_swz<2, 2, true>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane, 32);
+      const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int ch = wave * 64 + mb * 32 + n;
+        const float bb = (hd ? b1y : b1x)[ch];
+        float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+        float s = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = acc[mb][nb][r] + bb;
+            acc[mb][nb][r] = v;
+            if (pt < rt.valid) {
+              dst[(size_t)pt * 256] = v;
+              s += v;
+            }
+          }
+        // GN group = 8 consecutive channels = 8 consecutive lanes, both half-waves
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 32);
+        const float mean = s * inv_cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float d = acc[mb][nb][r] - mean;
+            m2 += pt < rt.valid ? d * d : 0.f;
+          }
+        m2 += __shfl_xor(m2, 1);
+        m2 += __shfl_xor(m2, 2);
+        m2 += __shfl_xor(m2, 4);
+        m2 += __shfl_xor(m2, 32);
+        if ((lane & 7) == 0 && h == 0) {
+          float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
+          out[0] = mean;
+          out[1] = m2;
+        }
+      }
+    }
+    __syncthreads();  // a0 is rewritten for the second head
+  }
+}
+
+// GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
+__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1stat,
+                                                 const float* __restrict__ gam1x, const float* __restrict__ bet1x,
+                                                 const float* __restrict__ gam1y, const float* __restrict__ bet1y,
+                                                 const float* __restrict__ neckx, const float* __restrict__ necky,
+                                                 const float* __restrict__ wpx, const float* __restrict__ wpy,
+                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
+  const int hd = blockIdx.y;
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int c0 = lane * 4;  // this lane's 4 channels
+  const float* gam = hd ? gam1y : gam1x;
+  const float* bet = hd ? bet1y : bet1x;
+  const float* neck = hd ? necky : neckx;
+  const float* wp = hd ? wpy : wpx;
+  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
+  const float mean = st[0], rstd = st[1];
+  float sc[4], sh[4], nk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * gam[c0 + q];
+    sh[q] = bet[c0 + q] - mean * sc[q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
+  }
+  const float* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
+  float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int p = wave; p < rt.valid; p += 4) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)p * 256));
+    const float w = wp[rt.gp0 + p];
+    float z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = nk[c][0] * z[0];
+      t = fmaf(nk[c][1], z[1], t);
+      t = fmaf(nk[c][2], z[2], t);
+      t = fmaf(nk[c][3], z[3], t);
+      a3[c] = fmaf(w, t, a3[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a3[c] = wave_sum(a3[c]);
+  if (lane == 0) {
+    red[wave][0] = a3[0];
+    red[wave][1] = a3[1];
+    red[wave][2] = a3[2];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    rpart[(((size_t)rt.obj * 2 + hd) * T + rt.t) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}
