@@ -51,34 +51,46 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
-// One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*nkc.
+// One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*NKC.
 //   wp   : fragment-packed weights, already offset to [first m-block][first k-chunk][lane]
 //   wp_mb: float4 stride between consecutive m-blocks  (= (Ktotal/8)*64)
-//   xrow : LDS pointer &act[(lane&31)*ldx + 4*(lane>>5)] of point block 0
-//   x_nb : float stride between point blocks (= 32*ldx)
-template <int MB, int NB, bool SWAP>
-__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
-                                          const float* xrow, int x_nb, int nkc) {
-  f32x4 a_cur[MB], a_nxt[MB];
+//   x    : LDS image of point block 0 of this wave tile, [point][ld]; SWZ selects the XOR-swizzled layout
+// Software pipeline: the A fragments (L2) and B fragments (LDS) of chunk kc+PFD are issued BEFORE the
+// 4*MB*NB MFMAs of chunk kc and pinned there with sched_barrier - left alone, hipcc sinks the loads down
+// to their first use (to save registers) and every chunk then eats a full L2 round trip.  PFD chunks are
+// in flight: 1 is enough behind 32 MFMAs (MB=4), the thin MB=1/2 layers need 2-3 to cover L2 latency.
+// NKC is a template parameter so the ring-buffer indices below are compile-time constants (a runtime-indexed
+// register array would go to scratch).
+template <int MB, int NB, bool SWAP, bool SWZ, int NKC, int PFD>
+__device__ __forceinline__ void gemm_core(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
+                                          const float* x, int ld, int lane) {
+  static_assert(PFD >= 1 && PFD <= NKC, "prefetch depth");
+  constexpr int R = PFD + 1;
+  const int n = lane & 31, h = lane >> 5, sw = lane & 15;
+  const float* xrow = x + n * ld;
+  f32x4 a[R][MB], b[R][NB];
+  auto issue = [&](int kc, int slot) {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wp[mb * wp_mb];
-#pragma unroll 2
-  for (int kc = 0; kc < nkc; ++kc) {
-    const int kn = (kc + 1 < nkc) ? kc + 1 : kc;  // last iteration re-loads (harmless, keeps the loop branch-free)
+    for (int mb = 0; mb < MB; ++mb) a[slot][mb] = wp[mb * wp_mb + kc * 64];
+    const int coff = SWZ ? (((2 * kc + h) ^ sw) << 2) : (kc * 8 + 4 * h);
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wp[mb * wp_mb + kn * 64];
-    f32x4 b[NB];
+    for (int nb = 0; nb < NB; ++nb) b[slot][nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
+  };
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(xrow + nb * x_nb + kc * 8);
+  for (int d = 0; d < PFD; ++d) issue(d, d);
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    if (kc + PFD < NKC) issue(kc + PFD, (kc + PFD) % R);
+    __builtin_amdgcn_sched_barrier(0);
+    const int c = kc % R;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = SWAP ? mfma32(b[nb][s], a_cur[mb][s], acc[mb][nb]) : mfma32(a_cur[mb][s], b[nb][s], acc[mb][nb]);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+          acc[mb][nb] = SWAP ? mfma32(b[c][nb][s], a[c][mb][s], acc[mb][nb]) : mfma32(a[c][mb][s], b[c][nb][s], acc[mb][nb]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -87,36 +99,6 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const f32x4* __
 // group over 16 distinct 4-bank slots exactly like the +4 skew does, but costs no LDS bytes - which
 // is what lets two 80 KiB workgroups share one CU in the rotation head.
 __device__ __forceinline__ int swz_off(int row, int chunk, int ld) { return row * ld + ((chunk ^ (row & 15)) << 2); }
-
-// gemm_tile over a swizzled activation image `x` ([64 points][ld floats], ld % 64 == 0).
-template <int MB, int NB, bool SWAP>
-__device__ __forceinline__ void gemm_tile_swz(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
-                                              const float* x, int ld, int lane, int nkc) {
-  const int n = lane & 31, h = lane >> 5, sw = lane & 15;
-  const float* xrow = x + n * ld;
-  f32x4 a_cur[MB], a_nxt[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wp[mb * wp_mb];
-#pragma unroll 2
-  for (int kc = 0; kc < nkc; ++kc) {
-    const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wp[mb * wp_mb + kn * 64];
-    const int coff = ((2 * kc + h) ^ sw) << 2;
-    f32x4 b[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = SWAP ? mfma32(b[nb][s], a_cur[mb][s], acc[mb][nb]) : mfma32(a_cur[mb][s], b[nb][s], acc[mb][nb]);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
-  }
-}
 
 // "normal"-orientation epilogue: out[point][ch] = act(acc + bias[ch]) as float4 per register quad.
 template <int MB, int NB, bool RELU>

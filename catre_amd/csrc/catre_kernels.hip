@@ -190,8 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   __syncthreads();
   {  // conv2 64->128: wave -> m-block `wave`, both point blocks
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    gemm_tile<1, 2, false>(acc, wp2 + (wave * 8) * 64 + lane, 0, a1 + (lane & 31) * LD64 + 4 * (lane >> 5),
-                           32 * LD64, 8);
+    gemm_core<1, 2, false, false, 8, 3>(acc, wp2 + (wave * 8) * 64 + lane, 0, a1, LD64, lane);
     store_tile_lds<1, 2, true>(acc, a2, LD128, wave * 32, b2, lane);
   }
   __syncthreads();
@@ -203,8 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_tile<4, 2, true>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2 + (lane & 31) * LD128 + 4 * (lane >> 5),
-                          32 * LD128, 16);
+    gemm_core<4, 2, true, false, 16, 1>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2, LD128, lane);
     max_tile_store<4, 2>(acc, out, mblk0 * 32, b3, true, lane);
   }
 }
@@ -237,15 +235,13 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   {  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks, one per wave
     const int mblk = wave >> 1, nb = wave & 1;
     f32x16 acc[1][1] = {{zero16()}};
-    gemm_tile<1, 1, false>(acc, wpf1 + (mblk * 8) * 64 + lane, 0,
-                           h1 + (nb * 32 + (lane & 31)) * LD64 + 4 * (lane >> 5), 0, 8);
+    gemm_core<1, 1, false, false, 8, 4>(acc, wpf1 + (mblk * 8) * 64 + lane, 0, h1 + nb * 32 * LD64, LD64, lane);
     store_tile_lds<1, 1, true>(acc, f1 + nb * 32 * LD64, LD64, mblk * 32, bf1, lane);
   }
   __syncthreads();
   {  // fstn.conv2 64->128
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    gemm_tile<1, 2, false>(acc, wpf2 + (wave * 8) * 64 + lane, 0, f1 + (lane & 31) * LD64 + 4 * (lane >> 5),
-                           32 * LD64, 8);
+    gemm_core<1, 2, false, false, 8, 3>(acc, wpf2 + (wave * 8) * 64 + lane, 0, f1, LD64, lane);
     store_tile_lds<1, 2, true>(acc, f2, LD128, wave * 32, bf2, lane);
   }
   __syncthreads();
@@ -256,8 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_tile<4, 2, true>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2 + (lane & 31) * LD128 + 4 * (lane >> 5),
-                          32 * LD128, 16);
+    gemm_core<4, 2, true, false, 16, 1>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2, LD128, lane);
     max_tile_store<4, 2>(acc, out, mblk0 * 32, bf3, true, lane);
   }
 }
@@ -345,8 +340,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     // conv2 64->128: 4 m-blocks x 2 point blocks over 8 waves
     const int mblk = wave >> 1, nb = wave & 1;
     f32x16 acc[1][1] = {{zero16()}};
-    gemm_tile<1, 1, false>(acc, wp2 + (mblk * 8) * 64 + lane, 0,
-                           pf + (nb * 32 + (lane & 31)) * LD64 + 4 * (lane >> 5), 0, 8);
+    gemm_core<1, 1, false, false, 8, 4>(acc, wp2 + (mblk * 8) * 64 + lane, 0, pf + nb * 32 * LD64, LD64, lane);
     store_tile_lds<1, 1, true>(acc, a2 + nb * 32 * LD128, LD128, mblk * 32, b2, lane);
   }
   __syncthreads();
@@ -359,14 +353,12 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     {  // conv3 chunk: out channels [hh*256, +256): 8 m-blocks, one per wave, K = 128
       const int mblk = hh * 8 + wave;
       f32x16 acc3[1][2] = {{zero16(), zero16()}};
-      gemm_tile<1, 2, false>(acc3, wp3 + (mblk * 16) * 64 + lane, 0, a2 + (lane & 31) * LD128 + 4 * (lane >> 5),
-                             32 * LD128, 16);
+      gemm_core<1, 2, false, false, 16, 3>(acc3, wp3 + (mblk * 16) * 64 + lane, 0, a2, LD128, lane);
       store_tile_lds<1, 2, true>(acc3, a3, LD256, wave * 32, b3 + hh * 256, lane);
     }
     __syncthreads();
     // conv4 partial sum over k in [hh*256, +256): wave owns out channels [wave*128, +128)
-    gemm_tile<4, 2, true>(acc4, wp4 + ((wave * 4) * 64 + hh * 32) * 64 + lane, 64 * 64,
-                          a3 + (lane & 31) * LD256 + 4 * (lane >> 5), 32 * LD256, 32);
+    gemm_core<4, 2, true, false, 32, 1>(acc4, wp4 + ((wave * 4) * 64 + hh * 32) * 64 + lane, 64 * 64, a3, LD256, lane);
     if (hh == 0) __syncthreads();  // a3 is rewritten by the second chunk
   }
   max_tile_store<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, b4, false, lane);
@@ -589,8 +581,7 @@ __device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64
 __device__ __forceinline__ void rot_layer0(f32x16 (&acc)[1][2], const f32x4* __restrict__ wpl0, const float* pf,
                                            int wave, int lane) {
   acc[0][0] = acc[0][1] = zero16();
-  gemm_tile<1, 2, false>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf + (lane & 31) * LD64 + 4 * (lane >> 5), 32 * LD64,
-                         8);
+  gemm_core<1, 2, false, false, 8, 3>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf, LD64, lane);
 }
 
 __global__ __launch_bounds__(512) void k_rot_l0_stats(const float* __restrict__ pointfeat,

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
       f32x16 acc[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-      gemm_tile_swz<2, 2, false>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane, 8);
+      gemm_core<2, 2, false, true, 8, 2>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane);
       const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256;
       const float* gam = hd ? gam0y : gam0x;
       const float* bet = hd ? bet0y : bet0x;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
       f32x16 acc[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-      gemm_tile_swz<2, 2, true>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane, 32);
+      gemm_core<2, 2, true, true, 32, 2>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane);
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
