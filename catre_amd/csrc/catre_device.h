@@ -61,37 +61,65 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // in flight: 1 is enough behind 32 MFMAs (MB=4), the thin MB=1/2 layers need 2-3 to cover L2 latency.
 // NKC is a template parameter so the ring-buffer indices below are compile-time constants (a runtime-indexed
 // register array would go to scratch).
-template <int MB, int NB, bool SWAP, bool SWZ, int NKC, int PFD>
-__device__ __forceinline__ void gemm_core(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
-                                          const float* x, int ld, int lane) {
-  static_assert(PFD >= 1 && PFD <= NKC, "prefetch depth");
-  constexpr int R = PFD + 1;
-  const int n = lane & 31, h = lane >> 5, sw = lane & 15;
-  const float* xrow = x + n * ld;
-  f32x4 a[R][MB], b[R][NB];
-  auto issue = [&](int kc, int slot) {
+template <int MB, int NB, bool SWAP, bool SWZ, int NKC, int PFD, int PFB = 1>
+struct GemmPipe {
+  // PFD: chunks of A (weights, L2 latency ~1 us under load) in flight; PFB: chunks of B (LDS) in flight.
+  static_assert(PFD >= 1 && PFD <= NKC && PFB >= 1 && PFB <= PFD, "prefetch depth");
+  static constexpr int RA = PFD + 1, RB = PFB + 1;
+  f32x4 a[RA][MB], b[RB][NB];
+  const f32x4* wp;
+  int wp_mb;
+
+  __device__ __forceinline__ void issue_a(int kc) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a[slot][mb] = wp[mb * wp_mb + kc * 64];
-    const int coff = SWZ ? (((2 * kc + h) ^ sw) << 2) : (kc * 8 + 4 * h);
+    for (int mb = 0; mb < MB; ++mb) a[kc % RA][mb] = wp[mb * wp_mb + kc * 64];
+  }
+  // Issue the first PFD weight chunks.  They do not depend on LDS, so a kernel calls this BEFORE the
+  // epilogue + barrier of the previous layer: the L2 round trip then overlaps that work instead of
+  // sitting exposed at the head of the layer.
+  __device__ __forceinline__ void prefetch(const f32x4* __restrict__ wp_, int wp_mb_) {
+    wp = wp_;
+    wp_mb = wp_mb_;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[slot][nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
-  };
-#pragma unroll
-  for (int d = 0; d < PFD; ++d) issue(d, d);
-#pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) {
-    if (kc + PFD < NKC) issue(kc + PFD, (kc + PFD) % R);
-    __builtin_amdgcn_sched_barrier(0);
-    const int c = kc % R;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = SWAP ? mfma32(b[c][nb][s], a[c][mb][s], acc[mb][nb]) : mfma32(a[c][mb][s], b[c][nb][s], acc[mb][nb]);
+    for (int d = 0; d < PFD; ++d) issue_a(d);
     __builtin_amdgcn_sched_barrier(0);
   }
+  __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const float* x, int ld, int lane) {
+    const int n = lane & 31, h = lane >> 5, sw = lane & 15;
+    const float* xrow = x + n * ld;
+    auto issue_b = [&](int kc) {
+      const int coff = SWZ ? (((2 * kc + h) ^ sw) << 2) : (kc * 8 + 4 * h);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[kc % RB][nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
+    };
+#pragma unroll
+    for (int d = 0; d < PFB; ++d) issue_b(d);
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc + PFD < NKC) issue_a(kc + PFD);
+      if (kc + PFB < NKC) issue_b(kc + PFB);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ca = kc % RA, cb = kc % RB;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] =
+                SWAP ? mfma32(b[cb][nb][s], a[ca][mb][s], acc[mb][nb]) : mfma32(a[ca][mb][s], b[cb][nb][s], acc[mb][nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// one-shot form: prefetch + run back to back
+template <int MB, int NB, bool SWAP, bool SWZ, int NKC, int PFD, int PFB = 1>
+__device__ __forceinline__ void gemm_core(f32x16 (&acc)[MB][NB], const f32x4* __restrict__ wp, int wp_mb,
+                                          const float* x, int ld, int lane) {
+  GemmPipe<MB, NB, SWAP, SWZ, NKC, PFD, PFB> g;
+  g.prefetch(wp, wp_mb);
+  g.run(acc, x, ld, lane);
 }
 
 // XOR-swizzled LDS images (no row padding): the 16-byte chunk c of row r lives at chunk c ^ (r & 15).
@@ -121,6 +149,65 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MB][NB], floa
           v[q] = RELU ? fmaxf(t, 0.f) : t;
         }
         *reinterpret_cast<f32x4*>(out + (nb * 32 + n) * ldo + ch) = v;
+      }
+    }
+}
+
+// Same epilogue into an XOR-swizzled image: `out` is the [64][ldo] tile base, channels are absolute.
+template <int MB, int NB, bool RELU>
+__device__ __forceinline__ void store_tile_lds_swz(const f32x16 (&acc)[MB][NB], float* out, int ldo, int ch0,
+                                                   const float* __restrict__ bias, int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = ch0 + mb * 32 + 8 * g + 4 * h;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = acc[mb][nb][4 * g + q] + bv[q];
+          v[q] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f32x4*>(out + swz_off(nb * 32 + n, ch >> 2, ldo)) = v;
+      }
+    }
+}
+
+// Bias quads of a "normal"-orientation wave tile, loaded ahead of the layer (pinned by the caller's
+// sched_barrier) so the epilogue does not pay a global round trip.
+template <int MB>
+__device__ __forceinline__ void load_bias_quads(f32x4 (&bv)[MB][4], const float* __restrict__ bias, int ch0, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[mb][g] = *reinterpret_cast<const f32x4*>(bias + ch0 + mb * 32 + 8 * g + 4 * h);
+}
+
+template <int MB, int NB, bool RELU, bool SWZ>
+__device__ __forceinline__ void store_tile_lds_pre(const f32x16 (&acc)[MB][NB], float* out, int ldo, int ch0,
+                                                   const f32x4 (&bv)[MB][4], int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = ch0 + mb * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = acc[mb][nb][4 * g + q] + bv[mb][g][q];
+          v[q] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        const int off = SWZ ? swz_off(nb * 32 + n, ch >> 2, ldo) : (nb * 32 + n) * ldo + ch;
+        *reinterpret_cast<f32x4*>(out + off) = v;
       }
     }
 }

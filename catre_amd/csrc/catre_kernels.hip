@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_core<4, 2, true, false, 16, 1>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2, LD128, lane);
+    gemm_core<4, 2, true, false, 16, 2, 1>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2, LD128, lane);
     max_tile_store<4, 2>(acc, out, mblk0 * 32, b3, true, lane);
   }
 }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_core<4, 2, true, false, 16, 1>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2, LD128, lane);
+    gemm_core<4, 2, true, false, 16, 2, 1>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2, LD128, lane);
     max_tile_store<4, 2>(acc, out, mblk0 * 32, bf3, true, lane);
   }
 }
@@ -260,11 +260,11 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
 // ------------------------------------------------------------------------------------------
 // a3+a5: trunk.  x' = x T3 -> relu(conv1) -> pointfeat = h1^T T64 -> relu(conv2) -> relu(conv3)
 // -> conv4 -> max  (pointnet.py:98-116).  512 threads = 8 waves, 1 workgroup per CU.
-// conv3's 512 outputs are produced in two 256-channel chunks so that the LDS image of the
-// conv4 input is 64 KiB; the conv4 accumulators (1024 ch x 64 pts = 128 VGPR per lane over 8
-// waves) stay in registers across both chunks.
+// The whole 64-point x 512-channel conv4 input lives in LDS (128 KiB, XOR-swizzled, no padding) next to
+// the conv3 input (32 KiB): exactly the 160 KiB of a CU.  conv4 is then ONE K=512 sweep per wave
+// (1024 ch x 64 pts = 128 accumulator VGPRs per lane over 8 waves) with no barrier inside.
 // ------------------------------------------------------------------------------------------
-#define TRUNK_SMEM (TP * LD256 + TP * LD128)
+#define TRUNK_SMEM (TP * 512 + TP * 128)
 
 __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ trans64, const float* __restrict__ Wc1,
@@ -272,19 +272,32 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
                                                const float* __restrict__ b3, const f32x4* __restrict__ wp4,
                                                const float* __restrict__ b4, float* __restrict__ pm,
-                                               float* __restrict__ pointfeat, int B, int N, int M) {
+                                               float* __restrict__ pointfeat, int B, int N, int M,
+                                               unsigned long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
-  // phase-1/2 buffers alias the conv3-chunk image a3 (dead before a3 is first written)
+#define TRUNK_STAMP(i)                                                                     \
+  do {                                                                                     \
+    if (trace && lane == 0) trace[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  // phase-1/2 buffers alias the conv4 input image a3 (dead before a3 is first written)
   float* h1 = smem;                      // [64][68]
   float* t64 = smem + TP * LD64;         // [64][64]
   float* pf = smem + TP * LD64 + 4096;   // [64][68]
-  float* a3 = smem;                      // [64][260]
-  float* a2 = smem + TP * LD256;         // [64][132]
+  float* a3 = smem;                      // [64][512] swizzled
+  float* a2 = smem + TP * 512;           // [64][128] swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
   const bool ft = trans64 != nullptr;
+  TRUNK_STAMP(0);
 
+  // conv2 64->128: 4 m-blocks x 2 point blocks over 8 waves.  Its first weight chunks and bias are
+  // requested now, long before they are needed.
+  const int mblk2 = wave >> 1, nb2 = wave & 1;
+  GemmPipe<1, 1, false, false, 8, 4> g2;
+  g2.prefetch(wp2 + (mblk2 * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, mblk2 * 32, lane);
   {
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     }
   }
   __syncthreads();
+  TRUNK_STAMP(1);
   if (ft) {
     if (wave < 4) {  // pointfeat[j][n] = sum_i T64[i][j] h1[i][n]  (pointnet.py:107-109); A operand from LDS
       const int mblk = wave >> 1, nb = wave & 1;
@@ -320,48 +334,78 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   } else {
     pf = h1;
   }
+  TRUNK_STAMP(2);
+  // conv3 128->512: 16 m-blocks, two per wave; request its first weight chunks and bias now
+  GemmPipe<2, 2, false, true, 16, 3, 1> g3;
+  g3.prefetch(wp3 + (wave * 2 * 16) * 64 + lane, 16 * 64);
+  f32x4 bv3[2][4];
+  load_bias_quads<2>(bv3, b3, wave * 64, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  const int pf_row = tid >> 3, pf_c4 = tid & 7;
+  f32x4 pf_out0 = {0.f, 0.f, 0.f, 0.f}, pf_out1 = {0.f, 0.f, 0.f, 0.f};
+  float pf_max = 0.f;
   {
-    // pointfeat tile -> HBM, point-major [cloud points][64], fully coalesced 16 KiB
-    float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
-                                            : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
-    const int row = tid >> 3, c4 = tid & 7;
-    if (row < ti.valid) {
-      f32x4* d = reinterpret_cast<f32x4*>(dstbase + row * 64);
-      const f32x4* s = reinterpret_cast<const f32x4*>(pf + row * LD64);
-      d[c4] = s[c4];
-      d[c4 + 8] = s[c4 + 8];
+    // pointfeat tile -> registers now, -> HBM after the last barrier (a __syncthreads waits for this wave's
+    // outstanding stores, so storing here would park all 8 waves behind a write acknowledge)
+    if (pf_row < ti.valid) {
+      const f32x4* s = reinterpret_cast<const f32x4*>(pf + pf_row * LD64);
+      pf_out0 = s[pf_c4];
+      pf_out1 = s[pf_c4 + 8];
     }
-    if (tid < 64) {  // max_n pointfeat (second half of flat_pcl_feat, CATRE_disR_shared.py:69)
-      float m = pf[tid];
-#pragma unroll 8
-      for (int p = 1; p < TP; ++p) m = fmaxf(m, pf[p * LD64 + tid]);
-      pm[(size_t)blockIdx.x * PMW + 1024 + tid] = m;
+    {  // max_n pointfeat (second half of flat_pcl_feat, CATRE_disR_shared.py:69): wave w reduces points
+       // [8w, 8w+8) for channel `lane`, then 64 threads merge the 8 partials (scratch sits in the still unused
+       // tail of the a3 region; the extra barrier is cheap, all waves arrive together)
+      float* scratch = smem + 2 * TP * LD64 + 4096;  // [8][64]
+      const float* col = pf + (wave * 8) * LD64 + lane;
+      float m = col[0];
+#pragma unroll
+      for (int p = 1; p < 8; ++p) m = fmaxf(m, col[p * LD64]);
+      scratch[wave * 64 + lane] = m;
+      __syncthreads();
+      if (tid < 64) {
+        m = scratch[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, scratch[w * 64 + tid]);
+        pf_max = m;
+      }
     }
-    // conv2 64->128: 4 m-blocks x 2 point blocks over 8 waves
-    const int mblk = wave >> 1, nb = wave & 1;
     f32x16 acc[1][1] = {{zero16()}};
-    gemm_core<1, 1, false, false, 8, 4>(acc, wp2 + (mblk * 8) * 64 + lane, 0, pf + nb * 32 * LD64, LD64, lane);
-    store_tile_lds<1, 1, true>(acc, a2 + nb * 32 * LD128, LD128, mblk * 32, b2, lane);
+    g2.run(acc, pf + nb2 * 32 * LD64, LD64, lane);
+    store_tile_lds_pre<1, 1, true, true>(acc, a2 + nb2 * 32 * 128, 128, mblk2 * 32, bv2, lane);
   }
   __syncthreads();
-
+  TRUNK_STAMP(3);
+  // conv4 512->1024: wave owns out channels [wave*128, +128); first weight chunks + bias requested now
+  GemmPipe<4, 2, true, true, 64, 2, 1> g4;
+  g4.prefetch(wp4 + ((wave * 4) * 64) * 64 + lane, 64 * 64);
+  {
+    f32x16 acc3[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) acc3[mb][0] = acc3[mb][1] = zero16();
+    g3.run(acc3, a2, 128, lane);
+    store_tile_lds_pre<2, 2, true, true>(acc3, a3, 512, wave * 64, bv3, lane);
+    TRUNK_STAMP(4);
+  }
+  __syncthreads();
+  TRUNK_STAMP(5);
+  {  // deferred stores of the pointfeat tile (point-major [cloud points][64], coalesced 16 KiB) and its max
+    float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
+                                            : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
+    if (pf_row < ti.valid) {
+      f32x4* d = reinterpret_cast<f32x4*>(dstbase + pf_row * 64);
+      d[pf_c4] = pf_out0;
+      d[pf_c4 + 8] = pf_out1;
+    }
+    if (tid < 64) pm[(size_t)blockIdx.x * PMW + 1024 + tid] = pf_max;
+  }
   f32x16 acc4[4][2];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    {  // conv3 chunk: out channels [hh*256, +256): 8 m-blocks, one per wave, K = 128
-      const int mblk = hh * 8 + wave;
-      f32x16 acc3[1][2] = {{zero16(), zero16()}};
-      gemm_core<1, 2, false, false, 16, 3>(acc3, wp3 + (mblk * 16) * 64 + lane, 0, a2, LD128, lane);
-      store_tile_lds<1, 2, true>(acc3, a3, LD256, wave * 32, b3 + hh * 256, lane);
-    }
-    __syncthreads();
-    // conv4 partial sum over k in [hh*256, +256): wave owns out channels [wave*128, +128)
-    gemm_core<4, 2, true, false, 32, 1>(acc4, wp4 + ((wave * 4) * 64 + hh * 32) * 64 + lane, 64 * 64, a3, LD256, lane);
-    if (hh == 0) __syncthreads();  // a3 is rewritten by the second chunk
-  }
+  g4.run(acc4, a3, 512, lane);
+  TRUNK_STAMP(6);
   max_tile_store<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, b4, false, lane);
+  TRUNK_STAMP(7);
+#undef TRUNK_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -581,7 +625,7 @@ __device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64
 __device__ __forceinline__ void rot_layer0(f32x16 (&acc)[1][2], const f32x4* __restrict__ wpl0, const float* pf,
                                            int wave, int lane) {
   acc[0][0] = acc[0][1] = zero16();
-  gemm_core<1, 2, false, false, 8, 3>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf, LD64, lane);
+  gemm_core<1, 2, false, false, 8, 2>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf, LD64, lane);
 }
 
 __global__ __launch_bounds__(512) void k_rot_l0_stats(const float* __restrict__ pointfeat,
@@ -901,6 +945,7 @@ struct ProfState {
   hipEvent_t* ev = nullptr;  // 2 per record
 };
 ProfState g_prof;
+unsigned long long* g_trunk_trace = nullptr;  // catre_debug_trunk_trace
 
 struct ProfScope {
   hipStream_t st;
@@ -1050,7 +1095,8 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
     ProfScope ps(CATRE_K_TRUNK, st);
   hipLaunchKernelGGL(k_trunk, dim3(tiles), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W],
                      prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),
-                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M);
+                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
+                     g_trunk_trace);
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
   return check_launch();
@@ -1197,6 +1243,11 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   return CATRE_OK;
 }
 
+
+int catre_debug_trunk_trace(void* device_buffer) {
+  g_trunk_trace = (unsigned long long*)device_buffer;
+  return CATRE_OK;
+}
 
 int catre_profile_enable(int kernel_id, int max_records) {
   for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);

@@ -204,6 +204,10 @@ int catre_profile_enable(int kernel_id, int max_records);
 /* Wait for the recorded events, write per-launch durations (ms) and reset the record counter. */
 int catre_profile_collect(float* ms_out, int max_out, int* n_out);
 
+/* Debug aid: when non-NULL, every k_trunk workgroup writes 8 waves x 8 shader-clock stamps (u64) at its phase
+ * boundaries into `device_buffer` ([tiles][8 waves][8]); NULL disables.  Process-global. */
+int catre_debug_trunk_trace(void* device_buffer);
+
 const char* catre_status_string(int status);
 
 /* Build identification: "catre_hip gfx950 <version>" */
