@@ -232,3 +232,29 @@ __device__ __forceinline__ void max_tile_store(const f32x16 (&acc)[MB][NB], floa
     }
   }
 }
+
+// per-lane bias of a "swapped"-orientation wave tile (lane owns channel ch0 + mb*32 + lane%32)
+template <int MB>
+__device__ __forceinline__ void load_bias_lane(float (&bl)[MB], const float* __restrict__ bias, int ch0, int lane) {
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) bl[mb] = bias[ch0 + mb * 32 + (lane & 31)];
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void max_tile_store_pre(const f32x16 (&acc)[MB][NB], float* __restrict__ out, int ch0,
+                                                   const float (&bl)[MB], bool relu, int lane) {
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float m = acc[mb][0][0];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mb][nb][r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane < 32) {
+      const float v = m + bl[mb];
+      out[ch0 + mb * 32 + lane] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+

@@ -182,28 +182,45 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
 
+  // weights / biases of the first MFMA layer are requested before anything else
+  GemmPipe<1, 2, false, false, 8, 3> g2;
+  g2.prefetch(wp2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
   {  // conv1 3->64 on the VALU: thread = (point, 16-channel group)
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
     conv3_relu_row<16>(x, y, z, W1, b1, wave * 16, a1 + lane * LD64);
   }
   __syncthreads();
+  // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks
+  GemmPipe<4, 2, true, false, 16, 2, 1> g3a, g3b;
+  float bl[2][4];
+  g3a.prefetch(wp3 + ((wave * 8) * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<4>(bl[0], b3, (wave * 8) * 32, lane);
+  load_bias_lane<4>(bl[1], b3, (wave * 8 + 4) * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
   {  // conv2 64->128: wave -> m-block `wave`, both point blocks
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    gemm_core<1, 2, false, false, 8, 3>(acc, wp2 + (wave * 8) * 64 + lane, 0, a1, LD64, lane);
-    store_tile_lds<1, 2, true>(acc, a2, LD128, wave * 32, b2, lane);
+    g2.run(acc, a1, LD64, lane);
+    store_tile_lds_pre<1, 2, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
-  // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks
   float* out = pm + (size_t)blockIdx.x * PMW;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int mblk0 = wave * 8 + pass * 4;
+  {
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_core<4, 2, true, false, 16, 2, 1>(acc, wp3 + (mblk0 * 16) * 64 + lane, 16 * 64, a2, LD128, lane);
-    max_tile_store<4, 2>(acc, out, mblk0 * 32, b3, true, lane);
+    g3a.run(acc, a2, LD128, lane);
+    g3b.prefetch(wp3 + ((wave * 8 + 4) * 16) * 64 + lane, 16 * 64);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+  }
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3b.run(acc, a2, LD128, lane);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -225,6 +242,11 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
 
+  const int mblk1 = wave >> 1, nb1 = wave & 1;
+  GemmPipe<1, 1, false, false, 8, 4> g1;
+  g1.prefetch(wpf1 + (mblk1 * 8) * 64 + lane, 0);
+  f32x4 bv1[1][4];
+  load_bias_quads<1>(bv1, bf1, mblk1 * 32, lane);
   {
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
@@ -232,28 +254,44 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     conv3_relu_row<16>(x, y, z, Wc1, bc1, wave * 16, h1 + lane * LD64);
   }
   __syncthreads();
+  GemmPipe<1, 2, false, false, 8, 3> g2;
+  g2.prefetch(wpf2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, bf2, wave * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
   {  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks, one per wave
-    const int mblk = wave >> 1, nb = wave & 1;
     f32x16 acc[1][1] = {{zero16()}};
-    gemm_core<1, 1, false, false, 8, 4>(acc, wpf1 + (mblk * 8) * 64 + lane, 0, h1 + nb * 32 * LD64, LD64, lane);
-    store_tile_lds<1, 1, true>(acc, f1 + nb * 32 * LD64, LD64, mblk * 32, bf1, lane);
+    g1.run(acc, h1 + nb1 * 32 * LD64, LD64, lane);
+    store_tile_lds_pre<1, 1, true, false>(acc, f1 + nb1 * 32 * LD64, LD64, mblk1 * 32, bv1, lane);
   }
   __syncthreads();
+  GemmPipe<4, 2, true, false, 16, 2, 1> g3a, g3b;
+  float bl[2][4];
+  g3a.prefetch(wpf3 + ((wave * 8) * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<4>(bl[0], bf3, (wave * 8) * 32, lane);
+  load_bias_lane<4>(bl[1], bf3, (wave * 8 + 4) * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
   {  // fstn.conv2 64->128
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    gemm_core<1, 2, false, false, 8, 3>(acc, wpf2 + (wave * 8) * 64 + lane, 0, f1, LD64, lane);
-    store_tile_lds<1, 2, true>(acc, f2, LD128, wave * 32, bf2, lane);
+    g2.run(acc, f1, LD64, lane);
+    store_tile_lds_pre<1, 2, true, false>(acc, f2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
   float* out = pm + (size_t)blockIdx.x * PMW;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {  // fstn.conv3 128->1024 + max
-    const int mblk0 = wave * 8 + pass * 4;
+  {  // fstn.conv3 128->1024 + max, two passes of 4 m-blocks
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-    gemm_core<4, 2, true, false, 16, 2, 1>(acc, wpf3 + (mblk0 * 16) * 64 + lane, 16 * 64, f2, LD128, lane);
-    max_tile_store<4, 2>(acc, out, mblk0 * 32, bf3, true, lane);
+    g3a.run(acc, f2, LD128, lane);
+    g3b.prefetch(wpf3 + ((wave * 8 + 4) * 16) * 64 + lane, 16 * 64);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+  }
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3b.run(acc, f2, LD128, lane);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -378,6 +416,9 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   // conv4 512->1024: wave owns out channels [wave*128, +128); first weight chunks + bias requested now
   GemmPipe<4, 2, true, true, 64, 2, 1> g4;
   g4.prefetch(wp4 + ((wave * 4) * 64) * 64 + lane, 64 * 64);
+  float bl4[4];
+  load_bias_lane<4>(bl4, b4, wave * 128, lane);
+  __builtin_amdgcn_sched_barrier(0);
   {
     f32x16 acc3[2][2];
 #pragma unroll
@@ -403,7 +444,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   for (int mb = 0; mb < 4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
   g4.run(acc4, a3, 512, lane);
   TRUNK_STAMP(6);
-  max_tile_store<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, b4, false, lane);
+  max_tile_store_pre<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, bl4, false, lane);
   TRUNK_STAMP(7);
 #undef TRUNK_STAMP
 }
@@ -428,30 +469,50 @@ __global__ void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ ou
 // generic y = act(x W^T + b) (+ I_k): one wave per 32x32 output block, operands straight from
 // L2 (F.linear in pointnet.py:31-33,64-66 and the global-feature half of RotHead layer 0).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_linear(const float* __restrict__ X, int ldx, const float* __restrict__ W,
-                                               int ldw, const float* __restrict__ bias, float* __restrict__ Y,
-                                               int ldy, int R, int J, int K, int relu, int iden_k) {
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                int ldw, const float* __restrict__ bias, float* __restrict__ Y,
+                                                int ldy, int R, int J, int K, int relu, int iden_k) {
+  // 4 waves split K (interleaved 8-wide chunks), each with 4 loads in flight; partial 32x32 blocks are
+  // summed through LDS in wave order (deterministic).
+  __shared__ float part[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = min((int)blockIdx.x * 32 + i, R - 1), j = min((int)blockIdx.y * 32 + i, J - 1);
   const f32x4* xa = reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + 4 * h);
   const f32x4* wb = reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + 4 * h);
   f32x16 acc = zero16();
   const int nkc = K / 8;
-#pragma unroll 4
-  for (int kc = 0; kc < nkc; ++kc) {
+  int kc = wave;
+  for (; kc + 12 < nkc; kc += 16) {  // 4 chunks of this wave per trip
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = xa[(kc + 4 * u) * 2];
+      b[u] = wb[(kc + 4 * u) * 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);  // D[row r][col j]
+  }
+  for (; kc < nkc; kc += 4) {
     const f32x4 a = xa[kc * 2], b = wb[kc * 2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);  // D[row r][col j]
+    for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
   }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) part[wave][reg][lane] = acc[reg];
+  __syncthreads();
   const int col = blockIdx.y * 32 + i;
   if (col >= J) return;
   const float bv = bias ? bias[col] : 0.f;
   const float idv = (iden_k > 0 && col < iden_k * iden_k && (col % (iden_k + 1)) == 0) ? 1.f : 0.f;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+  for (int q = 0; q < 4; ++q) {  // wave w finishes registers 4w..4w+3 -> rows 8w + q + 4h
+    const int reg = wave * 4 + q;
+    const int row = blockIdx.x * 32 + q + 8 * wave + 4 * h;
     if (row < R) {
-      float v = acc[reg] + bv;
+      float v = ((part[0][reg][lane] + part[1][reg][lane]) + part[2][reg][lane]) + part[3][reg][lane] + bv;
       if (relu) v = fmaxf(v, 0.f);
       Y[(size_t)row * ldy + col] = v + idv;
     }
@@ -482,7 +543,7 @@ __device__ __forceinline__ float group8_norm_gelu(float v, float gamma, float be
   return gelu_erf(fmaf(v, sc, beta - mean * sc));
 }
 
-__global__ __launch_bounds__(256) void k_ts_head(const float* __restrict__ gfeat, const float* __restrict__ pose,
+__global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfeat, const float* __restrict__ pose,
                                                  const float* __restrict__ scale, const float* __restrict__ W0T,
                                                  const float* __restrict__ b0, const float* __restrict__ g0,
                                                  const float* __restrict__ be0, const float* __restrict__ W1T,
@@ -493,13 +554,15 @@ __global__ __launch_bounds__(256) void k_ts_head(const float* __restrict__ gfeat
                                                  float* __restrict__ ds, int B, int in_dim, int with_kps,
                                                  int with_scale, int with_trans) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* feat = sm;                    // [TS_OB][in_dim]
-  float* hbuf = sm + TS_OB * in_dim;   // [TS_OB][256]
-  const int tid = threadIdx.x;
+  float* feat = sm;                          // [TS_OB][in_dim]
+  float* hbuf = sm + TS_OB * in_dim;         // [TS_OB][256]
+  float* kpart = hbuf + TS_OB * 256;         // [4][TS_OB][256] K-slice partial sums
+  // 1024 threads: 4 K-slices x 256 output channels; slice partials are merged in slice order
+  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
   const int b0i = blockIdx.x * TS_OB;
   for (int o = 0; o < TS_OB; ++o) {
     const int b = min(b0i + o, B - 1);
-    for (int k = tid; k < in_dim; k += 256) {
+    for (int k = threadIdx.x; k < in_dim; k += 1024) {
       int kk = k;
       float v;
       if (kk < PMW) {
@@ -523,35 +586,54 @@ __global__ __launch_bounds__(256) void k_ts_head(const float* __restrict__ gfeat
   }
   __syncthreads();
   float acc[TS_OB];
-#pragma unroll
-  for (int o = 0; o < TS_OB; ++o) acc[o] = b0[tid];
-#pragma unroll 4
-  for (int k = 0; k < in_dim; ++k) {
-    const float w = W0T[(size_t)k * 256 + tid];
-#pragma unroll
-    for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * in_dim + k], w, acc[o]);
-  }
   {
-    const float ga = g0[tid], be = be0[tid];
+    const int k0 = (in_dim * ks) / 4, k1 = (in_dim * (ks + 1)) / 4;
 #pragma unroll
-    for (int o = 0; o < TS_OB; ++o) hbuf[o * 256 + tid] = group8_norm_gelu(acc[o], ga, be);
+    for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+      const float w = W0T[(size_t)k * 256 + tid];
+#pragma unroll
+      for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * in_dim + k], w, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) kpart[(ks * TS_OB + o) * 256 + tid] = acc[o];
   }
   __syncthreads();
+  if (ks == 0) {
+    const float ga = g0[tid], be = be0[tid], bb = b0[tid];
 #pragma unroll
-  for (int o = 0; o < TS_OB; ++o) acc[o] = b1[tid];
-#pragma unroll 4
-  for (int k = 0; k < 256; ++k) {
-    const float w = W1T[k * 256 + tid];
-#pragma unroll
-    for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(hbuf[o * 256 + k], w, acc[o]);
+    for (int o = 0; o < TS_OB; ++o) {
+      const float v = bb + (((kpart[o * 256 + tid] + kpart[(TS_OB + o) * 256 + tid]) +
+                             kpart[(2 * TS_OB + o) * 256 + tid]) + kpart[(3 * TS_OB + o) * 256 + tid]);
+      hbuf[o * 256 + tid] = group8_norm_gelu(v, ga, be);
+    }
   }
   __syncthreads();
   {
-    const float ga = g1[tid], be = be1[tid];
 #pragma unroll
-    for (int o = 0; o < TS_OB; ++o) hbuf[o * 256 + tid] = group8_norm_gelu(acc[o], ga, be);
+    for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
+#pragma unroll 4
+    for (int k = ks * 64; k < ks * 64 + 64; ++k) {
+      const float w = W1T[k * 256 + tid];
+#pragma unroll
+      for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(hbuf[o * 256 + k], w, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) kpart[(ks * TS_OB + o) * 256 + tid] = acc[o];
   }
   __syncthreads();
+  if (ks == 0) {
+    const float ga = g1[tid], be = be1[tid], bb = b1[tid];
+#pragma unroll
+    for (int o = 0; o < TS_OB; ++o) {
+      const float v = bb + (((kpart[o * 256 + tid] + kpart[(TS_OB + o) * 256 + tid]) +
+                             kpart[(2 * TS_OB + o) * 256 + tid]) + kpart[(3 * TS_OB + o) * 256 + tid]);
+      hbuf[o * 256 + tid] = group8_norm_gelu(v, ga, be);
+    }
+  }
+  __syncthreads();
+  if (ks != 0) return;
   if (tid < TS_OB * 6) {
     const int o = tid / 6, c = tid % 6;
     const int b = b0i + o;
@@ -926,11 +1008,11 @@ inline const f32x4* pk4(const float* packed, size_t off) { return reinterpret_ca
 int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
                 float* out, int k, int R, hipStream_t st) {
   // relu(fc1) -> relu(fc2) -> fc3 + I_k   (pointnet.py:31-40 / 64-77)
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(64), 0, st, pooled, 1024, prm[base], 1024,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(256), 0, st, pooled, 1024, prm[base], 1024,
                      prm[base + 1], h1, 512, R, 512, 1024, 1, 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(64), 0, st, h1, 512, prm[base + 2], 512,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(256), 0, st, h1, 512, prm[base + 2], 512,
                      prm[base + 3], h2, 256, R, 256, 512, 1, 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(64), 0, st, h2, 256, prm[base + 4], 256,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(256), 0, st, h2, 256, prm[base + 4], 256,
                      prm[base + 5], out, k * k, R, k * k, 256, 0, k);
   return check_launch();
 }
@@ -1057,7 +1139,7 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
 int catre_linear(const float* x, int ldx, const float* Wt, int ldw, const float* bias, float* y, int ldy, int R, int J,
                  int K, int relu, int add_identity_k, void* stream) {
   REQUIRE(x && Wt && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(64), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
                      bias, y, ldy, R, J, K, relu, add_identity_k);
   return check_launch();
 }
@@ -1109,11 +1191,11 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
   const int expect = PMW * (o->with_kps_feature ? 2 : 1) + (o->with_init_scale ? 3 : 0) + (o->with_init_trans ? 3 : 0);
   if (o->ts_in_dim != expect) return CATRE_ERR_BAD_ARG;
   const PackLayout L = pack_layout(o->ts_in_dim);
-  const size_t smem = (size_t)TS_OB * (o->ts_in_dim + 256) * sizeof(float);
+  const size_t smem = (size_t)TS_OB * (o->ts_in_dim + 256 + 4 * 256) * sizeof(float);
   if (smem > 64 * 1024) return CATRE_ERR_UNSUPPORTED;
   {
     ProfScope ps(CATRE_K_TS_HEAD, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_ts_head, dim3((B + TS_OB - 1) / TS_OB), dim3(256), smem, (hipStream_t)stream, gfeat, init_pose,
+  hipLaunchKernelGGL(k_ts_head, dim3((B + TS_OB - 1) / TS_OB), dim3(1024), smem, (hipStream_t)stream, gfeat, init_pose,
                      init_scale, packed + L.ts_w0t, prm[CATRE_P_TS_L0_B], prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B],
                      packed + L.ts_w1t, prm[CATRE_P_TS_L1_B], prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B],
                      prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B], prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B],
@@ -1131,7 +1213,7 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   // global-feature half of layer 0 for every cloud: bias0[hd][cloud][:] = W0[:, :1024] g_cloud + b0
   for (int hd = 0; hd < 2; ++hd) {
     const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
-    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64), 0, st, gfeat, PMW, prm[base], PMW,
+    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(256), 0, st, gfeat, PMW, prm[base], PMW,
                        prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
   }
   {
