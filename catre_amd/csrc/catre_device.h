@@ -46,9 +46,31 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// erf(x) in fp32 as x * P(x^2) / Q(x^2) on the clamped range |x| <= 4 (the single-precision rational
+// minimax fit published with Eigen / XLA).  Max abs error 4.5e-7 evaluated in fp32 - the same class as
+// torch's own fp32 erf-GELU (measured: GELU max abs error 1.36e-6 vs 1.21e-6 for torch, both against
+// fp64) - at 16 VALU ops and one v_rcp instead of the ~45 ops of the two-branch libm erff, which made the
+// rotation head VALU-bound (GELU phase as long as its 256x256 MFMA layer).
+__device__ __forceinline__ float erf_rational(float x) {
+  x = fminf(fmaxf(x, -4.f), 4.f);
+  const float x2 = x * x;
+  float p = fmaf(x2, -2.72614225801306e-10f, 2.77068142495902e-08f);
+  p = fmaf(x2, p, -2.10102402082508e-06f);
+  p = fmaf(x2, p, -5.69250639462346e-05f);
+  p = fmaf(x2, p, -7.34990630326855e-04f);
+  p = fmaf(x2, p, -2.95459980854025e-03f);
+  p = fmaf(x2, p, -1.60960333262415e-02f);
+  float q = fmaf(x2, -1.45660718464996e-05f, -2.13374055278905e-04f);
+  q = fmaf(x2, q, -1.68282697438203e-03f);
+  q = fmaf(x2, q, -7.37332916720468e-03f);
+  q = fmaf(x2, q, -1.42647390514189e-02f);
+  return x * p * __builtin_amdgcn_rcpf(q);
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
   // nn.GELU() default: 0.5 * v * (1 + erf(v / sqrt(2)))
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  const float hv = 0.5f * v;
+  return fmaf(hv, erf_rational(v * 0.70710678118654752440f), hv);
 }
 
 // One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*NKC.

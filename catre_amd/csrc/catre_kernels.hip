@@ -953,7 +953,7 @@ PackLayout pack_layout(int ts_in) {
 }
 
 struct WsLayout {
-  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, gn0stat, gn1stat, y1, rpart,
+  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, aff0, gn1stat, y1, rpart,
       total;  // offsets in floats
 };
 
@@ -983,7 +983,7 @@ WsLayout ws_layout(int B, int N, int M) {
   L.bias0 = take(2 * 2 * b * 256);
   L.gn0 = take(b * 2 * T * 64);
   L.gn1 = take(b * 2 * T * 64);
-  L.gn0stat = take(b * 2 * 64);
+  L.aff0 = take(b * 2 * 2 * 2 * 256);
   L.gn1stat = take(b * 2 * 64);
   L.y1 = take(b * 2 * P * 256);
   L.rpart = take(b * 2 * T * 4);
@@ -1221,14 +1221,14 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   hipLaunchKernelGGL(k_rot_l0_stats, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
                      pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, B, N, M);
   }
-  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn0, ws + W.gn0stat, N, M);
+  hipLaunchKernelGGL(k_gn0_affine, dim3(B * 2), dim3(256), 0, st, ws + W.gn0, bias0, prm[CATRE_P_ROTX_GN0_W],
+                     prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
     hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                       pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0stat, prm[CATRE_P_ROTX_GN0_W],
-                       prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B],
-                       pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]), prm[CATRE_P_ROTX_L1_B],
-                       prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M);
+                       pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),
+                       prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
+                       g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
   }
   hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
   {

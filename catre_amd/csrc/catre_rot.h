@@ -23,6 +23,35 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ pa
   stat[((size_t)blockIdx.x * 32 + g) * 2 + 1] = rstd;
 }
 
+// GN0 statistics -> per-channel affine of the fused "bias + GroupNorm" that follows rot-head layer 0:
+//   gelu_in = (acc + bias0[cloud][ch]) * sc + (beta - mean*sc) = acc * sc + sh,   sc = rstd * gamma
+// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256].  One block of 256 threads per (object, head).
+__global__ __launch_bounds__(256) void k_gn0_affine(const float* __restrict__ part, const float* __restrict__ bias0,
+                                                    const float* __restrict__ gamx, const float* __restrict__ betx,
+                                                    const float* __restrict__ gamy, const float* __restrict__ bety,
+                                                    float* __restrict__ aff, int B, int N, int M) {
+  __shared__ float st[64];
+  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
+  const int obj = blockIdx.x >> 1, hd = blockIdx.x & 1, ch = threadIdx.x;
+  if (ch < 32) {
+    float mean, rstd;
+    merge_gn(part + (size_t)blockIdx.x * T * 64, ch, T, TN, N, M, mean, rstd);
+    st[ch * 2] = mean;
+    st[ch * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  const float mean = st[(ch >> 3) * 2], rstd = st[(ch >> 3) * 2 + 1];
+  const float sc = rstd * (hd ? gamy : gamx)[ch];
+  const float sh0 = (hd ? bety : betx)[ch] - mean * sc;
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    const float b0 = bias0[((size_t)hd * 2 * B + (cl ? B + obj : obj)) * 256 + ch];
+    float* o = aff + (((size_t)blockIdx.x * 2 + cl) * 2) * 256;
+    o[ch] = sc;
+    o[256 + ch] = fmaf(b0, sc, sh0);
+  }
+}
+
 __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ pointfeat, const RotTile& rt, float* pf,
                                                  int tid) {
   // 256 threads: 64 rows x 4 lanes x 4 float4 (16 chunks per row)
@@ -37,15 +66,20 @@ __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ point
 }
 
 __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
-                                                   const f32x4* __restrict__ wpl0y, const float* __restrict__ bias0,
-                                                   const float* __restrict__ gn0stat /*[B][2][32][2]*/,
-                                                   const float* __restrict__ gam0x, const float* __restrict__ bet0x,
-                                                   const float* __restrict__ gam0y, const float* __restrict__ bet0y,
+                                                   const f32x4* __restrict__ wpl0y,
+                                                   const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
                                                    const f32x4* __restrict__ wpl1x, const f32x4* __restrict__ wpl1y,
                                                    const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                    float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
-                                                   int M) {
+                                                   int M, unsigned long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
+  int stamp_i = 0;
+#define ROT_STAMP()                                                                                      \
+  do {                                                                                                   \
+    if (trace && (threadIdx.x & 63) == 0)                                                                \
+      trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + stamp_i] = __builtin_readcyclecounter(); \
+    ++stamp_i;                                                                                           \
+  } while (0)
   float* pf = smem;            // [64][64]  swizzled
   float* a0 = smem + TP * 64;  // [64][256] swizzled
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,49 +87,60 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
   const RotTile rt = rot_tile(blockIdx.x, B, N, M);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   const int P = N + M;
+  ROT_STAMP();
   load_pf_tile_swz(pointfeat, rt, pf, tid);
   __syncthreads();
+  ROT_STAMP();
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll 1
   for (int hd = 0; hd < 2; ++hd) {
     {
-      // layer 0 recompute: wave -> channels [wave*64, +64), "normal" orientation
+      // layer 0 recompute: wave -> channels [wave*64, +64), "normal" orientation.  The fused bias+GN affine
+      // of this (object, head, cloud) is requested before the GEMM so the epilogue never waits on HBM/L2.
+      const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
+      // epilogue step i = (mb, g) = (i >> 2, i & 3) needs the sc/sh quads of channels mb*32 + 8g + 4h ..+3; a ring of
+      // three keeps two steps in flight (the first two are requested before the GEMM)
+      f32x4 scr[3], shr[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
+        shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
       gemm_core<2, 2, false, true, 8, 2>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane);
-      const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256;
-      const float* gam = hd ? gam0y : gam0x;
-      const float* bet = hd ? bet0y : bet0x;
-      const float* st = gn0stat + ((size_t)rt.obj * 2 + hd) * 64;
+      ROT_STAMP();
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + c);
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(gam + c);
-          const f32x4 ev = *reinterpret_cast<const f32x4*>(bet + c);
-          const float mean = st[(c >> 3) * 2], rstd = st[(c >> 3) * 2 + 1];
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            f32x4 z;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float sc = rstd * gv[q];
-              z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q] + bv[q], sc, ev[q] - mean * sc));
-            }
-            *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
-          }
+      for (int i = 0; i < 8; ++i) {
+        const int mb = i >> 2, g = i & 3;
+        if (i + 2 < 8) {
+          const int j = i + 2;
+          scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
+          shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x4 z;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q], scr[i % 3][q], shr[i % 3][q]));
+          *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
+        }
+      }
     }
+    ROT_STAMP();
     __syncthreads();
+    ROT_STAMP();
     {
       // layer 1 (256->256), "swapped": lane owns channels wave*64 + mb*32 + n and 32 of the tile's points
       f32x16 acc[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
       gemm_core<2, 2, true, true, 32, 2>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane);
+      ROT_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
@@ -103,18 +148,31 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
         const float bb = (hd ? b1y : b1x)[ch];
         float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
+        if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
+          float* dh = dst + (size_t)(4 * h) * 256;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = acc[mb][nb][r] + bb;
-            acc[mb][nb][r] = v;
-            if (pt < rt.valid) {
-              dst[(size_t)pt * 256] = v;
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mb][nb][r] + bb;
+              acc[mb][nb][r] = v;
+              dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
               s += v;
             }
-          }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              const float v = acc[mb][nb][r] + bb;
+              acc[mb][nb][r] = v;
+              if (pt < rt.valid) {
+                dst[(size_t)pt * 256] = v;
+                s += v;
+              }
+            }
+        }
         // GN group = 8 consecutive channels = 8 consecutive lanes, both half-waves
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
@@ -141,8 +199,11 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
         }
       }
     }
+    ROT_STAMP();
     __syncthreads();  // a0 is rewritten for the second head
+    ROT_STAMP();
   }
+#undef ROT_STAMP
 }
 
 // GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
