@@ -129,6 +129,10 @@ CASES = {
     "refine_b2_allo": (2, 256, 256, 2, 6, 0, None, {"MODEL.CATRE.ROT_HEAD.ROT_TYPE": "allo_rot6d"}),
     "refine_b2_norefscale_nozc": (2, 256, 256, 2, 7, 0, None, {
         "MODEL.REFINE_SCLAE": False, "INPUT.ZERO_CENTER_INPUT": False}),
+    # BASELINE.json config 5 shape (N=2048 observed, M=1024 prior, K=8 deep iteration), fp32
+    "refine_b1_n2048_k8": (1, 2048, 1024, 8, 9, 0, None, {}),
+    # PointNet without the feature transform (PCLNET.INIT_CFG.feature_transform=False, pointnet.py:105)
+    "refine_b2_noft": (2, 192, 128, 2, 10, 0, None, {"MODEL.CATRE.PCLNET.INIT_CFG.feature_transform": False}),
     "refine_b2_kpsfeat_trans": (2, 256, 256, 2, 8, 0, None, {
         "MODEL.CATRE.TS_HEAD.WITH_KPS_FEATURE": True, "MODEL.CATRE.TS_HEAD.WITH_INIT_TRANS": True,
         "MODEL.CATRE.TS_HEAD.INIT_CFG.in_dim": 1088 * 2 + 3 + 3}),

@@ -100,6 +100,7 @@ def test_stages_match_oracle_and_goldens(name):
 
     # a2..a6 PointNet stages
     st = rt.stage_pointnet(x, tfd, True)
+    assert model.pcl_net.feature_transform
     with torch.no_grad():
         _, dx = O.pointnet_feat(ox, sd, detail=True)
         _, dk = O.pointnet_feat(ok, sd, detail=True)

@@ -35,6 +35,9 @@ def test_oracle_matches_reference_outputs(name):
         "stage_scale_deltas": d["scale_deltas"],
     }
     for k, v in pairs.items():
+        if v is None:  # no feature transform in this config
+            assert k not in ref
+            continue
         np.testing.assert_allclose(v.numpy(), ref[k], atol=5e-6, rtol=1e-5, err_msg=k)
 
 
