@@ -279,3 +279,50 @@ def test_errors():
     from catre_amd.CATRE_disR_shared import build_model_optimizer
     with pytest.raises(NotImplementedError):
         build_model_optimizer(cfg, is_test=True)
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (5, 63, 65), (3, 64, 64), (2, 129, 1), (7, 130, 257), (4, 2, 300)])
+def test_ragged_shapes_match_oracle(B, N, M):
+    """Edge shapes: single points, tile boundaries +-1, tails in both clouds, B not a multiple of anything."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+    from oracle import catre_oracle as O
+
+    K = 2
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=K, device=DEV)
+    model, sd = build_model(cfg, 3)
+    batch = synth.make_inputs(B, N, M, seed=40 + B)
+    out = model.refine(to_dev(batch), n_iter=K)
+    cfg_cpu = default_cfg(num_pcl=N, num_kps=M, n_iter=K, device="cpu")
+    with torch.no_grad():
+        want = O.refine_k(batch, sd, cfg_cpu, n_iter=K)
+    for i in range(1, K + 1):
+        assert (out[f"pose_{i}"].cpu() - want[f"pose_{i}"]).abs().max() <= TIGHT, (B, N, M, i)
+        assert (out[f"scale_{i}"].cpu() - want[f"scale_{i}"]).abs().max() <= TIGHT, (B, N, M, i)
+
+
+def test_input_layouts_and_streams():
+    """The module takes x / tfd_kps with ANY strides (contiguous [B,3,N], the reference's permuted view, a
+    sliced view) and runs on whatever stream is current."""
+    g = load_golden("refine_b2_small")
+    model, _ = build_model(g["cfg"], g["salt"])
+    b = to_dev(g["batch"])
+    from catre_amd.batching import batch_updater_test
+
+    batch_updater_test(model.cfg, b)
+    kw = dict(init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"], mean_scales=b["obj_mean_scales"])
+    with torch.no_grad():
+        ref = model(b["x"], b["tfd_kps"], cur_iter=1, **kw)["pose_1"]
+        xc, kc = b["x"].contiguous(), b["tfd_kps"].contiguous()
+        assert xc.stride() != b["x"].stride()
+        assert torch.equal(model(xc, kc, cur_iter=1, **kw)["pose_1"], ref)
+        big = torch.zeros(2, 3, 2 * g["N"] + 5, device=DEV)
+        big[:, :, 3:3 + 2 * g["N"]:2] = b["x"]
+        xs = big[:, :, 3:3 + 2 * g["N"]:2]  # point stride 2
+        assert torch.equal(model(xs, kc, cur_iter=1, **kw)["pose_1"], ref)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            alt = model(b["x"], b["tfd_kps"], cur_iter=1, **kw)["pose_1"]
+        s.synchronize()
+        assert torch.equal(alt, ref)
+    assert np.abs(ref.cpu().numpy() - g["ref"]["pose_1"]).max() <= TIGHT
