@@ -913,6 +913,8 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
   }
 }
 
+#include "catre_train.h"
+
 // ==========================================================================================
 // host side: packed-weight and workspace layouts, launchers, C ABI
 // ==========================================================================================
@@ -1367,5 +1369,7 @@ int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream) 
   }
   return check_launch();
 }
+
+#include "catre_train_api.inc"
 
 }  // extern "C"

@@ -1,0 +1,693 @@
+// catre_train.h - building blocks of the TRAINING path (forward with saved activations + backward).
+//
+// Round-1 design: correctness and coverage first.  Training runs the layers UNFUSED on point-major
+// activation matrices [rows = points of all clouds, channels] in HBM (288 GB makes the ~10 GB of saved
+// activations at B=256 a non-issue); every op below has a hand-written forward and backward kernel and is
+// chained by torch.autograd (catre_amd/train_ops.py).  The fused inference kernels are untouched.
+//
+//   gemm_rows : Y[R,J]  = act(X[R,K] W^T + b) (* mask)     MFMA, 64-row tiles, X chunk in LDS, packed W from L2
+//               (also the data-gradient GEMM: dX = dY W with W packed transposed, mask = ReLU mask)
+//   gemm_tn   : dW[J,K] = dY[R,J]^T X[R,K]                 MFMA, 128x128 tiles, rows split over workgroups,
+//               deterministic two-stage reduction
+//   the rest  : column sums, per-cloud bias, max-pool with argmax (+ sparse gather/scatter backward),
+//               per-cloud 3x3 / 64x64 transforms, GroupNorm over points / rows, GELU, conv_p weighted sum,
+//               rot6d + pose-update backward.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// weight packing for gemm_rows: logical matrix Wl[J][K]; transpose=1 reads Wl[j][k] = src[k*ld + j]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, int transpose, float* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= J * K) return;
+  const int s = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+  const int nkc = K / 8;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 8 + 4 * (lane >> 5) + s;
+  dst[idx] = transpose ? src[(size_t)col * ld + row] : src[(size_t)row * ld + col];
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
+// wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "normal" orientation: 4 consecutive channels/lane.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NKC>
+__global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
+                                                   const float* __restrict__ bias, const float* __restrict__ mask,
+                                                   int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
+                                                   int relu) {
+  constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
+  constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
+  __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * TP;
+  const int nblk = J / 32, nkc_total = K / 8, nchunks = K / KC;
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+  const bool active = wave < nblk;  // waves beyond the channel count only help staging
+  for (int c = 0; c < nchunks; ++c) {
+    if (c) __syncthreads();
+    // stage X[r0..r0+64, c*KC .. +KC) : coalesced float4 along K, swizzled rows
+    constexpr int F4 = KC / 4;
+    for (int i = tid; i < TP * F4; i += 512) {
+      const int row = i / F4, ch = i % F4;
+      const int gr = min(r0 + row, R - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+      *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v;
+    }
+    __syncthreads();
+    if (active) {
+      // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
+      GemmPipe<MB, 2, false, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
+      // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
+      g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
+      g.run(acc, xs, LDX, lane);
+    }
+  }
+  if (!active) return;
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int blk = wave + 8 * mb;
+    if (blk >= nblk) break;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = blk * 32 + 8 * g + 4 * h;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int r = r0 + nb * 32 + n;
+        if (r < R) {
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float t = acc[mb][nb][4 * g + q] + bv[q];
+            v[q] = relu ? fmaxf(t, 0.f) : t;
+          }
+          if (mask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (size_t)r * ldm + ch);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(Y + (size_t)r * ldy + ch) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: dW[J,K] = sum_r dY[r,J]^T X[r,K] over rows [row_lo, row_hi) of this split.
+// 512 threads, 128x128 output tile: wave w -> j-block w>>1 (of 4), k-blocks {2(w&1), 2(w&1)+1}.
+// 32-row slabs are staged transposed in LDS ([col][row], row contiguous, +4 skew) so both MFMA fragments
+// are 16-byte reads along the contraction (row) index.  Partials go to part[split][J*K].
+// ------------------------------------------------------------------------------------------------
+#define TN_LD 36  // 32 rows + 4 skew
+__global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                 int ldx, float* __restrict__ part, int J, int K, int R,
+                                                 int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float ys[128 * TN_LD];
+  __shared__ __attribute__((aligned(16))) float xsT[128 * TN_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int row_lo = blockIdx.z * rows_per_split, row_hi = min(R, row_lo + rows_per_split);
+  const int jb = wave >> 1, kb0 = 2 * (wave & 1);
+  f32x16 acc[2] = {zero16(), zero16()};
+  const int i = lane & 31, h = lane >> 5;
+  for (int rs = row_lo; rs < row_hi; rs += 32) {
+    __syncthreads();
+    // stage 32 rows x 128 cols of each operand, transposed
+    for (int e = tid; e < 32 * 32; e += 512) {
+      const int row = e >> 5, c4 = e & 31;  // c4: float4 column index
+      const int gr = rs + row;
+      f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (gr < row_hi) {
+        const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
+        if (jc < J) vy = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+        if (kc < K) vx = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ys[(c4 * 4 + q) * TN_LD + row] = vy[q];
+        xsT[(c4 * 4 + q) * TN_LD + row] = vx[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 rows
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ys + (jb * 32 + i) * TN_LD + c * 8 + 4 * h);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xsT + ((kb0 + kb) * 32 + i) * TN_LD + c * 8 + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[kb] = mfma32(a[s], b[s], acc[kb]);  // D[j][k]
+      }
+    }
+  }
+  // D[row = j][col = k]: lane holds col k = lane&31, rows (reg&3)+8(reg>>2)+4h
+  float* out = part + (size_t)blockIdx.z * J * K;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = k0 + (kb0 + kb) * 32 + i;
+    if (k >= K) continue;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int j = j0 + jb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (j < J) out[(size_t)j * K + k] = acc[kb][reg];
+    }
+  }
+}
+
+// out[i] = sum_s part[s][i]  (fixed order: deterministic)
+__global__ void k_reduce_splits(const float* __restrict__ part, float* __restrict__ out, int n, int splits,
+                                int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// column sums: part[split][J] = sum over rows of the split of dY[r][j]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
+                                                int J, int rows_per_split) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int lo = blockIdx.y * rows_per_split, hi = min(R, lo + rows_per_split);
+  if (j >= J) return;
+  float s = 0.f;
+  for (int r = lo; r < hi; ++r) s += dY[(size_t)r * ld + j];
+  part[(size_t)blockIdx.y * J + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cloud layout helper: rows of all observed clouds first (B*N), then all prior clouds (B*M)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cloud_of_row(int r, int B, int N, int M) { return r < B * N ? r / N : B + (r - B * N) / M; }
+__device__ __forceinline__ void cloud_rows(int c, int B, int N, int M, int& r0, int& n) {
+  if (c < B) {
+    r0 = c * N;
+    n = N;
+  } else {
+    r0 = B * N + (c - B) * M;
+    n = M;
+  }
+}
+
+// Y[r][j] (+)= bias[cloud(r)][j]   (rot-head layer 0: global-feature half as a per-cloud bias)
+__global__ void k_rowbias_add(float* __restrict__ Y, int ld, const float* __restrict__ bias, int R, int J, int B, int N,
+                              int M) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)R * (J / 4)) return;
+  const int r = idx / (J / 4), j4 = idx % (J / 4);
+  // rows here are ordered per OBJECT ([obs N | prior M] per object): cloud = obs or prior of object r / (N+M)
+  const int obj = r / (N + M), p = r % (N + M);
+  const int c = p < N ? obj : B + obj;
+  f32x4* y = reinterpret_cast<f32x4*>(Y + (size_t)r * ld) + j4;
+  const f32x4 b = *(reinterpret_cast<const f32x4*>(bias + (size_t)c * J) + j4);
+  f32x4 v = *y;
+  v[0] += b[0];
+  v[1] += b[1];
+  v[2] += b[2];
+  v[3] += b[3];
+  *y = v;
+}
+
+// dbias[c][j] = sum over the rows of cloud c (object-major row order as above) of dY[r][j]
+__global__ __launch_bounds__(256) void k_rowbias_bwd(const float* __restrict__ dY, int ld, float* __restrict__ dbias,
+                                                     int J, int B, int N, int M) {
+  const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= J) return;
+  const int obj = c < B ? c : c - B;
+  const int r0 = obj * (N + M) + (c < B ? 0 : N), n = c < B ? N : M;
+  float s = 0.f;
+  for (int r = 0; r < n; ++r) s += dY[(size_t)(r0 + r) * ld + j];
+  dbias[(size_t)c * J + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool over the points of each cloud with argmax (cloud-major rows), and its sparse backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ Y, int ld, float* __restrict__ out,
+                                                     int* __restrict__ idx, int J, int B, int N, int M) {
+  const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= J) return;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  float m = Y[(size_t)r0 * ld + j];
+  int am = 0;
+  for (int r = 1; r < n; ++r) {
+    const float v = Y[(size_t)(r0 + r) * ld + j];
+    if (v > m) {  // first maximum wins, like torch.max
+      m = v;
+      am = r;
+    }
+  }
+  out[(size_t)c * J + j] = m;
+  idx[(size_t)c * J + j] = r0 + am;
+}
+
+// scatter: dY[idx[c][j]][j] = dout[c][j] on a zeroed dY (dense form, for the narrow pools)
+__global__ void k_maxpool_scatter(const float* __restrict__ dout, const int* __restrict__ idx, float* __restrict__ dY,
+                                  int ld, int C, int J) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * J) return;
+  const int j = i % J;
+  dY[(size_t)idx[i] * ld + j] = dout[i];
+}
+
+// Sparse backward of  Y = X W^T + b ; g = max_rows Y  without materialising dY:
+//   dW[j][:] = sum_c dg[c][j] * X[idx[c][j]][:]      (one workgroup per output channel j)
+__global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ dg, const int* __restrict__ idx,
+                                                      const float* __restrict__ X, int ldx, float* __restrict__ dW,
+                                                      float* __restrict__ db, int C, int J, int K) {
+  const int j = blockIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // K <= 1024 with 256 threads
+  float sb = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = dg[(size_t)c * J + j];
+    sb += g;
+    if (g == 0.f) continue;
+    const float* xr = X + (size_t)idx[(size_t)c * J + j] * ldx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = threadIdx.x + 256 * u;
+      if (k < K) acc[u] = fmaf(g, xr[k], acc[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = threadIdx.x + 256 * u;
+    if (k < K) dW[(size_t)j * K + k] = acc[u];
+  }
+  if (threadIdx.x == 0 && db) db[j] = sb;
+}
+
+//   dX[idx[c][j]][:] += dg[c][j] * W[j][:]  on a zeroed dX (one workgroup per cloud, channels in order)
+__global__ __launch_bounds__(256) void k_maxlin_bwd_x(const float* __restrict__ dg, const int* __restrict__ idx,
+                                                      const float* __restrict__ W, int ldw, float* __restrict__ dX,
+                                                      int ldx, int J, int K) {
+  const int c = blockIdx.x;
+  for (int j = 0; j < J; ++j) {
+    const float g = dg[(size_t)c * J + j];
+    if (g == 0.f) continue;  // wave-uniform
+    float* xr = dX + (size_t)idx[(size_t)c * J + j] * ldx;
+    const float* wr = W + (size_t)j * ldw;
+    for (int k = threadIdx.x; k < K; k += 256) xr[k] = fmaf(g, wr[k], xr[k]);
+    __syncthreads();  // the next channel may hit the same row
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-cloud transforms  Y[r][:] = X[r][:] T[c]   (k = 3: input transform, k = 64: feature transform)
+// transpose=1 multiplies by T[c]^T (the data gradient).  VALU kernel: 0.2 % of the FLOPs of the path.
+// ------------------------------------------------------------------------------------------------
+template <int KD>
+__global__ __launch_bounds__(256) void k_cloud_matmul(const float* __restrict__ X, int ldx, const float* __restrict__ T,
+                                                      float* __restrict__ Y, int ldy, int R, int B, int N, int M,
+                                                      int transpose) {
+  __shared__ float ts[KD * KD];
+  // one workgroup handles 256/KD rows... keep it simple: block = 64 rows of ONE cloud
+  const int c = blockIdx.y;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const int rb = blockIdx.x * 64;
+  if (rb >= n) return;
+  for (int i = threadIdx.x; i < KD * KD; i += 256) {
+    const int a = i / KD, b = i % KD;
+    ts[i] = transpose ? T[(size_t)c * KD * KD + b * KD + a] : T[(size_t)c * KD * KD + i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * KD; e += 256) {
+    const int row = e / KD, j = e % KD;
+    if (rb + row >= n) continue;
+    const float* xr = X + (size_t)(r0 + rb + row) * ldx;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < KD; ++i) s = fmaf(xr[i], ts[i * KD + j], s);
+    Y[(size_t)(r0 + rb + row) * ldy + j] = s;
+  }
+}
+
+// dT[c][i][j] = sum_r X[r][i] dY[r][j] over the rows of cloud c
+template <int KD>
+__global__ __launch_bounds__(256) void k_cloud_matmul_bwd_t(const float* __restrict__ X, int ldx,
+                                                            const float* __restrict__ dY, int ldy,
+                                                            float* __restrict__ dT, int B, int N, int M) {
+  __shared__ float xs[32 * KD], ys[32 * KD];
+  const int c = blockIdx.x;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  constexpr int PER = (KD * KD + 255) / 256;
+  float acc[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) acc[u] = 0.f;
+  for (int rs = 0; rs < n; rs += 32) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * KD; e += 256) {
+      const int row = e / KD, i = e % KD;
+      const bool ok = rs + row < n;
+      xs[e] = ok ? X[(size_t)(r0 + rs + row) * ldx + i] : 0.f;
+      ys[e] = ok ? dY[(size_t)(r0 + rs + row) * ldy + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int o = threadIdx.x + 256 * u;
+      if (o < KD * KD) {
+        const int i = o / KD, j = o % KD;
+        float s = acc[u];
+        for (int row = 0; row < 32; ++row) s = fmaf(xs[row * KD + i], ys[row * KD + j], s);
+        acc[u] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int o = threadIdx.x + 256 * u;
+    if (o < KD * KD) dT[(size_t)c * KD * KD + o] = acc[u];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise
+// ------------------------------------------------------------------------------------------------
+__global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dX, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dX[i] = Y[i] > 0.f ? dY[i] : 0.f;
+}
+
+__device__ __forceinline__ float gelu_grad(float v) {
+  // d/dv [0.5 v (1 + erf(v/sqrt2))] = 0.5 (1 + erf(v/sqrt2)) + v * exp(-v^2/2) / sqrt(2 pi)
+  const float cdf = 0.5f * (1.0f + erf_rational(v * 0.70710678118654752440f));
+  return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32, 256) + GELU over the P points of an object (rows object-major, 256 channels)
+//   stats  : per (object, group) mean / rstd over P x 8 values       (two-pass, one workgroup per (object, group))
+//   forward: a = gelu(y*sc + sh)
+//   backward (dy from da): dyhat = da*gelu'(yhat); dxhat = dyhat*gamma;
+//              dy = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat));  dgamma, dbeta column sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gnp_stats(const float* __restrict__ Y, float* __restrict__ stat, int P) {
+  __shared__ float red[8];
+  const int obj = blockIdx.x, g = blockIdx.y;
+  const float* base = Y + (size_t)obj * P * 256 + g * 8;
+  const int n = P * 8;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) s += base[(size_t)(e >> 3) * 256 + (e & 7)];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  float q = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const float d = base[(size_t)(e >> 3) * 256 + (e & 7)] - mean;
+    q = fmaf(d, d, q);
+  }
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)n;
+    stat[((size_t)obj * 32 + g) * 2] = mean;
+    stat[((size_t)obj * 32 + g) * 2 + 1] = 1.0f / sqrtf(var + 1e-5f);
+  }
+}
+
+__global__ void k_gnp_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ stat,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ A,
+                               int P, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = i & 63;  // float4 index within the 256-channel row
+  const size_t row = i >> 6;
+  const int obj = row / P, g = c4 >> 1;
+  const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
+  const f32x4 y = reinterpret_cast<const f32x4*>(Y)[i];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
+  f32x4 a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float sc = rstd * ga[q];
+    a[q] = gelu_erf(fmaf(y[q], sc, be[q] - mean * sc));
+  }
+  reinterpret_cast<f32x4*>(A)[i] = a;
+}
+
+// pass 1 of the backward: per (object, group) sums S1 = sum dxhat, S2 = sum dxhat*xhat, and per-(object, channel)
+// partial dgamma / dbeta (summed over objects by k_reduce_splits)
+__global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ dA, const float* __restrict__ Y,
+                                                      const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ sums,
+                                                      float* __restrict__ dgb_part, int P) {
+  // one workgroup per (object); thread = channel
+  const int obj = blockIdx.x, ch = threadIdx.x, g = ch >> 3;
+  const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
+  const float ga = gamma[ch], be = beta[ch];
+  const float sc = rstd * ga, sh = be - mean * sc;
+  float s1 = 0.f, s2 = 0.f, dga = 0.f, dbe = 0.f;
+  const float* y = Y + (size_t)obj * P * 256 + ch;
+  const float* da = dA + (size_t)obj * P * 256 + ch;
+  for (int p = 0; p < P; ++p) {
+    const float yv = y[(size_t)p * 256];
+    const float xh = (yv - mean) * rstd;
+    const float dyh = da[(size_t)p * 256] * gelu_grad(fmaf(yv, sc, sh));
+    dga = fmaf(dyh, xh, dga);
+    dbe += dyh;
+    const float dxh = dyh * ga;
+    s1 += dxh;
+    s2 = fmaf(dxh, xh, s2);
+  }
+  // group = 8 consecutive lanes
+  s1 += __shfl_xor(s1, 1);
+  s1 += __shfl_xor(s1, 2);
+  s1 += __shfl_xor(s1, 4);
+  s2 += __shfl_xor(s2, 1);
+  s2 += __shfl_xor(s2, 2);
+  s2 += __shfl_xor(s2, 4);
+  if ((ch & 7) == 0) {
+    sums[((size_t)obj * 32 + g) * 2] = s1;
+    sums[((size_t)obj * 32 + g) * 2 + 1] = s2;
+  }
+  dgb_part[((size_t)obj * 2) * 256 + ch] = dga;
+  dgb_part[((size_t)obj * 2 + 1) * 256 + ch] = dbe;
+}
+
+__global__ void k_gnp_bwd_apply(const float* __restrict__ dA, const float* __restrict__ Y,
+                                const float* __restrict__ stat, const float* __restrict__ sums,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ dY, int P, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = i & 63;
+  const size_t row = i >> 6;
+  const int obj = row / P, g = c4 >> 1;
+  const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + g) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + g) * 2 + 1] * inv_m;
+  const f32x4 y = reinterpret_cast<const f32x4*>(Y)[i], da = reinterpret_cast<const f32x4*>(dA)[i];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
+  f32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float sc = rstd * ga[q];
+    const float xh = (y[q] - mean) * rstd;
+    const float dxh = da[q] * gelu_grad(fmaf(y[q], sc, be[q] - mean * sc)) * ga[q];
+    o[q] = rstd * (dxh - m1 - xh * m2);
+  }
+  reinterpret_cast<f32x4*>(dY)[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32,256) + GELU on rows [R,256] (ts head): groups of 8 channels inside a row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gnr_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ A, int R) {
+  const int r = blockIdx.x, ch = threadIdx.x;
+  A[(size_t)r * 256 + ch] = group8_norm_gelu(Y[(size_t)r * 256 + ch], gamma[ch], beta[ch]);
+}
+
+__global__ __launch_bounds__(256) void k_gnr_gelu_bwd(const float* __restrict__ dA, const float* __restrict__ Y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ dY, float* __restrict__ dgb_part, int R) {
+  const int r = blockIdx.x, ch = threadIdx.x;
+  const float v = Y[(size_t)r * 256 + ch];
+  float s = v;
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  const float mean = s * 0.125f;
+  const float d = v - mean;
+  float q = d * d;
+  q += __shfl_xor(q, 1);
+  q += __shfl_xor(q, 2);
+  q += __shfl_xor(q, 4);
+  const float rstd = 1.0f / sqrtf(q * 0.125f + 1e-5f);
+  const float xh = d * rstd, ga = gamma[ch];
+  const float dyh = dA[(size_t)r * 256 + ch] * gelu_grad(fmaf(xh, ga, beta[ch]));
+  const float dxh = dyh * ga;
+  float s1 = dxh, s2 = dxh * xh;
+  s1 += __shfl_xor(s1, 1);
+  s1 += __shfl_xor(s1, 2);
+  s1 += __shfl_xor(s1, 4);
+  s2 += __shfl_xor(s2, 1);
+  s2 += __shfl_xor(s2, 2);
+  s2 += __shfl_xor(s2, 4);
+  dY[(size_t)r * 256 + ch] = rstd * (dxh - s1 * 0.125f - xh * s2 * 0.125f);
+  dgb_part[((size_t)r * 2) * 256 + ch] = dyh * xh;
+  dgb_part[((size_t)r * 2 + 1) * 256 + ch] = dyh;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_p: out[b][c] = sum_p w[p] * Y[b*P + p][c] + bias   (Y [B*P, 3] after the neck), and backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wsum_fwd(const float* __restrict__ Y, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int P) {
+  __shared__ float red[4][3];
+  const int b = blockIdx.x;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float wp = w[p];
+    const float* y = Y + ((size_t)b * P + p) * 3;
+    a[0] = fmaf(wp, y[0], a[0]);
+    a[1] = fmaf(wp, y[1], a[1]);
+    a[2] = fmaf(wp, y[2], a[2]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a[c] = wave_sum(a[c]);
+  if ((threadIdx.x & 63) == 0)
+    for (int c = 0; c < 3; ++c) red[threadIdx.x >> 6][c] = a[c];
+  __syncthreads();
+  if (threadIdx.x < 3)
+    out[b * 3 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + (bias ? bias[0] : 0.f);
+}
+
+// dY[b*P+p][c] = w[p]*dout[b][c];  dw_part[b][p] = sum_c dout[b][c]*Y[b*P+p][c]
+__global__ void k_wsum_bwd(const float* __restrict__ dout, const float* __restrict__ Y, const float* __restrict__ w,
+                           float* __restrict__ dY, float* __restrict__ dw_part, int B, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P) return;
+  const int b = i / P, p = i % P;
+  const float* d = dout + b * 3;
+  const float* y = Y + (size_t)i * 3;
+  const float wp = w[p];
+  dY[(size_t)i * 3 + 0] = wp * d[0];
+  dY[(size_t)i * 3 + 1] = wp * d[1];
+  dY[(size_t)i * 3 + 2] = wp * d[2];
+  dw_part[i] = d[0] * y[0] + d[1] * y[1] + d[2] * y[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of rot6d -> R (rot_reps.py:46-55) and pose_scale_from_delta_init (ego rotation types)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float* __restrict__ d_scale,
+                                  const float* __restrict__ rot6d, const float* __restrict__ dtr,
+                                  const float* __restrict__ dsr, const float* __restrict__ pose0,
+                                  const float* __restrict__ scale0, const float* __restrict__ mean_scales,
+                                  const float* __restrict__ Ks, catre_opts o, float* __restrict__ d_rot6d,
+                                  float* __restrict__ d_dt, float* __restrict__ d_ds, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p0 = pose0 + b * 12;
+  const float* dp = d_pose + b * 12;
+  // R' = dR @ R0  ->  d(dR)[i][k] = sum_j dR'[i][j] R0[k][j]
+  float gR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gR[i * 3 + k] = dp[i * 4 + 0] * p0[k * 4 + 0] + dp[i * 4 + 1] * p0[k * 4 + 1] + dp[i * 4 + 2] * p0[k * 4 + 2];
+  // recompute x, y, z
+  const float a[3] = {rot6d[b * 6 + 0], rot6d[b * 6 + 1], rot6d[b * 6 + 2]};
+  const float bb[3] = {rot6d[b * 6 + 3], rot6d[b * 6 + 4], rot6d[b * 6 + 5]};
+  const float na = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
+  const float x[3] = {a[0] / na, a[1] / na, a[2] / na};
+  float w[3];
+  cross3(x, bb, w);
+  const float nw = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
+  const float z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};
+  // columns: dR[:,0] = x, dR[:,1] = y = z cross x, dR[:,2] = z
+  float gx[3] = {gR[0], gR[3], gR[6]}, gy[3] = {gR[1], gR[4], gR[7]}, gz[3] = {gR[2], gR[5], gR[8]};
+  float t[3];
+  // y = z x x : dz += x cross gy ; dx += gy cross z
+  cross3(x, gy, t);
+  gz[0] += t[0];
+  gz[1] += t[1];
+  gz[2] += t[2];
+  cross3(gy, z, t);
+  gx[0] += t[0];
+  gx[1] += t[1];
+  gx[2] += t[2];
+  // z = w/|w|
+  const float zg = z[0] * gz[0] + z[1] * gz[1] + z[2] * gz[2];
+  const float gw[3] = {(gz[0] - z[0] * zg) / nw, (gz[1] - z[1] * zg) / nw, (gz[2] - z[2] * zg) / nw};
+  // w = x cross b : dx += b cross gw ; db = gw cross x
+  cross3(bb, gw, t);
+  gx[0] += t[0];
+  gx[1] += t[1];
+  gx[2] += t[2];
+  float gb[3];
+  cross3(gw, x, gb);
+  const float xg = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
+  d_rot6d[b * 6 + 0] = (gx[0] - x[0] * xg) / na;
+  d_rot6d[b * 6 + 1] = (gx[1] - x[1] * xg) / na;
+  d_rot6d[b * 6 + 2] = (gx[2] - x[2] * xg) / na;
+  d_rot6d[b * 6 + 3] = gb[0];
+  d_rot6d[b * 6 + 4] = gb[1];
+  d_rot6d[b * 6 + 5] = gb[2];
+  // translation
+  const float gt[3] = {dp[3], dp[7], dp[11]};
+  const float t0[3] = {p0[3], p0[7], p0[11]};
+  float gd[3];
+  if (!o.delta_t_space_3d) {
+    const float d0 = dtr[b * 3] * o.delta_t_weight, d1 = dtr[b * 3 + 1] * o.delta_t_weight,
+                d2 = dtr[b * 3 + 2] * o.delta_t_weight;
+    const float zsrc = t0[2];
+    const float ztgt = o.delta_z_deepim ? zsrc / expf(d2) : d2 * zsrc;
+    const float fx = o.k_aware ? Ks[b * 9 + 0] : 1.f, fy = o.k_aware ? Ks[b * 9 + 4] : 1.f;
+    const float ux = d0 / fx + t0[0] / zsrc, uy = d1 / fy + t0[1] / zsrc;
+    const float gzt = gt[2] + gt[0] * ux + gt[1] * uy;  // d loss / d ztgt
+    gd[0] = gt[0] * ztgt / fx;
+    gd[1] = gt[1] * ztgt / fy;
+    gd[2] = o.delta_z_deepim ? -gzt * ztgt : gzt * zsrc;
+  } else {
+    gd[0] = gt[0];
+    gd[1] = gt[1];
+    gd[2] = gt[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d_dt[b * 3 + i] = gd[i] * o.delta_t_weight;
+  // scale
+  const float* sb = o.scale_base_mean ? mean_scales + b * 3 : scale0 + b * 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float g = o.refine_scale ? d_scale[b * 3 + i] : 0.f;
+    d_ds[b * 3 + i] = o.scale_mul ? g * sb[i] * expf(dsr[b * 3 + i]) : g;
+  }
+}
+
+// part [S][2][256] -> out_a[256] (blockIdx.x == 0) / out_b[256] (blockIdx.x == 1), fixed order
+__global__ __launch_bounds__(256) void k_reduce_splits2(const float* __restrict__ part, float* __restrict__ out_a,
+                                                        float* __restrict__ out_b, int S, int accumulate) {
+  const int which = blockIdx.x, ch = threadIdx.x;
+  float* out = which ? out_b : out_a;
+  float s = accumulate ? out[ch] : 0.f;
+  for (int k = 0; k < S; ++k) s += part[((size_t)k * 2 + which) * 256 + ch];
+  out[ch] = s;
+}
+
+// dst[0] (=|+=) sum(src[0..n))
+__global__ void k_sum_acc(const float* __restrict__ src, int n, float* __restrict__ dst, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += src[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] = (accumulate ? dst[0] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
+}

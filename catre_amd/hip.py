@@ -79,6 +79,29 @@ _SIGS = {
     "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_colmax": (_I, [_P, _P, _I, _I, _I, _P]),
+    # training ops (include/catre_hip.h "training ops")
+    "catre_op_pack": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "catre_op_gemm_rows": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "catre_op_gemm_tn_ws_bytes": (_SZ, [_I, _I, _I]),
+    "catre_op_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _SZ, _P]),
+    "catre_op_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P, _SZ, _P]),
+    "catre_op_reduce_splits": (_I, [_P, _P, _I, _I, _I, _P]),
+    "catre_op_rowbias_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_op_rowbias_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_op_maxpool_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "catre_op_maxpool_scatter": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_w": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_x": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_op_cloud_matmul": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_op_cloud_matmul_bwd_t": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_op_relu_bwd": (_I, [_P, _P, _P, _SZ, _P]),
+    "catre_op_gnp_gelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "catre_op_gnp_gelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _P]),
+    "catre_op_gnr_gelu_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
+    "catre_op_gnr_gelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _P]),
+    "catre_op_wsum_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "catre_op_wsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _P]),
+    "catre_op_pose_update_bwd": (_I, [_P] * 13 + [_I, _P]),
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),

@@ -1,0 +1,424 @@
+"""Training ops: ``torch.autograd.Function`` wrappers whose forward AND backward are HIP kernels
+(``catre_op_*`` in ``include/catre_hip.h``).  torch supplies tensors, the autograd graph and pure data
+movement (``cat`` / ``pad`` / ``reshape`` / ``contiguous``); no torch arithmetic op touches activations.
+
+Row orders used below: "cloud-major" = B*N observed rows then B*M prior rows; "object-major" =
+[N observed | M prior] per object.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+_scratch = {}
+
+
+def _ws(nbytes, device):
+    """Grow-only scratch (stream-ordered reuse: every op that uses it runs on the current stream)."""
+    buf = _scratch.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _scratch[device] = buf
+    return buf
+
+
+def _st(t):
+    return hip.stream_ptr(t.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _pad_cols(t, mult):
+    k = t.shape[-1]
+    r = (-k) % mult
+    return t if r == 0 else F.pad(t, (0, r))
+
+
+# ------------------------------------------------------------------------------------------------- GEMMs
+def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0):
+    """y[R,J] = act(x[R,K] w[J,K]^T + bias) (zeroed where mask<=0).  Picks the tiled row kernel when the
+    shape allows, else the one-block-per-32x32 kernel (small R or odd J)."""
+    lib = hip.load()
+    R, K = x.shape
+    J = w.shape[0]
+    dev = x.device
+    y = torch.empty(R, J, dtype=torch.float32, device=dev)
+    big = (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) \
+        and R >= 256 and identity_k == 0
+    if big:
+        wp = torch.empty(J * K, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+        hip.check(lib.catre_op_gemm_rows(hip.ptr(x), x.stride(0), hip.ptr(wp), hip.ptr(bias), hip.ptr(mask),
+                                         mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J, K,
+                                         int(relu), _st(x)), "catre_op_gemm_rows")
+    else:
+        assert K % 8 == 0 and mask is None
+        hip.check(lib.catre_linear(hip.ptr(x), x.stride(0), hip.ptr(w), w.stride(0), hip.ptr(bias), hip.ptr(y), J, R, J,
+                                   K, int(relu), int(identity_k), _st(x)), "catre_linear")
+    return y
+
+
+def _gemm_tn(dy, x):
+    """dW[J,K] = dy[R,J]^T x[R,K] (deterministic split reduction)."""
+    lib = hip.load()
+    R, J = dy.shape
+    K = x.shape[1]
+    dy4, x4 = _pad_cols(dy, 4), _pad_cols(x, 4)
+    J4, K4 = dy4.shape[1], x4.shape[1]
+    dw = torch.empty(J4, K4, dtype=torch.float32, device=dy.device)
+    need = lib.catre_op_gemm_tn_ws_bytes(J4, K4, R)
+    ws = _ws(need, dy.device)
+    hip.check(lib.catre_op_gemm_tn(hip.ptr(dy4), dy4.stride(0), hip.ptr(x4), x4.stride(0), hip.ptr(dw), J4, K4, R, 0,
+                                   hip.ptr(ws), ws.numel(), _st(dy)), "catre_op_gemm_tn")
+    return dw[:J, :K]
+
+
+def _colsum(dy):
+    lib = hip.load()
+    R, J = dy.shape
+    out = torch.empty(J, dtype=torch.float32, device=dy.device)
+    ws = _ws(256 * J * 4, dy.device)
+    hip.check(lib.catre_op_colsum(hip.ptr(dy), dy.stride(0), R, J, hip.ptr(out), 0, hip.ptr(ws), ws.numel(), _st(dy)),
+              "catre_op_colsum")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b); W may be a Conv1d weight [J,K,1].  identity_k adds vec(I_k) (STN tails)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, identity_k):
+        w2 = w.reshape(w.shape[0], -1)
+        K = w2.shape[1]
+        xk, wk = _c(_pad_cols(x, 8)), _c(_pad_cols(w2, 8))
+        y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu, ctx.K, ctx.has_b = relu, K, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        lib = hip.load()
+        dy = _c(dy)
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            hip.check(lib.catre_op_relu_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(g), dy.numel(), _st(dy)), "catre_op_relu_bwd")
+            dy = g
+        w2 = w.reshape(w.shape[0], -1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
+            wt = _c(_pad_cols(w2.t(), 8))          # [K, J8]
+            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False)   # [R, K]
+            if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
+                dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
+            elif x.shape[1] < dx.shape[1]:
+                dx = _c(dx[:, : x.shape[1]])
+        if ctx.needs_input_grad[1]:
+            kw = min(w2.shape[1], x.shape[1])
+            dw = _gemm_tn(dy, _c(x))[:, :kw]
+            if kw < w2.shape[1]:
+                dw = F.pad(dw, (0, w2.shape[1] - kw))
+            dw = _c(dw).reshape(w.shape)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dy)
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, relu=False, identity_k=0):
+    return _Linear.apply(x, w, b, relu, identity_k)
+
+
+# ------------------------------------------------------------------------------------------------- linear + max-pool
+class _LinearMaxPool(torch.autograd.Function):
+    """g[C,J] = act(max over the points of each cloud of (x W^T + b)); rows cloud-major.  The [rows,J]
+    pre-pool activation only lives inside forward; backward is sparse (gather / scatter at the argmax rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, B, N, M):
+        lib = hip.load()
+        w2 = _c(w.reshape(w.shape[0], -1))
+        J, K = w2.shape
+        y = _gemm_nt(_c(x), w2, b, False)
+        C = 2 * B if M > 0 else B
+        g = torch.empty(C, J, dtype=torch.float32, device=x.device)
+        idx = torch.empty(C, J, dtype=torch.int32, device=x.device)
+        hip.check(lib.catre_op_maxpool_fwd(hip.ptr(y), J, hip.ptr(g), hip.ptr(idx), J, B, N, M, _st(x)), "catre_op_maxpool_fwd")
+        del y
+        if relu:
+            g = _Relu.forward_only(g)
+        ctx.save_for_backward(x, w, idx, g if relu else None)
+        ctx.relu, ctx.dims = relu, (B, N, M, C, J, K)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, w, idx, g = ctx.saved_tensors
+        B, N, M, C, J, K = ctx.dims
+        lib = hip.load()
+        dg = _c(dg)
+        if ctx.relu:
+            t = torch.empty_like(dg)
+            hip.check(lib.catre_op_relu_bwd(hip.ptr(dg), hip.ptr(g), hip.ptr(t), dg.numel(), _st(dg)), "catre_op_relu_bwd")
+            dg = t
+        w2 = _c(w.reshape(J, K))
+        xc = _c(x)
+        dw = torch.empty(J, K, dtype=torch.float32, device=x.device)
+        db = torch.empty(J, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_maxlin_bwd_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(xc), xc.stride(0), hip.ptr(dw), hip.ptr(db),
+                                            C, J, K, _st(x)), "catre_op_maxlin_bwd_w")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(xc)
+            hip.check(lib.catre_op_maxlin_bwd_x(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx), dx.stride(0), C, J,
+                                                K, _st(x)), "catre_op_maxlin_bwd_x")
+        return dx, dw.reshape(w.shape), db, None, None, None, None
+
+
+class _Relu:
+    @staticmethod
+    def forward_only(g):
+        # relu on the tiny pooled tensor: relu_bwd(dy=g, y=g) == where(g > 0, g, 0)
+        lib = hip.load()
+        out = torch.empty_like(g)
+        hip.check(lib.catre_op_relu_bwd(hip.ptr(g), hip.ptr(g), hip.ptr(out), g.numel(), _st(g)), "catre_op_relu_bwd")
+        return out
+
+
+def linear_maxpool(x, w, b, relu, B, N, M):
+    return _LinearMaxPool.apply(x, w, b, relu, B, N, M)
+
+
+class _MaxPool(torch.autograd.Function):
+    """Plain max over the points of each cloud (dense scatter backward) - used for max_n pointfeat."""
+
+    @staticmethod
+    def forward(ctx, y, B, N, M):
+        lib = hip.load()
+        y = _c(y)
+        J = y.shape[1]
+        C = 2 * B if M > 0 else B
+        g = torch.empty(C, J, dtype=torch.float32, device=y.device)
+        idx = torch.empty(C, J, dtype=torch.int32, device=y.device)
+        hip.check(lib.catre_op_maxpool_fwd(hip.ptr(y), J, hip.ptr(g), hip.ptr(idx), J, B, N, M, _st(y)), "catre_op_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(y.shape)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (idx,) = ctx.saved_tensors
+        lib = hip.load()
+        dg = _c(dg)
+        dy = torch.zeros(ctx.shape, dtype=torch.float32, device=dg.device)
+        hip.check(lib.catre_op_maxpool_scatter(hip.ptr(dg), hip.ptr(idx), hip.ptr(dy), ctx.shape[1], dg.shape[0],
+                                               dg.shape[1], _st(dg)), "catre_op_maxpool_scatter")
+        return dy, None, None, None
+
+
+def maxpool_points(y, B, N, M):
+    return _MaxPool.apply(y, B, N, M)
+
+
+# ------------------------------------------------------------------------------------------------- per-cloud transforms
+class _CloudMatmul(torch.autograd.Function):
+    """y[r,:] = x[r,:kd] T[cloud(r)]; output has `out_cols` columns (zero beyond kd) so it can feed the MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, T, B, N, M, out_cols):
+        lib = hip.load()
+        kd = T.shape[-1]
+        x, T = _c(x), _c(T)
+        R = x.shape[0]
+        y = torch.zeros(R, out_cols, dtype=torch.float32, device=x.device) if out_cols != kd else \
+            torch.empty(R, kd, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_cloud_matmul(hip.ptr(x), x.stride(0), hip.ptr(T), hip.ptr(y), out_cols, kd, B, N, M, 0,
+                                            _st(x)), "catre_op_cloud_matmul")
+        ctx.save_for_backward(x, T)
+        ctx.dims = (B, N, M, kd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, T = ctx.saved_tensors
+        B, N, M, kd = ctx.dims
+        lib = hip.load()
+        dy = _c(dy)
+        dx = dT = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x) if x.shape[1] != kd else torch.empty_like(x)
+            hip.check(lib.catre_op_cloud_matmul(hip.ptr(dy), dy.stride(0), hip.ptr(T), hip.ptr(dx), dx.stride(0), kd, B, N,
+                                                M, 1, _st(x)), "catre_op_cloud_matmul^T")
+        if ctx.needs_input_grad[1]:
+            dT = torch.empty_like(T)
+            hip.check(lib.catre_op_cloud_matmul_bwd_t(hip.ptr(x), x.stride(0), hip.ptr(dy), dy.stride(0), hip.ptr(dT), kd,
+                                                      B, N, M, _st(x)), "catre_op_cloud_matmul_bwd_t")
+        return dx, dT, None, None, None, None
+
+
+def cloud_matmul(x, T, B, N, M, out_cols=None):
+    return _CloudMatmul.apply(x, T, B, N, M, T.shape[-1] if out_cols is None else out_cols)
+
+
+# ------------------------------------------------------------------------------------------------- per-cloud bias
+class _RowBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias, B, N, M):
+        lib = hip.load()
+        y = y.clone()
+        bias = _c(bias)
+        hip.check(lib.catre_op_rowbias_add(hip.ptr(y), y.stride(0), hip.ptr(bias), y.shape[1], B, N, M, _st(y)),
+                  "catre_op_rowbias_add")
+        ctx.dims = (B, N, M)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, M = ctx.dims
+        lib = hip.load()
+        dy = _c(dy)
+        J = dy.shape[1]
+        db = torch.empty(2 * B if M > 0 else B, J, dtype=torch.float32, device=dy.device)
+        hip.check(lib.catre_op_rowbias_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(db), J, B, N, M, _st(dy)), "catre_op_rowbias_bwd")
+        return dy, db, None, None, None
+
+
+def rowbias_add(y, bias, B, N, M):
+    """y [B*(N+M), J] object-major += bias[cloud] (bias [2B, J])."""
+    return _RowBias.apply(y, bias, B, N, M)
+
+
+# ------------------------------------------------------------------------------------------------- GroupNorm + GELU
+class _GNPointsGelu(torch.autograd.Function):
+    """gelu(GroupNorm(32,256)(y)) with statistics over the P points of each object (rows object-major)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, B, P):
+        lib = hip.load()
+        y = _c(y)
+        a = torch.empty_like(y)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=y.device)
+        hip.check(lib.catre_op_gnp_gelu_fwd(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a), hip.ptr(stat), B, P,
+                                            _st(y)), "catre_op_gnp_gelu_fwd")
+        ctx.save_for_backward(y, gamma, beta, stat)
+        ctx.dims = (B, P)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        y, gamma, beta, stat = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        da = _c(da)
+        dy = torch.empty_like(y)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _ws(B * (64 + 512) * 4, y.device)
+        hip.check(lib.catre_op_gnp_gelu_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta),
+                                            hip.ptr(dy), hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), ws.numel(), B, P,
+                                            _st(y)), "catre_op_gnp_gelu_bwd")
+        return dy, dg, db, None, None
+
+
+def gn_points_gelu(y, gamma, beta, B, P):
+    return _GNPointsGelu.apply(y, gamma, beta, B, P)
+
+
+class _GNRowsGelu(torch.autograd.Function):
+    """gelu(GroupNorm(32,256)(y)) on a [R,256] matrix (groups of 8 channels inside each row; ts head)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta):
+        lib = hip.load()
+        y = _c(y)
+        a = torch.empty_like(y)
+        hip.check(lib.catre_op_gnr_gelu_fwd(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a), y.shape[0], _st(y)),
+                  "catre_op_gnr_gelu_fwd")
+        ctx.save_for_backward(y, gamma, beta)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        y, gamma, beta = ctx.saved_tensors
+        lib = hip.load()
+        da = _c(da)
+        R = y.shape[0]
+        dy = torch.empty_like(y)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _ws(R * 512 * 4, y.device)
+        hip.check(lib.catre_op_gnr_gelu_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(dy),
+                                            hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), ws.numel(), R, _st(y)),
+                  "catre_op_gnr_gelu_bwd")
+        return dy, dg, db
+
+
+def gn_rows_gelu(y, gamma, beta):
+    return _GNRowsGelu.apply(y, gamma, beta)
+
+
+# ------------------------------------------------------------------------------------------------- conv_p
+class _WSum(torch.autograd.Function):
+    """out[b,:] = sum_p w[p] * y[b*P+p, :3] + bias  (the point-wise Conv1d(P,1,1) of RotHead)."""
+
+    @staticmethod
+    def forward(ctx, y3, w, bias, B, P):
+        lib = hip.load()
+        y3 = _c(y3)
+        wv = _c(w.reshape(-1))
+        out = torch.empty(B, 3, dtype=torch.float32, device=y3.device)
+        hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bias), hip.ptr(out), B, P, _st(y3)), "catre_op_wsum_fwd")
+        ctx.save_for_backward(y3, w, bias)
+        ctx.dims = (B, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y3, w, bias = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        dout = _c(dout)
+        wv = _c(w.reshape(-1))
+        dy = torch.empty_like(y3)
+        dw = torch.empty(P, dtype=torch.float32, device=y3.device)
+        dbias = torch.empty(1, dtype=torch.float32, device=y3.device) if bias is not None else None
+        ws = _ws(B * P * 4, y3.device)
+        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy), hip.ptr(dw), hip.ptr(dbias), 0,
+                                        hip.ptr(ws), ws.numel(), B, P, _st(y3)), "catre_op_wsum_bwd")
+        return dy, dw.reshape(w.shape), dbias, None, None
+
+
+def weighted_point_sum(y3, w, bias, B, P):
+    return _WSum.apply(y3, w, bias, B, P)
+
+
+# ------------------------------------------------------------------------------------------------- pose update
+class _PoseUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks, opts):
+        from .runtime import pose_update
+
+        pose, scale = pose_update(rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks, opts)
+        ctx.save_for_backward(rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks)
+        ctx.opts = opts
+        return pose, scale
+
+    @staticmethod
+    def backward(ctx, d_pose, d_scale):
+        rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks = ctx.saved_tensors
+        lib = hip.load()
+        B = rot6d.shape[0]
+        g6, gt, gs = torch.empty_like(rot6d), torch.empty_like(dt), torch.empty_like(ds)
+        c = lambda t: _c(t) if t is not None else None
+        hip.check(lib.catre_op_pose_update_bwd(hip.ptr(c(d_pose)), hip.ptr(c(d_scale)), hip.ptr(c(rot6d)), hip.ptr(c(dt)),
+                                               hip.ptr(c(ds)), hip.ptr(c(init_pose)), hip.ptr(c(init_scale)),
+                                               hip.ptr(c(mean_scales)), hip.ptr(c(Ks)), ctypes.byref(ctx.opts), hip.ptr(g6),
+                                               hip.ptr(gt), hip.ptr(gs), B, _st(rot6d)), "catre_op_pose_update_bwd")
+        return g6, gt, gs, None, None, None, None, None
+
+
+def pose_update_autograd(rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks, opts):
+    return _PoseUpdate.apply(_c(rot6d), _c(dt), _c(ds), _c(init_pose), _c(init_scale), mean_scales, Ks, opts)

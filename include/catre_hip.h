@@ -210,6 +210,51 @@ int catre_debug_trunk_trace(void* device_buffer);
 
 const char* catre_status_string(int status);
 
+/* ---- training ops (forward with saved activations + backward), chained by torch.autograd ------------------
+ * The training path runs the layers unfused on point-major activation matrices [rows, channels] in HBM; each
+ * op has a hand-written forward and backward kernel.  Replaced reference arithmetic: torch.nn.functional
+ * conv1d(k=1)/linear, relu, max over points, bmm with the STN transforms, group_norm, gelu, the conv_p
+ * weighted sum and the autograd of rot6d_to_mat_batch / pose_scale_from_delta_init - i.e. what
+ * `losses.backward()` (core/catre/engine/engine.py:349) differentiates through.  Row orders: "cloud-major" =
+ * B*N observed rows then B*M prior rows; "object-major" = [N observed | M prior] per object. */
+int catre_op_pack(const float* src, int ld, int J, int K, int transpose, float* dst, void* stream);
+int catre_op_gemm_rows(const float* X, int ldx, const float* Wp, const float* bias, const float* mask, int ldm,
+                       float* Y, int ldy, int R, int J, int K, int relu, void* stream);
+size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
+int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
+                    void* stream);
+int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);
+int catre_op_rowbias_add(float* Y, int ld, const float* bias, int J, int B, int N, int M, void* stream);
+int catre_op_rowbias_bwd(const float* dY, int ld, float* dbias, int J, int B, int N, int M, void* stream);
+int catre_op_maxpool_fwd(const float* Y, int ld, float* out, int* idx, int J, int B, int N, int M, void* stream);
+int catre_op_maxpool_scatter(const float* dout, const int* idx, float* dY, int ld, int C, int J, void* stream);
+int catre_op_maxlin_bwd_w(const float* dg, const int* idx, const float* X, int ldx, float* dW, float* db, int C,
+                          int J, int K, void* stream);
+int catre_op_maxlin_bwd_x(const float* dg, const int* idx, const float* W, int ldw, float* dX, int ldx, int C, int J,
+                          int K, void* stream);
+int catre_op_cloud_matmul(const float* X, int ldx, const float* T, float* Y, int ldy, int kd, int B, int N, int M,
+                          int transpose, void* stream);
+int catre_op_cloud_matmul_bwd_t(const float* X, int ldx, const float* dY, int ldy, float* dT, int kd, int B, int N,
+                                int M, void* stream);
+int catre_op_relu_bwd(const float* dY, const float* Y, float* dX, size_t n, void* stream);
+int catre_op_gnp_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, float* stat, int B, int P,
+                          void* stream);
+int catre_op_gnp_gelu_bwd(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
+                          float* dY, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int B,
+                          int P, void* stream);
+int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
+int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
+                          float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);
+int catre_op_wsum_fwd(const float* Y, const float* w, const float* bias, float* out, int B, int P, void* stream);
+int catre_op_wsum_bwd(const float* dout, const float* Y, const float* w, float* dY, float* dw, float* dbias,
+                      int accumulate, void* ws, size_t ws_bytes, int B, int P, void* stream);
+int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const float* rot6d, const float* trans_deltas,
+                             const float* scale_deltas, const float* init_pose, const float* init_scale,
+                             const float* mean_scales, const float* Ks, const catre_opts* opts, float* d_rot6d,
+                             float* d_dt, float* d_ds, int B, void* stream);
+
 /* Build identification: "catre_hip gfx950 <version>" */
 const char* catre_version(void);
 

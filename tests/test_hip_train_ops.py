@@ -1,0 +1,203 @@
+"""Each training op (forward AND backward HIP kernels, catre_op_*) against plain torch autograd in fp64 on the
+same inputs.  Tolerance: fp32 re-association only (2e-5 abs + 2e-5 rel on O(1) data)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cmp(got, want, what, atol=2e-5, rtol=2e-5):
+    np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.detach().double().numpy(), atol=atol, rtol=rtol,
+                               err_msg=what)
+
+
+def _leaf(t):
+    return t.clone().to(DEV).requires_grad_(True), t.clone().double().requires_grad_(True)
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("R,K,J,relu", [(300, 64, 128, True), (700, 128, 512, True), (1000, 512, 1024, False),
+                                        (520, 3, 64, True), (515, 256, 3, False), (6, 1091, 256, False),
+                                        (10, 256, 9, False), (300, 256, 256, False), (257, 64, 64, True)])
+def test_linear_fwd_bwd(R, K, J, relu):
+    from catre_amd import train_ops as T
+
+    g = _gen(R + K + J)
+    x, xr = _leaf(torch.randn(R, K, generator=g))
+    w, wr = _leaf(torch.randn(J, K, 1, generator=g) / K ** 0.5)
+    b, br = _leaf(torch.randn(J, generator=g) * 0.1)
+    y = T.linear(x, w, b, relu=relu)
+    yr = F.linear(xr, wr[:, :, 0], br)
+    yr = yr.relu() if relu else yr
+    _cmp(y, yr, "y")
+    dy = torch.randn(R, J, generator=g)
+    y.backward(dy.to(DEV))
+    yr.backward(dy.double())
+    _cmp(x.grad, xr.grad, "dx")
+    _cmp(w.grad, wr.grad, "dw", atol=2e-4, rtol=2e-5)
+    _cmp(b.grad, br.grad, "db", atol=2e-4, rtol=2e-5)
+
+
+def test_linear_identity_tail():
+    from catre_amd import train_ops as T
+
+    g = _gen(1)
+    x, xr = _leaf(torch.randn(6, 256, generator=g))
+    w, wr = _leaf(torch.randn(9, 256, generator=g) / 16)
+    b, br = _leaf(torch.randn(9, generator=g) * 0.1)
+    y = T.linear(x, w, b, identity_k=3)
+    yr = F.linear(xr, wr, br) + torch.eye(3, dtype=torch.float64).reshape(1, 9)
+    _cmp(y, yr, "y")
+    y.sum().backward()
+    yr.sum().backward()
+    _cmp(x.grad, xr.grad, "dx")
+    _cmp(w.grad, wr.grad, "dw")
+
+
+def _cloud_slices(B, N, M):
+    sl = [(b * N, N) for b in range(B)] + [(B * N + b * M, M) for b in range(B)]
+    return sl
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_linear_maxpool(relu):
+    from catre_amd import train_ops as T
+
+    B, N, M, K, J = 3, 200, 70, 128, 1024
+    g = _gen(7)
+    R = B * (N + M)
+    x, xr = _leaf(torch.randn(R, K, generator=g))
+    w, wr = _leaf(torch.randn(J, K, 1, generator=g) / K ** 0.5)
+    b, br = _leaf(torch.randn(J, generator=g) * 0.1)
+    out = T.linear_maxpool(x, w, b, relu, B, N, M)
+    yr = F.linear(xr, wr[:, :, 0], br)
+    ref = torch.stack([yr[s:s + n].max(0)[0] for s, n in _cloud_slices(B, N, M)])
+    ref = ref.relu() if relu else ref
+    _cmp(out, ref, "pooled")
+    dg = torch.randn(2 * B, J, generator=g)
+    out.backward(dg.to(DEV))
+    ref.backward(dg.double())
+    _cmp(x.grad, xr.grad, "dx")
+    _cmp(w.grad, wr.grad, "dw", atol=1e-4)
+    _cmp(b.grad, br.grad, "db", atol=1e-4)
+
+
+def test_maxpool_points_and_cloud_matmul():
+    from catre_amd import train_ops as T
+
+    B, N, M = 2, 130, 45
+    R = B * (N + M)
+    g = _gen(9)
+    for kd, oc in ((3, 8), (64, 64)):
+        x, xr = _leaf(torch.randn(R, kd, generator=g))
+        Tm, Tr = _leaf(torch.randn(2 * B, kd, kd, generator=g) / kd ** 0.5 + torch.eye(kd))
+        y = T.cloud_matmul(x, Tm, B, N, M, out_cols=oc)
+        ref = torch.cat([xr[s:s + n] @ Tr[c] for c, (s, n) in enumerate(_cloud_slices(B, N, M))])
+        _cmp(y[:, :kd], ref, f"cloud_matmul {kd}")
+        if oc > kd:
+            assert float(y[:, kd:].abs().max()) == 0.0
+        p = T.maxpool_points(y, B, N, M)
+        pref = torch.stack([ref[s:s + n].max(0)[0] for s, n in _cloud_slices(B, N, M)])
+        _cmp(p[:, :kd], pref, "maxpool")
+        dy = torch.randn(R, oc, generator=g)
+        dp = torch.randn(2 * B, oc, generator=g)
+        (y * dy.to(DEV)).sum().backward(retain_graph=True)
+        (p * dp.to(DEV)).sum().backward()
+        ((ref * dy[:, :kd].double()).sum() + (pref * dp[:, :kd].double()).sum()).backward()
+        _cmp(x.grad, xr.grad, f"dx {kd}")
+        _cmp(Tm.grad, Tr.grad, f"dT {kd}", atol=1e-4)
+
+
+def test_rowbias_gn_points_wsum():
+    from catre_amd import train_ops as T
+
+    B, N, M = 3, 100, 60
+    P = N + M
+    g = _gen(11)
+    y, yr = _leaf(torch.randn(B * P, 256, generator=g))
+    bias, biasr = _leaf(torch.randn(2 * B, 256, generator=g))
+    ga, gar = _leaf(1 + 0.1 * torch.randn(256, generator=g))
+    be, ber = _leaf(0.1 * torch.randn(256, generator=g))
+    wn, wnr = _leaf(torch.randn(3, 256, 1, generator=g) / 16)
+    bn, bnr = _leaf(torch.randn(3, generator=g) * 0.1)
+    wp, wpr = _leaf(torch.rand(1, P, 1, generator=g) / P)
+    bp, bpr = _leaf(torch.randn(1, generator=g) * 0.1)
+    z = T.rowbias_add(y, bias, B, N, M)
+    a = T.gn_points_gelu(z, ga, be, B, P)
+    y3 = T.linear(a, wn, bn)
+    out = T.weighted_point_sum(y3, wp, bp, B, P)
+    # reference: [B,256,P] layout like the reference rot head
+    zr = yr.reshape(B, P, 256)
+    bfull = torch.cat([biasr[:B].unsqueeze(1).expand(B, N, 256), biasr[B:].unsqueeze(1).expand(B, M, 256)], 1)
+    zr = (zr + bfull).permute(0, 2, 1)
+    ar = F.gelu(F.group_norm(zr, 32, gar, ber, 1e-5))
+    y3r = F.conv1d(ar, wnr, bnr)                         # [B,3,P]
+    outr = F.conv1d(y3r.permute(0, 2, 1), wpr, bpr).squeeze(1)   # [B,3]
+    _cmp(out, outr, "out", atol=1e-5)
+    d = torch.randn(B, 3, generator=g)
+    out.backward(d.to(DEV))
+    outr.backward(d.double())
+    for got, want, nm in ((y, yr, "dy"), (bias, biasr, "dbias"), (ga, gar, "dgamma"), (be, ber, "dbeta"),
+                          (wn, wnr, "dneck"), (bn, bnr, "dneck_b"), (wp, wpr, "dwp"), (bp, bpr, "dbp")):
+        _cmp(got.grad, want.grad, nm, atol=2e-5, rtol=1e-4)
+
+
+def test_gn_rows_gelu():
+    from catre_amd import train_ops as T
+
+    g = _gen(12)
+    y, yr = _leaf(torch.randn(7, 256, generator=g))
+    ga, gar = _leaf(1 + 0.1 * torch.randn(256, generator=g))
+    be, ber = _leaf(0.1 * torch.randn(256, generator=g))
+    a = T.gn_rows_gelu(y, ga, be)
+    ar = F.gelu(F.group_norm(yr, 32, gar, ber, 1e-5))
+    _cmp(a, ar, "a")
+    d = torch.randn(7, 256, generator=g)
+    a.backward(d.to(DEV))
+    ar.backward(d.double())
+    _cmp(y.grad, yr.grad, "dy", rtol=1e-4)
+    _cmp(ga.grad, gar.grad, "dgamma", rtol=1e-4)
+    _cmp(be.grad, ber.grad, "dbeta", rtol=1e-4)
+
+
+@pytest.mark.parametrize("space,zstyle,ka,stype", [("image", "cosypose", True, "iter_add"), ("image", "deepim", False, "mean_mul"),
+                                                   ("3D", "cosypose", True, "iter_add")])
+def test_pose_update_bwd(space, zstyle, ka, stype):
+    from catre_amd import hip
+    from catre_amd import train_ops as T
+    from oracle import catre_oracle as O
+
+    g = _gen(13)
+    B = 9
+    r6, r6r = _leaf(torch.randn(B, 6, generator=g))
+    dt, dtr = _leaf(torch.tensor([0.0, 0.0, 1.0]) + 0.05 * torch.randn(B, 3, generator=g))
+    ds, dsr = _leaf(0.05 * torch.randn(B, 3, generator=g))
+    R0 = O.quat2mat_torch(torch.randn(B, 4, generator=g))
+    t0 = torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(B, 3, generator=g)
+    pose0 = torch.cat([R0, t0.unsqueeze(-1)], -1)
+    s0 = 0.1 + 0.1 * torch.rand(B, 3, generator=g)
+    ms = 0.1 + 0.1 * torch.rand(B, 3, generator=g)
+    K = torch.tensor([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]]).repeat(B, 1, 1)
+    o = hip.CatreOpts()
+    o.delta_t_space_3d = int(space == "3D"); o.delta_z_deepim = int(zstyle != "cosypose"); o.k_aware = int(ka)
+    o.scale_mul = int("add" not in stype); o.scale_base_mean = int("iter" not in stype); o.refine_scale = 1
+    o.delta_t_weight = 0.7; o.allo_eps = 1e-4
+    pose, scale = T.pose_update_autograd(r6, dt, ds, pose0.to(DEV), s0.to(DEV), ms.to(DEV), K.to(DEV), o)
+    Rr, tr, sr = O.pose_scale_from_delta_init(
+        O.rot6d_to_mat_batch(r6r), dtr, dsr, R0.double(), t0.double(), (s0 if "iter" in stype else ms).double(),
+        Ks=K.double(), K_aware=ka, delta_T_space=space, delta_T_weight=0.7, delta_z_style=zstyle, scale_type=stype)
+    _cmp(pose[:, :, :3], Rr, "R", atol=3e-6)
+    _cmp(pose[:, :, 3], tr, "t", atol=3e-6)
+    gp = torch.randn(B, 3, 4, generator=g)
+    gs = torch.randn(B, 3, generator=g)
+    ((pose * gp.to(DEV)).sum() + (scale * gs.to(DEV)).sum()).backward()
+    ((Rr * gp[:, :, :3].double()).sum() + (tr * gp[:, :, 3].double()).sum() + (sr * gs.double()).sum()).backward()
+    _cmp(r6.grad, r6r.grad, "d_rot6d", atol=1e-4, rtol=1e-4)
+    _cmp(dt.grad, dtr.grad, "d_dt", atol=1e-4, rtol=1e-4)
+    _cmp(ds.grad, dsr.grad, "d_ds", atol=1e-5, rtol=1e-4)
