@@ -1,0 +1,98 @@
+"""Autograd-connected forward of one refine iteration for TRAINING (``do_loss=True`` path of the reference's
+``CATRE_disR_shared.forward``, ``core/catre/models/CATRE_disR_shared.py:57-124``).
+
+Same arithmetic as the fused inference kernels, but laid out layer by layer on point-major activation
+matrices so that ``torch.autograd`` can chain the hand-written HIP backward kernels of
+``catre_amd/train_ops.py``.  The restructurings of the inference path are kept (the repeated global
+feature becomes a per-cloud bias of rot-head layer 0; the ``[B,1088,N]`` tensors are never built), so the
+gradients equal the reference's up to fp32 re-association.
+"""
+import torch
+
+from . import hip
+from . import train_ops as T
+
+
+def _points_rows(x):
+    """[B,3,n] (any strides) -> [B*n, 3] contiguous rows (pure data movement)."""
+    return x.permute(0, 2, 1).reshape(-1, 3).contiguous()
+
+
+def _stn(rows, p, prefix, k, B, N, M):
+    """STN3d / STNkd on cloud-major rows [R, k] -> [C, k, k]  (pointnet.py:24-41 / 57-78)."""
+    w = lambda n: p[f"{prefix}.{n}"]
+    h = T.linear(rows, w("conv1.weight"), w("conv1.bias"), relu=True)
+    h = T.linear(h, w("conv2.weight"), w("conv2.bias"), relu=True)
+    g = T.linear_maxpool(h, w("conv3.weight"), w("conv3.bias"), True, B, N, M)  # relu(conv3) then max
+    h = T.linear(g, w("fc1.weight"), w("fc1.bias"), relu=True)
+    h = T.linear(h, w("fc2.weight"), w("fc2.bias"), relu=True)
+    t = T.linear(h, w("fc3.weight"), w("fc3.bias"), identity_k=k)
+    return t.view(-1, k, k)
+
+
+def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
+    """PointNetfeat on cloud-major point rows [B*N + B*M, 3] -> (g [C,1024], pointfeat [R,64])  (pointnet.py:97-116)."""
+    w = lambda n: p[f"{prefix}.{n}"]
+    trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M)
+    x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8)                    # x^T @ trans, zero-padded to 8 columns
+    h1 = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True)         # [R,64]
+    if feature_transform:
+        trans_feat = _stn(h1, p, f"{prefix}.fstn", 64, B, N, M)
+        pf = T.cloud_matmul(h1, trans_feat, B, N, M)
+    else:
+        pf = h1
+    h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True)
+    h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True)
+    g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M)   # conv4 has no ReLU (:114)
+    return g, pf
+
+
+def _rot_head(g, pf_obj, p, prefix, B, N, M):
+    """RotHead.forward (heads/conv_out_per_rot_head.py:126-140) on the never-materialised cat(pcl_feat,kps_feat)."""
+    w = lambda n: p[f"{prefix}.{n}"]
+    P = N + M
+    W0 = w("layers.0.weight").reshape(256, 1088)
+    bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))       # [2B,256]: global half + conv bias
+    y = T.linear(pf_obj, W0[:, 1024:].contiguous(), None)                    # [B*P,256]
+    y = T.rowbias_add(y, bias0, B, N, M)
+    a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P)
+    y = T.linear(a, w("layers.3.weight"), w("layers.3.bias"))
+    a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P)
+    y3 = T.linear(a, w("neck.0.weight"), w("neck.0.bias"))                   # [B*P,3]
+    return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)
+
+
+def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None):
+    """p: {state_dict key: live parameter}.  Returns (pose [B,3,4], scale [B,3], aux dict) - autograd-connected."""
+    if opts.is_allo:
+        raise NotImplementedError("training with allo_rot6d: the pose-update backward implements the ego rotation types")
+    B, N, M = x.shape[0], x.shape[2], tfd_kps.shape[2]
+    hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
+    hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)
+    pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
+    g, pf = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform))
+    pfmax = T.maxpool_points(pf, B, N, M)                                     # max_n pointfeat (flat_pcl_feat tail)
+
+    feats = [g[:B], pfmax[:B]]
+    if opts.with_kps_feature:
+        feats += [g[B:], pfmax[B:]]
+    if opts.with_init_scale:
+        feats.append(init_scale)
+    if opts.with_init_trans:
+        feats.append(init_pose[:, :3, 3])
+    ts_feat = torch.cat(feats, 1)                                             # [B, ts_in]
+    h = T.linear(ts_feat, p["ts_head.linears.0.weight"], p["ts_head.linears.0.bias"])
+    h = T.gn_rows_gelu(h, p["ts_head.linears.1.weight"], p["ts_head.linears.1.bias"])
+    h = T.linear(h, p["ts_head.linears.3.weight"], p["ts_head.linears.3.bias"])
+    h = T.gn_rows_gelu(h, p["ts_head.linears.4.weight"], p["ts_head.linears.4.bias"])
+    dt = T.linear(h, p["ts_head.fc_t.weight"], p["ts_head.fc_t.bias"])
+    ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
+
+    # rot head input in object-major order: [N observed | M prior] per object (CATRE_disR_shared.py:86)
+    pf_obj = torch.cat([pf[: B * N].view(B, N, 64), pf[B * N:].view(B, M, 64)], 1).reshape(B * (N + M), 64)
+    rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
+    ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
+    rot6d = torch.cat([rx, ry], 1)
+
+    pose, scale = T.pose_update_autograd(rot6d, dt, ds, init_pose, init_scale, mean_scales, K_zoom, opts)
+    return pose, scale, dict(rot6d=rot6d, trans_deltas=dt, scale_deltas=ds)
