@@ -76,14 +76,38 @@ class CATRE_disR_shared(nn.Module):
     ):
         """x [B,3,N], tfd_kps [B,3,M] (any strides), init_pose [B,3,4], init_scale [B,3], K_zoom [B,3,3]
         -> ``{"pose_{cur_iter}": [B,3,4], "scale_{cur_iter}": [B,3]}`` (reference ``:122-124``)."""
-        if do_loss:
-            raise NotImplementedError(
-                "do_loss=True (training) needs the backward kernels and the device-side loss (SURVEY.md 8f-1); "
-                "round 1 of catre_amd implements the inference path."
-            )
-        _no_grad_only(self, x, tfd_kps, init_pose, init_scale)
-        pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, self._opts)
-        return {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not (do_loss or needs_grad):
+            # inference: the fused kernels (one launch chain, nothing saved)
+            pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, self._opts)
+            return {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
+
+        # training / autograd: layer-by-layer HIP ops chained by torch.autograd (catre_amd/train_forward.py).
+        # Like the reference, gradients flow to the parameters only: the caller detaches the fed-back pose
+        # (engine.py:324-325) and x / tfd_kps come from the data batch.
+        from .train_forward import forward_train
+
+        pose, scale, _ = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
+                                       K_zoom, mean_scales)
+        out_dict = {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
+        if not do_loss:
+            return out_dict
+        assert gt_ego_rot is not None and (gt_trans is not None)
+        from .losses import catre_loss
+
+        loss_dict = catre_loss(self.cfg, out_rot=pose[:, :3, :3], out_trans=pose[:, :3, 3], out_scale=scale,
+                               gt_rot=gt_ego_rot, gt_trans=gt_trans, gt_scale=gt_scale, obj_kps=obj_kps,
+                               sym_info=sym_info)
+        # the reference also pushes ~15 `.item()` scalars per call into detectron2's EventStorage
+        # (CATRE_disR_shared.py:127-164): logging, deliberately left out - each one is a host sync.
+        return out_dict, loss_dict
+
+    def catre_loss(self, out_rot, out_trans, out_scale, gt_rot=None, gt_trans=None, gt_scale=None, obj_kps=None,
+                   sym_info=None):
+        """Same signature as the reference method (``:168-178``)."""
+        from .losses import catre_loss
+
+        return catre_loss(self.cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info)
 
     @torch.no_grad()
     def refine(self, batch, n_iter=None):

@@ -305,3 +305,75 @@ def colmax(x):
 
 
 GELU_C = 1.0 / math.sqrt(2.0)
+
+
+# ----------------------------------------------------------------------------- training loss
+def get_closest_rot_batch(pred_rots, gt_rots, sym_infos):
+    """``core/utils/pose_utils.py:472-528``: per object, the symmetry-equivalent ground-truth rotation with the
+    smallest rotational error ``re`` (``lib/pysixd/pose_error.py:359-374``) to the prediction; strict ``<`` keeps
+    the first minimum, starting from the un-rotated ground truth."""
+    import numpy as np
+
+    out = gt_rots.clone()
+    P = pred_rots.detach().cpu().double().numpy()
+    G = gt_rots.detach().cpu().double().numpy()
+
+    def re(a, b):
+        tr = min(np.trace(a @ b.T), 3.0)
+        return np.rad2deg(np.arccos(min(1.0, max(-1.0, 0.5 * (tr - 1.0)))))
+
+    for i, sym in enumerate(sym_infos):
+        if sym is None:
+            continue
+        sym = np.asarray(sym, dtype=np.float64).reshape(-1, 3, 3)
+        best, err = G[i], re(P[i], G[i])
+        for k in range(sym.shape[0]):
+            cand = G[i] @ sym[k]
+            e = re(P[i], cand)
+            if e < err:
+                err, best = e, cand
+        out[i] = torch.as_tensor(best, dtype=gt_rots.dtype)
+    return out
+
+
+def catre_loss(out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info, loss_cfg):
+    """``CATRE_disR_shared.catre_loss`` (``core/catre/models/CATRE_disR_shared.py:168-288``) with ``PyPMLoss``
+    (``core/catre/losses/pm_loss.py:85-194``) for the shipped loss types (L1 PM / angular rot / L1 y-axis / L1 t,s)."""
+    ld = {}
+    if loss_cfg.PM_LW > 0:
+        assert loss_cfg.PM_LOSS_TYPE.lower() == "l1" and loss_cfg.PM_R_ONLY and loss_cfg.PM_WITH_SCALE
+        g = get_closest_rot_batch(out_rot, gt_rot, sym_info) if loss_cfg.PM_LOSS_SYM else gt_rot
+        est = (out_rot.unsqueeze(1) @ (obj_kps * out_scale.unsqueeze(1)).unsqueeze(-1)).squeeze(-1)
+        tgt = (g.unsqueeze(1) @ (obj_kps * gt_scale.unsqueeze(1)).unsqueeze(-1)).squeeze(-1)
+        ld["loss_PM_R"] = 3 * F.l1_loss(est, tgt) * loss_cfg.PM_LW
+    if loss_cfg.ROT_LW > 0:
+        sym_mask = torch.tensor([0 if s is None else 1 for s in sym_info])
+        ns, sy = torch.where(sym_mask == 0)[0], torch.where(sym_mask == 1)[0]
+        if len(ns) > 0:
+            assert loss_cfg.ROT_LOSS_TYPE == "angular"
+            m = torch.bmm(out_rot[ns], gt_rot[ns].transpose(1, 2))
+            cos = (torch.einsum("bii->b", m) - 1) / 2
+            ld["loss_rot"] = ((1 - cos) / 2).mean() * loss_cfg.ROT_LW
+        if len(sy) > 0:
+            assert loss_cfg.ROT_YAXIS_LOSS_TYPE == "L1"
+            ld["loss_yaxis_rot"] = F.l1_loss(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
+    if loss_cfg.TRANS_LW > 0:
+        assert loss_cfg.TRANS_LOSS_TYPE == "L1" and loss_cfg.TRANS_LOSS_DISENTANGLE
+        ld["loss_trans_xy"] = F.l1_loss(out_trans[:, :2], gt_trans[:, :2]) * loss_cfg.TRANS_LW
+        ld["loss_trans_z"] = F.l1_loss(out_trans[:, 2], gt_trans[:, 2]) * loss_cfg.TRANS_LW
+    if loss_cfg.SCALE_LW > 0:
+        assert loss_cfg.SCALE_LOSS_TYPE == "L1"
+        ld["loss_scale"] = F.l1_loss(out_scale, gt_scale) * loss_cfg.SCALE_LW
+    return ld
+
+
+def y_axis_symmetries(n):
+    """n-1 rotations about the y axis by multiples of 2*pi/n (shape of ``get_axis_symmetry_transformations``,
+    ``lib/pysixd/misc.py:220-231``, for the NOCS y-symmetric categories ``ref/nocs.py:138-158``)."""
+    import numpy as np
+
+    out = []
+    for i in range(1, n):
+        a = 2.0 * np.pi * i / n
+        out.append([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    return np.asarray(out, dtype=np.float32)

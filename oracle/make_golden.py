@@ -139,6 +139,65 @@ CASES = {
 }
 
 
+TRAIN_CASES = {
+    # name: (B, N, M, seed, salt, symmetric object indices, #sym rotations)
+    "train_b4": (4, 128, 96, 21, 0, (1, 3), 12),
+}
+
+
+def train_sym_info(B, sym_idx, nsym):
+    from oracle.catre_oracle import y_axis_symmetries
+
+    return [y_axis_symmetries(nsym) if i in sym_idx else None for i in range(B)]
+
+
+def run_reference_train(cfg, batch, sym_info, salt=0):
+    """One training iteration of the reference (engine.py:293-349 without the optimizer): batch_updater_test
+    pose-apply, model(..., do_loss=True), sum of the loss dict, backward.  Records the losses and, per parameter,
+    the gradient L2 norm and its first 64 entries."""
+    ref_shim.install()
+    from core.catre.engine.batch_test import batch_updater_test
+
+    model = ref_shim.build_reference_model(cfg).train()
+    sd = synth.recipe_state_dict({k: v.shape for k, v in model.state_dict().items()}, salt)
+    model.load_state_dict(sd, strict=True)
+    b = {k: (v.clone() if isinstance(v, torch.Tensor) else copy.deepcopy(v)) for k, v in batch.items()}
+    batch_updater_test(cfg, b, device="cpu")
+    out_dict, loss_dict = model(
+        b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+        obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
+        obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1,
+    )
+    losses = sum(loss_dict.values())
+    losses.backward()
+    out = {"pose_1": _np(out_dict["pose_1"]), "scale_1": _np(out_dict["scale_1"])}
+    for k, v in loss_dict.items():
+        out[f"loss__{k}"] = _np(v.reshape(1))
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            out[f"gradnone__{k}"] = np.zeros(1, dtype=np.float32)
+        else:
+            out[f"gradnorm__{k}"] = _np(p.grad.norm().reshape(1))
+            out[f"gradhead__{k}"] = _np(p.grad.reshape(-1)[:64])
+    return out
+
+
+def make_train_golden(name):
+    B, N, M, seed, salt, sym_idx, nsym = TRAIN_CASES[name]
+    batch = synth.make_inputs(B, N, M, seed=seed)
+    cfg = reference_cfg(N, M, {})
+    out = run_reference_train(cfg, batch, train_sym_info(B, sym_idx, nsym), salt)
+    arrays = {f"in_{k}": _np(v) for k, v in batch.items()}
+    arrays.update(out)
+    arrays["meta"] = np.array([B, N, M, 1, seed, salt], dtype=np.int64)
+    arrays["meta_sym"] = np.array(list(sym_idx) + [nsym], dtype=np.int64)
+    arrays["meta_overrides"] = np.array(repr([]))
+    path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    print("   losses:", {k[6:]: float(v[0]) for k, v in out.items() if k.startswith("loss__")})
+
+
 def bottle_prior():
     """The reference's data file for category 'bottle' (config 1 of BASELINE.json)."""
     import pickle
@@ -152,7 +211,12 @@ def main(argv=None):
     names = (argv or sys.argv[1:]) or list(CASES)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
+    if not (argv or sys.argv[1:]):
+        names = names + list(TRAIN_CASES)
     for name in names:
+        if name in TRAIN_CASES:
+            make_train_golden(name)
+            continue
         B, N, M, K, seed, salt, prior, ov = CASES[name]
         pr = bottle_prior() if prior == "bottle" else None
         batch = synth.make_inputs(B, N, M, seed=seed, prior=pr)

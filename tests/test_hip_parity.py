@@ -272,8 +272,9 @@ def test_errors():
         model.refine(bad, n_iter=1)
     with pytest.raises(TypeError):
         model.refine(dict(b, pcl=b["pcl"].double()), n_iter=1)
-    with pytest.raises(NotImplementedError):
-        model(b["pcl"].permute(0, 2, 1), b["obj_kps"].permute(0, 2, 1), b["obj_pose_est"], b["obj_scale_est"], do_loss=True)
+    with pytest.raises(AssertionError):  # do_loss=True needs the ground truth (reference :126)
+        model(b["pcl"].permute(0, 2, 1), b["obj_kps"].permute(0, 2, 1), b["obj_pose_est"], b["obj_scale_est"],
+              K_zoom=b["K"], do_loss=True)
     cfg = default_cfg()
     cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_quat"
     from catre_amd.CATRE_disR_shared import build_model_optimizer

@@ -62,3 +62,79 @@ def test_forward_train_and_all_param_grads(name):
         err = float((got - want).abs().max()) / scale_ref
         assert err <= 2e-4, f"{name}: grad of {k}: rel-to-max error {err:.2e} (max |grad| {scale_ref:.3e})"
     assert unused == 6
+
+
+def test_module_training_step_matches_reference_golden():
+    """model(..., do_loss=True) -> (out_dict, loss_dict); sum(loss).backward(): the six loss terms and the parameter
+    gradients against the reference's own training iteration (tests/golden/train_b4.npz)."""
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+    from tests.util import load_train_golden
+
+    g = load_train_golden("train_b4")
+    cfg = g["cfg"].__deepcopy__({})
+    cfg.MODEL.DEVICE = DEV
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.to(DEV) for k, v in recipe_sd(cfg, g["salt"]).items()}, strict=True)
+    model.train()
+    b = {k: v.to(DEV) for k, v in g["batch"].items()}
+    batch_updater_test(cfg, b)
+    out_dict, loss_dict = model(
+        b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+        obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
+        obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=g["sym_info"], do_loss=True, cur_iter=1)
+    ref = g["ref"]
+    assert np.abs(out_dict["pose_1"].detach().cpu().numpy() - ref["pose_1"]).max() <= 2e-5
+    assert set(loss_dict) == {k[6:] for k in ref if k.startswith("loss__")}
+    for k, v in loss_dict.items():
+        np.testing.assert_allclose(v.item(), ref[f"loss__{k}"][0], rtol=1e-4, atol=1e-7, err_msg=k)
+    losses = sum(loss_dict.values())
+    assert torch.isfinite(losses)
+    losses.backward()
+    for k, p in model.named_parameters():
+        if f"gradnone__{k}" in ref:
+            assert p.grad is None, k
+            continue
+        nrm = float(ref[f"gradnorm__{k}"][0])
+        got = p.grad.cpu()
+        np.testing.assert_allclose(float(got.norm()), nrm, rtol=1e-3, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(got.reshape(-1)[:64].numpy(), ref[f"gradhead__{k}"], atol=1e-3 * nrm + 1e-9, rtol=0,
+                                   err_msg=k)
+    # an optimizer step runs on the HIP-computed gradients and changes the next forward (weights are re-packed)
+    before = model.refine(b, n_iter=1)["pose_1"].clone()
+    opt.step()
+    after = model.refine(b, n_iter=1)["pose_1"]
+    assert torch.isfinite(after).all() and (after - before).abs().max() > 0
+
+
+def test_ddp_world1_wraps_and_steps():
+    """The reference wraps the model in DistributedDataParallel(find_unused_parameters=True)
+    (core/catre/main_catre.py:154-160); world_size 1 over RCCL exercises the reducer hooks on the HIP gradients."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+    from tests.util import load_train_golden
+
+    g = load_train_golden("train_b4")
+    cfg = g["cfg"].__deepcopy__({})
+    cfg.MODEL.DEVICE = DEV
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        model, opt = build_model_optimizer(cfg, is_test=False)
+        model.load_state_dict({k: v.to(DEV) for k, v in recipe_sd(cfg, g["salt"]).items()}, strict=True)
+        ddp = DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, find_unused_parameters=True)
+        b = {k: v.to(DEV) for k, v in g["batch"].items()}
+        batch_updater_test(cfg, b)
+        _, loss_dict = ddp(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                           gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                           mean_scales=b["obj_mean_scales"], sym_info=g["sym_info"], do_loss=True, cur_iter=1)
+        sum(loss_dict.values()).backward()
+        nrm = float(g["ref"]["gradnorm__pcl_net.conv4.weight"][0])
+        assert abs(float(model.pcl_net.conv4.weight.grad.norm()) - nrm) <= 1e-3 * nrm
+        opt.step()
+    finally:
+        dist.destroy_process_group()

@@ -72,3 +72,34 @@ def test_oracle_maxpool_permutation_invariant():
         _, d2 = O.pointnet_feat(x[:, :, perm], sd, detail=True)
     np.testing.assert_allclose(d1["g"].numpy(), d2["g"].numpy(), atol=1e-6)
     np.testing.assert_allclose(d1["trans"].numpy(), d2["trans"].numpy(), atol=1e-6)
+
+
+def test_oracle_training_losses_and_grads_match_reference():
+    """Oracle forward + loss + torch autograd vs the reference's own training iteration (do_loss=True, backward):
+    the six loss terms, and per parameter the gradient norm and its first 64 entries."""
+    from tests.util import load_train_golden
+
+    g = load_train_golden("train_b4")
+    cfg, b = g["cfg"], g["batch"]
+    sd = {k: v.clone().requires_grad_(True) for k, v in recipe_sd(cfg, g["salt"]).items()}
+    x, tfd = O.pose_apply(b["pcl"], b["obj_kps"], b["obj_pose_est"], b["obj_scale_est"])
+    pose, scale = O.model_forward(x, tfd, b["obj_pose_est"], b["obj_scale_est"], sd, cfg, K_zoom=b["K"],
+                                  mean_scales=b["obj_mean_scales"])
+    ld = O.catre_loss(pose[:, :, :3], pose[:, :, 3], scale, b["gt_rot"], b["gt_trans"], b["gt_scale"], b["obj_kps"],
+                      g["sym_info"], cfg.MODEL.CATRE.LOSS_CFG)
+    ref = g["ref"]
+    assert set(ld) == {k[6:] for k in ref if k.startswith("loss__")}
+    for k, v in ld.items():
+        np.testing.assert_allclose(v.item(), ref[f"loss__{k}"][0], rtol=2e-5, atol=1e-7, err_msg=k)
+    sum(ld.values()).backward()
+    n_none = 0
+    for k, p in sd.items():
+        if f"gradnone__{k}" in ref:
+            assert p.grad is None
+            n_none += 1
+            continue
+        nrm = float(ref[f"gradnorm__{k}"][0])
+        np.testing.assert_allclose(float(p.grad.norm()), nrm, rtol=2e-4, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(p.grad.reshape(-1)[:64].numpy(), ref[f"gradhead__{k}"], atol=2e-4 * nrm + 1e-9, rtol=0,
+                                   err_msg=k)
+    assert n_none == 6

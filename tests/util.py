@@ -41,3 +41,17 @@ def state_shapes(cfg):
 
 def recipe_sd(cfg, salt=0):
     return synth.recipe_state_dict(state_shapes(cfg), salt)
+
+
+def load_train_golden(name):
+    from oracle.catre_oracle import y_axis_symmetries
+
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False)
+    B, N, M, K, seed, salt = (int(v) for v in z["meta"])
+    sym = [int(v) for v in z["meta_sym"]]
+    sym_idx, nsym = sym[:-1], sym[-1]
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=K, device="cpu")
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    sym_info = [y_axis_symmetries(nsym) if i in sym_idx else None for i in range(B)]
+    ref = {k: z[k] for k in z.files if not k.startswith(("in_", "meta"))}
+    return dict(B=B, N=N, M=M, seed=seed, salt=salt, cfg=cfg, batch=batch, sym_info=sym_info, ref=ref)
