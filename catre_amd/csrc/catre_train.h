@@ -175,12 +175,22 @@ __global__ void k_reduce_splits(const float* __restrict__ part, float* __restric
 // column sums: part[split][J] = sum over rows of the split of dY[r][j]
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
                                                 int J, int rows_per_split) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  // a block covers JB = min(J, 256) columns with 256/JB row lanes, so narrow matrices still use every thread
+  __shared__ float red[256];
+  const int JB = J < 256 ? J : 256;
+  const int RL = 256 / JB;  // row lanes (>= 1); threads beyond RL*JB idle
+  const int col = threadIdx.x % JB, rl = threadIdx.x / JB;
+  const int j = blockIdx.x * 256 + col;
   const int lo = blockIdx.y * rows_per_split, hi = min(R, lo + rows_per_split);
-  if (j >= J) return;
   float s = 0.f;
-  for (int r = lo; r < hi; ++r) s += dY[(size_t)r * ld + j];
-  part[(size_t)blockIdx.y * J + j] = s;
+  if (rl < RL && j < J)
+    for (int r = lo + rl; r < hi; r += RL) s += dY[(size_t)r * ld + j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && j < J) {
+    for (int k = 1; k < RL; ++k) s += red[k * JB + col];
+    part[(size_t)blockIdx.y * J + j] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,19 +451,21 @@ __global__ void k_gnp_gelu_fwd(const float* __restrict__ Y, const float* __restr
 
 // pass 1 of the backward: per (object, group) sums S1 = sum dxhat, S2 = sum dxhat*xhat, and per-(object, channel)
 // partial dgamma / dbeta (summed over objects by k_reduce_splits)
+#define GNP_CH 128  // rows per workgroup in the backward reduction pass
 __global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ dA, const float* __restrict__ Y,
                                                       const float* __restrict__ stat, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ sums,
+                                                      const float* __restrict__ beta, float* __restrict__ sums_part,
                                                       float* __restrict__ dgb_part, int P) {
-  // one workgroup per (object); thread = channel
-  const int obj = blockIdx.x, ch = threadIdx.x, g = ch >> 3;
+  // workgroup = (object, chunk of GNP_CH rows); thread = channel.  Partials are merged in chunk order.
+  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, ch = threadIdx.x, g = ch >> 3;
   const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
   const float ga = gamma[ch], be = beta[ch];
   const float sc = rstd * ga, sh = be - mean * sc;
   float s1 = 0.f, s2 = 0.f, dga = 0.f, dbe = 0.f;
+  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
   const float* y = Y + (size_t)obj * P * 256 + ch;
   const float* da = dA + (size_t)obj * P * 256 + ch;
-  for (int p = 0; p < P; ++p) {
+  for (int p = p0; p < p1; ++p) {
     const float yv = y[(size_t)p * 256];
     const float xh = (yv - mean) * rstd;
     const float dyh = da[(size_t)p * 256] * gelu_grad(fmaf(yv, sc, sh));
@@ -470,12 +482,23 @@ __global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ 
   s2 += __shfl_xor(s2, 1);
   s2 += __shfl_xor(s2, 2);
   s2 += __shfl_xor(s2, 4);
+  const size_t slot = (size_t)obj * nch + chunk;
   if ((ch & 7) == 0) {
-    sums[((size_t)obj * 32 + g) * 2] = s1;
-    sums[((size_t)obj * 32 + g) * 2 + 1] = s2;
+    sums_part[(slot * 32 + g) * 2] = s1;
+    sums_part[(slot * 32 + g) * 2 + 1] = s2;
   }
-  dgb_part[((size_t)obj * 2) * 256 + ch] = dga;
-  dgb_part[((size_t)obj * 2 + 1) * 256 + ch] = dbe;
+  dgb_part[(slot * 2) * 256 + ch] = dga;
+  dgb_part[(slot * 2 + 1) * 256 + ch] = dbe;
+}
+
+// sums[obj][32][2] = sum over chunks of sums_part[obj][chunk][32][2]
+__global__ void k_gnp_bwd_sums_finalize(const float* __restrict__ sums_part, float* __restrict__ sums, int B, int nch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 64) return;
+  const int obj = i / 64, e = i % 64;
+  float s = 0.f;
+  for (int c = 0; c < nch; ++c) s += sums_part[((size_t)obj * nch + c) * 64 + e];
+  sums[i] = s;
 }
 
 __global__ void k_gnp_bwd_apply(const float* __restrict__ dA, const float* __restrict__ Y,

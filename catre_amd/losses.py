@@ -47,7 +47,8 @@ def get_closest_rot_batch(pred_rots, gt_rots, sym_infos):
     prediction.  ``re`` is a decreasing function of trace(R_pred R_cand^T), so the arg-max of the trace is taken;
     the first maximum wins, like the reference's strict ``<`` scan that starts at the un-rotated ground truth."""
     sym, valid = _sym_tensor(sym_infos, gt_rots.device, gt_rots.dtype)
-    cand = gt_rots.unsqueeze(1) @ sym                                   # [B,S+1,3,3]
+    # 3x3 products as broadcast multiply-adds: torch.matmul would dispatch thousands of tiny GEMMs to hipBLASLt
+    cand = (gt_rots.unsqueeze(1).unsqueeze(-1) * sym.unsqueeze(-3)).sum(-2)   # [B,S+1,3,3] = R_gt @ S_k
     tr = (pred_rots.detach().unsqueeze(1) * cand).sum((-1, -2))         # trace(P C^T) = sum_ij P_ij C_ij
     tr = torch.clamp(0.5 * (torch.clamp(tr, max=3.0) - 1.0), -1.0, 1.0)
     tr = torch.where(valid, tr, torch.full_like(tr, -2.0))
@@ -67,8 +68,8 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
             pe, pt = obj_kps * out_scale.unsqueeze(1), obj_kps * gt_scale.unsqueeze(1)
         else:
             pe = pt = obj_kps
-        est = (out_rot.unsqueeze(1) @ pe.unsqueeze(-1)).squeeze(-1)
-        tgt = (g.unsqueeze(1) @ pt.unsqueeze(-1)).squeeze(-1)
+        est = (out_rot.unsqueeze(1) * pe.unsqueeze(-2)).sum(-1)          # R (kps * s) per point, [B,M,3]
+        tgt = (g.unsqueeze(1) * pt.unsqueeze(-2)).sum(-1)
         ld["loss_PM_R"] = 3 * F.l1_loss(est, tgt) * loss_cfg.PM_LW
     if loss_cfg.ROT_LW > 0:
         # index lists are built on the host from the python list: no device->host sync (torch.where would force one)
@@ -76,8 +77,7 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
         sy = torch.tensor([i for i, s in enumerate(sym_info) if s is not None], dtype=torch.long, device=out_rot.device)
         if ns.numel() > 0:
             if loss_cfg.ROT_LOSS_TYPE == "angular":
-                m = torch.bmm(out_rot[ns], gt_rot[ns].transpose(1, 2))
-                cos = (torch.einsum("bii->b", m) - 1) / 2
+                cos = ((out_rot[ns] * gt_rot[ns]).sum((-1, -2)) - 1) / 2     # trace(R_pred R_gt^T)
                 ld["loss_rot"] = ((1 - cos) / 2).mean() * loss_cfg.ROT_LW
             elif loss_cfg.ROT_LOSS_TYPE == "L2":
                 ld["loss_rot"] = torch.pow(out_rot[ns] - gt_rot[ns], 2).mean() * loss_cfg.ROT_LW

@@ -317,7 +317,8 @@ class _GNPointsGelu(torch.autograd.Function):
         da = _c(da)
         dy = torch.empty_like(y)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
-        ws = _ws(B * (64 + 512) * 4, y.device)
+        nch = (P + 127) // 128
+        ws = _ws((B * 64 + B * nch * (64 + 512) + (B * nch // 64 + 1) * 512) * 4, y.device)
         hip.check(lib.catre_op_gnp_gelu_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta),
                                             hip.ptr(dy), hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), ws.numel(), B, P,
                                             _st(y)), "catre_op_gnp_gelu_bwd")
