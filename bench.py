@@ -85,12 +85,91 @@ def cpu_baseline(cfg_fn, sd):
     }
 
 
+def bench_train(args, world, rank, dev, dist, cfg_fn):
+    """BASELINE.json configs 3/4: one step = the reference's train loop body for one data batch
+    (core/catre/engine/engine.py:293-355): K_ITER x (pose-apply, forward + loss, backward, optimizer step), the fed-back
+    pose detached.  With N > 1 the model is wrapped in DistributedDataParallel exactly like
+    core/catre/main_catre.py:154-160 and gradients are all-reduced over RCCL (17.19 MB per backward)."""
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+
+    cfg = cfg_fn(str(dev))
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="Adam", lr=1e-5, weight_decay=0)  # Ranger is host-side Python (SURVEY 8f-4)
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    sd = synth.recipe_state_dict(expected_state_shapes(cfg))
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    model.train()
+    net = model
+    if dist is not None:
+        from torch.nn.parallel import DistributedDataParallel
+
+        net = DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False, find_unused_parameters=True)
+    batch = {k: v.to(dev) for k, v in synth.make_inputs(B_PER_GPU, N_PTS, M_PTS, seed=2000 + rank).items()}
+    ang = torch.arange(1, 314, dtype=torch.float32) * (2 * 3.141592653589793 / 314)
+    sym = torch.zeros(313, 3, 3)
+    sym[:, 0, 0], sym[:, 0, 2], sym[:, 1, 1], sym[:, 2, 0], sym[:, 2, 2] = ang.cos(), ang.sin(), 1.0, -ang.sin(), ang.cos()
+    sym = sym.numpy()  # 313 y-axis symmetry rotations (MAX_SYM_DISC_STEP=0.01, lib/pysixd/misc.py:220-231)
+    sym_info = [sym if (i % 6) in (0, 1, 3) else None for i in range(B_PER_GPU)]  # bottle / bowl / can (ref/nocs.py:138-158)
+
+    def one_step():
+        b = dict(batch)
+        poses_est = scales_est = None
+        for it in range(1, K_ITER + 1):
+            batch_updater_test(cfg, b, poses_est=poses_est, scales_est=scales_est)
+            out, ld = net(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                          gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                          mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=it)
+            poses_est, scales_est = out[f"pose_{it}"].detach(), out[f"scale_{it}"].detach()
+            sum(ld.values()).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return poses_est
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(last).all()
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        value = world * B_PER_GPU * K_ITER * args.steps / dt
+        print(json.dumps({
+            "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)", "value": round(value, 1),
+            "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "B=256 objects/GPU, N=M=1024, K=4 x (forward + loss + backward + Adam step); "
+                                   "half the objects y-symmetric with 313 candidate rotations; "
+                                   + ("DDP gradient all-reduce over RCCL" if world > 1 else "single rank"),
+                       "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER},
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("refine", "train"), default="refine",
+                    help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +195,9 @@ def main():
 
     def cfg_fn(device):
         return default_cfg(num_pcl=N_PTS, num_kps=M_PTS, n_iter=K_ITER, device=device)
+
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev, dist, cfg_fn)
 
     cfg = cfg_fn(str(dev))
     model, _ = build_model_optimizer(cfg, is_test=True)
