@@ -95,7 +95,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 
     cfg = cfg_fn(str(dev))
-    cfg.SOLVER.OPTIMIZER_CFG = dict(type="Adam", lr=1e-5, weight_decay=0)  # Ranger is host-side Python
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=1e-5, weight_decay=0, clean_grads=True)  # shipped optimiser, fused HIP step
     model, opt = build_model_optimizer(cfg, is_test=False)
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
     model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
@@ -152,7 +152,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
             "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "B=256 objects/GPU, N=M=1024, K=4 x (forward + loss + backward + Adam step); "
+            "config": {"workload": "B=256 objects/GPU, N=M=1024, K=4 x (forward + loss + backward + fused Ranger step); "
                                    "half the objects y-symmetric with 313 candidate rotations; "
                                    + ("DDP gradient all-reduce over RCCL" if world > 1 else "single rank"),
                        "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER},

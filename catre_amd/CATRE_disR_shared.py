@@ -131,12 +131,17 @@ class CATRE_disR_shared(nn.Module):
 
 def _build_optimizer(cfg, params_lr_list):
     """Stand-in for ``core/utils/solver_utils.build_optimizer_with_params`` (reference ``:75-87``): the
-    Ranger optimiser of the shipped config is host-side Python outside the hot path."""
+    shipped config's Ranger is ``catre_amd.ranger.Ranger`` (one fused multi-tensor HIP step); other
+    types resolve to ``torch.optim``."""
     ocfg = dict(cfg.SOLVER.get("OPTIMIZER_CFG", {}) or {})
     typ = ocfg.pop("type", "Adam")
     lr = ocfg.pop("lr", float(cfg.SOLVER.BASE_LR))
     wd = ocfg.pop("weight_decay", float(cfg.SOLVER.get("WEIGHT_DECAY", 0.0)))
     groups = [dict(params=list(g["params"]), lr=g["lr"]) for g in params_lr_list]
+    if typ == "Ranger":  # the shipped config (…_120e.py:49): fused multi-tensor HIP step, SURVEY.md 8f-4
+        from .ranger import Ranger
+
+        return Ranger(groups, lr=lr, weight_decay=wd, **ocfg)
     if hasattr(torch.optim, typ):
         return getattr(torch.optim, typ)(groups, lr=lr, weight_decay=wd)
     logger.warning("optimizer %s is not part of the hot path; using torch.optim.RAdam with the same param groups", typ)

@@ -714,3 +714,71 @@ __global__ void k_sum_acc(const float* __restrict__ src, int n, float* __restric
   __syncthreads();
   if (threadIdx.x == 0) dst[0] = (accumulate ? dst[0] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
 }
+
+// ------------------------------------------------------------------------------------------------
+// f4: fused multi-tensor Ranger step (RAdam + Lookahead + gradient centralization) with the train loop's
+// grad nan_to_num folded in.  Replaces the per-tensor Python loop of lib/torch_utils/solver/ranger.py:102-202
+// (~70 tensors x ~15 torch ops, K times per data batch) and core/catre/engine/engine.py:351-353.
+// The host computes the scalar step sizes; the device table carries one RangerTensor per parameter.
+// ------------------------------------------------------------------------------------------------
+struct RangerTensor {
+  float* p;
+  const float* g;
+  float* m;      // exp_avg
+  float* v;      // exp_avg_sq
+  float* slow;   // lookahead slow weights
+  int numel;
+  int row_len;   // > 0: centralize the gradient over rows of this length (dims 1.. of a conv / fc weight)
+  int row_off;   // first slot of this tensor in the row-mean buffer
+  float lr_step; // step_size * lr
+  float wd_lr;   // weight_decay * lr
+  int adaptive;  // N_sma > threshold: divide by sqrt(v) + eps
+  int lookahead; // step % k == 0: merge into the slow weights
+  int pad;
+};
+static_assert(sizeof(RangerTensor) == 72, "host packs this struct with the same layout");
+
+__device__ __forceinline__ float ranger_clean(float g, int clean, float lim) {
+  if (!clean) return g;
+  if (g != g) return 0.f;
+  return fminf(fmaxf(g, -lim), lim);
+}
+
+// one wave per (tensor, row): mean of the (cleaned) gradient row
+__global__ __launch_bounds__(64) void k_ranger_rowmean(const RangerTensor* __restrict__ T, const int* __restrict__ row_tensor,
+                                                       float* __restrict__ rowmean, int clean, float lim) {
+  const int row = blockIdx.x;
+  const RangerTensor t = T[row_tensor[row]];
+  const int r = row - t.row_off;
+  const float* g = t.g + (size_t)r * t.row_len;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < t.row_len; i += 64) s += ranger_clean(g[i], clean, lim);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) rowmean[row] = s / (float)t.row_len;
+}
+
+#define RANGER_CHUNK 4096
+__global__ __launch_bounds__(256) void k_ranger_update(const RangerTensor* __restrict__ T, const int2* __restrict__ chunks,
+                                                       const float* __restrict__ rowmean, float beta1, float beta2,
+                                                       float eps, float alpha, int clean, float lim) {
+  const int2 c = chunks[blockIdx.x];
+  const RangerTensor t = T[c.x];
+  const int end = min(t.numel, c.y + RANGER_CHUNK);
+  for (int i = c.y + threadIdx.x; i < end; i += 256) {
+    float g = ranger_clean(t.g[i], clean, lim);
+    if (t.row_len > 0) g -= rowmean[t.row_off + i / t.row_len];
+    const float v = t.v[i] * beta2 + (1.f - beta2) * g * g;
+    const float m = t.m[i] * beta1 + (1.f - beta1) * g;
+    t.v[i] = v;
+    t.m[i] = m;
+    float p = t.p[i];
+    if (t.wd_lr != 0.f) p -= t.wd_lr * p;
+    p -= t.adaptive ? t.lr_step * (m / (sqrtf(v) + eps)) : t.lr_step * m;
+    if (t.lookahead) {
+      const float s = t.slow[i] + alpha * (p - t.slow[i]);
+      t.slow[i] = s;
+      p = s;
+    }
+    t.p[i] = p;
+  }
+}

@@ -1,0 +1,122 @@
+"""Ranger (RAdam + Lookahead + gradient centralization) as ONE fused multi-tensor HIP step.
+
+Same class name, constructor arguments, defaults and per-parameter ``state`` keys (``step``, ``exp_avg``,
+``exp_avg_sq``, ``slow_buffer``) as the reference's ``lib/torch_utils/solver/ranger.py:31-202`` - so optimizer
+checkpoints written by either load into the other - but the update of all ~70 parameter tensors is two kernel
+launches (``catre_op_ranger_step``) instead of ~1000 tiny torch ops per step, K times per data batch.  The
+train loop's ``nan_to_num(grad, nan=0, posinf=1e5, neginf=-1e5)`` (``core/catre/engine/engine.py:351-353``) can
+be folded into the same pass with ``clean_grads=True``.
+
+The scalar RAdam rectification terms (N_sma, step size) are computed on the host in double precision exactly
+like the reference; everything per element runs on the device in fp32.
+"""
+import math
+
+import numpy as np
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import hip
+
+_CHUNK = 4096
+_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("slow", "<u8"), ("numel", "<i4"),
+                 ("row_len", "<i4"), ("row_off", "<i4"), ("lr_step", "<f4"), ("wd_lr", "<f4"), ("adaptive", "<i4"),
+                 ("lookahead", "<i4"), ("pad", "<i4")])
+assert _REC.itemsize == 72
+
+
+class Ranger(Optimizer):
+    def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5,
+                 weight_decay=0, use_gc=True, gc_conv_only=False, clean_grads=False, grad_limit=1e5):
+        if not 0.0 <= alpha <= 1.0:
+            raise ValueError(f"Invalid slow update rate: {alpha}")
+        if not 1 <= k:
+            raise ValueError(f"Invalid lookahead steps: {k}")
+        if not lr > 0:
+            raise ValueError(f"Invalid Learning Rate: {lr}")
+        if not eps > 0:
+            raise ValueError(f"Invalid eps: {eps}")
+        defaults = dict(lr=lr, alpha=alpha, k=k, step_counter=0, betas=betas, N_sma_threshhold=N_sma_threshhold, eps=eps,
+                        weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.N_sma_threshhold = N_sma_threshhold
+        self.alpha = alpha
+        self.k = k
+        self.use_gc = use_gc
+        self.gc_gradient_threshold = 3 if gc_conv_only else 1
+        self.clean_grads = bool(clean_grads)
+        self.grad_limit = float(grad_limit)
+        self._layout = None  # (key, chunks_dev, row_tensor_dev, rowmean_ws, n_chunks, total_rows)
+
+    # ---------------------------------------------------------------- scalar RAdam terms (reference :150-170)
+    def _step_terms(self, step, beta1, beta2):
+        beta2_t = beta2 ** step
+        n_max = 2 / (1 - beta2) - 1
+        n_sma = n_max - 2 * step * beta2_t / (1 - beta2_t)
+        if n_sma > self.N_sma_threshhold:
+            size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (
+                1 - beta1 ** step)
+            return size, True
+        return 1.0 / (1 - beta1 ** step), False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = hip.load()
+        recs, dev = [], None
+        groups_betas = {tuple(g["betas"]) for g in self.param_groups}
+        groups_eps = {g["eps"] for g in self.param_groups}
+        if len(groups_betas) != 1 or len(groups_eps) != 1:
+            raise NotImplementedError("fused Ranger: betas / eps must be the same in every param group (lr, weight_decay, k may differ)")
+        (beta1, beta2), eps = next(iter(groups_betas)), next(iter(groups_eps))
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Ranger optimizer does not support sparse gradients")
+                hip.require_dev_f32(p, "parameter")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                hip.require_dev_f32(g, "gradient")
+                if not p.is_contiguous():
+                    raise ValueError("fused Ranger needs contiguous parameters")
+                dev = p.device
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["slow_buffer"] = p.detach().clone(memory_format=torch.contiguous_format)
+                st["step"] += 1
+                size, adaptive = self._step_terms(st["step"], beta1, beta2)
+                gc = self.use_gc and p.dim() > self.gc_gradient_threshold
+                recs.append((p, g, st, size * group["lr"], group["weight_decay"] * group["lr"], adaptive,
+                             st["step"] % group["k"] == 0, (p.numel() // p.shape[0]) if gc else 0))
+        if not recs:
+            return None
+        key = tuple((r[0].data_ptr(), r[0].numel(), r[7]) for r in recs)
+        if self._layout is None or self._layout[0] != key:
+            chunks, row_tensor, off = [], [], 0
+            for ti, r in enumerate(recs):
+                n = r[0].numel()
+                chunks += [(ti, o) for o in range(0, n, _CHUNK)]
+                if r[7] > 0:
+                    row_tensor += [ti] * (n // r[7])
+            chunks_dev = torch.tensor(chunks, dtype=torch.int32).to(dev)
+            rt_dev = torch.tensor(row_tensor if row_tensor else [0], dtype=torch.int32).to(dev)
+            ws = torch.empty(max(len(row_tensor), 1), dtype=torch.float32, device=dev)
+            self._layout = (key, chunks_dev, rt_dev, ws, len(chunks), len(row_tensor))
+        _, chunks_dev, rt_dev, ws, n_chunks, total_rows = self._layout
+        table = np.zeros(len(recs), dtype=_REC)
+        row_off = 0
+        for i, (p, g, st, lr_step, wd_lr, adaptive, look, row_len) in enumerate(recs):
+            table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                        st["slow_buffer"].data_ptr(), p.numel(), row_len, row_off, lr_step, wd_lr, int(adaptive), int(look), 0)
+            if row_len > 0:
+                row_off += p.numel() // row_len
+        table_dev = torch.from_numpy(table.view(np.uint8)).to(dev)
+        keep = [r[1] for r in recs]  # contiguous gradient copies must outlive the launch
+        hip.check(lib.catre_op_ranger_step(hip.ptr(table_dev), len(recs), hip.ptr(chunks_dev), n_chunks, hip.ptr(rt_dev),
+                                           total_rows, hip.ptr(ws), beta1, beta2, eps, self.alpha, int(self.clean_grads),
+                                           self.grad_limit, hip.stream_ptr(dev)), "catre_op_ranger_step")
+        del keep
+        return None

@@ -255,6 +255,16 @@ int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const fl
                              const float* mean_scales, const float* Ks, const catre_opts* opts, float* d_rot6d,
                              float* d_dt, float* d_ds, int B, void* stream);
 
+/* f4: one fused multi-tensor Ranger step = RAdam + Lookahead + gradient centralization
+ * (lib/torch_utils/solver/ranger.py:102-202) with the train loop's grad nan_to_num folded in
+ * (core/catre/engine/engine.py:351-353).  `tensors`: device array of n_tensors 72-byte records
+ * {float* p; const float* g; float* exp_avg; float* exp_avg_sq; float* slow; int numel, row_len, row_off;
+ *  float lr_step, wd_lr; int adaptive, lookahead, pad;}; `chunks`: device array of {int tensor, offset} pairs
+ * (4096 elements each); `row_tensor[total_rows]`: tensor index of every centralized gradient row. */
+int catre_op_ranger_step(const void* tensors, int n_tensors, const void* chunks, int n_chunks, const int* row_tensor,
+                         int total_rows, float* rowmean_ws, float beta1, float beta2, float eps, float alpha,
+                         int clean_grads, float grad_limit, void* stream);
+
 /* Build identification: "catre_hip gfx950 <version>" */
 const char* catre_version(void);
 

@@ -198,6 +198,46 @@ def make_train_golden(name):
     print("   losses:", {k[6:]: float(v[0]) for k, v in out.items() if k.startswith("loss__")})
 
 
+RANGER_SHAPES = [(8, 5, 1), (6, 7), (9,), (4, 3, 2, 2), (16, 40)]
+RANGER_STEPS = 14
+
+
+def ranger_problem(seed=31):
+    """Seeded parameters and per-step gradients (one NaN / +inf / -inf injected) shared by the golden and the tests."""
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.randn(s, generator=g) for s in RANGER_SHAPES]
+    grads = [[torch.randn(s, generator=g) * (0.5 + 0.1 * t) for s in RANGER_SHAPES] for t in range(RANGER_STEPS)]
+    grads[3][1][0, 0] = float("nan")
+    grads[4][4][2, 5] = float("inf")
+    grads[9][0][1, 1, 0] = float("-inf")
+    return params, grads
+
+
+def make_ranger_golden():
+    """The reference's own Ranger class (lib/torch_utils/solver/ranger.py) stepped on CPU, two param groups."""
+    ref_shim.install()
+    from lib.torch_utils.solver.ranger import Ranger
+    from lib.torch_utils.misc import nan_to_num
+
+    params, grads = ranger_problem()
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = Ranger([dict(params=ps[:3], lr=2e-2), dict(params=ps[3:], lr=5e-3, weight_decay=0.1)], lr=1e-2)
+    out = {}
+    for t in range(RANGER_STEPS):
+        for p, g in zip(ps, grads[t]):
+            p.grad = g.clone()
+            nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)  # engine.py:351-353
+        opt.step()
+        for i, p in enumerate(ps):
+            out[f"p{i}_step{t + 1}"] = _np(p.data)
+    for i, p in enumerate(ps):
+        st = opt.state[p]
+        out[f"exp_avg{i}"], out[f"exp_avg_sq{i}"], out[f"slow{i}"] = _np(st["exp_avg"]), _np(st["exp_avg_sq"]), _np(st["slow_buffer"])
+    path = os.path.join(GOLDEN_DIR, "ranger_steps.npz")
+    np.savez_compressed(path, **out)
+    print(f"ranger_steps: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def bottle_prior():
     """The reference's data file for category 'bottle' (config 1 of BASELINE.json)."""
     import pickle
@@ -211,8 +251,12 @@ def main(argv=None):
     names = (argv or sys.argv[1:]) or list(CASES)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
+    if "ranger" in names:
+        make_ranger_golden()
+        names = [n for n in names if n != "ranger"]
     if not (argv or sys.argv[1:]):
         names = names + list(TRAIN_CASES)
+        make_ranger_golden()
     for name in names:
         if name in TRAIN_CASES:
             make_train_golden(name)

@@ -11,7 +11,7 @@ from oracle.catre_oracle import y_axis_symmetries
 
 def run(B, N=1024, M=1024, reps=3):
     cfg = default_cfg(num_pcl=N, num_kps=M, device="cuda:0")
-    cfg.SOLVER.OPTIMIZER_CFG = dict(type="Adam", lr=1e-4, weight_decay=0)
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type=os.environ.get("CATRE_OPT", "Ranger"), lr=1e-4, weight_decay=0)
     model, opt = build_model_optimizer(cfg, is_test=False)
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
     model.load_state_dict({k: v.cuda() for k, v in sd.items()}); model.train()
