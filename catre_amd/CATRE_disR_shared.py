@@ -43,6 +43,23 @@ class CATRE_disR_shared(nn.Module):
                 f"{self._opts.ts_in_dim} implied by WITH_KPS_FEATURE / WITH_INIT_SCALE / WITH_INIT_TRANS"
             )
         self._rt = None
+        self._opts_bf16 = type(self._opts).from_buffer_copy(self._opts)
+        self._opts_bf16.compute_dtype = hip.DTYPE_BF16
+
+    def _inference_opts(self):
+        """fp32 kernels unless reduced precision is requested the way the reference requests it - by running
+        the forward under ``torch.cuda.amp.autocast`` (``engine.py:304``, ``TEST.AMP_TEST`` in
+        ``catre_evaluator.py``) - or explicitly with ``cfg.MODEL.CATRE.COMPUTE_DTYPE = "bf16"``.  Reduced precision
+        means bf16 GEMM operands with fp32 accumulation / GroupNorm statistics / SO(3) update (an fp16 autocast
+        request maps to the same kernels)."""
+        want = self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)
+        if want is None:
+            return self._opts_bf16 if torch.is_autocast_enabled() else self._opts
+        if want in ("bf16", "bfloat16"):
+            return self._opts_bf16
+        if want in ("fp32", "float32"):
+            return self._opts
+        raise ValueError(f"MODEL.CATRE.COMPUTE_DTYPE={want!r}: expected 'fp32' or 'bf16'")
 
     # -- runtime is per-instance state that must never be shared by copies of the module
     def __getstate__(self):
@@ -79,7 +96,8 @@ class CATRE_disR_shared(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not (do_loss or needs_grad):
             # inference: the fused kernels (one launch chain, nothing saved)
-            pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, self._opts)
+            pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales,
+                                                      self._inference_opts())
             return {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
 
         # training / autograd: layer-by-layer HIP ops chained by torch.autograd (catre_amd/train_forward.py).
@@ -121,7 +139,7 @@ class CATRE_disR_shared(nn.Module):
         n_iter = int(self.cfg.MODEL.CATRE.N_ITER_TEST if n_iter is None else n_iter)
         poses, scales = self._runtime().refine_k(
             batch["pcl"], batch["obj_kps"], batch["obj_pose_est"], batch["obj_scale_est"], batch.get("K"),
-            batch.get("obj_mean_scales"), self._opts, n_iter,
+            batch.get("obj_mean_scales"), self._inference_opts(), n_iter,
         )
         out = {}
         for i in range(n_iter + 1):

@@ -1,0 +1,694 @@
+// catre_bf16.h - the reduced-precision variant of the fused refine path (BASELINE config 5: "bf16 with fp32
+// SO(3) accumulate"; the reference reaches it through torch.cuda.amp.autocast, engine.py:304 / TEST.AMP_TEST).
+// Included by catre_kernels.hip after the fp32 kernels.
+//
+// What is bf16 and what is not
+//   * operands of every 1x1-conv GEMM over points (STN conv2/3, STNkd conv1-3, the 64x64 feature transform, trunk
+//     conv2-4, rot-head layers 0/1) are rounded to bf16 (RNE) - weights once at pack time, activations when they are
+//     written to LDS; the products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate);
+//   * bias, ReLU, max-pool, GroupNorm statistics, GELU, the FC tails, the ts head, rot6d->SO(3) and the pose update
+//     stay fp32;
+//   * the two activations that travel through HBM (pointfeat [P][64] and rot-head y1 [P][256]) are stored as bf16.
+//
+// LDS images.  An activation image is [64 points][C channels] bf16 stored as 16-byte CHUNKS of 8 channels,
+// CP = C/8 chunks per row, chunk c of row r at chunk index c ^ key(r) (XOR swizzle: the 16 rows of a
+// ds_read_b128 lane group land on 16 distinct 4-bank slots; key = r&15 for rows of >= 256 B, (r>>1)&7 for the
+// 128-byte rows of the 64-channel images).  The channels inside a 16-wide k-group are stored in "k-slot" order:
+//     chunk 2G   = channels 16G + {0,1,2,3, 8, 9,10,11}
+//     chunk 2G+1 = channels 16G + {4,5,6,7,12,13,14,15}
+// which is exactly what one lane holds of a 32x32 MFMA result in the "normal" orientation (rows = channels,
+// cols = points: register quad g of half-wave h = channels 8g+4h..+3), so an epilogue writes ONE ds_write_b128
+// per 8 results.  The contraction index of the next layer is permuted the same way in its packed weights
+// (k_pack_frag_bf), which only re-orders an fp32 sum.
+//
+// Packed weights: u32x4 index ((mblk*(K/16) + kc)*64 + lane) holds, for row mblk*32 + (lane&31), the 8 bf16 of
+// chunk 2kc + (lane>>5) in k-slot order - one coalesced 1 KiB load per wave feeds one K=16 MFMA.
+#pragma once
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
+                                                 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {  // v_cvt_pk_bf16_f32 (RNE)
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ u32x4 pack_bf8(const float (&v)[8]) {
+  u32x4 w;
+  w[0] = pack_bf2(v[0], v[1]);
+  w[1] = pack_bf2(v[2], v[3]);
+  w[2] = pack_bf2(v[4], v[5]);
+  w[3] = pack_bf2(v[6], v[7]);
+  return w;
+}
+
+template <int CP>
+__device__ __forceinline__ int bf_key(int row) {
+  return CP >= 16 ? (row & 15) : ((row >> 1) & (CP - 1));
+}
+template <int CP>
+__device__ __forceinline__ int bf_off(int row, int chunk) {
+  return row * CP + (chunk ^ bf_key<CP>(row));
+}
+
+// weights -> bf16 fragments in k-slot order (layout only + the RNE rounding)
+__global__ void k_pack_frag_bf(const float* __restrict__ src, int ld, int coloff, int rows, int K,
+                               unsigned short* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * K) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9;
+  const int nkc = K / 16;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 16 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+  dst[idx] = __builtin_bit_cast(unsigned short, (__bf16)src[(size_t)row * ld + coloff + col]);
+}
+
+// K-sweep of a wave tile of MB x NB 32x32 blocks, K = 8*CP (CP chunks per LDS row, NKC = CP/2 MFMA steps).
+// Same software pipeline as GemmPipe: weight fragments stream L2 -> registers PFD steps ahead, activation
+// fragments LDS -> registers PFB steps ahead, both pinned with sched_barrier.
+template <int MB, int NB, bool SWAP, int CP, int PFD, int PFB = 1>
+struct GemmPipeB {
+  static constexpr int NKC = CP / 2;
+  static_assert(PFD >= 1 && PFD <= NKC && PFB >= 1 && PFB <= PFD, "prefetch depth");
+  static constexpr int RA = PFD + 1, RB = PFB + 1;
+  u32x4 a[RA][MB], b[RB][NB];
+  const u32x4* wp;
+  int wp_mb;
+
+  __device__ __forceinline__ void issue_a(int kc) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a[kc % RA][mb] = wp[mb * wp_mb + kc * 64];
+  }
+  __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wp_, int wp_mb_) {
+    wp = wp_;
+    wp_mb = wp_mb_;
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) issue_a(d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // x: image row of point 0 of this wave tile (a multiple of 32 rows into the image)
+  __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const u32x4* x, int lane) {
+    const int n = lane & 31, h = lane >> 5, key = bf_key<CP>(n);
+    const u32x4* xrow = x + n * CP;
+    auto issue_b = [&](int kc) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[kc % RB][nb] = xrow[nb * 32 * CP + ((2 * kc + h) ^ key)];
+    };
+#pragma unroll
+    for (int d = 0; d < PFB; ++d) issue_b(d);
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc + PFD < NKC) issue_a(kc + PFD);
+      if (kc + PFB < NKC) issue_b(kc + PFB);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ca = kc % RA, cb = kc % RB;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = SWAP ? mfma_bf(b[cb][nb], a[ca][mb], acc[mb][nb]) : mfma_bf(a[ca][mb], b[cb][nb], acc[mb][nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// "normal"-orientation epilogue: act(acc + bias) -> bf16 image, one 16-byte chunk per 8 results.
+// mblk0 = absolute index of the wave tile's first 32-channel block; img = image row of point 0 of the tile.
+template <int MB, int NB, bool RELU, int CP>
+__device__ __forceinline__ void store_tile_bf(const f32x16 (&acc)[MB][NB], u32x4* img, int mblk0,
+                                              const f32x4 (&bv)[MB][4], int lane) {
+  const int n = lane & 31, h = lane >> 5, key = bf_key<CP>(n);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = 4 * (mblk0 + mb) + 2 * s + h;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v[8];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float t = acc[mb][nb][4 * (2 * s + g2) + q] + bv[mb][2 * s + g2][q];
+            v[4 * g2 + q] = RELU ? fmaxf(t, 0.f) : t;
+          }
+        img[(nb * 32 + n) * CP + (chunk ^ key)] = pack_bf8(v);
+      }
+    }
+}
+
+// conv 3 -> 16 channels [16*grp, +16) of one point on the VALU (fp32), ReLU, -> the two chunks of k-group grp
+__device__ __forceinline__ void conv3_relu_chunks(float x, float y, float z, const float* __restrict__ W,
+                                                  const float* __restrict__ b, int grp, u32x4* row, int key) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = grp * 16 + r;
+    float t = b[ch];
+    t = fmaf(W[ch * 3 + 0], x, t);
+    t = fmaf(W[ch * 3 + 1], y, t);
+    t = fmaf(W[ch * 3 + 2], z, t);
+    v[r] = fmaxf(t, 0.f);
+  }
+  const float c0[8] = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
+  const float c1[8] = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
+  row[(2 * grp) ^ key] = pack_bf8(c0);
+  row[(2 * grp + 1) ^ key] = pack_bf8(c1);
+}
+
+// channel of element e of chunk c (k-slot order)
+__device__ __forceinline__ int bf_chunk_channel(int c, int e) { return 16 * (c >> 1) + 8 * (e >> 2) + 4 * (c & 1) + (e & 3); }
+
+// ------------------------------------------------------------------------------------------
+// a2: STN3d conv stack (pointnet.py:24-28), bf16 operands.  256 threads, 24 KiB LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float* __restrict__ W1,
+                                                     const float* __restrict__ b1, const u32x4* __restrict__ wp2,
+                                                     const float* __restrict__ b2, const u32x4* __restrict__ wp3,
+                                                     const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
+                                                     int M) {
+  __shared__ u32x4 smem[TP * 8 + TP * 16];
+  u32x4* a1 = smem;           // [64][64 ch]
+  u32x4* a2 = smem + TP * 8;  // [64][128 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+
+  GemmPipeB<1, 2, false, 8, 3> g2;  // conv2 64->128: wave -> m-block `wave`
+  g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    conv3_relu_chunks(x, y, z, W1, b1, wave, a1 + lane * 8, bf_key<8>(lane));
+  }
+  __syncthreads();
+  // conv3 128->1024 + max: wave owns m-blocks [8*wave, +8) in two passes of 4
+  GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
+  float bl[2][4];
+  g3a.prefetch(wp3 + ((wave * 8) * 8) * 64 + lane, 8 * 64);
+  load_bias_lane<4>(bl[0], b3, (wave * 8) * 32, lane);
+  load_bias_lane<4>(bl[1], b3, (wave * 8 + 4) * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, a1, lane);
+    store_tile_bf<1, 2, true, 16>(acc, a2, wave, bv2, lane);
+  }
+  __syncthreads();
+  float* out = pm + (size_t)blockIdx.x * PMW;
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3a.run(acc, a2, lane);
+    g3b.prefetch(wp3 + ((wave * 8 + 4) * 8) * 64 + lane, 8 * 64);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+  }
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3b.run(acc, a2, lane);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3+a4: x T3 -> relu(conv1) -> STNkd conv stack 64->64->128->1024 (+ReLU) + per-tile max, bf16 operands.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float* __restrict__ trans3,
+                                                     const float* __restrict__ Wc1, const float* __restrict__ bc1,
+                                                     const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
+                                                     const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
+                                                     const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
+                                                     float* __restrict__ pm, int B, int N, int M) {
+  __shared__ u32x4 smem[2 * TP * 8 + TP * 16];
+  u32x4* h1 = smem;
+  u32x4* f1 = smem + TP * 8;
+  u32x4* f2 = smem + 2 * TP * 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+
+  const int mblk1 = wave >> 1, nb1 = wave & 1;
+  GemmPipeB<1, 1, false, 8, 4> g1;  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks
+  g1.prefetch(wpf1 + (mblk1 * 4) * 64 + lane, 0);
+  f32x4 bv1[1][4];
+  load_bias_quads<1>(bv1, bf1, mblk1 * 32, lane);
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_chunks(x, y, z, Wc1, bc1, wave, h1 + lane * 8, bf_key<8>(lane));
+  }
+  __syncthreads();
+  GemmPipeB<1, 2, false, 8, 3> g2;
+  g2.prefetch(wpf2 + (wave * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, bf2, wave * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][1] = {{zero16()}};
+    g1.run(acc, h1 + nb1 * 32 * 8, lane);
+    store_tile_bf<1, 1, true, 8>(acc, f1 + nb1 * 32 * 8, mblk1, bv1, lane);
+  }
+  __syncthreads();
+  GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
+  float bl[2][4];
+  g3a.prefetch(wpf3 + ((wave * 8) * 8) * 64 + lane, 8 * 64);
+  load_bias_lane<4>(bl[0], bf3, (wave * 8) * 32, lane);
+  load_bias_lane<4>(bl[1], bf3, (wave * 8 + 4) * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, f1, lane);
+    store_tile_bf<1, 2, true, 16>(acc, f2, wave, bv2, lane);
+  }
+  __syncthreads();
+  float* out = pm + (size_t)blockIdx.x * PMW;
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3a.run(acc, f2, lane);
+    g3b.prefetch(wpf3 + ((wave * 8 + 4) * 8) * 64 + lane, 8 * 64);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+  }
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3b.run(acc, f2, lane);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3+a5: trunk (pointnet.py:98-116), bf16 operands.  256 threads and exactly 80 KiB of LDS so that TWO
+// workgroups share a CU: while one sweeps conv4 (MFMA/L2-bound) the other runs its short, latency-bound
+// prologue (conv1, feature transform, conv2, conv3) - with the 16x faster matrix rate those phases would
+// otherwise be ~1/3 of a lone workgroup's time.
+//   a3 [64][512 ch] 64 KiB | a2 [64][128 ch] 16 KiB; h1 / T64 image / pointfeat image alias the a3 region.
+// pointfeat leaves as bf16 chunks [point][8] (k-slot order) - the layout the rotation head consumes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float* __restrict__ trans3,
+                                                     const float* __restrict__ trans64, const float* __restrict__ Wc1,
+                                                     const float* __restrict__ bc1, const u32x4* __restrict__ wp2,
+                                                     const float* __restrict__ b2, const u32x4* __restrict__ wp3,
+                                                     const float* __restrict__ b3, const u32x4* __restrict__ wp4,
+                                                     const float* __restrict__ b4, float* __restrict__ pm,
+                                                     u32x4* __restrict__ pointfeat, int B, int N, int M) {
+  __shared__ u32x4 smem[TP * 64 + TP * 16];
+  u32x4* a3 = smem;
+  u32x4* a2 = smem + TP * 64;
+  u32x4* h1 = smem;                                            // [64][8]
+  u32x4* tA = smem + TP * 8;                                   // [64 j][8]: T64 transposed, rows = out channel j
+  u32x4* pf = smem + 2 * TP * 8;                               // [64][8]
+  float* scratch = reinterpret_cast<float*>(smem + 3 * TP * 8);  // [4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const bool ft = trans64 != nullptr;
+  const int n = lane & 31, h = lane >> 5;
+
+  GemmPipeB<1, 2, false, 8, 3> g2;  // conv2 64->128: wave -> m-block `wave`, both point blocks
+  g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_chunks(x, y, z, Wc1, bc1, wave, (ft ? h1 : pf) + lane * 8, bf_key<8>(lane));
+    if (ft) {  // A-operand image of the feature transform: row j holds T64[i][j] over i (pointnet.py:107-109)
+      const float* src = trans64 + (size_t)ti.cloud * 4096 + (wave * 16) * 64 + lane;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = src[r * 64];
+      const float c0[8] = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
+      const float c1[8] = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
+      const int key = bf_key<8>(lane);
+      tA[lane * 8 + ((2 * wave) ^ key)] = pack_bf8(c0);
+      tA[lane * 8 + ((2 * wave + 1) ^ key)] = pack_bf8(c1);
+    }
+  }
+  __syncthreads();
+  if (ft) {
+    {  // pointfeat[j][p] = sum_i T64[i][j] h1[i][p]: 2 m-blocks x 2 point blocks, one per wave
+      const int mblk = wave >> 1, nb = wave & 1, key = bf_key<8>(n);
+      f32x16 acc[1][1] = {{zero16()}};
+      const u32x4* ar = tA + (mblk * 32 + n) * 8;
+      const u32x4* br = h1 + (nb * 32 + n) * 8;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) acc[0][0] = mfma_bf(ar[(2 * kc + h) ^ key], br[(2 * kc + h) ^ key], acc[0][0]);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 zb[1][4] = {{z4, z4, z4, z4}};
+      store_tile_bf<1, 1, false, 8>(acc, pf + nb * 32 * 8, mblk, zb, lane);
+    }
+    __syncthreads();
+  }
+  // conv3 128->512: wave owns m-blocks [4*wave, +4) in two passes of 2; first weights + bias requested now
+  GemmPipeB<2, 2, false, 16, 3, 1> g3a, g3b;
+  g3a.prefetch(wp3 + ((wave * 4) * 8) * 64 + lane, 8 * 64);
+  f32x4 bv3[2][4];
+  load_bias_quads<2>(bv3, b3, wave * 128, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  // pointfeat tile -> registers (stored to HBM after the last barrier) and its per-channel max over the tile
+  const int pf_cc = tid & 7, pf_row = tid >> 3;  // 8 chunks x 32 rows, rows r and r+32
+  const u32x4 pfc0 = pf[bf_off<8>(pf_row, pf_cc)], pfc1 = pf[bf_off<8>(pf_row + 32, pf_cc)];
+  {
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[2 * i] = fmaxf(bf_lo(pfc0[i]), bf_lo(pfc1[i]));
+      m[2 * i + 1] = fmaxf(bf_hi(pfc0[i]), bf_hi(pfc1[i]));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 8));
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 16));
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 32));
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) scratch[wave * 64 + bf_chunk_channel(lane, e)] = m[e];
+    }
+  }
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, pf, lane);
+    store_tile_bf<1, 2, true, 16>(acc, a2, wave, bv2, lane);
+  }
+  __syncthreads();
+  float pf_max = 0.f;
+  if (tid < 64) pf_max = fmaxf(fmaxf(scratch[tid], scratch[64 + tid]), fmaxf(scratch[128 + tid], scratch[192 + tid]));
+  __syncthreads();  // scratch / pf / h1 live inside a3, which conv3 overwrites next
+  {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3a.run(acc, a2, lane);
+    g3b.prefetch(wp3 + ((wave * 4 + 2) * 8) * 64 + lane, 8 * 64);
+    store_tile_bf<2, 2, true, 64>(acc, a3, wave * 4, bv3, lane);
+    load_bias_quads<2>(bv3, b3, wave * 128 + 64, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3b.run(acc, a2, lane);
+    store_tile_bf<2, 2, true, 64>(acc, a3, wave * 4 + 2, bv3, lane);
+  }
+  // conv4 512->1024 + max: wave owns m-blocks [8*wave, +8) in two passes of 4
+  GemmPipeB<4, 2, true, 64, 2, 1> g4a, g4b;
+  g4a.prefetch(wp4 + ((wave * 8) * 32) * 64 + lane, 32 * 64);
+  float bl4[2][4];
+  load_bias_lane<4>(bl4[0], b4, (wave * 8) * 32, lane);
+  load_bias_lane<4>(bl4[1], b4, (wave * 8 + 4) * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  {  // deferred HBM stores (a barrier would otherwise wait for their acknowledge)
+    const size_t prow0 = ti.is_obs ? (size_t)ti.obj * N + ti.p0 : (size_t)B * N + (size_t)ti.obj * M + ti.p0;
+    if (pf_row < ti.valid) pointfeat[(prow0 + pf_row) * 8 + pf_cc] = pfc0;
+    if (pf_row + 32 < ti.valid) pointfeat[(prow0 + pf_row + 32) * 8 + pf_cc] = pfc1;
+    if (tid < 64) pm[(size_t)blockIdx.x * PMW + 1024 + tid] = pf_max;
+  }
+  float* out = pm + (size_t)blockIdx.x * PMW;
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g4a.run(acc, a3, lane);
+    g4b.prefetch(wp4 + ((wave * 8 + 4) * 32) * 64 + lane, 32 * 64);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl4[0], false, lane);
+  }
+  {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g4b.run(acc, a3, lane);
+    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl4[1], false, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a9: rotation heads, bf16 operands (structure of k_rot_l0_stats / k_rot_l1 / k_rot_out).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_pf_tile_bf(const u32x4* __restrict__ pointfeat, const RotTile& rt, u32x4* pf, int tid,
+                                                int nthreads) {
+  for (int i = tid; i < TP * 8; i += nthreads) {
+    const int row = i >> 3, c = i & 7;
+    const int srow = min(row, rt.valid - 1);
+    pf[bf_off<8>(row, c)] = pointfeat[(rt.pf_off / 64 + srow) * 8 + c];
+  }
+}
+
+__global__ __launch_bounds__(512) void k_rot_l0_stats_bf(const u32x4* __restrict__ pointfeat,
+                                                         const u32x4* __restrict__ wpl0x,
+                                                         const u32x4* __restrict__ wpl0y,
+                                                         const float* __restrict__ bias0 /*[2][2B][256]*/,
+                                                         float* __restrict__ gn0 /*[B][2][T][64]*/, int B, int N,
+                                                         int M) {
+  __shared__ u32x4 pf[TP * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  load_pf_tile_bf(pointfeat, rt, pf, tid, 512);
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+  const float cnt = 8.f * (float)rt.valid;
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    GemmPipeB<1, 2, false, 8, 2> g;
+    g.prefetch((hd ? wpl0y : wpl0x) + (wave * 4) * 64 + lane, 0);
+    g.run(acc, pf, lane);
+    const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
+    float* out = gn0 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + 8 * g4 + 4 * h);
+      float v[2][4];
+      float s = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bool ok = nb * 32 + n < rt.valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[nb][q] = acc[0][nb][4 * g4 + q] + bv[q];
+          s += ok ? v[nb][q] : 0.f;
+        }
+      }
+      const float mean = wave_sum(s) / cnt;
+      float m2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bool ok = nb * 32 + n < rt.valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = v[nb][q] - mean;
+          m2 += ok ? d * d : 0.f;
+        }
+      }
+      m2 = wave_sum(m2);
+      if (lane == 0) {
+        out[(wave * 4 + g4) * 2] = mean;
+        out[(wave * 4 + g4) * 2 + 1] = m2;
+      }
+    }
+  }
+}
+
+// layer 0 recompute -> fused (bias + GN0) affine -> GELU -> bf16 image -> layer 1 -> y1 (bf16, HBM) + GN1 partials.
+// 256 threads, 40 KiB LDS, 2 workgroups per CU (the kernel is VALU-bound on the exact-erf GELU).
+__global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ pointfeat,
+                                                      const u32x4* __restrict__ wpl0x, const u32x4* __restrict__ wpl0y,
+                                                      const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
+                                                      const u32x4* __restrict__ wpl1x, const u32x4* __restrict__ wpl1y,
+                                                      const float* __restrict__ b1x, const float* __restrict__ b1y,
+                                                      unsigned short* __restrict__ y1, float* __restrict__ gn1, int B,
+                                                      int N, int M) {
+  __shared__ u32x4 smem[TP * 8 + TP * 32];
+  u32x4* pf = smem;           // [64][64 ch]
+  u32x4* a0 = smem + TP * 8;  // [64][256 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  const int P = N + M;
+  load_pf_tile_bf(pointfeat, rt, pf, tid, 256);
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    {
+      // wave -> channels [wave*64, +64) = m-blocks 2*wave, 2*wave+1
+      const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
+      f32x4 scr[3], shr[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
+        shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      GemmPipeB<2, 2, false, 8, 2> g0;
+      g0.prefetch((hd ? wpl0y : wpl0x) + (wave * 2 * 4) * 64 + lane, 4 * 64);
+      g0.run(acc, pf, lane);
+      const int key = bf_key<32>(n);
+      float zprev[2][4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // step i = (mb, register quad g): channels mb*32 + 8g + 4h .. +3
+        const int mb = i >> 2, g = i & 3;
+        if (i + 2 < 8) {
+          const int j = i + 2;
+          scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
+          shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          float z[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q], scr[i % 3][q], shr[i % 3][q]));
+          if ((g & 1) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zprev[nb][q] = z[q];
+          } else {  // quads g-1 and g complete chunk 4*(2*wave+mb) + 2*(g>>1) + h
+            const float v[8] = {zprev[nb][0], zprev[nb][1], zprev[nb][2], zprev[nb][3], z[0], z[1], z[2], z[3]};
+            const int chunk = 4 * (2 * wave + mb) + 2 * (g >> 1) + h;
+            a0[(nb * 32 + n) * 32 + (chunk ^ key)] = pack_bf8(v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // layer 1 (256->256), "swapped": lane owns channel wave*64 + mb*32 + n and 32 of the tile's points
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      GemmPipeB<2, 2, true, 32, 2> g1;
+      g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64);
+      g1.run(acc, a0, lane);
+      const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int ch = wave * 64 + mb * 32 + n;
+        const float bb = (hd ? b1y : b1x)[ch];
+        unsigned short* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+        float s = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = acc[mb][nb][r] + bb;
+            acc[mb][nb][r] = v;
+            if (pt < rt.valid) {
+              dst[(size_t)pt * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
+              s += v;
+            }
+          }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 32);
+        const float mean = s * inv_cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float d = acc[mb][nb][r] - mean;
+            m2 += pt < rt.valid ? d * d : 0.f;
+          }
+        m2 += __shfl_xor(m2, 1);
+        m2 += __shfl_xor(m2, 2);
+        m2 += __shfl_xor(m2, 4);
+        m2 += __shfl_xor(m2, 32);
+        if ((lane & 7) == 0 && h == 0) {
+          float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
+          out[0] = mean;
+          out[1] = m2;
+        }
+      }
+    }
+    __syncthreads();  // a0 is rewritten for the second head
+  }
+}
+
+// GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; reads the bf16 y1.
+__global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __restrict__ y1,
+                                                    const float* __restrict__ gn1stat, const float* __restrict__ gam1x,
+                                                    const float* __restrict__ bet1x, const float* __restrict__ gam1y,
+                                                    const float* __restrict__ bet1y, const float* __restrict__ neckx,
+                                                    const float* __restrict__ necky, const float* __restrict__ wpx,
+                                                    const float* __restrict__ wpy, float* __restrict__ rpart, int B,
+                                                    int N, int M) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
+  const int hd = blockIdx.y;
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int c0 = lane * 4;
+  const float* gam = hd ? gam1y : gam1x;
+  const float* bet = hd ? bet1y : bet1x;
+  const float* neck = hd ? necky : neckx;
+  const float* wp = hd ? wpy : wpx;
+  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
+  const float mean = st[0], rstd = st[1];
+  float sc[4], sh[4], nk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * gam[c0 + q];
+    sh[q] = bet[c0 + q] - mean * sc[q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
+  }
+  const unsigned short* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
+  float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int p = wave; p < rt.valid; p += 4) {
+    const u32x2 u = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src + (size_t)p * 256));
+    const float v[4] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
+    const float w = wp[rt.gp0 + p];
+    float z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = nk[c][0] * z[0];
+      t = fmaf(nk[c][1], z[1], t);
+      t = fmaf(nk[c][2], z[2], t);
+      t = fmaf(nk[c][3], z[3], t);
+      a3[c] = fmaf(w, t, a3[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a3[c] = wave_sum(a3[c]);
+  if (lane == 0) {
+    red[wave][0] = a3[0];
+    red[wave][1] = a3[1];
+    red[wave][2] = a3[2];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    rpart[(((size_t)rt.obj * 2 + hd) * T + rt.t) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}

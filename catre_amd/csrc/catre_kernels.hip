@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
   }
 }
 
+#include "catre_bf16.h"
 #include "catre_train.h"
 
 // ==========================================================================================
@@ -924,6 +925,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PackLayout {
   size_t stn_c2, stn_c3, fstn_c1, fstn_c2, fstn_c3, c2, c3, c4, rot_l0[2], rot_l1[2], ts_w0t, ts_w1t, sumwp, total;
+  // bf16 fragment packs of the same matrices (catre_bf16.h), offsets in floats
+  size_t bf_stn_c2, bf_stn_c3, bf_fstn_c1, bf_fstn_c2, bf_fstn_c3, bf_c2, bf_c3, bf_c4, bf_rot_l0[2], bf_rot_l1[2];
 };
 
 PackLayout pack_layout(int ts_in) {
@@ -947,6 +950,18 @@ PackLayout pack_layout(int ts_in) {
     L.rot_l1[h] = take(256 * 256);
   }
   L.sumwp = take(64);
+  L.bf_stn_c2 = take(128 * 64 / 2);
+  L.bf_stn_c3 = take(1024 * 128 / 2);
+  L.bf_fstn_c1 = take(64 * 64 / 2);
+  L.bf_fstn_c2 = take(128 * 64 / 2);
+  L.bf_fstn_c3 = take(1024 * 128 / 2);
+  L.bf_c2 = take(128 * 64 / 2);
+  L.bf_c3 = take(512 * 128 / 2);
+  L.bf_c4 = take(1024 * 512 / 2);
+  for (int h = 0; h < 2; ++h) {
+    L.bf_rot_l0[h] = take(256 * 64 / 2);
+    L.bf_rot_l1[h] = take(256 * 256 / 2);
+  }
   // everything above is independent of ts_in (the stage entry points rely on that)
   L.ts_w0t = take((size_t)ts_in * 256);
   L.ts_w1t = take(256 * 256);
@@ -1006,6 +1021,7 @@ inline int n_clouds(int B, int M) { return M > 0 ? 2 * B : B; }
   } while (0)
 
 inline const f32x4* pk4(const float* packed, size_t off) { return reinterpret_cast<const f32x4*>(packed + off); }
+inline const u32x4* pkb(const float* packed, size_t off) { return reinterpret_cast<const u32x4*>(packed + off); }
 
 int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
                 float* out, int k, int R, hipStream_t st) {
@@ -1084,6 +1100,25 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     const int n = rows * K;
     hipLaunchKernelGGL(k_pack_frag, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K, packed + off);
   };
+  auto frag_bf = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
+    if (!src) return;
+    const int n = rows * K;
+    hipLaunchKernelGGL(k_pack_frag_bf, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
+                       reinterpret_cast<unsigned short*>(packed + off));
+  };
+  frag_bf(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.bf_stn_c2);
+  frag_bf(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.bf_stn_c3);
+  frag_bf(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.bf_fstn_c1);
+  frag_bf(prm[CATRE_P_FSTN_CONV2_W], 64, 0, 128, 64, L.bf_fstn_c2);
+  frag_bf(prm[CATRE_P_FSTN_CONV3_W], 128, 0, 1024, 128, L.bf_fstn_c3);
+  frag_bf(prm[CATRE_P_CONV2_W], 64, 0, 128, 64, L.bf_c2);
+  frag_bf(prm[CATRE_P_CONV3_W], 128, 0, 512, 128, L.bf_c3);
+  frag_bf(prm[CATRE_P_CONV4_W], 512, 0, 1024, 512, L.bf_c4);
+  for (int h = 0; h < 2; ++h) {
+    const int base = h ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
+    frag_bf(prm[base], PMW, 1024, 256, 64, L.bf_rot_l0[h]);
+    frag_bf(prm[base + 4], 256, 0, 256, 256, L.bf_rot_l1[h]);
+  }
   frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);
   frag(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.stn_c3);
   frag(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.fstn_c1);
@@ -1265,6 +1300,85 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
   return check_launch();
 }
 
+// One refine iteration on the bf16-operand kernels (catre_bf16.h); same launch chain, same workspace (pointfeat and
+// y1 hold bf16 in their fp32-sized slots), fp32 FC tails / ts head / pose update shared with the fp32 path.
+static int refine_iter_bf(const catre_points* pts, const float* init_pose, const float* init_scale,
+                          const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                          const catre_opts* o, float* pose_out, float* scale_out, float* ws, const WsLayout& W, int B,
+                          int N, int M, hipStream_t st) {
+  const PackLayout L = pack_layout(1);
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM, tiles = B * T;
+  int rc;
+  {
+    ProfScope ps(CATRE_K_STN3D, st);
+    hipLaunchKernelGGL(k_stn3d_bf, dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+                       prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
+                       pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+  }
+  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
+    return rc;
+  const float* t64 = nullptr;
+  if (o->feature_transform) {
+    {
+      ProfScope ps(CATRE_K_STNKD, st);
+      hipLaunchKernelGGL(k_stnkd_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+                         prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
+                         pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
+                         prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+    }
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+    if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
+      return rc;
+    t64 = ws + W.trans64;
+  }
+  u32x4* pointfeat = reinterpret_cast<u32x4*>(ws + W.pointfeat);
+  {
+    ProfScope ps(CATRE_K_TRUNK, st);
+    hipLaunchKernelGGL(k_trunk_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
+                       prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
+                       prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M);
+  }
+  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
+  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, (void*)st)))
+    return rc;
+  float* bias0 = ws + W.bias0;
+  for (int hd = 0; hd < 2; ++hd) {
+    const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
+    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(256), 0, st, ws + W.gfeat, PMW, prm[base], PMW,
+                       prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
+  }
+  {
+    ProfScope ps(CATRE_K_ROT_L0_STATS, st);
+    hipLaunchKernelGGL(k_rot_l0_stats_bf, dim3(B * T), dim3(512), 0, st, pointfeat, pkb(packed, L.bf_rot_l0[0]),
+                       pkb(packed, L.bf_rot_l0[1]), bias0, ws + W.gn0, B, N, M);
+  }
+  hipLaunchKernelGGL(k_gn0_affine, dim3(B * 2), dim3(256), 0, st, ws + W.gn0, bias0, prm[CATRE_P_ROTX_GN0_W],
+                     prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
+  unsigned short* y1 = reinterpret_cast<unsigned short*>(ws + W.y1);
+  {
+    ProfScope ps(CATRE_K_ROT_L1, st);
+    hipLaunchKernelGGL(k_rot_l1_bf, dim3(B * T), dim3(256), 0, st, pointfeat, pkb(packed, L.bf_rot_l0[0]),
+                       pkb(packed, L.bf_rot_l0[1]), ws + W.aff0, pkb(packed, L.bf_rot_l1[0]),
+                       pkb(packed, L.bf_rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], y1, ws + W.gn1, B,
+                       N, M);
+  }
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
+  {
+    ProfScope ps(CATRE_K_ROT_OUT, st);
+    hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1stat, prm[CATRE_P_ROTX_GN1_W],
+                       prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
+                       prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
+                       prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+  }
+  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
+                     ws + W.rot6d, B, T);
+  if ((rc = check_launch())) return rc;
+  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                           scale_out, B, (void*)st);
+}
+
 int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
                       const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
                       const catre_opts* o, float* pose_out, float* scale_out, void* workspace, size_t ws_bytes, int B,
@@ -1276,6 +1390,10 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (o->compute_dtype == CATRE_DTYPE_BF16)
+    return refine_iter_bf(pts, init_pose, init_scale, mean_scales, Ks, prm, packed, o, pose_out, scale_out, ws, W, B, N, M,
+                          st);
+  if (o->compute_dtype != CATRE_DTYPE_F32) return CATRE_ERR_UNSUPPORTED;
   // STN3d (pointnet.py:98) on both clouds
   if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) return rc;
   if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))

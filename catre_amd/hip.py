@@ -51,7 +51,11 @@ class CatreOpts(ctypes.Structure):
         ("allo_eps", ctypes.c_float),
         ("ts_in_dim", ctypes.c_int32),
         ("rot_input_is_matrix", ctypes.c_int32),
+        ("compute_dtype", ctypes.c_int32),
     ]
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 
 class CatrePoints(ctypes.Structure):

@@ -94,7 +94,12 @@ typedef struct catre_opts {
   float   allo_eps;            /* eps of allo_to_ego_mat_torch, 1e-4 (CATRE_disR_shared.py:112)  */
   int32_t ts_in_dim;           /* TS_HEAD.INIT_CFG.in_dim; must equal the gathered feature width */
   int32_t rot_input_is_matrix; /* catre_pose_update only: `rot6d` holds [B,3,3] matrices (get_rot_mat already applied) */
+  int32_t compute_dtype;       /* catre_refine_iter / catre_refine_k: CATRE_DTYPE_F32 (default) or CATRE_DTYPE_BF16 -
+                                * what torch.cuda.amp.autocast selects in the reference (engine.py:304, TEST.AMP_TEST):
+                                * bf16 GEMM operands, fp32 accumulation / GroupNorm statistics / SO(3) update          */
 } catre_opts;
+
+enum { CATRE_DTYPE_F32 = 0, CATRE_DTYPE_BF16 = 1 };
 
 /* ---- sizes ---------------------------------------------------------------------------- */
 

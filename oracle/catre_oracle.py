@@ -24,6 +24,31 @@ import torch
 import torch.nn.functional as F
 
 
+# ----------------------------------------------------------------------------- reduced-precision emulation
+# The reference reaches reduced precision through torch.cuda.amp.autocast (engine.py:304, TEST.AMP_TEST).  The HIP
+# bf16 path rounds only the OPERANDS of the per-point GEMMs to bf16 and keeps fp32 accumulation, bias, ReLU, max,
+# GroupNorm statistics, GELU, FC tails, ts head and the pose update (catre_amd/csrc/catre_bf16.h).  Inside
+# ``with operand_rounding("bf16"):`` the functions below apply exactly that rounding (RNE) at exactly those places,
+# so the bf16 kernels can be checked to fp32-re-association accuracy instead of only to bf16 accuracy.
+_ROUND = {"mode": None}
+
+
+class operand_rounding:
+    def __init__(self, mode):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev, _ROUND["mode"] = _ROUND["mode"], self.mode
+
+    def __exit__(self, *a):
+        _ROUND["mode"] = self.prev
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(t.dtype) if _ROUND["mode"] == "bf16" else t
+
+
 # ----------------------------------------------------------------------------- a1
 def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
     """``batch_updater_test`` core, ``core/catre/engine/batch_test.py:81-97`` with
@@ -50,9 +75,12 @@ def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
 def stn(x, sd, prefix, k):
     """``STN3d.forward`` / ``STNkd.forward``, ``core/catre/models/pointnets/pointnet.py:24-41,57-78``."""
     w = lambda n: sd[f"{prefix}.{n}"]
-    h = F.relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")))
-    h = F.relu(F.conv1d(h, w("conv2.weight"), w("conv2.bias")))
-    h = F.relu(F.conv1d(h, w("conv3.weight"), w("conv3.bias")))
+    if k == 3:  # 3 -> 64 runs on the VALU in fp32
+        h = F.relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")))
+    else:
+        h = F.relu(F.conv1d(_q(x), _q(w("conv1.weight")), w("conv1.bias")))
+    h = F.relu(F.conv1d(_q(h), _q(w("conv2.weight")), w("conv2.bias")))
+    h = F.relu(F.conv1d(_q(h), _q(w("conv3.weight")), w("conv3.bias")))
     h = torch.max(h, 2)[0]  # [B,1024]
     pooled = h
     h = F.relu(F.linear(h, w("fc1.weight"), w("fc1.bias")))
@@ -69,15 +97,15 @@ def pointnet_feat(x, sd, prefix="pcl_net", feature_transform=True, global_feat=F
     n_pts = x.shape[2]
     trans, pool3 = stn(x, sd, f"{prefix}.stn", 3)
     h = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)  # :100-102
-    h = F.relu(F.conv1d(h, w("conv1.weight"), w("conv1.bias")))  # :103
+    h = _q(F.relu(F.conv1d(h, w("conv1.weight"), w("conv1.bias"))))  # :103
     trans_feat, pool64 = None, None
     if feature_transform:
         trans_feat, pool64 = stn(h, sd, f"{prefix}.fstn", 64)  # :106
-        h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)  # :107-109
+        h = _q(torch.bmm(h.transpose(2, 1), _q(trans_feat)).transpose(2, 1))  # :107-109
     pointfeat = h  # :111
-    h = F.relu(F.conv1d(h, w("conv2.weight"), w("conv2.bias")))
-    h = F.relu(F.conv1d(h, w("conv3.weight"), w("conv3.bias")))
-    h = F.conv1d(h, w("conv4.weight"), w("conv4.bias"))  # no ReLU, :114
+    h = F.relu(F.conv1d(h, _q(w("conv2.weight")), w("conv2.bias")))
+    h = F.relu(F.conv1d(_q(h), _q(w("conv3.weight")), w("conv3.bias")))
+    h = F.conv1d(_q(h), _q(w("conv4.weight")), w("conv4.bias"))  # no ReLU, :114
     g = torch.max(h, 2)[0]  # :115-116
     if global_feat:
         out = g
@@ -111,11 +139,26 @@ def ts_head(feat, sd, prefix="ts_head", num_gn_groups=32):
 def rot_head_single(feat, sd, prefix, num_gn_groups=32):
     """``RotHead.forward``, ``heads/conv_out_per_rot_head.py:126-140``.  feat [B,1088,P] -> [B,3]."""
     w = lambda n: sd[f"{prefix}.{n}"]
-    h = F.conv1d(feat, w("layers.0.weight"), w("layers.0.bias"))
-    h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
-    h = gelu_exact(h)
-    h = F.conv1d(h, w("layers.3.weight"), w("layers.3.bias"))
-    h = F.group_norm(h, num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
+    if _ROUND["mode"] is None:
+        h = F.conv1d(feat, w("layers.0.weight"), w("layers.0.bias"))
+        h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+        h = gelu_exact(h)
+        h = F.conv1d(h, w("layers.3.weight"), w("layers.3.bias"))
+        h = F.group_norm(h, num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
+    else:
+        # global-feature channels (0..1023) go through the fp32 FC kernel, the 64 pointfeat channels (already
+        # rounded) through the bf16 GEMM; y1 is stored rounded but normalised with the statistics of the
+        # unrounded values
+        w0 = w("layers.0.weight")
+        h = F.conv1d(feat[:, :1024], w0[:, :1024], w("layers.0.bias")) + F.conv1d(_q(feat[:, 1024:]), _q(w0[:, 1024:]))
+        h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+        h = gelu_exact(h)
+        h = F.conv1d(_q(h), _q(w("layers.3.weight")), w("layers.3.bias"))
+        B, C, P = h.shape
+        hg = h.reshape(B, num_gn_groups, -1)
+        mean, var = hg.mean(-1, keepdim=True), hg.var(-1, unbiased=False, keepdim=True)
+        h = ((_q(h).reshape(B, num_gn_groups, -1) - mean) / torch.sqrt(var + 1e-5)).reshape(B, C, P)
+        h = h * w("layers.4.weight").reshape(1, C, 1) + w("layers.4.bias").reshape(1, C, 1)
     h = gelu_exact(h)
     h = F.conv1d(h, w("neck.0.weight"), w("neck.0.bias"))  # [B,3,P]
     h = h.permute(0, 2, 1)  # [B,P,3]

@@ -30,7 +30,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 def _np(t):
-    return t.detach().cpu().numpy().copy()
+    return t.detach().float().cpu().numpy().copy()
 
 
 def reference_cfg(N, M, overrides=None):
@@ -48,8 +48,9 @@ def reference_cfg(N, M, overrides=None):
     return cfg
 
 
-def run_reference(cfg, batch, n_iter, salt=0):
-    """The loop of catre_evaluator.py:292-311 with the reference's own batch_updater_test + model."""
+def run_reference(cfg, batch, n_iter, salt=0, amp_dtype=None):
+    """The loop of catre_evaluator.py:292-311 with the reference's own batch_updater_test + model; with
+    ``amp_dtype`` the forward runs under autocast like ``catre_evaluator.py``'s ``amp_test`` branch."""
     ref_shim.install()
     from core.catre.engine.batch_test import batch_updater_test
 
@@ -102,11 +103,13 @@ def run_reference(cfg, batch, n_iter, salt=0):
             if i == 1:
                 cap["x_in"] = _np(b["x"][:, :, :64])
                 cap["tfd_kps_in"] = _np(b["tfd_kps"][:, :, :64])
-            o = model(
-                b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"],
-                K_zoom=b["K"], obj_class=b["obj_cls"], mean_scales=b["obj_mean_scales"],
-                do_loss=False, cur_iter=i,
-            )
+            with torch.autocast("cpu", dtype=amp_dtype, enabled=amp_dtype is not None):
+                o = model(
+                    b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"],
+                    K_zoom=b["K"], obj_class=b["obj_cls"], mean_scales=b["obj_mean_scales"],
+                    do_loss=False, cur_iter=i,
+                )
+            o = {k: v.float() for k, v in o.items()}
             poses_est, scales_est = o[f"pose_{i}"], o[f"scale_{i}"]
             out[f"pose_{i}"], out[f"scale_{i}"] = _np(poses_est), _np(scales_est)
     for h in hs:
@@ -198,6 +201,24 @@ def make_train_golden(name):
     print("   losses:", {k[6:]: float(v[0]) for k, v in out.items() if k.startswith("loss__")})
 
 
+AMP_CASES = ("refine_b2_n1024", "refine_b1_n2048_k8")
+
+
+def make_amp_golden():
+    """The reference under bf16 autocast on the inputs of two fp32 cases: only pose_i / scale_i are kept (the
+    inputs live in the fp32 fixture).  Used to characterise what 'reduced precision' costs the REFERENCE."""
+    out = {}
+    for name in AMP_CASES:
+        B, N, M, K, seed, salt, prior, ov = CASES[name]
+        batch = synth.make_inputs(B, N, M, seed=seed)
+        r = run_reference(reference_cfg(N, M, ov), batch, K, salt, amp_dtype=torch.bfloat16)
+        for i in range(K + 1):
+            out[f"{name}__pose_{i}"], out[f"{name}__scale_{i}"] = r[f"pose_{i}"], r[f"scale_{i}"]
+    path = os.path.join(GOLDEN_DIR, "amp_bf16_reference.npz")
+    np.savez_compressed(path, **out)
+    print(f"amp: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 RANGER_SHAPES = [(8, 5, 1), (6, 7), (9,), (4, 3, 2, 2), (16, 40)]
 RANGER_STEPS = 14
 
@@ -254,9 +275,13 @@ def main(argv=None):
     if "ranger" in names:
         make_ranger_golden()
         names = [n for n in names if n != "ranger"]
+    if "amp" in names:
+        make_amp_golden()
+        names = [n for n in names if n != "amp"]
     if not (argv or sys.argv[1:]):
         names = names + list(TRAIN_CASES)
         make_ranger_golden()
+        make_amp_golden()
     for name in names:
         if name in TRAIN_CASES:
             make_train_golden(name)
