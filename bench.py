@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 B_PER_GPU, N_PTS, M_PTS, K_ITER = 256, 1024, 1024, 4
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: BF16 dense (no sparsity)
 
 # algorithmic FLOPs: per point of one cloud through k_trunk
 #   pointfeat = h1^T T64 (2*64*64) + conv2 (2*64*128) + conv3 (2*128*512) + conv4 (2*512*1024) + conv1/T3 (2*3*64 + 18)
@@ -170,7 +171,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("refine", "train"), default="refine",
                     help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 (the headline, BASELINE parity bar 1e-4) or bf16 GEMM operands (BASELINE config 5)")
+    ap.add_argument("--shape", choices=("headline", "config5"), default="headline",
+                    help="headline: N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8")
     args = ap.parse_args()
+    global N_PTS, K_ITER
+    if args.shape == "config5":
+        N_PTS, K_ITER = 2048, 8
+    bf16 = args.dtype == "bf16"
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +214,7 @@ def main():
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
     model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
     model.eval()
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = args.dtype
     # each rank refines its own shard of the global batch (disjoint seeds)
     batch = {k: v.to(dev) for k, v in synth.make_inputs(B_PER_GPU, N_PTS, M_PTS, seed=1000 + rank).items()}
 
@@ -259,16 +270,16 @@ def main():
         obj_iters = world * B_PER_GPU * K_ITER * args.steps
         value = obj_iters / dt
         trunk_avg_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
-        trunk_flops = 2 * B_PER_GPU * N_PTS * TRUNK_FLOPS_PER_POINT  # N == M: 2B clouds of N points per launch
+        trunk_flops = B_PER_GPU * (N_PTS + M_PTS) * TRUNK_FLOPS_PER_POINT  # all points of both clouds per launch
         achieved = trunk_flops / (trunk_avg_ms * 1e-3) / 1e12 if trunk_ms else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_trunk_hbm_bytes.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not bf16 and args.shape == "headline":
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         path_flops = flops_per_object_iteration(N_PTS, M_PTS)
         line = {
-            "metric": "pose-refine iters/sec (B=256, N=1024, K=4)",
+            "metric": f"pose-refine iters/sec (B=256, N={N_PTS}, K={K_ITER})" + (" [bf16 operands]" if bf16 else ""),
             "value": round(value, 1),
             "unit": "object-iterations/s",
             "n_gpus": world,
@@ -278,23 +289,24 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "B=256 objects/GPU, N=1024 observed + M=1024 prior points, K=4 refine iterations, "
-                            "forward-only (eval loop of catre_evaluator.py:292-311), fp32 MFMA",
+                "workload": f"B=256 objects/GPU, N={N_PTS} observed + M={M_PTS} prior points, K={K_ITER} refine iterations, "
+                            "forward-only (eval loop of catre_evaluator.py:292-311), "
+                            + ("bf16 MFMA operands / fp32 accumulate" if bf16 else "fp32 MFMA"),
                 "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER,
                 "parallelism": f"batch-sharded x{world} (no data-path collective)",
             },
             "path_tflops": round(value * path_flops / 1e12, 2),
-            "path_frac_of_fp32_mfma_peak": round(value * path_flops / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "path_frac_of_mfma_peak": round(value * path_flops / 1e12 / (mfma_peak * world), 4),
             "roofline": {
-                "kernel": "k_trunk",
+                "kernel": "k_trunk_bf" if bf16 else "k_trunk",
                 "bound": "mfma",
                 "achieved": round(achieved, 2) if achieved else None,
-                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "peak": mfma_peak,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                "frac": round(achieved / mfma_peak, 4) if achieved else None,
                 "traffic": traffic,
                 "avg_launch_ms": round(trunk_avg_ms, 4),
                 "launches_timed": len(trunk_ms),
