@@ -310,8 +310,14 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
                                                      const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                      const float* __restrict__ b3, const u32x4* __restrict__ wp4,
                                                      const float* __restrict__ b4, float* __restrict__ pm,
-                                                     u32x4* __restrict__ pointfeat, int B, int N, int M) {
+                                                     u32x4* __restrict__ pointfeat, int B, int N, int M,
+                                                     unsigned long long* __restrict__ trace) {
   __shared__ u32x4 smem[TP * 64 + TP * 16];
+#define TRUNKB_STAMP(i)                                                                                    \
+  do {                                                                                                     \
+    if (trace && (threadIdx.x & 63) == 0)                                                                  \
+      trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter();      \
+  } while (0)
   u32x4* a3 = smem;
   u32x4* a2 = smem + TP * 64;
   u32x4* h1 = smem;                                            // [64][8]
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
   const bool ft = trans64 != nullptr;
   const int n = lane & 31, h = lane >> 5;
+  TRUNKB_STAMP(0);
 
   GemmPipeB<1, 2, false, 8, 3> g2;  // conv2 64->128: wave -> m-block `wave`, both point blocks
   g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0);
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
     }
   }
   __syncthreads();
+  TRUNKB_STAMP(1);
   if (ft) {
     {  // pointfeat[j][p] = sum_i T64[i][j] h1[i][p]: 2 m-blocks x 2 point blocks, one per wave
       const int mblk = wave >> 1, nb = wave & 1, key = bf_key<8>(n);
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
     }
     __syncthreads();
   }
+  TRUNKB_STAMP(2);
   // conv3 128->512: wave owns m-blocks [4*wave, +4) in two passes of 2; first weights + bias requested now
   GemmPipeB<2, 2, false, 16, 3, 1> g3a, g3b;
   g3a.prefetch(wp3 + ((wave * 4) * 8) * 64 + lane, 8 * 64);
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
   float pf_max = 0.f;
   if (tid < 64) pf_max = fmaxf(fmaxf(scratch[tid], scratch[64 + tid]), fmaxf(scratch[128 + tid], scratch[192 + tid]));
   __syncthreads();  // scratch / pf / h1 live inside a3, which conv3 overwrites next
+  TRUNKB_STAMP(3);
   {
     f32x16 acc[2][2];
 #pragma unroll
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
     g3b.run(acc, a2, lane);
     store_tile_bf<2, 2, true, 64>(acc, a3, wave * 4 + 2, bv3, lane);
   }
+  TRUNKB_STAMP(4);
   // conv4 512->1024 + max: wave owns m-blocks [8*wave, +8) in two passes of 4
   GemmPipeB<4, 2, true, 64, 2, 1> g4a, g4b;
   g4a.prefetch(wp4 + ((wave * 8) * 32) * 64 + lane, 32 * 64);
@@ -418,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
   load_bias_lane<4>(bl4[1], b4, (wave * 8 + 4) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  TRUNKB_STAMP(5);
   {  // deferred HBM stores (a barrier would otherwise wait for their acknowledge)
     const size_t prow0 = ti.is_obs ? (size_t)ti.obj * N + ti.p0 : (size_t)B * N + (size_t)ti.obj * M + ti.p0;
     if (pf_row < ti.valid) pointfeat[(prow0 + pf_row) * 8 + pf_cc] = pfc0;
@@ -432,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
     g4a.run(acc, a3, lane);
     g4b.prefetch(wp4 + ((wave * 8 + 4) * 32) * 64 + lane, 32 * 64);
     max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl4[0], false, lane);
+    TRUNKB_STAMP(6);
   }
   {
     f32x16 acc[4][2];
@@ -440,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
     g4b.run(acc, a3, lane);
     max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl4[1], false, lane);
   }
+  TRUNKB_STAMP(7);
+#undef TRUNKB_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -563,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           float z[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q], scr[i % 3][q], shr[i % 3][q]));
+          gelu_affine4(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
+                       scr[i % 3], shr[i % 3], z);
           if ((g & 1) == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) zprev[nb][q] = z[q];
@@ -653,7 +668,8 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
   const float* wp = hd ? wpy : wpx;
   const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
   const float mean = st[0], rstd = st[1];
-  float sc[4], sh[4], nk[3][4];
+  f32x4 sc, sh;
+  float nk[3][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     sc[q] = rstd * gam[c0 + q];
@@ -669,8 +685,7 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
     const float v[4] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
     const float w = wp[rt.gp0 + p];
     float z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+    gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float t = nk[c][0] * z[0];

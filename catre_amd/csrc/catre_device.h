@@ -73,6 +73,47 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return fmaf(hv, erf_rational(v * 0.70710678118654752440f), hv);
 }
 
+// Two GELUs per instruction stream: the same operation sequence as gelu_erf (bit-identical results) written on
+// float2 so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 - 17 packed ops + 2 v_rcp per PAIR instead of ~22 VALU ops
+// per element.  Used where GELU is the bottleneck (rotation head: 2 x 2 x 256 x (N+M) evaluations per object).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float a) {
+  f32x2 v = {a, a};
+  return v;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 erf_rational2(f32x2 x) {
+  x = __builtin_elementwise_min(__builtin_elementwise_max(x, splat2(-4.f)), splat2(4.f));
+  const f32x2 x2 = x * x;
+  f32x2 p = pk_fma(x2, splat2(-2.72614225801306e-10f), splat2(2.77068142495902e-08f));
+  p = pk_fma(x2, p, splat2(-2.10102402082508e-06f));
+  p = pk_fma(x2, p, splat2(-5.69250639462346e-05f));
+  p = pk_fma(x2, p, splat2(-7.34990630326855e-04f));
+  p = pk_fma(x2, p, splat2(-2.95459980854025e-03f));
+  p = pk_fma(x2, p, splat2(-1.60960333262415e-02f));
+  f32x2 q = pk_fma(x2, splat2(-1.45660718464996e-05f), splat2(-2.13374055278905e-04f));
+  q = pk_fma(x2, q, splat2(-1.68282697438203e-03f));
+  q = pk_fma(x2, q, splat2(-7.37332916720468e-03f));
+  q = pk_fma(x2, q, splat2(-1.42647390514189e-02f));
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  return x * p * r;
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+  const f32x2 hv = v * splat2(0.5f);
+  return pk_fma(hv, erf_rational2(v * splat2(0.70710678118654752440f)), hv);
+}
+// z[0..3] = gelu(v * sc + sh) on a register quad
+__device__ __forceinline__ void gelu_affine4(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
+                                             float (&z)[4]) {
+  const f32x2 a = {v0, v1}, b = {v2, v3}, sca = {sc[0], sc[1]}, scb = {sc[2], sc[3]}, sha = {sh[0], sh[1]},
+              shb = {sh[2], sh[3]};
+  const f32x2 za = gelu_erf2(pk_fma(a, sca, sha)), zb = gelu_erf2(pk_fma(b, scb, shb));
+  z[0] = za[0];
+  z[1] = za[1];
+  z[2] = zb[0];
+  z[3] = zb[1];
+}
+
 // One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*NKC.
 //   wp   : fragment-packed weights, already offset to [first m-block][first k-chunk][lane]
 //   wp_mb: float4 stride between consecutive m-blocks  (= (Ktotal/8)*64)

@@ -1337,7 +1337,8 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     ProfScope ps(CATRE_K_TRUNK, st);
     hipLaunchKernelGGL(k_trunk_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
                        prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
-                       prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M);
+                       prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
+                       g_trunk_trace);
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, (void*)st)))

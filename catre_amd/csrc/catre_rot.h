@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
         const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-          f32x4 z;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(acc[mb][nb][4 * g + q], scr[i % 3][q], shr[i % 3][q]));
+          float zz[4];
+          gelu_affine4(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
+                       scr[i % 3], shr[i % 3], zz);
+          const f32x4 z = {zz[0], zz[1], zz[2], zz[3]};
           *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
         }
       }
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
   const float* wp = hd ? wpy : wpx;
   const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
   const float mean = st[0], rstd = st[1];
-  float sc[4], sh[4], nk[3][4];
+  f32x4 sc, sh;
+  float nk[3][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     sc[q] = rstd * gam[c0 + q];
@@ -240,8 +242,7 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)p * 256));
     const float w = wp[rt.gp0 + p];
     float z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+    gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float t = nk[c][0] * z[0];
