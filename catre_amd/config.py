@@ -70,7 +70,26 @@ def default_cfg(num_pcl=1024, num_kps=1024, n_iter=4, device="cuda"):
             NUM_PCL=num_pcl,
             NUM_KPS=num_kps,
             KPS_TYPE="mean_shape",
+            WITH_NEG_AXIS=False,
             ZERO_CENTER_INPUT=True,
+            # train-side batch glue (configs/_base_/catre_base.py:44-86 under the NOCS_REAL experiment file :10-33)
+            INIT_POSE_TYPE_TRAIN=["gt_noise"],
+            INIT_SCALE_TYPE_TRAIN=["gt_noise"],
+            NOISE_ROT_STD_TRAIN=(10, 5, 2.5, 1.25),
+            NOISE_ROT_MAX_TRAIN=45,
+            NOISE_TRANS_STD_TRAIN=[(0.02, 0.02, 0.02), (0.01, 0.01, 0.01), (0.005, 0.005, 0.005)],
+            INIT_TRANS_MIN_Z=0.1,
+            NOISE_SCALE_STD_TRAIN=[(0.01, 0.01, 0.01), (0.005, 0.005, 0.005), (0.002, 0.002, 0.002)],
+            INIT_SCALE_MIN=0.04,
+            RANDOM_TRANS_MIN=[-0.35, -0.35, 0.5],
+            RANDOM_TRANS_MAX=[0.35, 0.35, 1.3],
+            RANDOM_SCALE_MIN=[0.04, 0.04, 0.04],
+            RANDOM_SCALE_MAX=[0.5, 0.3, 0.4],
+            CANONICAL_ROT=[(1, 0, 0, 0.5), (0, 0, 1, -0.7)],
+            CANONICAL_TRANS=[0, 0, 1.0],
+            CANONICAL_SIZE=[0.2, 0.2, 0.2],
+            BBOX3D_AUG_PROB=0.5,
+            RT_AUG_PROB=0.5,
         ),
         SOLVER=dict(
             IMS_PER_BATCH=16,

@@ -915,6 +915,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 
 #include "catre_bf16.h"
 #include "catre_train.h"
+#include "catre_aug.h"
 
 // ==========================================================================================
 // host side: packed-weight and workspace layouts, launchers, C ABI
@@ -1490,5 +1491,35 @@ int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream) 
 }
 
 #include "catre_train_api.inc"
+
+// ---- row f2: train-time batch glue --------------------------------------------------------------------------
+int catre_aug_points(const float* pcl, const float* pose, const float* scale, const int32_t* sym_flags,
+                     const float* bbox_ratios, const float* delta_r, const float* delta_t, float* pcl_out,
+                     float* pose_out, float* scale_out, int B, int N, void* stream) {
+  REQUIRE(pcl && pose && scale && pcl_out && pose_out && scale_out && B > 0 && N > 0);
+  REQUIRE((delta_r == nullptr) == (delta_t == nullptr));
+  AugParams prm;
+  prm.do_bbox = bbox_ratios != nullptr;
+  prm.do_rt = delta_r != nullptr;
+  for (int i = 0; i < 3; ++i) prm.ratios[i] = prm.do_bbox ? bbox_ratios[i] : 1.f;
+  for (int i = 0; i < 9; ++i) prm.delta_r[i] = prm.do_rt ? delta_r[i] : (i % 4 == 0 ? 1.f : 0.f);
+  for (int i = 0; i < 3; ++i) prm.delta_t[i] = prm.do_rt ? delta_t[i] : 0.f;
+  const int total = B * N;
+  hipLaunchKernelGGL(k_aug_points, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcl, pose, scale,
+                     sym_flags, prm, pcl_out, pose_out, scale_out, B, N);
+  return check_launch();
+}
+
+int catre_init_noise(const float* pose, const float* euler_deg, const float* trans_noise, float max_rot_deg,
+                     float min_z, float* pose_out, const float* scale, const float* scale_noise, float min_s,
+                     float max_s, float* scale_out, int B, void* stream) {
+  REQUIRE(B > 0 && (pose || scale));
+  if (pose) REQUIRE(euler_deg && trans_noise && pose_out);
+  if (scale) REQUIRE(scale_noise && scale_out);
+  hipLaunchKernelGGL(k_init_noise, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, euler_deg, trans_noise,
+                     max_rot_deg, max_rot_deg >= 0.f ? 1 : 0, min_z, pose_out, scale, scale_noise, min_s, max_s, scale_out,
+                     B);
+  return check_launch();
+}
 
 }  // extern "C"

@@ -273,6 +273,26 @@ int catre_op_ranger_step(const void* tensors, int n_tensors, const void* chunks,
 /* Build identification: "catre_hip gfx950 <version>" */
 const char* catre_version(void);
 
+/* ---- train-time batch glue on the device ----------------------------------------------- */
+
+/* aug_3d_bbox followed by aug_RT (core/catre/engine/engine_utils.py:107-172; called from batch_data,
+ * core/catre/engine/batching.py:84-88) over all B*N points in one launch:
+ *   p' = dR (R (ratios .* R^T (p - t)) + t + dt),  pose' = [dR R | dR (t + dt)],  scale' = scale .* ratios.
+ * bbox_ratios = HOST pointer to (ex, ey, ez) or NULL (no bbox aug); objects with sym_flags[b] != 0 use
+ * ((ex+ez)/2, ey, (ex+ez)/2) (:126-128).  delta_r[9] / delta_t[3] = HOST pointers (get_rotation_torch output and
+ * the translation shift) or both NULL.  pcl, pose, scale, sym_flags and the outputs are device pointers;
+ * pcl_out may alias pcl; pose_out / scale_out must NOT alias pose / scale (other threads still read them). */
+int catre_aug_points(const float* pcl, const float* pose, const float* scale, const int32_t* sym_flags,
+                     const float* bbox_ratios, const float* delta_r, const float* delta_t, float* pcl_out,
+                     float* pose_out, float* scale_out, int B, int N, void* stream);
+
+/* aug_poses_normal (core/utils/pose_aug.py:59-101) and aug_scale_normal (:10-35) given the normal noise the caller
+ * drew: euler_deg [B,3] ~ N(0, std_rot) (clamped to +-max_rot_deg here unless max_rot_deg < 0), trans_noise [B,3],
+ * scale_noise [B,3].  Either half may be skipped with pose == NULL / scale == NULL. */
+int catre_init_noise(const float* pose, const float* euler_deg, const float* trans_noise, float max_rot_deg,
+                     float min_z, float* pose_out, const float* scale, const float* scale_noise, float min_s,
+                     float max_s, float* scale_out, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

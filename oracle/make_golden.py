@@ -219,6 +219,84 @@ def make_amp_golden():
     print(f"amp: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def make_aug_golden(seed=77):
+    """Reference aug_3d_bbox / aug_RT / aug_poses_normal / aug_scale_normal (CPU) with the random draws replayed
+    and stored, so that the HIP kernels (which take the draws as inputs) can be checked against these outputs."""
+    ref_shim.install()
+    import random
+
+    from core.catre.engine import engine_utils as EU
+    from core.utils import pose_aug as PA
+
+    B, N = 6, 160
+    inp = synth.make_inputs(B, N, 32, seed=seed)
+    sym_flags = [0, 1, 0, 1, 1, 0]
+    batch = {"pcl": inp["pcl"].clone(), "obj_pose": torch.cat([inp["gt_rot"], inp["gt_trans"].unsqueeze(-1)], -1),
+             "obj_scale": inp["gt_scale"].clone(), "sym_info": [np.eye(3)[None] if f else None for f in sym_flags]}
+    out = {"in_pcl": _np(batch["pcl"]), "in_pose": _np(batch["obj_pose"]), "in_scale": _np(batch["obj_scale"]),
+           "in_sym": np.array(sym_flags, dtype=np.int32)}
+
+    def reseed():
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+
+    reseed()
+    EU.aug_3d_bbox(batch, device="cpu")
+    reseed()
+    ex, ey, ez = torch.rand(3)
+    out["bbox_ratios"] = np.array([ex * 0.4 + 0.8, ey * 0.4 + 0.8, ez * 0.4 + 0.8], dtype=np.float32)
+    out["bbox_pcl"], out["bbox_scale"] = _np(batch["pcl"]), _np(batch["obj_scale"])
+
+    reseed()
+    EU.aug_RT(batch, device="cpu")
+    reseed()
+    rx, ry, rz = torch.rand(3) * 15.0 * 2 - 15.0
+    tx, ty, tz = torch.rand(1) * 0.005 * 2 - 0.005, torch.rand(1) * 0.005 * 2 - 0.005, torch.rand(1) * 0.025 * 2 - 0.025
+    out["rt_delta_r"] = _np(EU.get_rotation_torch(rx, ry, rz))
+    out["rt_delta_t"] = np.array([tx, ty, tz], dtype=np.float32).reshape(3)
+    out["rt_pcl"], out["rt_pose"] = _np(batch["pcl"]), _np(batch["obj_pose"])
+
+    std_rot, std_trans, std_scale = (10, 5, 2.5, 1.25), [(0.02, 0.02, 0.02), (0.01, 0.01, 0.01), (0.005, 0.005, 0.005)], \
+        [(0.01, 0.01, 0.01), (0.005, 0.005, 0.005), (0.002, 0.002, 0.002)]
+    poses = batch["obj_pose"].clone()
+    poses[0, 2, 3] = 0.05  # exercises the min_z clamp
+    reseed()
+    out["noise_pose_out"] = _np(PA.aug_poses_normal(poses, std_rot=std_rot, std_trans=std_trans, max_rot=1.0, min_z=0.1))
+    reseed()
+    sr = np.random.choice(std_rot)
+    out["noise_euler_deg"] = _np(torch.normal(mean=0, std=sr, size=(B, 3)))
+    st = std_trans[np.random.choice(len(std_trans))]
+    out["noise_trans"] = _np(torch.normal(mean=torch.zeros(B, 3), std=torch.tensor(st).view(1, 3)))
+    out["noise_pose_in"] = _np(poses)
+    out["noise_sel"] = np.array([sr, *st], dtype=np.float64)
+
+    scales = batch["obj_scale"].clone()
+    scales[1, 0] = 0.041  # exercises the min_s clamp
+    reseed()
+    out["noise_scale_out"] = _np(PA.aug_scale_normal(scales, std_scale=std_scale, min_s=0.04))
+    reseed()
+    ss = std_scale[np.random.choice(len(std_scale))]
+    out["noise_scale"] = _np(torch.normal(mean=torch.zeros(B, 3), std=torch.tensor(ss).view(1, 3)))
+    out["noise_scale_in"] = _np(scales)
+
+    # self-check of the replayed draws against the restatement (fails loudly if the replay is wrong)
+    from oracle import aug_oracle as AO
+
+    t = torch.from_numpy
+    p1, s1 = AO.aug_3d_bbox(t(out["in_pcl"]), t(out["in_pose"]), t(out["in_scale"]), t(out["in_sym"]), out["bbox_ratios"])
+    assert np.abs(_np(p1) - out["bbox_pcl"]).max() < 1e-6 and np.abs(_np(s1) - out["bbox_scale"]).max() < 1e-7
+    p2, q2 = AO.aug_rt(p1, t(out["in_pose"]), t(out["rt_delta_r"]), t(out["rt_delta_t"]))
+    assert np.abs(_np(p2) - out["rt_pcl"]).max() < 1e-6 and np.abs(_np(q2) - out["rt_pose"]).max() < 1e-6
+    pn = AO.poses_from_noise(t(out["noise_pose_in"]), t(out["noise_euler_deg"]), t(out["noise_trans"]), 1.0, 0.1)
+    assert np.abs(_np(pn) - out["noise_pose_out"]).max() < 1e-6
+    sn = AO.scales_from_noise(t(out["noise_scale_in"]), t(out["noise_scale"]), 0.04, 0.45)
+    assert np.abs(_np(sn) - out["noise_scale_out"]).max() < 1e-7
+    path = os.path.join(GOLDEN_DIR, "aug_train.npz")
+    np.savez_compressed(path, **out)
+    print(f"aug: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 RANGER_SHAPES = [(8, 5, 1), (6, 7), (9,), (4, 3, 2, 2), (16, 40)]
 RANGER_STEPS = 14
 
@@ -275,6 +353,9 @@ def main(argv=None):
     if "ranger" in names:
         make_ranger_golden()
         names = [n for n in names if n != "ranger"]
+    if "aug" in names:
+        make_aug_golden()
+        names = [n for n in names if n != "aug"]
     if "amp" in names:
         make_amp_golden()
         names = [n for n in names if n != "amp"]
@@ -282,6 +363,7 @@ def main(argv=None):
         names = names + list(TRAIN_CASES)
         make_ranger_golden()
         make_amp_golden()
+        make_aug_golden()
     for name in names:
         if name in TRAIN_CASES:
             make_train_golden(name)
