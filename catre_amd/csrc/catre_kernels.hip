@@ -916,6 +916,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 #include "catre_bf16.h"
 #include "catre_train.h"
 #include "catre_aug.h"
+#include "catre_pcl.h"
 
 // ==========================================================================================
 // host side: packed-weight and workspace layouts, launchers, C ABI
@@ -1507,6 +1508,70 @@ int catre_aug_points(const float* pcl, const float* pose, const float* scale, co
   const int total = B * N;
   hipLaunchKernelGGL(k_aug_points, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcl, pose, scale,
                      sym_flags, prm, pcl_out, pose_out, scale_out, B, N);
+  return check_launch();
+}
+
+// ---- row f3: point-cloud preparation -----------------------------------------------------------------------
+namespace {
+struct PclWs {
+  size_t bins, choose, offsets, total, cand, total_ints;
+  int nchunks;
+};
+PclWs pcl_ws(int I, int H, int W) {
+  PclWs L;
+  L.nchunks = (H * W + PCL_CHUNK - 1) / PCL_CHUNK;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += align_up(n, 64);
+    return r;
+  };
+  L.bins = take((size_t)I * L.nchunks * 12);
+  L.choose = take(I);
+  L.offsets = take((size_t)I * L.nchunks);
+  L.total = take(I);
+  L.cand = take((size_t)I * H * W);
+  L.total_ints = o;
+  return L;
+}
+inline PclCam pcl_cam(const float* K9) { return PclCam{K9[0], K9[4], K9[2], K9[5]}; }
+}  // namespace
+
+size_t catre_pcl_workspace_bytes(int I, int H, int W) {
+  if (I <= 0 || H <= 0 || W <= 0) return 0;
+  return pcl_ws(I, H, W).total_ints * sizeof(int);
+}
+
+int catre_pcl_candidates(const float* depth, const float* K9, const unsigned char* masks, const float* poses,
+                         const float* scales, float ratio, int use_ball, int I, int H, int W, void* workspace,
+                         size_t ws_bytes, int32_t* counts_out, void* stream) {
+  REQUIRE(depth && K9 && poses && scales && workspace && I > 0 && H > 0 && W > 0 && (size_t)H * W < (1u << 30));
+  const PclWs L = pcl_ws(I, H, W);
+  if (ws_bytes < L.total_ints * sizeof(int)) return CATRE_ERR_WORKSPACE;
+  int* ws = (int*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const PclCam cam = pcl_cam(K9);
+  hipLaunchKernelGGL(k_pcl_count, dim3(L.nchunks, I), dim3(256), 0, st, depth, masks, poses, scales, cam, ratio, use_ball,
+                     H, W, L.nchunks, ws + L.bins);
+  hipLaunchKernelGGL(k_pcl_pick, dim3(I), dim3(256), 0, st, ws + L.bins, L.nchunks, 1, ws + L.choose, ws + L.offsets,
+                     ws + L.total);
+  hipLaunchKernelGGL(k_pcl_compact, dim3(L.nchunks, I), dim3(256), 0, st, depth, masks, poses, scales, cam, ratio,
+                     use_ball, H, W, L.nchunks, ws + L.choose, ws + L.offsets, ws + L.cand);
+  if (counts_out &&
+      hipMemcpyAsync(counts_out, ws + L.total, (size_t)I * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return CATRE_ERR_LAUNCH;
+  return check_launch();
+}
+
+int catre_pcl_sample(const float* depth, const float* K9, const void* workspace, size_t ws_bytes,
+                     const long long* sample_idx, unsigned long long seed, int I, int H, int W, int N, float* pcl_out,
+                     int32_t* pix_out, void* stream) {
+  REQUIRE(depth && K9 && workspace && pcl_out && I > 0 && H > 0 && W > 0 && N > 0);
+  const PclWs L = pcl_ws(I, H, W);
+  if (ws_bytes < L.total_ints * sizeof(int)) return CATRE_ERR_WORKSPACE;
+  const int* ws = (const int*)workspace;
+  hipLaunchKernelGGL(k_pcl_gather, dim3((N + 255) / 256, I), dim3(256), 0, (hipStream_t)stream, depth, pcl_cam(K9), H, W,
+                     ws + L.cand, ws + L.total, sample_idx, seed, N, pcl_out, pix_out);
   return check_launch();
 }
 

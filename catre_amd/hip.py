@@ -111,6 +111,9 @@ _SIGS = {
     "catre_aug_points": (_I, [_P] * 10 + [_I, _I, _P]),
     "catre_init_noise": (_I, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _I,
                               _P]),
+    "catre_pcl_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "catre_pcl_candidates": (_I, [_P, _P, _P, _P, _P, ctypes.c_float, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "catre_pcl_sample": (_I, [_P, _P, _P, _SZ, _P, ctypes.c_uint64, _I, _I, _I, _I, _P, _P, _P]),
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),

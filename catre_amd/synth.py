@@ -174,3 +174,46 @@ def make_inputs(B, N=1024, M=1024, seed=0, prior=None, dtype=torch.float32):
     out = {k: v.to(dtype).contiguous() for k, v in out.items()}
     out["obj_cls"] = torch.arange(B, dtype=torch.long) % 6
     return out
+
+
+def make_depth_scene(H=120, W=160, n_inst=5, seed=0):
+    """A synthetic depth frame for the point-cloud preparation: a tilted background plane with
+    ``n_inst`` ellipsoidal blobs in front of it, zero-depth holes, per-instance masks and poses.  The instances cover
+    the branches of the reference's ball crop: 0 regular; 1 a tiny object (radius floor 0.05 + growth); 2 a pose centre
+    a little off its mask (radius growth); 3 a pose centre far away (falls back to every masked pixel); 4 very few
+    masked pixels (candidate list tiled up to the sample count)."""
+    g = torch.Generator().manual_seed(seed)
+    K = torch.tensor([[0.9 * W, 0.0, W / 2 - 0.5], [0.0, 0.9 * W, H / 2 - 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = 1.6 + 0.002 * (u - W / 2) + 0.001 * (v - H / 2)
+    masks = torch.zeros(n_inst, H, W, dtype=torch.bool)
+    poses = torch.zeros(n_inst, 3, 4)
+    scales = torch.zeros(n_inst, 3)
+    for i in range(n_inst):
+        cu, cv = W * (0.15 + 0.7 * (i + 0.5) / n_inst), H * (0.3 + 0.4 * torch.rand(1, generator=g).item())
+        ru, rv = W * 0.07, H * 0.12
+        if i % 5 == 4:
+            ru, rv = 2.2, 1.6
+        inside = ((u - cu) / ru) ** 2 + ((v - cv) / rv) ** 2 < 1
+        zc = 0.9 + 0.1 * i
+        bump = zc - 0.05 * torch.sqrt(torch.clamp(1 - ((u - cu) / ru) ** 2 - ((v - cv) / rv) ** 2, min=0))
+        depth = torch.where(inside, bump, depth)
+        masks[i] = inside
+        q = torch.randn(4, generator=g)
+        q = q / q.norm()
+        w, x, y, z = q.tolist()
+        R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        t = torch.tensor([(cu - K[0, 2]) * zc / K[0, 0], (cv - K[1, 2]) * zc / K[1, 1], zc])
+        s = torch.tensor([0.12, 0.2, 0.15])
+        if i % 5 == 1:
+            s = s * 0.05
+        if i % 5 == 2:
+            t = t + torch.tensor([0.16, 0.0, 0.0])
+        if i % 5 == 3:
+            t = t + torch.tensor([0.0, 0.9, 0.5])
+        poses[i, :, :3], poses[i, :, 3], scales[i] = R, t, s
+    holes = torch.rand(H, W, generator=g) < 0.03
+    depth = torch.where(holes, torch.zeros_like(depth), depth).to(torch.float32)
+    return dict(depth=depth, K=K, masks=masks, poses=poses, scales=scales)

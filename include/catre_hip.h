@@ -293,6 +293,33 @@ int catre_init_noise(const float* pose, const float* euler_deg, const float* tra
                      float min_z, float* pose_out, const float* scale, const float* scale_noise, float min_s,
                      float max_s, float* scale_out, int B, void* stream);
 
+/* ---- point-cloud preparation (the step before the path) -------------------------------- */
+
+/* Candidate pixels of I instances of one depth map, all instances at once - replaces, per instance,
+ * backproject_th (lib/pysixd/misc.py:360-378) + sample_bp_depth (core/utils/cat_data_utils.py:209-226) + the
+ * radius search of crop_ball_from_pts (:289-304) as called from crop_ball_from_depth_image (:380-400) by the data
+ * loader (core/catre/datasets/data_loader.py:576-603):
+ *   valid = mask & (depth > 0);  radius = max(ratio * ||R s||, 0.05) grown x1.1 (at most 9 times) until >= 10 valid
+ *   points lie within it of the pose centre; no point at all -> every valid pixel (the `distance <= 1e9` fallback).
+ * use_ball = 0 keeps every valid pixel (crop_mask_depth_image, :352-377).  depth [H,W] fp32 metres (device),
+ * K9 = HOST 3x3 intrinsics row-major, masks [I,H,W] bytes (device) or NULL, poses [I,3,4], scales [I,3] (device).
+ * The ordered (row-major, = torch.nonzero order) candidate lists stay in `workspace`
+ * (catre_pcl_workspace_bytes); counts_out [I] (device, optional) receives their lengths. */
+size_t catre_pcl_workspace_bytes(int I, int H, int W);
+int catre_pcl_candidates(const float* depth, const float* K9, const unsigned char* masks, const float* poses,
+                         const float* scales, float ratio, int use_ball, int I, int H, int W, void* workspace,
+                         size_t ws_bytes, int32_t* counts_out, void* stream);
+
+/* N points per instance out of the candidate lists: the tail of crop_ball_from_pts (:305-320) - the list is tiled
+ * by doubling to a length L >= N, slot i takes element sample_idx[inst][i] of it (sample_idx [I,N] int64 on the
+ * device = the caller's torch.randperm(L)[:N], which reproduces the reference's random stream), or, with
+ * sample_idx == NULL, element perm_seed(i) of a keyed pseudo-random permutation of [0,L) evaluated on the device
+ * (no host round trip).  pcl_out [I,N,3]; pix_out [I,N] (optional) = the flat pixel index of every sample, for
+ * gathering rgb / NOCS maps.  Instances without any candidate produce zeros and pix -1. */
+int catre_pcl_sample(const float* depth, const float* K9, const void* workspace, size_t ws_bytes,
+                     const long long* sample_idx, unsigned long long seed, int I, int H, int W, int N, float* pcl_out,
+                     int32_t* pix_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,6 +297,55 @@ def make_aug_golden(seed=77):
     print(f"aug: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def make_pcl_golden(seed=11, N=96):
+    """Reference crop_ball_from_depth_image / crop_mask_depth_image per instance of a synthetic depth frame, with the
+    torch.randperm draws replayed and stored."""
+    ref_shim.install()
+    from core.utils import cat_data_utils as CU
+    from lib.pysixd import misc
+    from oracle import pcl_oracle as PO
+
+    sc = synth.make_depth_scene(seed=seed)
+    depth, K, masks, poses, scales = sc["depth"], sc["K"], sc["masks"], sc["poses"], sc["scales"]
+    H, W = depth.shape
+    I = len(masks)
+    depth_bp = misc.backproject_th(depth, K.numpy())
+    image = torch.zeros(H, W, 3, dtype=torch.uint8)
+    out = {f"in_{k}": _np(v) if v.dtype != torch.bool else v.numpy() for k, v in sc.items()}
+    out["meta"] = np.array([N, seed], dtype=np.int64)
+    for mode, ball in (("ball", True), ("mask", False)):
+        torch.manual_seed(seed)
+        ref = []
+        for i in range(I):
+            if ball:
+                _, pcl, _ = CU.crop_ball_from_depth_image(image, depth_bp, masks[i], poses[i], scales[i], ratio=0.5,
+                                                          cam_intrinsics=K, num_points=N, device="cpu", fps_sample=False)
+            else:
+                if int((masks[i] & (depth > 0)).sum()) < N:   # the reference recursion draws several permutations here
+                    pcl = torch.zeros(N, 3)
+                else:
+                    _, pcl, _ = CU.crop_mask_depth_image(image, depth_bp, masks[i], num_points=N)
+            ref.append(pcl.to(torch.float32))
+        out[f"{mode}_pcl"] = _np(torch.stack(ref))
+        torch.manual_seed(seed)
+        cnt, sidx = [], []
+        for i in range(I):
+            pix, bp = PO.candidates(depth, K, masks[i], poses[i], scales[i], 0.5, use_ball=ball)
+            cnt.append(len(pix))
+            if not ball and len(pix) < N:
+                sidx.append(torch.zeros(N, dtype=torch.long))
+                continue
+            s = torch.randperm(PO.tiled_length(len(pix), N))[:N]
+            sidx.append(s)
+            got, _ = PO.sample(pix, bp, s)
+            assert np.abs(_np(got) - out[f"{mode}_pcl"][i]).max() < 1e-7, (mode, i)
+        out[f"{mode}_counts"] = np.array(cnt, dtype=np.int64)
+        out[f"{mode}_sample_idx"] = _np(torch.stack(sidx)).astype(np.int64)
+    path = os.path.join(GOLDEN_DIR, "pcl_prep.npz")
+    np.savez_compressed(path, **out)
+    print(f"pcl: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); ball counts {out['ball_counts']}, mask counts {out['mask_counts']}")
+
+
 RANGER_SHAPES = [(8, 5, 1), (6, 7), (9,), (4, 3, 2, 2), (16, 40)]
 RANGER_STEPS = 14
 
@@ -353,6 +402,9 @@ def main(argv=None):
     if "ranger" in names:
         make_ranger_golden()
         names = [n for n in names if n != "ranger"]
+    if "pcl" in names:
+        make_pcl_golden()
+        names = [n for n in names if n != "pcl"]
     if "aug" in names:
         make_aug_golden()
         names = [n for n in names if n != "aug"]
@@ -364,6 +416,7 @@ def main(argv=None):
         make_ranger_golden()
         make_amp_golden()
         make_aug_golden()
+        make_pcl_golden()
     for name in names:
         if name in TRAIN_CASES:
             make_train_golden(name)
