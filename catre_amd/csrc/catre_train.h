@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
 #define TN_LD 36  // 32 rows + 4 skew
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
-                                                 int rows_per_split) {
+                                                 int rows_per_split, float* __restrict__ colpart) {
   __shared__ __attribute__((aligned(16))) float ys[128 * TN_LD];
   __shared__ __attribute__((aligned(16))) float xsT[128 * TN_LD];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   const int jb = wave >> 1, kb0 = 2 * (wave & 1);
   f32x16 acc[2] = {zero16(), zero16()};
   const int i = lane & 31, h = lane >> 5;
+  // bias gradient for free: the k-tile-0 workgroups also column-sum the dY tile they stage anyway
+  // (thread = column tid>>2, 8-row slice tid&3), which saves a separate pass over dY
+  const bool do_col = colpart != nullptr && blockIdx.y == 0;
+  float csum = 0.f;
   for (int rs = row_lo; rs < row_hi; rs += 32) {
     __syncthreads();
     // stage 32 rows x 128 cols of each operand, transposed
@@ -137,6 +141,11 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
       }
     }
     __syncthreads();
+    if (do_col) {
+      const float* yc = ys + (tid >> 2) * TN_LD + (tid & 3) * 8;
+      const f32x4 u = *reinterpret_cast<const f32x4*>(yc), v = *reinterpret_cast<const f32x4*>(yc + 4);
+      csum += ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 rows
       const f32x4 a = *reinterpret_cast<const f32x4*>(ys + (jb * 32 + i) * TN_LD + c * 8 + 4 * h);
@@ -147,6 +156,12 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
         for (int s = 0; s < 4; ++s) acc[kb] = mfma32(a[s], b[s], acc[kb]);  // D[j][k]
       }
     }
+  }
+  if (do_col) {
+    csum += __shfl_xor(csum, 1);
+    csum += __shfl_xor(csum, 2);
+    const int j = j0 + (tid >> 2);
+    if ((tid & 3) == 0 && j < J) colpart[(size_t)blockIdx.z * J + j] = csum;
   }
   // D[row = j][col = k]: lane holds col k = lane&31, rows (reg&3)+8(reg>>2)+4h
   float* out = part + (size_t)blockIdx.z * J * K;

@@ -62,18 +62,22 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0):
     return y
 
 
-def _gemm_tn(dy, x):
-    """dW[J,K] = dy[R,J]^T x[R,K] (deterministic split reduction)."""
+def _gemm_tn(dy, x, with_bias=False):
+    """dW[J,K] = dy[R,J]^T x[R,K] (deterministic split reduction); with_bias also returns db[J] = column sums of dy,
+    taken from the tiles the kernel stages anyway."""
     lib = hip.load()
     R, J = dy.shape
     K = x.shape[1]
     dy4, x4 = _pad_cols(dy, 4), _pad_cols(x, 4)
     J4, K4 = dy4.shape[1], x4.shape[1]
     dw = torch.empty(J4, K4, dtype=torch.float32, device=dy.device)
-    need = lib.catre_op_gemm_tn_ws_bytes(J4, K4, R)
+    db = torch.empty(J4, dtype=torch.float32, device=dy.device) if with_bias else None
+    need = lib.catre_op_gemm_tn_bias_ws_bytes(J4, K4, R)
     ws = _ws(need, dy.device)
-    hip.check(lib.catre_op_gemm_tn(hip.ptr(dy4), dy4.stride(0), hip.ptr(x4), x4.stride(0), hip.ptr(dw), J4, K4, R, 0,
-                                   hip.ptr(ws), ws.numel(), _st(dy)), "catre_op_gemm_tn")
+    hip.check(lib.catre_op_gemm_tn_bias(hip.ptr(dy4), dy4.stride(0), hip.ptr(x4), x4.stride(0), hip.ptr(dw), hip.ptr(db),
+                                        J4, K4, R, 0, hip.ptr(ws), ws.numel(), _st(dy)), "catre_op_gemm_tn_bias")
+    if with_bias:
+        return dw[:J, :K], db[:J]
     return dw[:J, :K]
 
 
@@ -119,13 +123,19 @@ class _Linear(torch.autograd.Function):
                 dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
             elif x.shape[1] < dx.shape[1]:
                 dx = _c(dx[:, : x.shape[1]])
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             kw = min(w2.shape[1], x.shape[1])
-            dw = _gemm_tn(dy, _c(x))[:, :kw]
+            if want_db:
+                dw, db = _gemm_tn(dy, _c(x), with_bias=True)
+                db = _c(db)
+            else:
+                dw = _gemm_tn(dy, _c(x))
+            dw = dw[:, :kw]
             if kw < w2.shape[1]:
                 dw = F.pad(dw, (0, w2.shape[1] - kw))
             dw = _c(dw).reshape(w.shape)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        elif want_db:
             db = _colsum(dy)
         return dx, dw, db, None, None
 

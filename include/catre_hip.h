@@ -228,6 +228,10 @@ int catre_op_gemm_rows(const float* X, int ldx, const float* Wp, const float* bi
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* weight AND bias gradient of y = x W^T + b in one pass over dY: dW = dY^T X, db = column sums of dY (db may be NULL) */
+size_t catre_op_gemm_tn_bias_ws_bytes(int J, int K, int R);
+int catre_op_gemm_tn_bias(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int J, int K, int R,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
 int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);
