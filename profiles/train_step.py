@@ -33,5 +33,5 @@ def run(B, N=1024, M=1024, reps=3):
     return {"B": B, "N": N, "M": M, "ms_per_train_iteration": round(dt * 1e3, 2), "train_object_iterations_per_s": round(B / dt, 1),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": float(l)}
 
-for B in (16, 64, 256):
+for B in ([int(v) for v in sys.argv[1:]] or (16, 64, 256)):
     print(json.dumps(run(B)))
