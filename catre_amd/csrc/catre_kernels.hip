@@ -469,12 +469,15 @@ __global__ void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ ou
 // generic y = act(x W^T + b) (+ I_k): one wave per 32x32 output block, operands straight from
 // L2 (F.linear in pointnet.py:31-33,64-66 and the global-feature half of RotHead layer 0).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int ldx, const float* __restrict__ W,
-                                                int ldw, const float* __restrict__ bias, float* __restrict__ Y,
-                                                int ldy, int R, int J, int K, int relu, int iden_k) {
-  // 4 waves split K (interleaved 8-wide chunks), each with 4 loads in flight; partial 32x32 blocks are
+#define LIN_WAVES 8
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restrict__ X, int ldx,
+                                                            const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ Y,
+                                                            int ldy, int R, int J, int K, int relu, int iden_k) {
+  // 8 waves split K (interleaved 8-wide chunks), each with up to 8 chunk pairs in flight - the kernel is a chain of
+  // L2 round trips, so the trip count (K/8/8/8 = 2 for K = 1024) is what sets its time; partial 32x32 blocks are
   // summed through LDS in wave order (deterministic).
-  __shared__ float part[4][16][64];
+  __shared__ float part[LIN_WAVES][16][64];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = min((int)blockIdx.x * 32 + i, R - 1), j = min((int)blockIdx.y * 32 + i, J - 1);
@@ -483,19 +486,19 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
   f32x16 acc = zero16();
   const int nkc = K / 8;
   int kc = wave;
-  for (; kc + 12 < nkc; kc += 16) {  // 4 chunks of this wave per trip
-    f32x4 a[4], b[4];
+  for (; kc + 7 * LIN_WAVES < nkc; kc += 8 * LIN_WAVES) {  // 8 chunks of this wave per trip
+    f32x4 a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = xa[(kc + 4 * u) * 2];
-      b[u] = wb[(kc + 4 * u) * 2];
+    for (int u = 0; u < 8; ++u) {
+      a[u] = xa[(kc + LIN_WAVES * u) * 2];
+      b[u] = wb[(kc + LIN_WAVES * u) * 2];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);  // D[row r][col j]
   }
-  for (; kc < nkc; kc += 4) {
+  for (; kc < nkc; kc += LIN_WAVES) {
     const f32x4 a = xa[kc * 2], b = wb[kc * 2];
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
@@ -508,11 +511,14 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
   const float bv = bias ? bias[col] : 0.f;
   const float idv = (iden_k > 0 && col < iden_k * iden_k && (col % (iden_k + 1)) == 0) ? 1.f : 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {  // wave w finishes registers 4w..4w+3 -> rows 8w + q + 4h
-    const int reg = wave * 4 + q;
-    const int row = blockIdx.x * 32 + q + 8 * wave + 4 * h;
+  for (int q = 0; q < 2; ++q) {  // wave w finishes registers 2w, 2w+1 -> rows (reg&3) + 8(reg>>2) + 4h
+    const int reg = wave * 2 + q;
+    const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     if (row < R) {
-      float v = ((part[0][reg][lane] + part[1][reg][lane]) + part[2][reg][lane]) + part[3][reg][lane] + bv;
+      float v = part[0][reg][lane];
+#pragma unroll
+      for (int w = 1; w < LIN_WAVES; ++w) v += part[w][reg][lane];
+      v += bv;
       if (relu) v = fmaxf(v, 0.f);
       Y[(size_t)row * ldy + col] = v + idv;
     }
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfea
     const int k0 = (in_dim * ks) / 4, k1 = (in_dim * (ks + 1)) / 4;
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
-#pragma unroll 4
+#pragma unroll 16
     for (int k = k0; k < k1; ++k) {
       const float w = W0T[(size_t)k * 256 + tid];
 #pragma unroll
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfea
   {
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
-#pragma unroll 4
+#pragma unroll 16
     for (int k = ks * 64; k < ks * 64 + 64; ++k) {
       const float w = W1T[k * 256 + tid];
 #pragma unroll
@@ -1028,11 +1034,11 @@ inline const u32x4* pkb(const float* packed, size_t off) { return reinterpret_ca
 int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
                 float* out, int k, int R, hipStream_t st) {
   // relu(fc1) -> relu(fc2) -> fc3 + I_k   (pointnet.py:31-40 / 64-77)
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(256), 0, st, pooled, 1024, prm[base], 1024,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(64 * LIN_WAVES), 0, st, pooled, 1024, prm[base], 1024,
                      prm[base + 1], h1, 512, R, 512, 1024, 1, 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(256), 0, st, h1, 512, prm[base + 2], 512,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, h1, 512, prm[base + 2], 512,
                      prm[base + 3], h2, 256, R, 256, 512, 1, 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(256), 0, st, h2, 256, prm[base + 4], 256,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(64 * LIN_WAVES), 0, st, h2, 256, prm[base + 4], 256,
                      prm[base + 5], out, k * k, R, k * k, 256, 0, k);
   return check_launch();
 }
@@ -1178,7 +1184,7 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
 int catre_linear(const float* x, int ldx, const float* Wt, int ldw, const float* bias, float* y, int ldy, int R, int J,
                  int K, int relu, int add_identity_k, void* stream) {
   REQUIRE(x && Wt && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0);
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
+  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(64 * LIN_WAVES), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
                      bias, y, ldy, R, J, K, relu, add_identity_k);
   return check_launch();
 }
@@ -1252,7 +1258,7 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   // global-feature half of layer 0 for every cloud: bias0[hd][cloud][:] = W0[:, :1024] g_cloud + b0
   for (int hd = 0; hd < 2; ++hd) {
     const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
-    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(256), 0, st, gfeat, PMW, prm[base], PMW,
+    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, gfeat, PMW, prm[base], PMW,
                        prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
   }
   {
@@ -1348,7 +1354,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   float* bias0 = ws + W.bias0;
   for (int hd = 0; hd < 2; ++hd) {
     const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
-    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(256), 0, st, ws + W.gfeat, PMW, prm[base], PMW,
+    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, ws + W.gfeat, PMW, prm[base], PMW,
                        prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
   }
   {
