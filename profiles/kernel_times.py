@@ -20,7 +20,7 @@ for name in ("stn3d", "stnkd", "trunk", "ts_head", "rot_l0_stats", "rot_l1", "ro
     hip.profile_kernel(name, 3 * K)
     for _ in range(3): model.refine(b, n_iter=K)
     ms = hip.profile_collect(3 * K); hip.profile_kernel(None, 0)
-    res[name] = round(sum(ms) / len(ms), 4)
+    res[name] = round(sum(ms) / len(ms), 4) if ms else None
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
