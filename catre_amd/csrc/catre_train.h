@@ -31,7 +31,11 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 // gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
 // wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "normal" orientation: 4 consecutive channels/lane.
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NKC>
+// MAXP: instead of storing Y, reduce the tile's 64 rows to a per-channel (max, arg-max row) pair - the forward of
+// linear + max-pool over points without materialising the [R, J] matrix (Y = float maxima [tiles][J], mask = the int
+// arg-max rows [tiles][J]).  Uses the "swapped" MFMA orientation so that a lane owns a channel and the reduction is
+// in-register; the first maximum wins, like torch.max.
+template <int MB, int NKC, bool MAXP = false>
 __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     __syncthreads();
     if (active) {
       // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
-      GemmPipe<MB, 2, false, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
+      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
       // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
       g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
       g.run(acc, xs, LDX, lane);
@@ -68,6 +72,41 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
   }
   if (!active) return;
   const int n = lane & 31, h = lane >> 5;
+  if constexpr (MAXP) {
+    // D[row = point][col = channel]: lane owns channel blk*32 + n and points (r&3) + 8(r>>2) + 4h + 32nb
+    int* amax = reinterpret_cast<int*>(const_cast<float*>(mask));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int blk = wave + 8 * mb;
+      if (blk >= nblk) break;
+      const int ch = blk * 32 + n;
+      const float bv = bias ? bias[ch] : 0.f;
+      float m = -INFINITY;
+      int am = 0;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // increasing point order inside a half-wave: strict > keeps the first
+          const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[mb][nb][r] + bv;
+          if (r0 + pt < R && v > m) {
+            m = v;
+            am = pt;
+          }
+        }
+      const float mo = __shfl_xor(m, 32);
+      const int ao = __shfl_xor(am, 32);
+      if (mo > m || (mo == m && ao < am)) {
+        m = mo;
+        am = ao;
+      }
+      if (h == 0) {
+        Y[(size_t)blockIdx.x * ldy + ch] = m;
+        amax[(size_t)blockIdx.x * ldy + ch] = r0 + am;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int blk = wave + 8 * mb;
@@ -256,6 +295,28 @@ __global__ __launch_bounds__(256) void k_rowbias_bwd(const float* __restrict__ d
 // ------------------------------------------------------------------------------------------------
 // max-pool over the points of each cloud with argmax (cloud-major rows), and its sparse backward
 // ------------------------------------------------------------------------------------------------
+// per-tile (max, arg-max row) partials [tiles][J] -> per-cloud; tiles never straddle clouds (N, M multiples of 64)
+__global__ __launch_bounds__(256) void k_maxpool_tiles(const float* __restrict__ pmax, const int* __restrict__ pidx,
+                                                       float* __restrict__ out, int* __restrict__ idx, int J, int B,
+                                                       int N, int M) {
+  const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= J) return;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const int t0 = r0 / TP, nt = n / TP;
+  float m = pmax[(size_t)t0 * J + j];
+  int am = pidx[(size_t)t0 * J + j];
+  for (int t = 1; t < nt; ++t) {
+    const float v = pmax[(size_t)(t0 + t) * J + j];
+    if (v > m) {  // tiles in row order: strict > keeps the first maximum
+      m = v;
+      am = pidx[(size_t)(t0 + t) * J + j];
+    }
+  }
+  out[(size_t)c * J + j] = m;
+  idx[(size_t)c * J + j] = am;
+}
+
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ Y, int ld, float* __restrict__ out,
                                                      int* __restrict__ idx, int J, int B, int N, int M) {
   const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;

@@ -154,12 +154,25 @@ class _LinearMaxPool(torch.autograd.Function):
         lib = hip.load()
         w2 = _c(w.reshape(w.shape[0], -1))
         J, K = w2.shape
-        y = _gemm_nt(_c(x), w2, b, False)
         C = 2 * B if M > 0 else B
         g = torch.empty(C, J, dtype=torch.float32, device=x.device)
         idx = torch.empty(C, J, dtype=torch.int32, device=x.device)
-        hip.check(lib.catre_op_maxpool_fwd(hip.ptr(y), J, hip.ptr(g), hip.ptr(idx), J, B, N, M, _st(x)), "catre_op_maxpool_fwd")
-        del y
+        xc = _c(x)
+        fused = (N % 64 == 0 and M % 64 == 0 and J % 32 == 0 and (J <= 256 or J in (512, 1024))
+                 and (K in (64, 128) or K % 256 == 0))
+        if fused:  # the max / arg-max is the GEMM's epilogue: the [rows, J] matrix never exists
+            wp = torch.empty(J * K, dtype=torch.float32, device=x.device)
+            hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+            need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)
+            ws = _ws(need, x.device)
+            hip.check(lib.catre_op_linear_maxpool(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(b), hip.ptr(g),
+                                                  hip.ptr(idx), J, K, B, N, M, hip.ptr(ws), ws.numel(), _st(x)),
+                      "catre_op_linear_maxpool")
+        else:
+            y = _gemm_nt(xc, w2, b, False)
+            hip.check(lib.catre_op_maxpool_fwd(hip.ptr(y), J, hip.ptr(g), hip.ptr(idx), J, B, N, M, _st(x)),
+                      "catre_op_maxpool_fwd")
+            del y
         if relu:
             g = _Relu.forward_only(g)
         ctx.save_for_backward(x, w, idx, g if relu else None)

@@ -225,6 +225,10 @@ const char* catre_status_string(int status);
 int catre_op_pack(const float* src, int ld, int J, int K, int transpose, float* dst, void* stream);
 int catre_op_gemm_rows(const float* X, int ldx, const float* Wp, const float* bias, const float* mask, int ldm,
                        float* Y, int ldy, int R, int J, int K, int relu, void* stream);
+/* linear + max-pool over the points of each cloud, fused (no [R,J] intermediate); N, M multiples of 64 */
+size_t catre_op_linear_maxpool_ws_bytes(int R, int J);
+int catre_op_linear_maxpool(const float* X, int ldx, const float* Wp, const float* bias, float* out, int* idx, int J,
+                            int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
