@@ -144,12 +144,18 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
 // 32-row slabs are staged transposed in LDS ([col][row], row contiguous, +4 skew) so both MFMA fragments
 // are 16-byte reads along the contraction (row) index.  Partials go to part[split][J*K].
 // ------------------------------------------------------------------------------------------------
-#define TN_LD 36  // 32 rows + 4 skew
+#define TN_ROWS 64  // rows of dY / X staged per step
+// dW partial [split][J][K] = dY[rows of the split, J]^T X[rows, K]; 128 x 128 output tile per workgroup, 8 waves x
+// (32 x 64).  The contraction runs over ROWS, and v_mfma_f32_32x32x2_f32 takes one A and one B value per lane per
+// instruction (A[i][k = lane>>5]), so the operands are staged ROW-MAJOR exactly as they sit in HBM (ds_write_b128,
+// conflict-free) and read back with ds_read_b32 - consecutive lanes, consecutive columns.  (The first version
+// staged them transposed with scalar stores: 16-way bank conflicts, 24 % of the fp32 MFMA rate.)  The next step's
+// global loads are issued into registers before the current step's 64 MFMAs.
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
                                                  int rows_per_split, float* __restrict__ colpart) {
-  __shared__ __attribute__((aligned(16))) float ys[128 * TN_LD];
-  __shared__ __attribute__((aligned(16))) float xsT[128 * TN_LD];
+  __shared__ __attribute__((aligned(16))) float ys[TN_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * 128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
@@ -158,49 +164,57 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   f32x16 acc[2] = {zero16(), zero16()};
   const int i = lane & 31, h = lane >> 5;
   // bias gradient for free: the k-tile-0 workgroups also column-sum the dY tile they stage anyway
-  // (thread = column tid>>2, 8-row slice tid&3), which saves a separate pass over dY
+  // (thread = column tid&127, 16-row slice tid>>7), which saves a separate pass over dY
   const bool do_col = colpart != nullptr && blockIdx.y == 0;
   float csum = 0.f;
-  for (int rs = row_lo; rs < row_hi; rs += 32) {
-    __syncthreads();
-    // stage 32 rows x 128 cols of each operand, transposed
-    for (int e = tid; e < 32 * 32; e += 512) {
-      const int row = e >> 5, c4 = e & 31;  // c4: float4 column index
-      const int gr = rs + row;
-      f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+  // staging: float4 slot e = tid + 512*u  ->  row e>>5, float4 column e&31   (u = 0..3)
+  f32x4 vy[4], vx[4];
+  auto fetch = [&](int rs) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 512 * u, row = e >> 5, c4 = e & 31, gr = rs + row;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      vy[u] = vx[u] = z;
       if (gr < row_hi) {
         const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
-        if (jc < J) vy = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
-        if (kc < K) vx = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
+        if (jc < J) vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
       }
+    }
+  };
+  fetch(row_lo);
+  for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
+    __syncthreads();  // the previous step's reads are done
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ys[(c4 * 4 + q) * TN_LD + row] = vy[q];
-        xsT[(c4 * 4 + q) * TN_LD + row] = vx[q];
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 512 * u;
+      *reinterpret_cast<f32x4*>(ys + e * 4) = vy[u];
+      *reinterpret_cast<f32x4*>(xs + e * 4) = vx[u];
     }
     __syncthreads();
+    if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);  // in flight during the MFMAs below
     if (do_col) {
-      const float* yc = ys + (tid >> 2) * TN_LD + (tid & 3) * 8;
-      const f32x4 u = *reinterpret_cast<const f32x4*>(yc), v = *reinterpret_cast<const f32x4*>(yc + 4);
-      csum += ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
+      const float* yc = ys + (tid >> 7) * 16 * 128 + (tid & 127);
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += yc[r * 128];
+      csum += t;
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 rows
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ys + (jb * 32 + i) * TN_LD + c * 8 + 4 * h);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(xsT + ((kb0 + kb) * 32 + i) * TN_LD + c * 8 + 4 * h);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[kb] = mfma32(a[s], b[s], acc[kb]);  // D[j][k]
-      }
+    const float* ya = ys + h * 128 + jb * 32 + i;
+    const float* xb = xs + h * 128 + kb0 * 32 + i;
+#pragma unroll 8
+    for (int t = 0; t < TN_ROWS / 2; ++t) {  // MFMA t contracts rows 2t (h = 0) and 2t + 1 (h = 1)
+      const float a = ya[t * 256];
+      acc[0] = mfma32(a, xb[t * 256], acc[0]);  // D[j][k]
+      acc[1] = mfma32(a, xb[t * 256 + 32], acc[1]);
     }
   }
   if (do_col) {
-    csum += __shfl_xor(csum, 1);
-    csum += __shfl_xor(csum, 2);
-    const int j = j0 + (tid >> 2);
-    if ((tid & 3) == 0 && j < J) colpart[(size_t)blockIdx.z * J + j] = csum;
+    __syncthreads();
+    ys[tid] = csum;  // [4 row slices][128 columns]
+    __syncthreads();
+    const int j = j0 + tid;
+    if (tid < 128 && j < J) colpart[(size_t)blockIdx.z * J + j] = (ys[tid] + ys[128 + tid]) + (ys[256 + tid] + ys[384 + tid]);
   }
   // D[row = j][col = k]: lane holds col k = lane&31, rows (reg&3)+8(reg>>2)+4h
   float* out = part + (size_t)blockIdx.z * J * K;
