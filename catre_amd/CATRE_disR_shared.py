@@ -94,6 +94,9 @@ class CATRE_disR_shared(nn.Module):
         """x [B,3,N], tfd_kps [B,3,M] (any strides), init_pose [B,3,4], init_scale [B,3], K_zoom [B,3,3]
         -> ``{"pose_{cur_iter}": [B,3,4], "scale_{cur_iter}": [B,3]}`` (reference ``:122-124``)."""
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if x.shape[0] == 0 and not do_loss:
+            # an empty batch (the evaluator skips those, catre_evaluator.py:280-281): nothing to launch
+            return {f"pose_{cur_iter}": init_pose.new_zeros(0, 3, 4), f"scale_{cur_iter}": init_scale.new_zeros(0, 3)}
         if not (do_loss or needs_grad):
             # inference: the fused kernels (one launch chain, nothing saved)
             pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales,
@@ -137,6 +140,12 @@ class CATRE_disR_shared(nn.Module):
         ``out_dict``: ``pose_0..pose_K`` / ``scale_0..scale_K``.
         """
         n_iter = int(self.cfg.MODEL.CATRE.N_ITER_TEST if n_iter is None else n_iter)
+        if batch["pcl"].shape[0] == 0:
+            out = {}
+            for i in range(n_iter + 1):
+                out[f"pose_{i}"] = batch["obj_pose_est"].new_zeros(0, 3, 4)
+                out[f"scale_{i}"] = batch["obj_scale_est"].new_zeros(0, 3)
+            return out
         poses, scales = self._runtime().refine_k(
             batch["pcl"], batch["obj_kps"], batch["obj_pose_est"], batch["obj_scale_est"], batch.get("K"),
             batch.get("obj_mean_scales"), self._inference_opts(), n_iter,

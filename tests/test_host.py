@@ -172,3 +172,23 @@ def test_recipe_is_deterministic():
     d = synth.make_inputs(3, 64, 32, seed=4)
     assert all(torch.equal(c[k], d[k]) for k in c)
     assert c["pcl"].shape == (3, 64, 3) and c["obj_kps"].shape == (3, 32, 3) and c["obj_pose_est"].shape == (3, 3, 4)
+
+
+def test_empty_batch_returns_empty_outputs_without_touching_the_device():
+    """The evaluator skips frames without instances (catre_evaluator.py:280-281); a zero-object batch is still a valid
+    call and must not need the GPU."""
+    import torch
+
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+    from catre_amd.config import default_cfg
+
+    cfg = default_cfg(num_pcl=64, num_kps=32, n_iter=2, device="cpu")
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    model.eval()
+    z = torch.zeros
+    with torch.no_grad():
+        out = model(z(0, 3, 64), z(0, 3, 32), init_pose=z(0, 3, 4), init_scale=z(0, 3), K_zoom=z(0, 3, 3), cur_iter=1)
+    assert out["pose_1"].shape == (0, 3, 4) and out["scale_1"].shape == (0, 3)
+    out = model.refine({"pcl": z(0, 64, 3), "obj_kps": z(0, 32, 3), "obj_pose_est": z(0, 3, 4), "obj_scale_est": z(0, 3),
+                        "K": z(0, 3, 3)})
+    assert sorted(out) == ["pose_0", "pose_1", "pose_2", "scale_0", "scale_1", "scale_2"] and out["pose_2"].shape == (0, 3, 4)
