@@ -39,7 +39,7 @@ template <int MB, int NKC, bool MAXP = false>
 __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
-                                                   int relu) {
+                                                   int relu, const float* __restrict__ xmask, int ldxm) {
   constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
   constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
   __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
@@ -58,7 +58,12 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     for (int i = tid; i < TP * F4; i += 512) {
       const int row = i / F4, ch = i % F4;
       const int gr = min(r0 + row, R - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+      if (xmask) {  // ReLU backward folded into the operand load: X .* (xmask > 0)
+        const f32x4 m = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
+      }
       *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v;
     }
     __syncthreads();
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
 // global loads are issued into registers before the current step's 64 MFMAs.
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
-                                                 int rows_per_split, float* __restrict__ colpart) {
+                                                 int rows_per_split, float* __restrict__ colpart,
+                                                 const float* __restrict__ ymask, int ldym) {
   __shared__ __attribute__((aligned(16))) float ys[TN_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * 128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -177,7 +183,14 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
       vy[u] = vx[u] = z;
       if (gr < row_hi) {
         const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
-        if (jc < J) vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+        if (jc < J) {
+          vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+          if (ymask) {  // ReLU backward folded into the operand load: dY .* (ymask > 0)
+            const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + (size_t)gr * ldym + jc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
+          }
+        }
         if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
       }
     }

@@ -39,43 +39,51 @@ def _pad_cols(t, mult):
 
 
 # ------------------------------------------------------------------------------------------------- GEMMs
-def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0):
-    """y[R,J] = act(x[R,K] w[J,K]^T + bias) (zeroed where mask<=0).  Picks the tiled row kernel when the
-    shape allows, else the one-block-per-32x32 kernel (small R or odd J)."""
+def _tiled_gemm_ok(R, J, K):
+    """Shapes the tiled row kernel (catre_op_gemm_rows) takes."""
+    return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= 256
+
+
+def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None):
+    """y[R,J] = act(x[R,K] w[J,K]^T + bias) (zeroed where mask<=0); with xmask the left operand is x .* (xmask > 0).
+    Picks the tiled row kernel when the shape allows, else the one-block-per-32x32 kernel (small R or odd J)."""
     lib = hip.load()
     R, K = x.shape
     J = w.shape[0]
     dev = x.device
     y = torch.empty(R, J, dtype=torch.float32, device=dev)
-    big = (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) \
-        and R >= 256 and identity_k == 0
+    big = _tiled_gemm_ok(R, J, K) and identity_k == 0
     if big:
         wp = torch.empty(J * K, dtype=torch.float32, device=dev)
         hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
-        hip.check(lib.catre_op_gemm_rows(hip.ptr(x), x.stride(0), hip.ptr(wp), hip.ptr(bias), hip.ptr(mask),
-                                         mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J, K,
-                                         int(relu), _st(x)), "catre_op_gemm_rows")
+        hip.check(lib.catre_op_gemm_rows_m(hip.ptr(x), x.stride(0), hip.ptr(xmask),
+                                           xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), hip.ptr(bias),
+                                           hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J,
+                                           K, int(relu), _st(x)), "catre_op_gemm_rows_m")
     else:
-        assert K % 8 == 0 and mask is None
+        assert K % 8 == 0 and mask is None and xmask is None
         hip.check(lib.catre_linear(hip.ptr(x), x.stride(0), hip.ptr(w), w.stride(0), hip.ptr(bias), hip.ptr(y), J, R, J,
                                    K, int(relu), int(identity_k), _st(x)), "catre_linear")
     return y
 
 
-def _gemm_tn(dy, x, with_bias=False):
+def _gemm_tn(dy, x, with_bias=False, ymask=None):
     """dW[J,K] = dy[R,J]^T x[R,K] (deterministic split reduction); with_bias also returns db[J] = column sums of dy,
-    taken from the tiles the kernel stages anyway."""
+    taken from the tiles the kernel stages anyway; with ymask, dy .* (ymask > 0) replaces dy (ReLU backward)."""
     lib = hip.load()
     R, J = dy.shape
     K = x.shape[1]
     dy4, x4 = _pad_cols(dy, 4), _pad_cols(x, 4)
+    ym4 = _pad_cols(ymask, 4) if ymask is not None else None
     J4, K4 = dy4.shape[1], x4.shape[1]
     dw = torch.empty(J4, K4, dtype=torch.float32, device=dy.device)
     db = torch.empty(J4, dtype=torch.float32, device=dy.device) if with_bias else None
     need = lib.catre_op_gemm_tn_bias_ws_bytes(J4, K4, R)
     ws = _ws(need, dy.device)
-    hip.check(lib.catre_op_gemm_tn_bias(hip.ptr(dy4), dy4.stride(0), hip.ptr(x4), x4.stride(0), hip.ptr(dw), hip.ptr(db),
-                                        J4, K4, R, 0, hip.ptr(ws), ws.numel(), _st(dy)), "catre_op_gemm_tn_bias")
+    hip.check(lib.catre_op_gemm_tn_bias_m(hip.ptr(dy4), dy4.stride(0), hip.ptr(ym4),
+                                          ym4.stride(0) if ym4 is not None else 0, hip.ptr(x4), x4.stride(0), hip.ptr(dw),
+                                          hip.ptr(db), J4, K4, R, 0, hip.ptr(ws), ws.numel(), _st(dy)),
+              "catre_op_gemm_tn_bias_m")
     if with_bias:
         return dw[:J, :K], db[:J]
     return dw[:J, :K]
@@ -109,16 +117,24 @@ class _Linear(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         lib = hip.load()
         dy = _c(dy)
-        if ctx.relu:
-            g = torch.empty_like(dy)
-            hip.check(lib.catre_op_relu_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(g), dy.numel(), _st(dy)), "catre_op_relu_bwd")
-            dy = g
         w2 = w.reshape(w.shape[0], -1)
+        ymask = None
+        if ctx.relu:
+            # ReLU backward: folded into the operand loads of the two GEMMs below when both take the tiled kernels,
+            # else as its own pass
+            R, J = dy.shape
+            if J % 8 == 0 and (not ctx.needs_input_grad[0] or _tiled_gemm_ok(R, w2.shape[1], J)):
+                ymask = _c(y)
+            else:
+                g = torch.empty_like(dy)
+                hip.check(lib.catre_op_relu_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(g), dy.numel(), _st(dy)),
+                          "catre_op_relu_bwd")
+                dy = g
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
             wt = _c(_pad_cols(w2.t(), 8))          # [K, J8]
-            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False)   # [R, K]
+            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask)   # [R, K]
             if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
                 dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
             elif x.shape[1] < dx.shape[1]:
@@ -127,15 +143,17 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             kw = min(w2.shape[1], x.shape[1])
             if want_db:
-                dw, db = _gemm_tn(dy, _c(x), with_bias=True)
+                dw, db = _gemm_tn(dy, _c(x), with_bias=True, ymask=ymask)
                 db = _c(db)
             else:
-                dw = _gemm_tn(dy, _c(x))
+                dw = _gemm_tn(dy, _c(x), ymask=ymask)
             dw = dw[:, :kw]
             if kw < w2.shape[1]:
                 dw = F.pad(dw, (0, w2.shape[1] - kw))
             dw = _c(dw).reshape(w.shape)
         elif want_db:
+            if ymask is not None:
+                dy = dy * (ymask > 0)
             db = _colsum(dy)
         return dx, dw, db, None, None
 

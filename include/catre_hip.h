@@ -229,6 +229,9 @@ int catre_op_gemm_rows(const float* X, int ldx, const float* Wp, const float* bi
 size_t catre_op_linear_maxpool_ws_bytes(int R, int J);
 int catre_op_linear_maxpool(const float* X, int ldx, const float* Wp, const float* bias, float* out, int* idx, int J,
                             int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
+/* catre_op_gemm_rows with the left operand masked on load, (X .* (xmask > 0)) Wl^T: the ReLU backward folded in */
+int catre_op_gemm_rows_m(const float* X, int ldx, const float* xmask, int ldxm, const float* Wp, const float* bias,
+                         const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -236,6 +239,8 @@ int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* d
 size_t catre_op_gemm_tn_bias_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn_bias(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int J, int K, int R,
                           int accumulate, void* ws, size_t ws_bytes, void* stream);
+int catre_op_gemm_tn_bias_m(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
+                            float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);
