@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
                                                  int rows_per_split, float* __restrict__ colpart,
-                                                 const float* __restrict__ ymask, int ldym) {
+                                                 const float* __restrict__ ymask, int ldym, size_t pitch) {
   __shared__ __attribute__((aligned(16))) float ys[TN_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * 128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,10 +227,11 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
     ys[tid] = csum;  // [4 row slices][128 columns]
     __syncthreads();
     const int j = j0 + tid;
-    if (tid < 128 && j < J) colpart[(size_t)blockIdx.z * J + j] = (ys[tid] + ys[128 + tid]) + (ys[256 + tid] + ys[384 + tid]);
+    if (tid < 128 && j < J)
+      colpart[(size_t)blockIdx.z * pitch + j] = (ys[tid] + ys[128 + tid]) + (ys[256 + tid] + ys[384 + tid]);
   }
   // D[row = j][col = k]: lane holds col k = lane&31, rows (reg&3)+8(reg>>2)+4h
-  float* out = part + (size_t)blockIdx.z * J * K;
+  float* out = part + (size_t)blockIdx.z * pitch;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int k = k0 + (kb0 + kb) * 32 + i;
@@ -249,11 +250,23 @@ __global__ void k_reduce_splits(const float* __restrict__ part, float* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = accumulate ? out[i] : 0.f;
+#pragma unroll 8
   for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
   out[i] = s;
 }
 
 // column sums: part[split][J] = sum over rows of the split of dY[r][j]
+// same with an explicit row pitch of the partial buffer
+__global__ void k_reduce_splits_p(const float* __restrict__ part, float* __restrict__ out, int n, int splits,
+                                  int accumulate, size_t pitch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+#pragma unroll 8
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * pitch + i];
+  out[i] = s;
+}
+
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
                                                 int J, int rows_per_split) {
   // a block covers JB = min(J, 256) columns with 256/JB row lanes, so narrow matrices still use every thread

@@ -76,8 +76,9 @@ def _gemm_tn(dy, x, with_bias=False, ymask=None):
     dy4, x4 = _pad_cols(dy, 4), _pad_cols(x, 4)
     ym4 = _pad_cols(ymask, 4) if ymask is not None else None
     J4, K4 = dy4.shape[1], x4.shape[1]
-    dw = torch.empty(J4, K4, dtype=torch.float32, device=dy.device)
-    db = torch.empty(J4, dtype=torch.float32, device=dy.device) if with_bias else None
+    buf = torch.empty(J4 * K4 + (J4 if with_bias else 0), dtype=torch.float32, device=dy.device)
+    dw = buf[: J4 * K4].view(J4, K4)
+    db = buf[J4 * K4:] if with_bias else None  # right behind dW: one split reduction covers both
     need = lib.catre_op_gemm_tn_bias_ws_bytes(J4, K4, R)
     ws = _ws(need, dy.device)
     hip.check(lib.catre_op_gemm_tn_bias_m(hip.ptr(dy4), dy4.stride(0), hip.ptr(ym4),
