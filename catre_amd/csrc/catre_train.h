@@ -390,18 +390,33 @@ __global__ void k_maxpool_scatter(const float* __restrict__ dout, const int* __r
 __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ dg, const int* __restrict__ idx,
                                                       const float* __restrict__ X, int ldx, float* __restrict__ dW,
                                                       float* __restrict__ db, int C, int J, int K) {
+  // dW[j][:] = sum_c dg[c][j] * X[argmax row of (c, j)][:]; one workgroup per channel, clouds in order (deterministic).
+  // The chain dg/idx -> row pointer -> X is two dependent global round trips per cloud: 8 clouds are in flight at once.
   const int j = blockIdx.x;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // K <= 1024 with 256 threads
   float sb = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float g = dg[(size_t)c * J + j];
-    sb += g;
-    if (g == 0.f) continue;
-    const float* xr = X + (size_t)idx[(size_t)c * J + j] * ldx;
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float g[8];
+    int row[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = threadIdx.x + 256 * u;
-      if (k < K) acc[u] = fmaf(g, xr[k], acc[u]);
+    for (int u = 0; u < 8; ++u) {
+      const int c = min(c0 + u, C - 1);
+      g[u] = c0 + u < C ? dg[(size_t)c * J + j] : 0.f;
+      row[u] = idx[(size_t)c * J + j];
+    }
+    float xv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = threadIdx.x + 256 * q;
+        xv[u][q] = k < K ? X[(size_t)row[u] * ldx + k] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sb += g[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(g[u], xv[u][q], acc[q]);
     }
   }
 #pragma unroll
@@ -411,8 +426,96 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
   }
   if (threadIdx.x == 0 && db) db[j] = sb;
 }
+// dX of linear + max-pool for one cloud per workgroup, every row written exactly once (no read-modify-write, no
+// pre-zeroed buffer, no barrier per channel):
+//   1. histogram of the arg-max rows of the cloud's J channels (LDS), exclusive scan -> bucket offsets
+//   2. one wave drops the channels into their row's bucket in ascending channel order (ballot ranking inside each
+//      64-channel chunk), so the per-row summation order - and with it every bit of the result - is fixed
+//   3. the waves walk the rows: dX[row][:] = sum over the row's channels of dg * W[channel][:], zeros for rows that
+//      were nobody's arg-max.
+#define MLX_MAXN 4096
+__global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restrict__ dg, const int* __restrict__ idx,
+                                                           const float* __restrict__ W, int ldw, float* __restrict__ dX,
+                                                           int ldx, int J, int K, int B, int N, int M) {
+  __shared__ int start[MLX_MAXN + 1];
+  __shared__ int fill[MLX_MAXN];
+  __shared__ int lst[1024];
+  __shared__ int part[256];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const float* g = dg + (size_t)c * J;
+  const int* ix = idx + (size_t)c * J;
+  for (int i = tid; i < n; i += 256) {
+    start[i] = 0;
+    fill[i] = 0;
+  }
+  __syncthreads();
+  for (int j = tid; j < J; j += 256)
+    if (g[j] != 0.f) atomicAdd(&start[ix[j] - r0], 1);
+  __syncthreads();
+  {  // exclusive scan of start[0..n): thread t owns a contiguous run of bins
+    const int per = (n + 255) / 256, lo = tid * per, hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += start[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int t = 0; t < 256; ++t) {
+        const int v = part[t];
+        part[t] = run;
+        run += v;
+      }
+      start[n] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+      const int v = start[i];
+      start[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int j0 = 0; j0 < J; j0 += 64) {
+      const int j = j0 + lane;
+      const bool live = j < J && g[min(j, J - 1)] != 0.f;
+      const int row = live ? ix[j] - r0 : -1;
+      unsigned long long todo = __ballot(live);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lrow = __shfl(row, leader);
+        const unsigned long long same = __ballot(live && row == lrow) & todo;
+        if (live && row == lrow) {
+          const int rank = __popcll(same & ((1ull << lane) - 1ull));
+          lst[start[lrow] + fill[lrow] + rank] = j;
+        }
+        if (lane == leader) fill[lrow] += __popcll(same);
+        todo &= ~same;
+      }
+    }
+  }
+  __syncthreads();
+  const int nf4 = K / 4;  // K % 4 == 0 (checked by the launcher)
+  for (int r = wave; r < n; r += 4) {
+    const int b = start[r], e = start[r + 1];
+    float* xr = dX + (size_t)(r0 + r) * ldx;
+    for (int q = lane; q < nf4; q += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = b; t < e; ++t) {
+        const int j = lst[t];
+        const float gv = g[j];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(gv, w[u], acc[u]);
+      }
+      *reinterpret_cast<f32x4*>(xr + q * 4) = acc;
+    }
+  }
+}
 
-//   dX[idx[c][j]][:] += dg[c][j] * W[j][:]  on a zeroed dX (one workgroup per cloud, channels in order)
 __global__ __launch_bounds__(256) void k_maxlin_bwd_x(const float* __restrict__ dg, const int* __restrict__ idx,
                                                       const float* __restrict__ W, int ldw, float* __restrict__ dX,
                                                       int ldx, int J, int K) {

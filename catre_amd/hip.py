@@ -102,6 +102,7 @@ _SIGS = {
     "catre_op_maxpool_scatter": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_w": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_x": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_x_rows": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_cloud_matmul": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_cloud_matmul_bwd_t": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "catre_op_relu_bwd": (_I, [_P, _P, _P, _SZ, _P]),

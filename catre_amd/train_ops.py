@@ -216,9 +216,14 @@ class _LinearMaxPool(torch.autograd.Function):
                                             C, J, K, _st(x)), "catre_op_maxlin_bwd_w")
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(xc)
-            hip.check(lib.catre_op_maxlin_bwd_x(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx), dx.stride(0), C, J,
-                                                K, _st(x)), "catre_op_maxlin_bwd_x")
+            if max(N, M) <= 4096 and J <= 1024 and K % 4 == 0 and xc.shape[1] == K:
+                dx = torch.empty_like(xc)  # every row is written (zeros where no channel had its maximum)
+                hip.check(lib.catre_op_maxlin_bwd_x_rows(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx),
+                                                         dx.stride(0), J, K, B, N, M, _st(x)), "catre_op_maxlin_bwd_x_rows")
+            else:
+                dx = torch.zeros_like(xc)
+                hip.check(lib.catre_op_maxlin_bwd_x(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx), dx.stride(0), C,
+                                                    J, K, _st(x)), "catre_op_maxlin_bwd_x")
         return dx, dw.reshape(w.shape), db, None, None, None, None
 
 

@@ -252,6 +252,10 @@ int catre_op_maxlin_bwd_w(const float* dg, const int* idx, const float* X, int l
                           int J, int K, void* stream);
 int catre_op_maxlin_bwd_x(const float* dg, const int* idx, const float* W, int ldw, float* dX, int ldx, int C, int J,
                           int K, void* stream);
+/* the same gradient written row by row (every row of dX[:, :K] exactly once, zeros included: no memset, no
+ * read-modify-write); points per cloud <= 4096 */
+int catre_op_maxlin_bwd_x_rows(const float* dg, const int* idx, const float* W, int ldw, float* dX, int ldx, int J, int K,
+                               int B, int N, int M, void* stream);
 int catre_op_cloud_matmul(const float* X, int ldx, const float* T, float* Y, int ldy, int kd, int B, int N, int M,
                           int transpose, void* stream);
 int catre_op_cloud_matmul_bwd_t(const float* X, int ldx, const float* dY, int ldy, float* dT, int kd, int B, int N,
