@@ -622,6 +622,64 @@ __device__ __forceinline__ float gelu_grad(float v) {
 //   backward (dy from da): dyhat = da*gelu'(yhat); dxhat = dyhat*gamma;
 //              dy = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat));  dgamma, dbeta column sums
 // ------------------------------------------------------------------------------------------------
+// GroupNorm(32, 256) statistics over [P points x 8 channels] per (object, group), in two steps that read whole
+// 1 KiB rows (the one-workgroup-per-group version below fetched 32 B of every row per workgroup: 1.7 TB/s):
+//   k_gnp_stats_chunk  (object, chunk of 128 rows): per group n, mean, M2 from sums shifted by the chunk's first value
+//   k_gnp_stats_final  per object: Chan merge of the chunks in order -> (mean, rstd)
+#define GNS_CH 128
+__global__ __launch_bounds__(256) void k_gnp_stats_chunk(const float* __restrict__ Y, float* __restrict__ part /*[B][nch][32][2]*/,
+                                                         int P, int nch) {
+  __shared__ float rs[4][32], rq[4][32];
+  const int obj = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+  const int c4 = tid & 63, rl = tid >> 6, grp = c4 >> 1;
+  const int p0 = chunk * GNS_CH, p1 = min(P, p0 + GNS_CH);
+  const float* base = Y + ((size_t)obj * P) * 256;
+  const float shift = base[(size_t)p0 * 256 + grp * 8];
+  float s = 0.f, q = 0.f;
+  for (int p = p0 + rl; p < p1; p += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * 256 + c4 * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float d = v[u] - shift;
+      s += d;
+      q = fmaf(d, d, q);
+    }
+  }
+  s += __shfl_xor(s, 1);  // the group's other 4 channels
+  q += __shfl_xor(q, 1);
+  if ((c4 & 1) == 0) {
+    rs[rl][grp] = s;
+    rq[rl][grp] = q;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const float S = (rs[0][tid] + rs[1][tid]) + (rs[2][tid] + rs[3][tid]);
+    const float Q = (rq[0][tid] + rq[1][tid]) + (rq[2][tid] + rq[3][tid]);
+    const float n = 8.f * (float)(p1 - p0);
+    const float sh = base[(size_t)p0 * 256 + tid * 8];
+    float* o = part + (((size_t)obj * nch + chunk) * 32 + tid) * 2;
+    o[0] = sh + S / n;       // chunk mean
+    o[1] = Q - S * S / n;    // chunk M2
+  }
+}
+
+__global__ __launch_bounds__(64) void k_gnp_stats_final(const float* __restrict__ part, float* __restrict__ stat, int P,
+                                                        int nch) {
+  const int obj = blockIdx.x, g = threadIdx.x;
+  if (g >= 32) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    const float nb = 8.f * (float)(min(P, (c + 1) * GNS_CH) - c * GNS_CH);
+    const float* o = part + (((size_t)obj * nch + c) * 32 + g) * 2;
+    const float nn = n + nb, delta = o[0] - mean;
+    mean += delta * (nb / nn);
+    m2 += o[1] + delta * delta * (n * nb / nn);
+    n = nn;
+  }
+  stat[((size_t)obj * 32 + g) * 2] = mean;
+  stat[((size_t)obj * 32 + g) * 2 + 1] = 1.0f / sqrtf(m2 / n + 1e-5f);
+}
+
 __global__ __launch_bounds__(256) void k_gnp_stats(const float* __restrict__ Y, float* __restrict__ stat, int P) {
   __shared__ float red[8];
   const int obj = blockIdx.x, g = blockIdx.y;
