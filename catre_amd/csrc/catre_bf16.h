@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// a9: rotation heads, bf16 operands (structure of k_rot_l0_stats / k_rot_l1 / k_rot_out).
+// a9: rotation heads, bf16 operands: layer-0 statistics pass, then the structure of k_rot_l1 / k_rot_out.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_pf_tile_bf(const u32x4* __restrict__ pointfeat, const RotTile& rt, u32x4* pf, int tid,
                                                 int nthreads) {

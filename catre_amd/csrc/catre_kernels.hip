@@ -659,8 +659,9 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfea
 // a9: rotation heads (heads/conv_out_per_rot_head.py:126-140) over the concatenated point
 // sequence [observed N | prior M] (CATRE_disR_shared.py:86), never materialised.
 //   layer 0 : y0 = W0[:,1024:] . pointfeat + (W0[:,:1024] . g_cloud + b0)      (bias0 from k_linear)
-//   GN(32,256) couples all N+M points of an object: statistics are accumulated as per-tile
-//   (mean, M2) and merged with Chan's formula in tile order (deterministic).
+//   GN(32,256) couples all N+M points of an object.  GN0: y0 is linear in pointfeat, so its statistics come from the
+//   per-cloud mean and scatter matrix of pointfeat (catre_gram.h) instead of a first pass over layer 0.  GN1: per-tile
+//   (mean, M2) partials merged with Chan's formula in tile order (deterministic).
 // Tiles never straddle the observed/prior boundary: T = ceil(N/64) + ceil(M/64) per object.
 // ------------------------------------------------------------------------------------------
 struct RotTile {
@@ -682,16 +683,6 @@ __device__ __forceinline__ RotTile rot_tile(int bid, int B, int N, int M) {
   return r;
 }
 
-__device__ __forceinline__ void load_pf_tile(const float* __restrict__ pointfeat, const RotTile& rt, float* pf,
-                                             int tid) {
-  const int row = tid >> 3, c4 = tid & 7;  // 512 threads: 64 rows x 8 lanes x 2 float4
-  const int srow = min(row, rt.valid - 1);
-  const f32x4* s = reinterpret_cast<const f32x4*>(pointfeat + rt.pf_off + (size_t)srow * 64);
-  f32x4* d = reinterpret_cast<f32x4*>(pf + row * LD64);
-  d[c4] = s[c4];
-  d[c4 + 8] = s[c4 + 8];
-}
-
 // Merge per-tile (mean, M2) partials of one (object, head, group) in tile order -> (mean, rstd)
 __device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64]*/, int group, int T, int TN, int N,
                                          int M, float& mean_out, float& rstd_out) {
@@ -707,68 +698,6 @@ __device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64
   }
   mean_out = mean;
   rstd_out = 1.0f / sqrtf(m2 / n + 1e-5f);
-}
-
-// y0 of one head for this wave's 32 channels x 64 points ("normal" orientation), incl. bias0
-__device__ __forceinline__ void rot_layer0(f32x16 (&acc)[1][2], const f32x4* __restrict__ wpl0, const float* pf,
-                                           int wave, int lane) {
-  acc[0][0] = acc[0][1] = zero16();
-  gemm_core<1, 2, false, false, 8, 2>(acc, wpl0 + (wave * 8) * 64 + lane, 0, pf, LD64, lane);
-}
-
-__global__ __launch_bounds__(512) void k_rot_l0_stats(const float* __restrict__ pointfeat,
-                                                      const f32x4* __restrict__ wpl0x,
-                                                      const f32x4* __restrict__ wpl0y,
-                                                      const float* __restrict__ bias0 /*[2][2B][256]*/,
-                                                      float* __restrict__ gn0 /*[B][2][T][64]*/, int B, int N,
-                                                      int M) {
-  __shared__ __attribute__((aligned(16))) float pf[TP * LD64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
-  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
-  load_pf_tile(pointfeat, rt, pf, tid);
-  __syncthreads();
-  const int n = lane & 31, h = lane >> 5;
-  const float cnt = 8.f * (float)rt.valid;
-#pragma unroll 1
-  for (int hd = 0; hd < 2; ++hd) {
-    f32x16 acc[1][2];
-    rot_layer0(acc, hd ? wpl0y : wpl0x, pf, wave, lane);
-    const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
-    float* out = gn0 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + 8 * g + 4 * h);
-      float v[2][4];
-      float s = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const bool ok = nb * 32 + n < rt.valid;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[nb][q] = acc[0][nb][4 * g + q] + bv[q];
-          s += ok ? v[nb][q] : 0.f;
-        }
-      }
-      const float mean = wave_sum(s) / cnt;
-      float m2 = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const bool ok = nb * 32 + n < rt.valid;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float d = v[nb][q] - mean;
-          m2 += ok ? d * d : 0.f;
-        }
-      }
-      m2 = wave_sum(m2);
-      if (lane == 0) {
-        out[(wave * 4 + g) * 2] = mean;
-        out[(wave * 4 + g) * 2 + 1] = m2;
-      }
-    }
-  }
 }
 
 #include "catre_rot.h"
@@ -920,6 +849,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 }
 
 #include "catre_bf16.h"
+#include "catre_gram.h"
 #include "catre_train.h"
 #include "catre_aug.h"
 #include "catre_pcl.h"
@@ -1010,7 +940,10 @@ WsLayout ws_layout(int B, int N, int M) {
   L.gn1 = take(b * 2 * T * 64);
   L.aff0 = take(b * 2 * 2 * 2 * 256);
   L.gn1stat = take(b * 2 * 64);
-  L.y1 = take(b * 2 * P * 256);
+  {  // y1 [b][2][P][256]; before it is written the region holds the pointfeat moments (catre_gram.h)
+    const size_t y1n = b * 2 * P * 256, mom = b * T * (4096 + 64) + b * 2 * (4096 + 64);
+    L.y1 = take(y1n > mom ? y1n : mom);
+  }
   L.rpart = take(b * 2 * T * 4);
   L.total = o;
   return L;
@@ -1261,13 +1194,22 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
     hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, gfeat, PMW, prm[base], PMW,
                        prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
   }
+  // GN0 statistics from second moments of pointfeat (catre_gram.h); the moment buffers borrow y1, which is only
+  // written by k_rot_l1 afterwards
+  float* gram = ws + W.y1;
+  float* tmean = gram + (size_t)B * T * 4096;
+  float* Scl = tmean + (size_t)B * T * 64;
+  float* mucl = Scl + (size_t)B * 2 * 4096;
   {
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
-  hipLaunchKernelGGL(k_rot_l0_stats, dim3(B * T), dim3(512), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                     pk4(packed, L.rot_l0[1]), bias0, ws + W.gn0, B, N, M);
+    const int TNc = (N + TP - 1) / TP, TMc = (M + TP - 1) / TP;
+    hipLaunchKernelGGL(k_pf_gram<false>, dim3(B * T), dim3(256), 0, st, (const void*)pointfeat, gram, tmean, B, N, M);
+    hipLaunchKernelGGL(k_gram_merge, dim3(B, 2, 4), dim3(256), (size_t)(TNc > TMc ? TNc : TMc) * 64 * sizeof(float), st, gram,
+                       tmean, Scl, mucl, B, N, M);
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Scl, mucl, prm[CATRE_P_ROTX_L0_W],
+                       prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
+                       prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   }
-  hipLaunchKernelGGL(k_gn0_affine, dim3(B * 2), dim3(256), 0, st, ws + W.gn0, bias0, prm[CATRE_P_ROTX_GN0_W],
-                     prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
     hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),

@@ -1,8 +1,8 @@
 // catre_rot.h - rotation-head kernels after the layer-0 statistics pass (included by catre_kernels.hip).
 //
 // a9 (heads/conv_out_per_rot_head.py:126-140) per (object, head), over the P = N+M concatenated points:
-//   y0 = W0[:,1024:] pointfeat + bias0(cloud)       -> GN0 statistics         (k_rot_l0_stats)
-//   k_gn_finalize: merge per-tile (mean, M2) partials in tile order (Chan) -> (mean, rstd) per group
+//   y0 = W0[:,1024:] pointfeat + bias0(cloud)       -> GN0 statistics from the moments of pointfeat (catre_gram.h;
+//                                                      the bf16 path: k_rot_l0_stats_bf + k_gn0_affine)
 //   a0 = gelu(GN0(y0));  y1 = W1 a0 + b1             -> y1 to HBM, GN1 partials (k_rot_l1)
 //   k_gn_finalize
 //   out[c] = sum_p w_p * (neck gelu(GN1(y1)))[c,p]                             (k_rot_out, HBM-bound)
