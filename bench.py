@@ -96,6 +96,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 
     cfg = cfg_fn(str(dev))
+    amp = args.dtype == "bf16"
     cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=1e-5, weight_decay=0, clean_grads=True)  # shipped optimiser, fused HIP step
     model, opt = build_model_optimizer(cfg, is_test=False)
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
@@ -118,9 +119,11 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
         poses_est = scales_est = None
         for it in range(1, K_ITER + 1):
             batch_updater_test(cfg, b, poses_est=poses_est, scales_est=scales_est)
-            out, ld = net(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
-                          gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
-                          mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=it)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):  # engine.py:304 (SOLVER.AMP.ENABLED)
+                out, ld = net(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"],
+                              K_zoom=b["K"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
+                              obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True,
+                              cur_iter=it)
             poses_est, scales_est = out[f"pose_{it}"].detach(), out[f"scale_{it}"].detach()
             sum(ld.values()).backward()
             opt.step()
@@ -149,11 +152,14 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
         print(json.dumps({
-            "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)", "value": round(value, 1),
+            "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else ""),
+            "value": round(value, 1),
             "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
             "config": {"workload": "B=256 objects/GPU, N=M=1024, K=4 x (forward + loss + backward + fused Ranger step); "
+                                   + ("bf16-operand forward / dgrad GEMMs under torch.autocast; " if amp else "")
+                                   +
                                    "half the objects y-symmetric with 313 candidate rotations; "
                                    + ("DDP gradient all-reduce over RCCL" if world > 1 else "single rank"),
                        "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER},

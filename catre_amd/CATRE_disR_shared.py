@@ -107,9 +107,13 @@ class CATRE_disR_shared(nn.Module):
         # Like the reference, gradients flow to the parameters only: the caller detaches the fed-back pose
         # (engine.py:324-325) and x / tfd_kps come from the data batch.
         from .train_forward import forward_train
+        from .train_ops import amp_mode
 
-        pose, scale, _ = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
-                                       K_zoom, mean_scales)
+        # under torch.autocast (SOLVER.AMP.ENABLED in the reference's loop) the row GEMMs take bf16 operands;
+        # cfg.MODEL.CATRE.COMPUTE_DTYPE forces either precision
+        with amp_mode(self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)):
+            pose, scale, _ = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
+                                           K_zoom, mean_scales)
         out_dict = {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
         if not do_loss:
             return out_dict

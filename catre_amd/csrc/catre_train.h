@@ -31,51 +31,12 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 // gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
 // wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "normal" orientation: 4 consecutive channels/lane.
 // ------------------------------------------------------------------------------------------------
-// MAXP: instead of storing Y, reduce the tile's 64 rows to a per-channel (max, arg-max row) pair - the forward of
-// linear + max-pool over points without materialising the [R, J] matrix (Y = float maxima [tiles][J], mask = the int
-// arg-max rows [tiles][J]).  Uses the "swapped" MFMA orientation so that a lane owns a channel and the reduction is
-// in-register; the first maximum wins, like torch.max.
-template <int MB, int NKC, bool MAXP = false>
-__global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
-                                                   const float* __restrict__ bias, const float* __restrict__ mask,
-                                                   int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
-                                                   int relu, const float* __restrict__ xmask, int ldxm) {
-  constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
-  constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
-  __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r0 = blockIdx.x * TP;
-  const int nblk = J / 32, nkc_total = K / 8, nchunks = K / KC;
-  f32x16 acc[MB][2];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-  const bool active = wave < nblk;  // waves beyond the channel count only help staging
-  for (int c = 0; c < nchunks; ++c) {
-    if (c) __syncthreads();
-    // stage X[r0..r0+64, c*KC .. +KC) : coalesced float4 along K, swizzled rows
-    constexpr int F4 = KC / 4;
-    for (int i = tid; i < TP * F4; i += 512) {
-      const int row = i / F4, ch = i % F4;
-      const int gr = min(r0 + row, R - 1);
-      f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
-      if (xmask) {  // ReLU backward folded into the operand load: X .* (xmask > 0)
-        const f32x4 m = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v;
-    }
-    __syncthreads();
-    if (active) {
-      // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
-      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
-      // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
-      g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
-      g.run(acc, xs, LDX, lane);
-    }
-  }
-  if (!active) return;
+// epilogue shared by the fp32 and bf16-operand row GEMMs: bias / ReLU / output mask -> Y, or (MAXP) the per-tile
+// max / arg-max over the 64 rows
+template <int MB, bool MAXP>
+__device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
+                                                   const float* __restrict__ mask, int ldm, float* __restrict__ Y,
+                                                   int ldy, int R, int relu, int r0, int nblk, int wave, int lane) {
   const int n = lane & 31, h = lane >> 5;
   if constexpr (MAXP) {
     // D[row = point][col = channel]: lane owns channel blk*32 + n and points (r&3) + 8(r>>2) + 4h + 32nb
@@ -143,12 +104,114 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
   }
 }
 
+// MAXP: instead of storing Y, reduce the tile's 64 rows to a per-channel (max, arg-max row) pair - the forward of
+// linear + max-pool over points without materialising the [R, J] matrix (Y = float maxima [tiles][J], mask = the int
+// arg-max rows [tiles][J]).  Uses the "swapped" MFMA orientation so that a lane owns a channel and the reduction is
+// in-register; the first maximum wins, like torch.max.
+template <int MB, int NKC, bool MAXP = false>
+__global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
+                                                   const float* __restrict__ bias, const float* __restrict__ mask,
+                                                   int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
+                                                   int relu, const float* __restrict__ xmask, int ldxm) {
+  constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
+  constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
+  __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * TP;
+  const int nblk = J / 32, nkc_total = K / 8, nchunks = K / KC;
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+  const bool active = wave < nblk;  // waves beyond the channel count only help staging
+  for (int c = 0; c < nchunks; ++c) {
+    if (c) __syncthreads();
+    // stage X[r0..r0+64, c*KC .. +KC) : coalesced float4 along K, swizzled rows
+    constexpr int F4 = KC / 4;
+    for (int i = tid; i < TP * F4; i += 512) {
+      const int row = i / F4, ch = i % F4;
+      const int gr = min(r0 + row, R - 1);
+      f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+      if (xmask) {  // ReLU backward folded into the operand load: X .* (xmask > 0)
+        const f32x4 m = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v;
+    }
+    __syncthreads();
+    if (active) {
+      // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
+      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
+      // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
+      g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
+      g.run(acc, xs, LDX, lane);
+    }
+  }
+  if (!active) return;
+  gemm_rows_epilogue<MB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm_tn: dW[J,K] = sum_r dY[r,J]^T X[r,K] over rows [row_lo, row_hi) of this split.
 // 512 threads, 128x128 output tile: wave w -> j-block w>>1 (of 4), k-blocks {2(w&1), 2(w&1)+1}.
 // 32-row slabs are staged transposed in LDS ([col][row], row contiguous, +4 skew) so both MFMA fragments
 // are 16-byte reads along the contraction (row) index.  Partials go to part[split][J*K].
 // ------------------------------------------------------------------------------------------------
+// ---- mixed precision (torch.autocast around the training forward, engine.py:304): the forward and dgrad row GEMMs
+// with bf16 operands and fp32 accumulation / outputs.  Weights: bf16 fragments in plain k order; the 64-row X tile is
+// converted while it is staged (whole K at once: 64 rows x 512 x 2 B = 64 KiB at most).
+__global__ void k_op_pack_bf(const float* __restrict__ src, int ld, int J, int K, int transpose,
+                             unsigned short* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= J * K) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9;
+  const int nkc = K / 16;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 16 + 8 * (lane >> 5) + e;
+  const float v = transpose ? src[(size_t)col * ld + row] : src[(size_t)row * ld + col];
+  dst[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+template <int MB, int CP, bool MAXP>
+__global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
+                                                      const float* __restrict__ xmask, int ldxm) {
+  constexpr int NKC = CP / 2;  // K = 8 * CP
+  __shared__ u32x4 xs[TP * CP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * TP;
+  const int nblk = J / 32;
+  for (int i = tid; i < TP * CP; i += 512) {
+    const int row = i / CP, ch = i % CP;
+    const int gr = min(r0 + row, R - 1);
+    const float* src = X + (size_t)gr * ldx + ch * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (xmask) {
+      const float* ms = xmask + (size_t)gr * ldxm + ch * 8;
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(ms), m1 = *reinterpret_cast<const f32x4*>(ms + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = m0[q] > 0.f ? v[q] : 0.f;
+        v[4 + q] = m1[q] > 0.f ? v[4 + q] : 0.f;
+      }
+    }
+    xs[bf_off<CP>(row, ch)] = pack_bf8(v);
+  }
+  __syncthreads();
+  if (wave >= nblk) return;
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+  GemmPipeB<MB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1), 1> g;
+  g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
+  g.run(acc, xs, lane);
+  gemm_rows_epilogue<MB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+}
+
 #define TN_ROWS 64  // rows of dY / X staged per step
 // dW partial [split][J][K] = dY[rows of the split, J]^T X[rows, K]; 128 x 128 output tile per workgroup, 8 waves x
 // (32 x 64).  The contraction runs over ROWS, and v_mfma_f32_32x32x2_f32 takes one A and one B value per lane per

@@ -88,6 +88,9 @@ _SIGS = {
     "catre_op_gemm_rows": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "catre_op_linear_maxpool_ws_bytes": (_SZ, [_I, _I]),
     "catre_op_linear_maxpool": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "catre_op_pack_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "catre_op_gemm_rows_bf16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "catre_op_linear_maxpool_bf16": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_gemm_tn_ws_bytes": (_SZ, [_I, _I, _I]),
     "catre_op_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_gemm_rows_m": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

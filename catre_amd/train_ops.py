@@ -39,12 +39,40 @@ def _pad_cols(t, mult):
 
 
 # ------------------------------------------------------------------------------------------------- GEMMs
+# Mixed precision: inside torch.autocast (what SOLVER.AMP.ENABLED does to the reference's forward, engine.py:304) the
+# forward and dgrad row GEMMs run with bf16 operands and fp32 accumulation / outputs.  `amp_mode("fp32" | "bf16")`
+# overrides the autocast state (cfg.MODEL.CATRE.COMPUTE_DTYPE).
+_AMP_OVERRIDE = [None]
+
+
+class amp_mode:
+    def __init__(self, mode):
+        assert mode in (None, "fp32", "float32", "bf16", "bfloat16"), mode
+        self.mode = None if mode is None else mode in ("bf16", "bfloat16")
+
+    def __enter__(self):
+        self.prev, _AMP_OVERRIDE[0] = _AMP_OVERRIDE[0], self.mode if self.mode is not None else _AMP_OVERRIDE[0]
+
+    def __exit__(self, *a):
+        _AMP_OVERRIDE[0] = self.prev
+
+
+def _amp():
+    return torch.is_autocast_enabled() if _AMP_OVERRIDE[0] is None else _AMP_OVERRIDE[0]
+
+
+def _pack_bf16(w, J, K, dev):
+    wp = torch.empty(J * K // 2, dtype=torch.float32, device=dev)  # J*K bf16
+    hip.check(hip.load().catre_op_pack_bf16(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(w)), "catre_op_pack_bf16")
+    return wp
+
+
 def _tiled_gemm_ok(R, J, K):
     """Shapes the tiled row kernel (catre_op_gemm_rows) takes."""
     return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= 256
 
 
-def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None):
+def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False):
     """y[R,J] = act(x[R,K] w[J,K]^T + bias) (zeroed where mask<=0); with xmask the left operand is x .* (xmask > 0).
     Picks the tiled row kernel when the shape allows, else the one-block-per-32x32 kernel (small R or odd J)."""
     lib = hip.load()
@@ -53,7 +81,13 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None):
     dev = x.device
     y = torch.empty(R, J, dtype=torch.float32, device=dev)
     big = _tiled_gemm_ok(R, J, K) and identity_k == 0
-    if big:
+    if big and amp and K in (64, 128, 256, 512):
+        wp = _pack_bf16(w, J, K, dev)
+        hip.check(lib.catre_op_gemm_rows_bf16(hip.ptr(x), x.stride(0), hip.ptr(xmask),
+                                              xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), hip.ptr(bias),
+                                              hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R,
+                                              J, K, int(relu), _st(x)), "catre_op_gemm_rows_bf16")
+    elif big:
         wp = torch.empty(J * K, dtype=torch.float32, device=dev)
         hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
         hip.check(lib.catre_op_gemm_rows_m(hip.ptr(x), x.stride(0), hip.ptr(xmask),
@@ -108,9 +142,10 @@ class _Linear(torch.autograd.Function):
         w2 = w.reshape(w.shape[0], -1)
         K = w2.shape[1]
         xk, wk = _c(_pad_cols(x, 8)), _c(_pad_cols(w2, 8))
-        y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k)
+        amp = _amp()
+        y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k, amp=amp)
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.relu, ctx.K, ctx.has_b = relu, K, b is not None
+        ctx.relu, ctx.K, ctx.has_b, ctx.amp = relu, K, b is not None, amp
         return y
 
     @staticmethod
@@ -135,7 +170,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
             wt = _c(_pad_cols(w2.t(), 8))          # [K, J8]
-            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask)   # [R, K]
+            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)   # [R, K]
             if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
                 dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
             elif x.shape[1] < dx.shape[1]:
@@ -179,7 +214,14 @@ class _LinearMaxPool(torch.autograd.Function):
         xc = _c(x)
         fused = (N % 64 == 0 and M % 64 == 0 and J % 32 == 0 and (J <= 256 or J in (512, 1024))
                  and (K in (64, 128) or K % 256 == 0))
-        if fused:  # the max / arg-max is the GEMM's epilogue: the [rows, J] matrix never exists
+        if fused and _amp() and K in (64, 128, 256, 512):
+            wp = _pack_bf16(w2, J, K, x.device)
+            need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)
+            ws = _ws(need, x.device)
+            hip.check(lib.catre_op_linear_maxpool_bf16(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(b), hip.ptr(g),
+                                                       hip.ptr(idx), J, K, B, N, M, hip.ptr(ws), ws.numel(), _st(x)),
+                      "catre_op_linear_maxpool_bf16")
+        elif fused:  # the max / arg-max is the GEMM's epilogue: the [rows, J] matrix never exists
             wp = torch.empty(J * K, dtype=torch.float32, device=x.device)
             hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
             need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)

@@ -232,6 +232,13 @@ int catre_op_linear_maxpool(const float* X, int ldx, const float* Wp, const floa
 /* catre_op_gemm_rows with the left operand masked on load, (X .* (xmask > 0)) Wl^T: the ReLU backward folded in */
 int catre_op_gemm_rows_m(const float* X, int ldx, const float* xmask, int ldxm, const float* Wp, const float* bias,
                          const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
+/* mixed precision (torch.autocast around the training forward, core/catre/engine/engine.py:304): the row GEMMs with
+ * bf16 operands and fp32 accumulation / outputs.  Wp from catre_op_pack_bf16 (J*K bf16); K in {64,128,256,512}. */
+int catre_op_pack_bf16(const float* src, int ld, int J, int K, int transpose, void* dst, void* stream);
+int catre_op_gemm_rows_bf16(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
+                            const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
+int catre_op_linear_maxpool_bf16(const float* X, int ldx, const void* Wp, const float* bias, float* out, int* idx, int J,
+                                 int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -20,9 +20,10 @@ def run(B, N=1024, M=1024, reps=3):
     sym_info = [sym if i % 3 == 0 else None for i in range(B)]
     batch_updater_test(cfg, b)
     def step():
-        _, ld = model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
-                      gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
-                      mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(os.environ.get("CATRE_AMP"))):
+            _, ld = model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                          gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                          mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1)
         loss = sum(ld.values()); loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
         return loss
     step(); torch.cuda.synchronize()

@@ -107,6 +107,57 @@ def test_module_training_step_matches_reference_golden():
     assert torch.isfinite(after).all() and (after - before).abs().max() > 0
 
 
+def test_amp_training_iteration_tracks_fp32():
+    """torch.autocast around the forward (the reference's SOLVER.AMP.ENABLED, engine.py:304) switches the forward and
+    dgrad row GEMMs to bf16 operands (fp32 accumulate / outputs).  Mixed-precision tolerances: every loss term within
+    3e-2 relative (+1e-3 abs) of the fp32 iteration, every large gradient with cosine similarity >= 0.98 and norm within
+    10 %; COMPUTE_DTYPE='fp32' forces full precision under autocast."""
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from oracle.catre_oracle import y_axis_symmetries
+
+    B, N, M = 8, 256, 192
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.to(DEV) for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()})
+    model.train()
+    b = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=17).items()}
+    batch_updater_test(cfg, b)
+    sym = [y_axis_symmetries(12) if i % 3 == 0 else None for i in range(B)]
+
+    def run(autocast, force=None):
+        model.cfg.MODEL.CATRE.COMPUTE_DTYPE = force
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out, ld = model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                            gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                            mean_scales=b["obj_mean_scales"], sym_info=sym, do_loss=True, cur_iter=1)
+        sum(ld.values()).backward()
+        return ({k: float(v) for k, v in ld.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                out["pose_1"].detach().clone())
+
+    l32, g32, p32 = run(False)
+    l16, g16, p16 = run(True)
+    lf, gf, pf = run(True, force="fp32")
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = None
+    assert torch.equal(pf, p32) and all(torch.equal(gf[k], g32[k]) for k in g32), "COMPUTE_DTYPE=fp32 must ignore autocast"
+    assert p16.dtype == torch.float32 and not torch.equal(p16, p32), "autocast did not reach the bf16 GEMMs"
+    assert (p16 - p32).abs().max() < 2e-2
+    for k in l32:
+        assert abs(l16[k] - l32[k]) <= 3e-2 * abs(l32[k]) + 1e-3, (k, l16[k], l32[k])
+    checked = 0
+    for k, g in g32.items():
+        if g.numel() < 4096 or float(g.norm()) < 1e-8:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), g16[k].reshape(-1), dim=0))
+        ratio = float(g16[k].norm() / g.norm())
+        assert cos >= 0.98 and 0.9 <= ratio <= 1.1, (k, cos, ratio)
+        checked += 1
+    assert checked >= 20
+
+
 def test_ddp_world1_wraps_and_steps():
     """The reference wraps the model in DistributedDataParallel(find_unused_parameters=True)
     (core/catre/main_catre.py:154-160); world_size 1 over RCCL exercises the reducer hooks on the HIP gradients."""
