@@ -4,21 +4,25 @@
 
 The reference picks the symmetry-equivalent ground-truth rotation per object in a Python/numpy loop on the
 host (``core/utils/pose_utils.py:472-528``: up to 314 ``re()`` evaluations per symmetric object and a
-device->host copy per refine iteration).  Here the candidates of the whole batch are scored at once on the
-device and no value ever leaves it, so a training step has no host synchronisation.
-
-These are O(B) / O(B*M*3) reductions on tensors that already live on the GPU; they are written with torch
-tensor ops (the model outputs they consume come from the HIP kernels and stay autograd-connected).
+device->host copy per refine iteration) and then evaluates the terms with ~100 small torch kernels.  Here the
+whole loss is two HIP launches forward (``catre_loss_fwd``: candidate arg-max, the point-matching sum and the
+per-object terms in one workgroup per object, then an ordered reduction) and one backward (``catre_loss_bwd``),
+chained into autograd by :class:`_FusedLoss`; no value ever leaves the device.
 """
+import ctypes
+
 import numpy as np
 import torch
-import torch.nn.functional as F
+
+from . import hip
 
 _sym_cache = {}
+_KEYS = ("loss_PM_R", "loss_rot", "loss_yaxis_rot", "loss_trans_xy", "loss_trans_z", "loss_scale")
 
 
 def _sym_tensor(sym_infos, device, dtype):
-    """list of [S_i,3,3] arrays or None -> (cands [B,Smax+1,3,3] with identity first / as padding, valid mask)."""
+    """list of [S_i,3,3] arrays or None -> (cands [B,Smax+1,3,3] with identity first / as padding, valid mask,
+    is_sym [B] int32)."""
     key = (tuple(id(s) if s is not None else None for s in sym_infos), str(device))
     hit = _sym_cache.get(key)
     if hit is not None:
@@ -26,83 +30,112 @@ def _sym_tensor(sym_infos, device, dtype):
     B = len(sym_infos)
     smax = max([0] + [np.asarray(s).reshape(-1, 3, 3).shape[0] for s in sym_infos if s is not None])
     cands = np.tile(np.eye(3, dtype=np.float32), (B, smax + 1, 1, 1))
-    valid = np.zeros((B, smax + 1), dtype=bool)
-    valid[:, 0] = True
+    valid = np.zeros((B, smax + 1), dtype=np.uint8)
+    valid[:, 0] = 1
     for i, s in enumerate(sym_infos):
         if s is None:
             continue
         s = np.asarray(s, dtype=np.float32).reshape(-1, 3, 3)
         cands[i, 1:1 + s.shape[0]] = s
-        valid[i, 1:1 + s.shape[0]] = True
-    out = (torch.from_numpy(cands).to(device=device, dtype=dtype), torch.from_numpy(valid).to(device))
+        valid[i, 1:1 + s.shape[0]] = 1
+    is_sym = np.array([0 if s is None else 1 for s in sym_infos], dtype=np.int32)
+    out = (torch.from_numpy(cands).to(device=device, dtype=dtype), torch.from_numpy(valid).to(device),
+           torch.from_numpy(is_sym).to(device))
     if len(_sym_cache) > 64:
         _sym_cache.clear()
     _sym_cache[key] = out
     return out
 
 
-@torch.no_grad()
-def get_closest_rot_batch(pred_rots, gt_rots, sym_infos):
-    """Batched ``get_closest_rot_batch``: per object argmin over {R_gt, R_gt @ S_k} of the rotational error to the
-    prediction.  ``re`` is a decreasing function of trace(R_pred R_cand^T), so the arg-max of the trace is taken;
-    the first maximum wins, like the reference's strict ``<`` scan that starts at the un-rotated ground truth."""
-    sym, valid = _sym_tensor(sym_infos, gt_rots.device, gt_rots.dtype)
-    # 3x3 products as broadcast multiply-adds: torch.matmul would dispatch thousands of tiny GEMMs to hipBLASLt
-    cand = (gt_rots.unsqueeze(1).unsqueeze(-1) * sym.unsqueeze(-3)).sum(-2)   # [B,S+1,3,3] = R_gt @ S_k
-    tr = (pred_rots.detach().unsqueeze(1) * cand).sum((-1, -2))         # trace(P C^T) = sum_ij P_ij C_ij
-    tr = torch.clamp(0.5 * (torch.clamp(tr, max=3.0) - 1.0), -1.0, 1.0)
-    tr = torch.where(valid, tr, torch.full_like(tr, -2.0))
-    best = torch.argmax(tr, dim=1)
-    return cand[torch.arange(cand.shape[0], device=cand.device), best]
+def _loss_cfg_struct(cfg, n_sym, n_nonsym):
+    lc = cfg.MODEL.CATRE.LOSS_CFG
+    c = hip.CatreLossCfg()
+    c.pm_on = int(lc.PM_LW > 0)
+    if c.pm_on and (lc.PM_LOSS_TYPE.lower() != "l1" or not lc.PM_R_ONLY or lc.get("PM_USE_BBOX", False)):
+        raise NotImplementedError("PM loss: the shipped configuration (L1, R-only) is implemented")
+    c.pm_sym, c.pm_with_scale = int(bool(lc.PM_LOSS_SYM)), int(bool(lc.PM_WITH_SCALE))
+    c.rot_on = int(lc.ROT_LW > 0)
+    if c.rot_on:
+        if lc.ROT_LOSS_TYPE not in ("angular", "L2"):
+            raise ValueError(f"Unknown rot loss type: {lc.ROT_LOSS_TYPE}")
+        if lc.ROT_YAXIS_LOSS_TYPE not in ("L1", "smoothL1"):
+            raise ValueError(f"Unknown rot yaxis loss type: {lc.ROT_YAXIS_LOSS_TYPE}")
+    c.rot_l2, c.yaxis_smooth = int(lc.ROT_LOSS_TYPE == "L2"), int(lc.ROT_YAXIS_LOSS_TYPE == "smoothL1")
+    c.trans_on = int(lc.TRANS_LW > 0)
+    if c.trans_on and lc.TRANS_LOSS_TYPE not in ("L1", "MSE"):
+        raise ValueError(f"Unknown trans loss type: {lc.TRANS_LOSS_TYPE}")
+    c.trans_mse, c.trans_split = int(lc.TRANS_LOSS_TYPE == "MSE"), int(bool(lc.TRANS_LOSS_DISENTANGLE))
+    c.scale_on = int(lc.SCALE_LW > 0)
+    if c.scale_on:
+        assert cfg.MODEL.REFINE_SCLAE
+        if lc.SCALE_LOSS_TYPE not in ("L1", "MSE"):
+            raise ValueError(f"Unknown scale loss type: {lc.SCALE_LOSS_TYPE}")
+    c.scale_mse = int(lc.SCALE_LOSS_TYPE == "MSE")
+    c.pm_lw, c.rot_lw, c.trans_lw, c.scale_lw = float(lc.PM_LW), float(lc.ROT_LW), float(lc.TRANS_LW), float(lc.SCALE_LW)
+    c.n_sym, c.n_nonsym = int(n_sym), int(n_nonsym)
+    return c
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, lcfg):
+        lib = hip.load()
+        B, M, S1 = pose.shape[0], (kps.shape[1] if kps is not None else 0), cands.shape[1]
+        dev = pose.device
+        best = torch.empty(B, dtype=torch.int32, device=dev)
+        part = torch.empty(B * 8, dtype=torch.float32, device=dev)
+        losses = torch.empty(6, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_loss_fwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
+                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(valid), hip.ptr(is_sym), ctypes.byref(lcfg),
+                                     hip.ptr(best), hip.ptr(part), hip.ptr(losses), B, M, S1, hip.stream_ptr(dev)),
+                  "catre_loss_fwd")
+        ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best)
+        ctx.lcfg, ctx.dims = lcfg, (B, M, S1)
+        return losses
+
+    @staticmethod
+    def backward(ctx, up):
+        pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best = ctx.saved_tensors
+        B, M, S1 = ctx.dims
+        lib = hip.load()
+        up = up.contiguous()
+        dpose, dscale = torch.empty_like(pose), torch.empty_like(scale)
+        hip.check(lib.catre_loss_bwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
+                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(up),
+                                     ctypes.byref(ctx.lcfg), hip.ptr(dpose), hip.ptr(dscale), B, M, S1,
+                                     hip.stream_ptr(pose.device)), "catre_loss_bwd")
+        return dpose, dscale, None, None, None, None, None, None, None, None
 
 
 def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info):
-    loss_cfg = cfg.MODEL.CATRE.LOSS_CFG
-    ld = {}
-    if loss_cfg.PM_LW > 0:
+    """-> the reference's loss dict (same keys, same values).  Gradients flow to out_rot / out_trans / out_scale."""
+    lc = cfg.MODEL.CATRE.LOSS_CFG
+    B = out_rot.shape[0]
+    dev = out_rot.device
+    sym_info = list(sym_info) if sym_info is not None else [None] * B
+    if lc.PM_LW > 0:
         assert (obj_kps is not None) and (gt_trans is not None) and (gt_rot is not None)
-        if loss_cfg.PM_LOSS_TYPE.lower() != "l1" or not loss_cfg.PM_R_ONLY or loss_cfg.get("PM_USE_BBOX", False):
-            raise NotImplementedError("PM loss: the shipped configuration (L1, R-only) is implemented")
-        g = get_closest_rot_batch(out_rot, gt_rot, sym_info) if loss_cfg.PM_LOSS_SYM else gt_rot
-        if loss_cfg.PM_WITH_SCALE:
-            pe, pt = obj_kps * out_scale.unsqueeze(1), obj_kps * gt_scale.unsqueeze(1)
+    cands, valid, is_sym = _sym_tensor(sym_info, dev, torch.float32)
+    n_sym = sum(1 for s in sym_info if s is not None)
+    lcfg = _loss_cfg_struct(cfg, n_sym, B - n_sym)
+    pose = torch.cat([out_rot, out_trans.unsqueeze(-1)], -1).contiguous()
+    f32 = lambda t: hip.require_dev_f32(t.contiguous(), "loss input") if t is not None else None
+    gs = f32(gt_scale) if gt_scale is not None else torch.zeros(B, 3, dtype=torch.float32, device=dev)
+    losses = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
+                              f32(obj_kps), cands, valid, is_sym, lcfg)
+    ld = {}
+    if lcfg.pm_on:
+        ld["loss_PM_R"] = losses[0]
+    if lcfg.rot_on:
+        if lcfg.n_nonsym > 0:
+            ld["loss_rot"] = losses[1]
+        if lcfg.n_sym > 0:
+            ld["loss_yaxis_rot"] = losses[2]
+    if lcfg.trans_on:
+        if lcfg.trans_split:
+            ld["loss_trans_xy"], ld["loss_trans_z"] = losses[3], losses[4]
         else:
-            pe = pt = obj_kps
-        est = (out_rot.unsqueeze(1) * pe.unsqueeze(-2)).sum(-1)          # R (kps * s) per point, [B,M,3]
-        tgt = (g.unsqueeze(1) * pt.unsqueeze(-2)).sum(-1)
-        ld["loss_PM_R"] = 3 * F.l1_loss(est, tgt) * loss_cfg.PM_LW
-    if loss_cfg.ROT_LW > 0:
-        # index lists are built on the host from the python list: no device->host sync (torch.where would force one)
-        ns = torch.tensor([i for i, s in enumerate(sym_info) if s is None], dtype=torch.long, device=out_rot.device)
-        sy = torch.tensor([i for i, s in enumerate(sym_info) if s is not None], dtype=torch.long, device=out_rot.device)
-        if ns.numel() > 0:
-            if loss_cfg.ROT_LOSS_TYPE == "angular":
-                cos = ((out_rot[ns] * gt_rot[ns]).sum((-1, -2)) - 1) / 2     # trace(R_pred R_gt^T)
-                ld["loss_rot"] = ((1 - cos) / 2).mean() * loss_cfg.ROT_LW
-            elif loss_cfg.ROT_LOSS_TYPE == "L2":
-                ld["loss_rot"] = torch.pow(out_rot[ns] - gt_rot[ns], 2).mean() * loss_cfg.ROT_LW
-            else:
-                raise ValueError(f"Unknown rot loss type: {loss_cfg.ROT_LOSS_TYPE}")
-        if sy.numel() > 0:
-            if loss_cfg.ROT_YAXIS_LOSS_TYPE == "L1":
-                ld["loss_yaxis_rot"] = F.l1_loss(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
-            elif loss_cfg.ROT_YAXIS_LOSS_TYPE == "smoothL1":
-                ld["loss_yaxis_rot"] = F.smooth_l1_loss(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
-            else:
-                raise ValueError(f"Unknown rot yaxis loss type: {loss_cfg.ROT_YAXIS_LOSS_TYPE}")
-    if loss_cfg.TRANS_LW > 0:
-        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}.get(loss_cfg.TRANS_LOSS_TYPE)
-        if fn is None:
-            raise ValueError(f"Unknown trans loss type: {loss_cfg.TRANS_LOSS_TYPE}")
-        if loss_cfg.TRANS_LOSS_DISENTANGLE:
-            ld["loss_trans_xy"] = fn(out_trans[:, :2], gt_trans[:, :2]) * loss_cfg.TRANS_LW
-            ld["loss_trans_z"] = fn(out_trans[:, 2], gt_trans[:, 2]) * loss_cfg.TRANS_LW
-        else:
-            ld["loss_trans_LPnP"] = fn(out_trans, gt_trans) * loss_cfg.TRANS_LW
-    if loss_cfg.SCALE_LW > 0:
-        assert cfg.MODEL.REFINE_SCLAE
-        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}.get(loss_cfg.SCALE_LOSS_TYPE)
-        if fn is None:
-            raise ValueError(f"Unknown scale loss type: {loss_cfg.SCALE_LOSS_TYPE}")
-        ld["loss_scale"] = fn(out_scale, gt_scale) * loss_cfg.SCALE_LW
+            ld["loss_trans_LPnP"] = losses[3]
+    if lcfg.scale_on:
+        ld["loss_scale"] = losses[5]
     return ld

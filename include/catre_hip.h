@@ -344,6 +344,34 @@ int catre_pcl_sample(const float* depth, const float* K9, const void* workspace,
                      const long long* sample_idx, unsigned long long seed, int I, int H, int W, int N, float* pcl_out,
                      int32_t* pix_out, void* stream);
 
+/* ---- the training loss on the device --------------------------------------------------- */
+
+/* Flags of cfg.MODEL.CATRE.LOSS_CFG that CATRE_disR_shared.catre_loss reads
+ * (core/catre/models/CATRE_disR_shared.py:168-288; PyPMLoss core/catre/losses/pm_loss.py:85-194, L1 / R-only form). */
+typedef struct catre_loss_cfg {
+  int32_t pm_on, pm_sym, pm_with_scale;     /* PM_LW > 0, PM_LOSS_SYM, PM_WITH_SCALE                              */
+  int32_t rot_on, rot_l2, yaxis_smooth;     /* ROT_LW > 0, ROT_LOSS_TYPE == "L2" (else angular), ROT_YAXIS "smoothL1" */
+  int32_t trans_on, trans_mse, trans_split; /* TRANS_LW > 0, TRANS_LOSS_TYPE == "MSE" (else L1), TRANS_LOSS_DISENTANGLE */
+  int32_t scale_on, scale_mse;
+  float pm_lw, rot_lw, trans_lw, scale_lw;
+  int32_t n_sym, n_nonsym;                  /* how many objects carry symmetry info / do not                       */
+} catre_loss_cfg;
+
+/* losses[6] = {loss_PM_R, loss_rot, loss_yaxis_rot, loss_trans_xy (or loss_trans_LPnP), loss_trans_z, loss_scale}.
+ * pose [B,3,4] = [R|t] estimate, scale [B,3]; cands [B,S1,3,3] = symmetry rotations per object with the identity
+ * first, valid [B,S1] bytes, is_sym [B]; the ground-truth rotation closest to the estimate among R_gt S_k
+ * (get_closest_rot_batch, core/utils/pose_utils.py:472-528) is chosen on the device, its index kept in best [B] for
+ * the backward.  part_ws: B*8 floats of scratch.  All pointers are device pointers. */
+int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                   const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
+                   const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, float* part_ws, float* losses, int B,
+                   int M, int S1, void* stream);
+/* dpose [B,3,4], dscale [B,3] = gradient of sum_i upstream[i] * losses[i] (upstream: 6 floats on the device) */
+int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                   const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
+                   const int32_t* best, const float* upstream, const catre_loss_cfg* cfg, float* dpose, float* dscale,
+                   int B, int M, int S1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -393,20 +393,26 @@ def catre_loss(out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kp
         sym_mask = torch.tensor([0 if s is None else 1 for s in sym_info])
         ns, sy = torch.where(sym_mask == 0)[0], torch.where(sym_mask == 1)[0]
         if len(ns) > 0:
-            assert loss_cfg.ROT_LOSS_TYPE == "angular"
-            m = torch.bmm(out_rot[ns], gt_rot[ns].transpose(1, 2))
-            cos = (torch.einsum("bii->b", m) - 1) / 2
-            ld["loss_rot"] = ((1 - cos) / 2).mean() * loss_cfg.ROT_LW
+            if loss_cfg.ROT_LOSS_TYPE == "angular":  # angular_distance, core/catre/losses/rot_loss.py
+                m = torch.bmm(out_rot[ns], gt_rot[ns].transpose(1, 2))
+                cos = (torch.einsum("bii->b", m) - 1) / 2
+                ld["loss_rot"] = ((1 - cos) / 2).mean() * loss_cfg.ROT_LW
+            else:  # "L2": rot_l2_loss = mean of squared element differences
+                assert loss_cfg.ROT_LOSS_TYPE == "L2"
+                ld["loss_rot"] = torch.pow(out_rot[ns] - gt_rot[ns], 2).mean() * loss_cfg.ROT_LW
         if len(sy) > 0:
-            assert loss_cfg.ROT_YAXIS_LOSS_TYPE == "L1"
-            ld["loss_yaxis_rot"] = F.l1_loss(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
+            fn = {"L1": F.l1_loss, "smoothL1": F.smooth_l1_loss}[loss_cfg.ROT_YAXIS_LOSS_TYPE]
+            ld["loss_yaxis_rot"] = fn(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
     if loss_cfg.TRANS_LW > 0:
-        assert loss_cfg.TRANS_LOSS_TYPE == "L1" and loss_cfg.TRANS_LOSS_DISENTANGLE
-        ld["loss_trans_xy"] = F.l1_loss(out_trans[:, :2], gt_trans[:, :2]) * loss_cfg.TRANS_LW
-        ld["loss_trans_z"] = F.l1_loss(out_trans[:, 2], gt_trans[:, 2]) * loss_cfg.TRANS_LW
+        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}[loss_cfg.TRANS_LOSS_TYPE]
+        if loss_cfg.TRANS_LOSS_DISENTANGLE:
+            ld["loss_trans_xy"] = fn(out_trans[:, :2], gt_trans[:, :2]) * loss_cfg.TRANS_LW
+            ld["loss_trans_z"] = fn(out_trans[:, 2], gt_trans[:, 2]) * loss_cfg.TRANS_LW
+        else:
+            ld["loss_trans_LPnP"] = fn(out_trans, gt_trans) * loss_cfg.TRANS_LW
     if loss_cfg.SCALE_LW > 0:
-        assert loss_cfg.SCALE_LOSS_TYPE == "L1"
-        ld["loss_scale"] = F.l1_loss(out_scale, gt_scale) * loss_cfg.SCALE_LW
+        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}[loss_cfg.SCALE_LOSS_TYPE]
+        ld["loss_scale"] = fn(out_scale, gt_scale) * loss_cfg.SCALE_LW
     return ld
 
 
