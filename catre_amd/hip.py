@@ -145,6 +145,18 @@ KERNEL_IDS = {"stn3d": 0, "stnkd": 1, "trunk": 2, "ts_head": 3, "rot_l0_stats": 
 
 _lib = None
 
+# Parameters updated through raw pointers (the fused Ranger step) do not bump torch's per-tensor version counter, so
+# everything that caches a derived form of the weights (HipRuntime's packed images) also keys on this epoch.
+_param_epoch = [0]
+
+
+def bump_param_epoch():
+    _param_epoch[0] += 1
+
+
+def param_epoch():
+    return _param_epoch[0]
+
 
 class CatreHipError(RuntimeError):
     pass

@@ -119,4 +119,5 @@ class Ranger(Optimizer):
                                            total_rows, hip.ptr(ws), beta1, beta2, eps, self.alpha, int(self.clean_grads),
                                            self.grad_limit, hip.stream_ptr(dev)), "catre_op_ranger_step")
         del keep
+        hip.bump_param_epoch()  # the kernel wrote the parameters behind torch's back: invalidate packed-weight caches
         return None

@@ -72,7 +72,7 @@ class HipRuntime:
         """(param pointer array, packed weights) - re-packed on the current stream if stale."""
         lib = hip.load()
         tensors = self._live_params()
-        fp = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        fp = (hip.param_epoch(),) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
         if fp != self._fingerprint or self._packed is None or self._packed.device != device:
             for k, t in zip(hip.PARAM_KEYS, tensors):
                 if t is not None and t.device != device:

@@ -88,3 +88,13 @@ def test_model_factory_builds_fused_ranger_and_it_trains():
         opt.zero_grad(set_to_none=True)
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    # the fused step writes parameters through raw pointers (no torch version bump): the inference path must still
+    # notice and re-pack its weight images
+    model.eval()
+    before = model.refine(b, n_iter=1)["pose_1"].clone()
+    for p in model.parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    for _ in range(3):
+        opt.step()
+    after = model.refine(b, n_iter=1)["pose_1"]
+    assert (after - before).abs().max() > 0, "stale packed weights after a fused Ranger step"
