@@ -97,6 +97,11 @@ class CATRE_disR_shared(nn.Module):
         if x.shape[0] == 0 and not do_loss:
             # an empty batch (the evaluator skips those, catre_evaluator.py:280-281): nothing to launch
             return {f"pose_{cur_iter}": init_pose.new_zeros(0, 3, 4), f"scale_{cur_iter}": init_scale.new_zeros(0, 3)}
+        if x.is_cuda and x.device.index != torch.cuda.current_device():
+            # kernels are launched on the stream of the tensors' device: make it current, like a torch op would
+            with torch.cuda.device(x.device):
+                return self.forward(x, tfd_kps, init_pose, init_scale, K_zoom, obj_class, gt_ego_rot, gt_trans, gt_scale,
+                                    obj_kps, mean_scales, sym_info, do_loss, cur_iter)
         if not (do_loss or needs_grad):
             # inference: the fused kernels (one launch chain, nothing saved)
             pose, scale = self._runtime().refine_iter(x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales,
@@ -150,10 +155,11 @@ class CATRE_disR_shared(nn.Module):
                 out[f"pose_{i}"] = batch["obj_pose_est"].new_zeros(0, 3, 4)
                 out[f"scale_{i}"] = batch["obj_scale_est"].new_zeros(0, 3)
             return out
-        poses, scales = self._runtime().refine_k(
-            batch["pcl"], batch["obj_kps"], batch["obj_pose_est"], batch["obj_scale_est"], batch.get("K"),
-            batch.get("obj_mean_scales"), self._inference_opts(), n_iter,
-        )
+        with torch.cuda.device(batch["pcl"].device if batch["pcl"].is_cuda else None):
+            poses, scales = self._runtime().refine_k(
+                batch["pcl"], batch["obj_kps"], batch["obj_pose_est"], batch["obj_scale_est"], batch.get("K"),
+                batch.get("obj_mean_scales"), self._inference_opts(), n_iter,
+            )
         out = {}
         for i in range(n_iter + 1):
             out[f"pose_{i}"], out[f"scale_{i}"] = poses[i], scales[i]

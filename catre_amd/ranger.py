@@ -115,9 +115,11 @@ class Ranger(Optimizer):
                 row_off += p.numel() // row_len
         table_dev = torch.from_numpy(table.view(np.uint8)).to(dev)
         keep = [r[1] for r in recs]  # contiguous gradient copies must outlive the launch
-        hip.check(lib.catre_op_ranger_step(hip.ptr(table_dev), len(recs), hip.ptr(chunks_dev), n_chunks, hip.ptr(rt_dev),
-                                           total_rows, hip.ptr(ws), beta1, beta2, eps, self.alpha, int(self.clean_grads),
-                                           self.grad_limit, hip.stream_ptr(dev)), "catre_op_ranger_step")
+        with torch.cuda.device(dev):
+            hip.check(lib.catre_op_ranger_step(hip.ptr(table_dev), len(recs), hip.ptr(chunks_dev), n_chunks,
+                                               hip.ptr(rt_dev), total_rows, hip.ptr(ws), beta1, beta2, eps, self.alpha,
+                                               int(self.clean_grads), self.grad_limit, hip.stream_ptr(dev)),
+                      "catre_op_ranger_step")
         del keep
         hip.bump_param_epoch()  # the kernel wrote the parameters behind torch's back: invalidate packed-weight caches
         return None
