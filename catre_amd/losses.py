@@ -26,7 +26,7 @@ def _sym_tensor(sym_infos, device, dtype):
     key = (tuple(id(s) if s is not None else None for s in sym_infos), str(device))
     hit = _sym_cache.get(key)
     if hit is not None:
-        return hit
+        return hit[0]
     B = len(sym_infos)
     smax = max([0] + [np.asarray(s).reshape(-1, 3, 3).shape[0] for s in sym_infos if s is not None])
     cands = np.tile(np.eye(3, dtype=np.float32), (B, smax + 1, 1, 1))
@@ -43,7 +43,7 @@ def _sym_tensor(sym_infos, device, dtype):
            torch.from_numpy(is_sym).to(device))
     if len(_sym_cache) > 64:
         _sym_cache.clear()
-    _sym_cache[key] = out
+    _sym_cache[key] = (out, list(sym_infos))  # the arrays stay referenced, so their ids cannot be recycled while cached
     return out
 
 
