@@ -282,7 +282,8 @@ def test_errors():
         build_model_optimizer(cfg, is_test=True)
 
 
-@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (5, 63, 65), (3, 64, 64), (2, 129, 1), (7, 130, 257), (4, 2, 300)])
+@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (5, 63, 65), (3, 64, 64), (2, 129, 1), (7, 130, 257), (4, 2, 300),
+                                   (1, 4096, 32)])
 def test_ragged_shapes_match_oracle(B, N, M):
     """Edge shapes: single points, tile boundaries +-1, tails in both clouds, B not a multiple of anything."""
     from catre_amd import synth
@@ -300,6 +301,15 @@ def test_ragged_shapes_match_oracle(B, N, M):
     for i in range(1, K + 1):
         assert (out[f"pose_{i}"].cpu() - want[f"pose_{i}"]).abs().max() <= TIGHT, (B, N, M, i)
         assert (out[f"scale_{i}"].cpu() - want[f"scale_{i}"]).abs().max() <= TIGHT, (B, N, M, i)
+
+
+def test_zero_iterations_returns_the_initial_estimate():
+    g = load_golden("refine_b2_small")
+    model, _ = build_model(g["cfg"], g["salt"])
+    b = to_dev(g["batch"])
+    out = model.refine(b, n_iter=0)
+    assert sorted(out) == ["pose_0", "scale_0"]
+    assert torch.equal(out["pose_0"], b["obj_pose_est"]) and torch.equal(out["scale_0"], b["obj_scale_est"])
 
 
 def test_input_layouts_and_streams():
