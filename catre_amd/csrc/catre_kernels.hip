@@ -1527,26 +1527,27 @@ int catre_pcl_sample(const float* depth, const float* K9, const void* workspace,
 // ---- row f1: training loss ---------------------------------------------------------------------------------
 int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
-                   const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, float* part_ws, float* losses, int B,
-                   int M, int S1, void* stream) {
-  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && part_ws && losses && B > 0 && S1 > 0);
+                   const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
+                   float* losses, int B, int M, int S1, void* stream) {
+  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && part_ws && losses && B > 0 &&
+          S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && valid && M > 0));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, st, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid,
                      is_sym, *cfg, best, part_ws, B, M, S1);
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, (const float*)part_ws, *cfg, losses, B, M);
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M);
   return check_launch();
 }
 
 int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
-                   const int32_t* best, const float* upstream, const catre_loss_cfg* cfg, float* dpose, float* dscale,
-                   int B, int M, int S1, void* stream) {
-  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && upstream && dpose && dscale && B > 0 &&
-          S1 > 0);
+                   const int32_t* best, const int32_t* counts, const float* upstream, const catre_loss_cfg* cfg,
+                   float* dpose, float* dscale, int B, int M, int S1, void* stream) {
+  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && upstream && dpose &&
+          dscale && B > 0 && S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && M > 0));
   hipLaunchKernelGGL(k_loss_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, pose, scale, gt_rot, gt_trans, gt_scale, kps,
-                     cands, is_sym, best, upstream, *cfg, dpose, dscale, B, M, S1);
+                     cands, is_sym, best, upstream, *cfg, counts, dpose, dscale, B, M, S1);
   return check_launch();
 }
 

@@ -160,16 +160,26 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
 }
 
 // losses[6] = PM_R, rot, yaxis_rot, trans_xy (or trans), trans_z, scale: objects summed in order, then normalised
-__global__ void k_loss_reduce(const float* __restrict__ part, LossCfg cfg, float* __restrict__ losses, int B, int M) {
+// counts[2] = {objects with symmetry info, without}: taken from is_sym on the device, so a captured graph stays valid
+// when the mix of objects changes from batch to batch
+__global__ void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
+                              float* __restrict__ losses, int* __restrict__ counts, int B, int M) {
   const int i = threadIdx.x;
   if (i >= 6) return;
+  int n_sym = 0;
+  for (int b = 0; b < B; ++b) n_sym += is_sym[b] != 0;
+  const int n_nonsym = B - n_sym;
+  if (i == 0) {
+    counts[0] = n_sym;
+    counts[1] = n_nonsym;
+  }
   float s = 0.f;
   for (int b = 0; b < B; ++b) s += part[(size_t)b * LOSS_NP + i];
   float v = 0.f;
   switch (i) {
     case 0: v = 3.f * (s / ((float)B * M * 3.f)) * cfg.pm_lw; break;
-    case 1: v = cfg.n_nonsym > 0 ? s / ((float)cfg.n_nonsym * (cfg.rot_l2 ? 9.f : 1.f)) * cfg.rot_lw : 0.f; break;
-    case 2: v = cfg.n_sym > 0 ? s / ((float)cfg.n_sym * 3.f) * cfg.rot_lw : 0.f; break;
+    case 1: v = n_nonsym > 0 ? s / ((float)n_nonsym * (cfg.rot_l2 ? 9.f : 1.f)) * cfg.rot_lw : 0.f; break;
+    case 2: v = n_sym > 0 ? s / ((float)n_sym * 3.f) * cfg.rot_lw : 0.f; break;
     case 3: v = s / ((float)B * (cfg.trans_split ? 2.f : 3.f)) * cfg.trans_lw; break;
     case 4: v = s / (float)B * cfg.trans_lw; break;
     case 5: v = s / ((float)B * 3.f) * cfg.scale_lw; break;
@@ -183,9 +193,10 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
                                                   const float* __restrict__ gt_scale, const float* __restrict__ kps,
                                                   const float* __restrict__ cands, const int* __restrict__ is_sym,
                                                   const int* __restrict__ best, const float* __restrict__ up, LossCfg cfg,
-                                                  float* __restrict__ dpose /*[B,3,4]*/, float* __restrict__ dscale, int B,
-                                                  int M, int S1) {
+                                                  const int* __restrict__ counts, float* __restrict__ dpose /*[B,3,4]*/,
+                                                  float* __restrict__ dscale, int B, int M, int S1) {
   __shared__ float red[4];
+  const int n_sym = counts[0], n_nonsym = counts[1];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* Pp = pose + b * 12;
   const float P[9] = {Pp[0], Pp[1], Pp[2], Pp[4], Pp[5], Pp[6], Pp[8], Pp[9], Pp[10]};
@@ -230,19 +241,19 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
   float dt[3] = {0.f, 0.f, 0.f};
   if (cfg.rot_on) {
     if (!is_sym[b]) {
-      if (cfg.n_nonsym > 0) {
+      if (n_nonsym > 0) {
         if (cfg.rot_l2) {
-          const float c = up[1] * cfg.rot_lw * 2.f / ((float)cfg.n_nonsym * 9.f);
+          const float c = up[1] * cfg.rot_lw * 2.f / ((float)n_nonsym * 9.f);
 #pragma unroll
           for (int e = 0; e < 9; ++e) dR[e] += c * (P[e] - G[e]);
         } else {
-          const float c = -up[1] * cfg.rot_lw / (4.f * (float)cfg.n_nonsym);
+          const float c = -up[1] * cfg.rot_lw / (4.f * (float)n_nonsym);
 #pragma unroll
           for (int e = 0; e < 9; ++e) dR[e] += c * G[e];
         }
       }
-    } else if (cfg.n_sym > 0) {
-      const float c = up[2] * cfg.rot_lw / ((float)cfg.n_sym * 3.f);
+    } else if (n_sym > 0) {
+      const float c = up[2] * cfg.rot_lw / ((float)n_sym * 3.f);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const float d = P[i * 3 + 1] - G[i * 3 + 1];

@@ -1,0 +1,125 @@
+"""One training refine-iteration - forward, loss, backward, optimizer step - captured in a HIP graph.
+
+The training path launches ~450 kernels per iteration, and everything in the iteration is shape-static and free of
+host synchronisation (device-side loss, fused optimizer), so it can be captured once and replayed:
+
+    step = GraphedTrainStep(model, optimizer, example_batch, sym_info)       # warm-up + capture
+    out_dict, loss_dict = step(x=..., tfd_kps=..., init_pose=..., ..., sym_info=[...])
+
+Per call the host only copies the batch into the static input buffers, advances the optimizer's scalar state
+(``Ranger.prepare_step`` -> a pinned table that is uploaded right before the replay) and replays the graph.  The
+outputs are static tensors that the next call overwrites (``clone()`` what must survive).  Shapes (B, N, M), the
+loss configuration and the maximum number of symmetry candidates are fixed at capture time; the mix of symmetric /
+non-symmetric objects may change freely (it lives in device tensors).
+
+This is an opt-in wrapper around the same module, kernels and optimizer - the reference's eager train loop
+(``core/catre/engine/engine.py:293-355``) keeps working unchanged.  Replays are bit-identical to the eager loop
+(``tests/test_hip_train.py::test_graphed_train_step_replays_the_eager_iteration``).
+
+Measured (``profiles/train_step_graphed.py``, one MI355X): 7.0 / 11.4 / 31.2 ms per iteration at B = 16 / 64 / 256,
+the same as the eager loop - the Python / launch side is NOT the bottleneck even at small object counts; what bounds a
+small-batch iteration is the serial chain of ~450 short kernels on the GPU itself (each a few microseconds of fixed
+latency).  The graph therefore only removes host CPU load (useful when data-loader workers compete for the cores);
+shortening small-batch iterations needs fewer, fatter kernels.
+"""
+import torch
+
+from . import hip
+from .losses import SymTensors
+from .ranger import Ranger
+
+_INPUTS = ("x", "tfd_kps", "init_pose", "init_scale", "K_zoom", "gt_ego_rot", "gt_trans", "gt_scale", "obj_kps",
+           "mean_scales")
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, example, sym_info, max_sym=None, warmup=3, amp=False):
+        if not isinstance(optimizer, Ranger):
+            raise TypeError("GraphedTrainStep needs the fused catre_amd.ranger.Ranger (its step is capturable)")
+        self.model, self.opt, self.amp = model, optimizer, bool(amp)
+        dev = example["x"].device
+        self.static = {k: example[k].detach().clone().contiguous() for k in _INPUTS if example.get(k) is not None}
+        B = self.static["x"].shape[0]
+        if max_sym is None:
+            max_sym = max([1] + [len(s) for s in sym_info if s is not None])
+        self.s1 = int(max_sym) + 1
+        self.sym = SymTensors.from_list(sym_info, dev, s1=self.s1)
+        self.sym = SymTensors(self.sym.cands.clone(), self.sym.valid.clone(), self.sym.is_sym.clone())  # own static buffers
+        self._B = B
+
+        def iteration():
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+                out, ld = self.model(self.static["x"], self.static["tfd_kps"], init_pose=self.static["init_pose"],
+                                     init_scale=self.static["init_scale"], K_zoom=self.static.get("K_zoom"),
+                                     gt_ego_rot=self.static["gt_ego_rot"], gt_trans=self.static["gt_trans"],
+                                     gt_scale=self.static["gt_scale"], obj_kps=self.static["obj_kps"],
+                                     mean_scales=self.static.get("mean_scales"), sym_info=self.sym, do_loss=True,
+                                     cur_iter=1)
+            loss = sum(ld.values())
+            loss.backward()
+            return out, ld
+
+        # warm-up on a side stream (allocates scratch, optimizer state, the packed-weight buffers).  The steps it
+        # takes are undone afterwards: parameters and optimizer state are restored to what the caller handed in.
+        params = [p for g in self.opt.param_groups for p in g["params"]]
+        snap_p = [p.detach().clone() for p in params]
+        snap_s = {p: (st["step"], st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["slow_buffer"].clone())
+                  for p, st in self.opt.state.items() if "exp_avg" in st}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.opt.zero_grad(set_to_none=True)
+                iteration()
+                self.opt.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for p, q in zip(params, snap_p):
+                p.copy_(q)
+            for p, st in self.opt.state.items():
+                if "exp_avg" not in st:
+                    continue
+                if p in snap_s:
+                    st["step"] = snap_s[p][0]
+                    st["exp_avg"].copy_(snap_s[p][1]); st["exp_avg_sq"].copy_(snap_s[p][2]); st["slow_buffer"].copy_(snap_s[p][3])
+                else:  # state created by the warm-up: back to a fresh optimizer's
+                    st["step"] = 0
+                    st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["slow_buffer"].copy_(p)
+        hip.bump_param_epoch()
+        torch.cuda.synchronize(dev)
+
+        # capture: gradients are allocated inside the graph's private pool, so their addresses are fixed
+        self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+            self.out, self.losses = iteration()
+            # host half runs now (addresses of the captured gradients go into the record table) ...
+            self.opt.prepare_step(wait=False)
+            # ... and only the kernels are captured; the table upload is issued eagerly before every replay
+            self.opt.launch_step(upload=False)
+        # the capture did not execute anything: undo the step counter it advanced
+        for st in self.opt.state.values():
+            if "step" in st:
+                st["step"] -= 1
+
+    @torch.no_grad()
+    def __call__(self, sym_info=None, **inputs):
+        for k, v in inputs.items():
+            if k not in self.static:
+                raise KeyError(f"unknown or uncaptured input {k!r}")
+            if v.shape != self.static[k].shape:
+                raise ValueError(f"{k}: captured with shape {tuple(self.static[k].shape)}, got {tuple(v.shape)}")
+            self.static[k].copy_(v, non_blocking=True)
+        if sym_info is not None:
+            new = SymTensors.from_list(sym_info, self.sym.cands.device, s1=self.s1)
+            if new.cands.shape != self.sym.cands.shape:
+                raise ValueError("more symmetry candidates than the graph was captured for (max_sym)")
+            self.sym.cands.copy_(new.cands, non_blocking=True)
+            self.sym.valid.copy_(new.valid, non_blocking=True)
+            self.sym.is_sym.copy_(new.is_sym, non_blocking=True)
+        self.opt.prepare_step()   # host: step counters, RAdam scalars -> pinned table
+        self.opt.upload_table()   # stream-ordered before the replay
+        self.graph.replay()
+        hip.bump_param_epoch()
+        return self.out, self.losses

@@ -61,8 +61,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 class CatreLossCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("pm_on", "pm_sym", "pm_with_scale", "rot_on", "rot_l2", "yaxis_smooth",
                                              "trans_on", "trans_mse", "trans_split", "scale_on", "scale_mse")] + \
-               [(n, ctypes.c_float) for n in ("pm_lw", "rot_lw", "trans_lw", "scale_lw")] + \
-               [("n_sym", ctypes.c_int32), ("n_nonsym", ctypes.c_int32)]
+               [(n, ctypes.c_float) for n in ("pm_lw", "rot_lw", "trans_lw", "scale_lw")]
 
 
 class CatrePoints(ctypes.Structure):
@@ -131,8 +130,8 @@ _SIGS = {
     "catre_pcl_workspace_bytes": (_SZ, [_I, _I, _I]),
     "catre_pcl_candidates": (_I, [_P, _P, _P, _P, _P, ctypes.c_float, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "catre_pcl_sample": (_I, [_P, _P, _P, _SZ, _P, ctypes.c_uint64, _I, _I, _I, _I, _P, _P, _P]),
-    "catre_loss_fwd": (_I, [_P] * 13 + [_I, _I, _I, _P]),
-    "catre_loss_bwd": (_I, [_P] * 13 + [_I, _I, _I, _P]),
+    "catre_loss_fwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
+    "catre_loss_bwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),

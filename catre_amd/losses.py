@@ -47,7 +47,7 @@ def _sym_tensor(sym_infos, device, dtype):
     return out
 
 
-def _loss_cfg_struct(cfg, n_sym, n_nonsym):
+def _loss_cfg_struct(cfg):
     lc = cfg.MODEL.CATRE.LOSS_CFG
     c = hip.CatreLossCfg()
     c.pm_on = int(lc.PM_LW > 0)
@@ -72,7 +72,6 @@ def _loss_cfg_struct(cfg, n_sym, n_nonsym):
             raise ValueError(f"Unknown scale loss type: {lc.SCALE_LOSS_TYPE}")
     c.scale_mse = int(lc.SCALE_LOSS_TYPE == "MSE")
     c.pm_lw, c.rot_lw, c.trans_lw, c.scale_lw = float(lc.PM_LW), float(lc.ROT_LW), float(lc.TRANS_LW), float(lc.SCALE_LW)
-    c.n_sym, c.n_nonsym = int(n_sym), int(n_nonsym)
     return c
 
 
@@ -83,28 +82,49 @@ class _FusedLoss(torch.autograd.Function):
         B, M, S1 = pose.shape[0], (kps.shape[1] if kps is not None else 0), cands.shape[1]
         dev = pose.device
         best = torch.empty(B, dtype=torch.int32, device=dev)
+        counts = torch.empty(2, dtype=torch.int32, device=dev)
         part = torch.empty(B * 8, dtype=torch.float32, device=dev)
         losses = torch.empty(6, dtype=torch.float32, device=dev)
         hip.check(lib.catre_loss_fwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
                                      hip.ptr(kps), hip.ptr(cands), hip.ptr(valid), hip.ptr(is_sym), ctypes.byref(lcfg),
-                                     hip.ptr(best), hip.ptr(part), hip.ptr(losses), B, M, S1, hip.stream_ptr(dev)),
-                  "catre_loss_fwd")
-        ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best)
+                                     hip.ptr(best), hip.ptr(counts), hip.ptr(part), hip.ptr(losses), B, M, S1,
+                                     hip.stream_ptr(dev)), "catre_loss_fwd")
+        ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts)
         ctx.lcfg, ctx.dims = lcfg, (B, M, S1)
         return losses
 
     @staticmethod
     def backward(ctx, up):
-        pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best = ctx.saved_tensors
+        pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts = ctx.saved_tensors
         B, M, S1 = ctx.dims
         lib = hip.load()
         up = up.contiguous()
         dpose, dscale = torch.empty_like(pose), torch.empty_like(scale)
         hip.check(lib.catre_loss_bwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
-                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(up),
+                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(counts), hip.ptr(up),
                                      ctypes.byref(ctx.lcfg), hip.ptr(dpose), hip.ptr(dscale), B, M, S1,
                                      hip.stream_ptr(pose.device)), "catre_loss_bwd")
         return dpose, dscale, None, None, None, None, None, None, None, None
+
+
+class SymTensors:
+    """Symmetry info already on the device (what :func:`catre_loss` builds from the python list): ``cands``
+    [B,S1,3,3] with the identity first, ``valid`` [B,S1] uint8, ``is_sym`` [B] int32.  Passing this instead of the list
+    keeps the call free of host->device copies (HIP-graph capture); both rotation terms are then always reported
+    (a term without objects is 0)."""
+
+    def __init__(self, cands, valid, is_sym):
+        self.cands, self.valid, self.is_sym = cands, valid, is_sym
+
+    @classmethod
+    def from_list(cls, sym_infos, device, s1=None):
+        cands, valid, is_sym = _sym_tensor(list(sym_infos), device, torch.float32)
+        if s1 is not None and cands.shape[1] < s1:  # pad to a fixed candidate count
+            pad = s1 - cands.shape[1]
+            eye = torch.eye(3, device=device).expand(cands.shape[0], pad, 3, 3)
+            cands = torch.cat([cands, eye], 1).contiguous()
+            valid = torch.cat([valid, torch.zeros(valid.shape[0], pad, dtype=valid.dtype, device=device)], 1).contiguous()
+        return cls(cands, valid, is_sym)
 
 
 def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info):
@@ -112,12 +132,17 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
     lc = cfg.MODEL.CATRE.LOSS_CFG
     B = out_rot.shape[0]
     dev = out_rot.device
-    sym_info = list(sym_info) if sym_info is not None else [None] * B
     if lc.PM_LW > 0:
         assert (obj_kps is not None) and (gt_trans is not None) and (gt_rot is not None)
-    cands, valid, is_sym = _sym_tensor(sym_info, dev, torch.float32)
-    n_sym = sum(1 for s in sym_info if s is not None)
-    lcfg = _loss_cfg_struct(cfg, n_sym, B - n_sym)
+    if isinstance(sym_info, SymTensors):
+        cands, valid, is_sym = sym_info.cands, sym_info.valid, sym_info.is_sym
+        n_sym = n_nonsym = 1  # unknown on the host: report both rotation terms
+    else:
+        sym_info = list(sym_info) if sym_info is not None else [None] * B
+        cands, valid, is_sym = _sym_tensor(sym_info, dev, torch.float32)
+        n_sym = sum(1 for s in sym_info if s is not None)
+        n_nonsym = B - n_sym
+    lcfg = _loss_cfg_struct(cfg)
     pose = torch.cat([out_rot, out_trans.unsqueeze(-1)], -1).contiguous()
     f32 = lambda t: hip.require_dev_f32(t.contiguous(), "loss input") if t is not None else None
     gs = f32(gt_scale) if gt_scale is not None else torch.zeros(B, 3, dtype=torch.float32, device=dev)
@@ -127,9 +152,9 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
     if lcfg.pm_on:
         ld["loss_PM_R"] = losses[0]
     if lcfg.rot_on:
-        if lcfg.n_nonsym > 0:
+        if n_nonsym > 0:
             ld["loss_rot"] = losses[1]
-        if lcfg.n_sym > 0:
+        if n_sym > 0:
             ld["loss_yaxis_rot"] = losses[2]
     if lcfg.trans_on:
         if lcfg.trans_split:

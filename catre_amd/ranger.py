@@ -8,7 +8,10 @@ train loop's ``nan_to_num(grad, nan=0, posinf=1e5, neginf=-1e5)`` (``core/catre/
 be folded into the same pass with ``clean_grads=True``.
 
 The scalar RAdam rectification terms (N_sma, step size) are computed on the host in double precision exactly
-like the reference; everything per element runs on the device in fp32.
+like the reference; everything per element runs on the device in fp32.  ``step()`` is split in two halves so that a
+captured HIP graph can replay it: :meth:`prepare_step` (host only: advances the step counters and fills a pinned
+table of pointers and scalars) and :meth:`launch_step` (device only: one asynchronous copy of that table and the
+kernels).
 """
 import math
 
@@ -46,7 +49,8 @@ class Ranger(Optimizer):
         self.gc_gradient_threshold = 3 if gc_conv_only else 1
         self.clean_grads = bool(clean_grads)
         self.grad_limit = float(grad_limit)
-        self._layout = None  # (key, chunks_dev, row_tensor_dev, rowmean_ws, n_chunks, total_rows)
+        self._layout = None   # cached per set of (param, grad) addresses: chunk / row tables, pinned + device record table
+        self._pending = None  # what prepare_step hands to launch_step
 
     # ---------------------------------------------------------------- scalar RAdam terms (reference :150-170)
     def _step_terms(self, step, beta1, beta2):
@@ -59,15 +63,16 @@ class Ranger(Optimizer):
             return size, True
         return 1.0 / (1 - beta1 ** step), False
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        lib = hip.load()
-        recs, dev = [], None
+    def prepare_step(self, wait=True):
+        """Host half of a step: state initialisation, step counters, RAdam scalars -> the pinned record table.
+        Returns False when no parameter has a gradient.  wait=False skips the (host-blocking) wait for the slot's
+        previous upload - only for callers that know it has completed, e.g. during graph capture."""
         groups_betas = {tuple(g["betas"]) for g in self.param_groups}
         groups_eps = {g["eps"] for g in self.param_groups}
         if len(groups_betas) != 1 or len(groups_eps) != 1:
             raise NotImplementedError("fused Ranger: betas / eps must be the same in every param group (lr, weight_decay, k may differ)")
         (beta1, beta2), eps = next(iter(groups_betas)), next(iter(groups_eps))
+        recs, dev = [], None
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -92,34 +97,73 @@ class Ranger(Optimizer):
                 recs.append((p, g, st, size * group["lr"], group["weight_decay"] * group["lr"], adaptive,
                              st["step"] % group["k"] == 0, (p.numel() // p.shape[0]) if gc else 0))
         if not recs:
-            return None
+            self._pending = None
+            return False
         key = tuple((r[0].data_ptr(), r[0].numel(), r[7]) for r in recs)
-        if self._layout is None or self._layout[0] != key:
-            chunks, row_tensor, off = [], [], 0
+        if self._layout is None or self._layout["key"] != key:
+            chunks, row_tensor = [], []
             for ti, r in enumerate(recs):
                 n = r[0].numel()
                 chunks += [(ti, o) for o in range(0, n, _CHUNK)]
                 if r[7] > 0:
                     row_tensor += [ti] * (n // r[7])
-            chunks_dev = torch.tensor(chunks, dtype=torch.int32).to(dev)
-            rt_dev = torch.tensor(row_tensor if row_tensor else [0], dtype=torch.int32).to(dev)
-            ws = torch.empty(max(len(row_tensor), 1), dtype=torch.float32, device=dev)
-            self._layout = (key, chunks_dev, rt_dev, ws, len(chunks), len(row_tensor))
-        _, chunks_dev, rt_dev, ws, n_chunks, total_rows = self._layout
-        table = np.zeros(len(recs), dtype=_REC)
+            # two pinned slots, used alternately: the host may fill one while the asynchronous upload of the other
+            # is still queued behind earlier GPU work
+            hosts = [torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._layout = dict(
+                key=key, n_chunks=len(chunks), total_rows=len(row_tensor),
+                chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
+                rows=torch.tensor(row_tensor if row_tensor else [0], dtype=torch.int32).to(dev),
+                ws=torch.empty(max(len(row_tensor), 1), dtype=torch.float32, device=dev),
+                hosts=hosts, tables=[h.numpy().view(_REC) for h in hosts], events=[None, None], slot=0,
+                dev=torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev),
+            )
+        L = self._layout
+        L["slot"] ^= 1
+        if wait and L["events"][L["slot"]] is not None:
+            L["events"][L["slot"]].synchronize()  # its previous upload (two steps ago) has long been consumed
+        table = L["tables"][L["slot"]]
         row_off = 0
         for i, (p, g, st, lr_step, wd_lr, adaptive, look, row_len) in enumerate(recs):
             table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                         st["slow_buffer"].data_ptr(), p.numel(), row_len, row_off, lr_step, wd_lr, int(adaptive), int(look), 0)
             if row_len > 0:
                 row_off += p.numel() // row_len
-        table_dev = torch.from_numpy(table.view(np.uint8)).to(dev)
-        keep = [r[1] for r in recs]  # contiguous gradient copies must outlive the launch
+        # the (possibly copied-to-contiguous) gradients must outlive the launch
+        self._pending = dict(n=len(recs), beta1=beta1, beta2=beta2, eps=eps, device=dev, keep=[r[1] for r in recs])
+        return True
+
+    def upload_table(self):
+        """Asynchronous copy of the record table prepare_step filled (current stream).  Not part of a captured graph:
+        a replaying caller issues it before every replay."""
+        pend, L = self._pending, self._layout
+        if pend is None:
+            return
+        with torch.cuda.device(pend["device"]):
+            L["dev"].copy_(L["hosts"][L["slot"]], non_blocking=True)
+            ev = L["events"][L["slot"]] or torch.cuda.Event()
+            ev.record()
+            L["events"][L["slot"]] = ev
+
+    def launch_step(self, upload=True):
+        """Device half: the fused kernels on the current stream (after the table upload unless the caller did it).
+        With upload=False this is capturable: only kernel launches on fixed device addresses."""
+        pend, L = self._pending, self._layout
+        if pend is None:
+            return
+        if upload:
+            self.upload_table()
+        lib = hip.load()
+        dev = pend["device"]
         with torch.cuda.device(dev):
-            hip.check(lib.catre_op_ranger_step(hip.ptr(table_dev), len(recs), hip.ptr(chunks_dev), n_chunks,
-                                               hip.ptr(rt_dev), total_rows, hip.ptr(ws), beta1, beta2, eps, self.alpha,
-                                               int(self.clean_grads), self.grad_limit, hip.stream_ptr(dev)),
-                      "catre_op_ranger_step")
-        del keep
+            hip.check(lib.catre_op_ranger_step(hip.ptr(L["dev"]), pend["n"], hip.ptr(L["chunks"]), L["n_chunks"],
+                                               hip.ptr(L["rows"]), L["total_rows"], hip.ptr(L["ws"]), pend["beta1"],
+                                               pend["beta2"], pend["eps"], self.alpha, int(self.clean_grads),
+                                               self.grad_limit, hip.stream_ptr(dev)), "catre_op_ranger_step")
         hip.bump_param_epoch()  # the kernel wrote the parameters behind torch's back: invalidate packed-weight caches
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.prepare_step():
+            self.launch_step()
         return None

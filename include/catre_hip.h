@@ -354,23 +354,23 @@ typedef struct catre_loss_cfg {
   int32_t trans_on, trans_mse, trans_split; /* TRANS_LW > 0, TRANS_LOSS_TYPE == "MSE" (else L1), TRANS_LOSS_DISENTANGLE */
   int32_t scale_on, scale_mse;
   float pm_lw, rot_lw, trans_lw, scale_lw;
-  int32_t n_sym, n_nonsym;                  /* how many objects carry symmetry info / do not                       */
 } catre_loss_cfg;
 
 /* losses[6] = {loss_PM_R, loss_rot, loss_yaxis_rot, loss_trans_xy (or loss_trans_LPnP), loss_trans_z, loss_scale}.
  * pose [B,3,4] = [R|t] estimate, scale [B,3]; cands [B,S1,3,3] = symmetry rotations per object with the identity
  * first, valid [B,S1] bytes, is_sym [B]; the ground-truth rotation closest to the estimate among R_gt S_k
  * (get_closest_rot_batch, core/utils/pose_utils.py:472-528) is chosen on the device, its index kept in best [B] for
- * the backward.  part_ws: B*8 floats of scratch.  All pointers are device pointers. */
+ * the backward, and counts [2] = {objects with, without symmetry info} (counted on the device, so nothing about the
+ * batch composition is baked into a captured graph).  part_ws: B*8 floats of scratch.  All pointers are device pointers. */
 int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
-                   const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, float* part_ws, float* losses, int B,
-                   int M, int S1, void* stream);
+                   const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
+                   float* losses, int B, int M, int S1, void* stream);
 /* dpose [B,3,4], dscale [B,3] = gradient of sum_i upstream[i] * losses[i] (upstream: 6 floats on the device) */
 int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
-                   const int32_t* best, const float* upstream, const catre_loss_cfg* cfg, float* dpose, float* dscale,
-                   int B, int M, int S1, void* stream);
+                   const int32_t* best, const int32_t* counts, const float* upstream, const catre_loss_cfg* cfg,
+                   float* dpose, float* dscale, int B, int M, int S1, void* stream);
 
 #ifdef __cplusplus
 }

@@ -246,3 +246,63 @@ def test_fused_loss_matches_oracle_values_and_gradients(variant):
         scale_ref = float(b.grad.abs().max()) + 1e-12
         err = float((a.grad.cpu().double() - b.grad).abs().max()) / scale_ref
         assert err <= 2e-5, (name, err)
+
+
+def test_graphed_train_step_replays_the_eager_iteration():
+    """GraphedTrainStep (forward + loss + backward + fused Ranger step in one HIP graph) against the eager loop on
+    the same batches: same losses, same parameters after every step (the same kernels run in the same order), the
+    caller's model / optimizer state untouched by the capture's warm-up, and a changing symmetric / non-symmetric mix."""
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from catre_amd.graphed import GraphedTrainStep
+    from oracle.catre_oracle import y_axis_symmetries
+
+    B, N, M = 6, 128, 64
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    sd = {k: v.to(DEV) for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()}
+    sym12, sym7 = y_axis_symmetries(12), y_axis_symmetries(7)
+    batches, syms = [], []
+    for i in range(4):
+        b = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=60 + i).items()}
+        batch_updater_test(cfg, b)
+        batches.append(b)
+        syms.append([(sym12 if (j + i) % 3 == 0 else (sym7 if (j * i) % 4 == 1 else None)) for j in range(B)])
+
+    def kwargs(b):
+        return dict(x=b["x"].contiguous(), tfd_kps=b["tfd_kps"].contiguous(), init_pose=b["obj_pose_est"],
+                    init_scale=b["obj_scale_est"], K_zoom=b["K"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"],
+                    gt_scale=b["gt_scale"], obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"])
+
+    # eager reference run
+    model_e, opt_e = build_model_optimizer(cfg, is_test=False)
+    model_e.load_state_dict(sd)
+    eager = []
+    for b, s in zip(batches, syms):
+        kw = kwargs(b)
+        out, ld = model_e(kw.pop("x"), kw.pop("tfd_kps"), sym_info=s, do_loss=True, cur_iter=1, **kw)
+        sum(ld.values()).backward()
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        eager.append(({k: float(v) for k, v in ld.items()}, out["pose_1"].detach().clone(),
+                      {k: p.detach().clone() for k, p in model_e.named_parameters()}))
+
+    model_g, opt_g = build_model_optimizer(cfg, is_test=False)
+    model_g.load_state_dict(sd)
+    step = GraphedTrainStep(model_g, opt_g, kwargs(batches[0]), syms[0], max_sym=12)
+    for k, p in model_g.named_parameters():
+        assert torch.equal(p, sd[k]), f"capture warm-up changed {k}"
+    assert all(st["step"] == 0 for st in opt_g.state.values())
+    for i, (b, s) in enumerate(zip(batches, syms)):
+        out, ld = step(sym_info=s, **kwargs(b))
+        torch.cuda.synchronize()
+        want_l, want_pose, want_p = eager[i]
+        for k, v in want_l.items():
+            np.testing.assert_allclose(float(ld[k]), v, rtol=1e-6, atol=1e-9, err_msg=f"step {i} {k}")
+        assert torch.equal(out["pose_1"], want_pose), f"step {i}: pose"
+        for k, p in model_g.named_parameters():
+            assert torch.equal(p, want_p[k]), f"step {i}: parameter {k}"
+    assert all(st["step"] == 4 for st in opt_g.state.values() if "step" in st)
+    with pytest.raises(ValueError):
+        step(x=torch.zeros(B + 1, 3, N, device=DEV))
