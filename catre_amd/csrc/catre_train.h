@@ -562,7 +562,9 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restri
   }
   __syncthreads();
   const int nf4 = K / 4;  // K % 4 == 0 (checked by the launcher)
-  for (int r = wave; r < n; r += 4) {
+  // rows are dealt round-robin to (workgroup of the cloud, wave): with few clouds the launcher gives every cloud
+  // several workgroups (each repeats the cheap bucketing above) so that the row walk is not one long serial chain
+  for (int r = blockIdx.y * 4 + wave; r < n; r += 4 * gridDim.y) {
     const int b = start[r], e = start[r + 1];
     float* xr = dX + (size_t)(r0 + r) * ldx;
     for (int q = lane; q < nf4; q += 64) {
