@@ -16,11 +16,10 @@ This is an opt-in wrapper around the same module, kernels and optimizer - the re
 (``core/catre/engine/engine.py:293-355``) keeps working unchanged.  Replays are bit-identical to the eager loop
 (``tests/test_hip_train.py::test_graphed_train_step_replays_the_eager_iteration``).
 
-Measured (``profiles/train_step_graphed.py``, one MI355X): 7.0 / 11.4 / 31.2 ms per iteration at B = 16 / 64 / 256,
-the same as the eager loop - the Python / launch side is NOT the bottleneck even at small object counts; what bounds a
-small-batch iteration is the serial chain of ~450 short kernels on the GPU itself (each a few microseconds of fixed
-latency).  The graph therefore only removes host CPU load (useful when data-loader workers compete for the cores);
-shortening small-batch iterations needs fewer, fatter kernels.
+Measured (``profiles/train_step_graphed.py``, one MI355X, N=M=1024): the eager loop has a host-side floor of
+~4.85 ms per iteration (B <= 16: ~450 launches); replaying takes 3.5 / 3.9 / 4.7 ms at B = 4 / 8 / 16 (1.4x / 1.26x /
+1.04x) and is on par with the eager loop from B = 32 up, where the GPU work itself (a serial chain of short kernels)
+is the bound.  Besides the small-batch gain the graph removes the per-iteration host CPU load.
 """
 import torch
 
