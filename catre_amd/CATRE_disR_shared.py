@@ -45,6 +45,8 @@ class CATRE_disR_shared(nn.Module):
         self._rt = None
         self._opts_bf16 = type(self._opts).from_buffer_copy(self._opts)
         self._opts_bf16.compute_dtype = hip.DTYPE_BF16
+        self._opts_split = type(self._opts).from_buffer_copy(self._opts)
+        self._opts_split.compute_dtype = hip.DTYPE_SPLIT
 
     def _inference_opts(self):
         """fp32 kernels unless reduced precision is requested the way the reference requests it - by running
@@ -59,7 +61,9 @@ class CATRE_disR_shared(nn.Module):
             return self._opts_bf16
         if want in ("fp32", "float32"):
             return self._opts
-        raise ValueError(f"MODEL.CATRE.COMPUTE_DTYPE={want!r}: expected 'fp32' or 'bf16'")
+        if want == "split":
+            return self._opts_split
+        raise ValueError(f"MODEL.CATRE.COMPUTE_DTYPE={want!r}: expected 'fp32', 'split' or 'bf16'")
 
     # -- runtime is per-instance state that must never be shared by copies of the module
     def __getstate__(self):

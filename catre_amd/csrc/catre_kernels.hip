@@ -849,6 +849,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 }
 
 #include "catre_bf16.h"
+#include "catre_split.h"
 #include "catre_gram.h"
 #include "catre_train.h"
 #include "catre_aug.h"
@@ -866,6 +867,8 @@ struct PackLayout {
   size_t stn_c2, stn_c3, fstn_c1, fstn_c2, fstn_c3, c2, c3, c4, rot_l0[2], rot_l1[2], ts_w0t, ts_w1t, sumwp, total;
   // bf16 fragment packs of the same matrices (catre_bf16.h), offsets in floats
   size_t bf_stn_c2, bf_stn_c3, bf_fstn_c1, bf_fstn_c2, bf_fstn_c3, bf_c2, bf_c3, bf_c4, bf_rot_l0[2], bf_rot_l1[2];
+  // hi + lo bf16 fragment packs of the three split-mode layers (catre_split.h), offsets in floats
+  size_t sp_stn_c3, sp_fstn_c3, sp_c4, sp_rot_l1[2];
 };
 
 PackLayout pack_layout(int ts_in) {
@@ -901,6 +904,10 @@ PackLayout pack_layout(int ts_in) {
     L.bf_rot_l0[h] = take(256 * 64 / 2);
     L.bf_rot_l1[h] = take(256 * 256 / 2);
   }
+  L.sp_stn_c3 = take(1024 * 128);
+  L.sp_fstn_c3 = take(1024 * 128);
+  L.sp_c4 = take(1024 * 512);
+  for (int h = 0; h < 2; ++h) L.sp_rot_l1[h] = take(256 * 256);
   // everything above is independent of ts_in (the stage entry points rely on that)
   L.ts_w0t = take((size_t)ts_in * 256);
   L.ts_w1t = take(256 * 256);
@@ -1061,6 +1068,17 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     frag_bf(prm[base], PMW, 1024, 256, 64, L.bf_rot_l0[h]);
     frag_bf(prm[base + 4], 256, 0, 256, 256, L.bf_rot_l1[h]);
   }
+  auto frag_sp = [&](const float* src, int ld, int rows, int K, size_t off) {
+    if (!src) return;
+    const int n = rows * K;
+    hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, 0, rows, K,
+                       reinterpret_cast<unsigned short*>(packed + off));
+  };
+  frag_sp(prm[CATRE_P_STN_CONV3_W], 128, 1024, 128, L.sp_stn_c3);
+  frag_sp(prm[CATRE_P_FSTN_CONV3_W], 128, 1024, 128, L.sp_fstn_c3);
+  frag_sp(prm[CATRE_P_CONV4_W], 512, 1024, 512, L.sp_c4);
+  frag_sp(prm[CATRE_P_ROTX_L0_W + 4], 256, 256, 256, L.sp_rot_l1[0]);
+  frag_sp(prm[CATRE_P_ROTY_L0_W + 4], 256, 256, 256, L.sp_rot_l1[1]);
   frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);
   frag(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.stn_c3);
   frag(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.fstn_c1);
@@ -1185,7 +1203,8 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
 }
 
 static int rot_head_impl(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
-                         float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st) {
+                         float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st,
+                         bool split = false) {
   const PackLayout L = pack_layout(1);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   float* bias0 = ws + W.bias0;
@@ -1213,10 +1232,15 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   }
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
-    hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                       pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),
-                       prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
-                       g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
+    if (split)
+      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                         pk4(packed, L.rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
+                         prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M);
+    else
+      hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                         pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),
+                         prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
+                         g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
   }
   hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
   {
@@ -1345,25 +1369,63 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   if (o->compute_dtype == CATRE_DTYPE_BF16)
     return refine_iter_bf(pts, init_pose, init_scale, mean_scales, Ks, prm, packed, o, pose_out, scale_out, ws, W, B, N, M,
                           st);
-  if (o->compute_dtype != CATRE_DTYPE_F32) return CATRE_ERR_UNSUPPORTED;
+  if (o->compute_dtype != CATRE_DTYPE_F32 && o->compute_dtype != CATRE_DTYPE_SPLIT) return CATRE_ERR_UNSUPPORTED;
+  const bool split = o->compute_dtype == CATRE_DTYPE_SPLIT;
+  const PackLayout PL = pack_layout(1);
+  const int tiles_all = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   // STN3d (pointnet.py:98) on both clouds
-  if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) return rc;
+  if (split) {
+    {
+      ProfScope ps(CATRE_K_STN3D, st);
+      hipLaunchKernelGGL(k_stn3d_split, dim3(tiles_all), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+                         prm[CATRE_P_STN_CONV1_B], pk4(packed, PL.stn_c2), prm[CATRE_P_STN_CONV2_B],
+                         pkb(packed, PL.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+    }
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+    if ((rc = check_launch())) return rc;
+  } else if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) {
+    return rc;
+  }
   if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
     return rc;
   const float* t64 = nullptr;
   if (o->feature_transform) {  // STNkd (pointnet.py:105-106)
-    if ((rc = catre_stnkd_pool(pts, ws + W.trans3, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream)))
+    if (split) {
+      {
+        ProfScope ps(CATRE_K_STNKD, st);
+        hipLaunchKernelGGL(k_stnkd_split, dim3(tiles_all), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+                           prm[CATRE_P_CONV1_B], pk4(packed, PL.fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
+                           pk4(packed, PL.fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),
+                           prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+      }
+      hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+      if ((rc = check_launch())) return rc;
+    } else if ((rc = catre_stnkd_pool(pts, ws + W.trans3, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M,
+                                      stream))) {
       return rc;
+    }
     if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
       return rc;
     t64 = ws + W.trans64;
   }
-  if ((rc = catre_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.gfeat, ws + W.pointfeat, workspace, ws_bytes, B, N,
-                        M, stream)))
+  if (split) {
+    {
+      ProfScope ps(CATRE_K_TRUNK, st);
+      hipLaunchKernelGGL(k_trunk_split, dim3(tiles_all), dim3(512), 0, st, *pts, ws + W.trans3, t64,
+                         prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],
+                         pk4(packed, PL.c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B], ws + W.pm,
+                         ws + W.pointfeat, B, N, M);
+    }
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
+    if ((rc = check_launch())) return rc;
+  } else if ((rc = catre_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.gfeat, ws + W.pointfeat, workspace, ws_bytes,
+                               B, N, M, stream))) {
     return rc;
+  }
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, stream)))
     return rc;
-  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st))) return rc;
+  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split)))
+    return rc;
   return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
                            scale_out, B, stream);
 }

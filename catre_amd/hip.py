@@ -55,7 +55,7 @@ class CatreOpts(ctypes.Structure):
     ]
 
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_SPLIT = 0, 1, 2
 
 
 class CatreLossCfg(ctypes.Structure):

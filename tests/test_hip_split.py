@@ -1,0 +1,93 @@
+"""'split' compute mode (catre_amd/csrc/catre_split.h): the three dominant GEMMs (STN conv3, trunk conv4, rot-head
+layer 1 = 87.5 % of the FLOPs) as split-bf16 MFMAs - every fp32 operand as hi + lo bf16, three products, fp32
+accumulation - everything else the fp32 kernels.  It has to meet the SAME bars as the pure fp32 path:
+the reference contract (R, t, s within 1e-4 abs of the reference after K iterations) and our internal 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-4
+TIGHT = 2e-5
+
+
+def _model(g_cfg, salt):
+    from tests.test_hip_parity import build_model
+
+    model, sd = build_model(g_cfg, salt)
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"
+    return model, sd
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_split_refine_k_matches_reference_goldens(name):
+    from tests.test_hip_parity import to_dev
+
+    g = load_golden(name)
+    model, _ = _model(g["cfg"], g["salt"])
+    out = model.refine(to_dev(g["batch"]), n_iter=g["K"])
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "fp32"
+    out32 = model.refine(to_dev(g["batch"]), n_iter=g["K"])
+    for i in range(1, g["K"] + 1):
+        for key in (f"pose_{i}", f"scale_{i}"):
+            err = np.abs(out[key].cpu().numpy() - g["ref"][key]).max()
+            assert err <= BAR, f"{name} {key}: {err:.3e} exceeds the 1e-4 contract"
+            assert err <= TIGHT, f"{name} {key}: {err:.3e} exceeds the internal 2e-5 bar"
+    assert not torch.equal(out[f"pose_{g['K']}"], out32[f"pose_{g['K']}"]), "split kernels did not run"
+
+
+def test_split_module_forward_loop_and_ragged_shapes():
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.config import default_cfg
+    from oracle import catre_oracle as O
+    from tests.test_hip_parity import DEV, to_dev
+
+    g = load_golden("refine_b3_ragged")
+    model, _ = _model(g["cfg"], g["salt"])
+    batch = to_dev(g["batch"])
+    poses_est = scales_est = None
+    with torch.no_grad():
+        for i in range(1, g["K"] + 1):
+            batch_updater_test(model.cfg, batch, poses_est=poses_est, scales_est=scales_est)
+            o = model(batch["x"], batch["tfd_kps"], init_pose=batch["obj_pose_est"], init_scale=batch["obj_scale_est"],
+                      K_zoom=batch["K"], mean_scales=batch["obj_mean_scales"], do_loss=False, cur_iter=i)
+            poses_est, scales_est = o[f"pose_{i}"], o[f"scale_{i}"]
+            assert np.abs(poses_est.cpu().numpy() - g["ref"][f"pose_{i}"]).max() <= TIGHT
+    for (B, N, M) in [(1, 1, 1), (5, 63, 65), (2, 129, 1), (3, 130, 257)]:
+        cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=2, device=DEV)
+        m2, sd = _model(cfg, 3)
+        b = synth.make_inputs(B, N, M, seed=40 + B)
+        out = m2.refine(to_dev(b), n_iter=2)
+        with torch.no_grad():
+            want = O.refine_k(b, sd, default_cfg(num_pcl=N, num_kps=M, n_iter=2, device="cpu"), n_iter=2)
+        for key in ("pose_2", "scale_2"):
+            assert (out[key].cpu() - want[key]).abs().max() <= TIGHT, (B, N, M, key)
+
+
+def test_split_full_size_properties():
+    """B=256, N=M=1024, K=4: finite, R in SO(3), bit-deterministic, independent of the batch an object sits in, and
+    within 2e-5 of the pure fp32 kernels on the same inputs."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+    from tests.test_hip_parity import DEV, to_dev
+
+    B, N, M, K = 256, 1024, 1024, 4
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=K, device=DEV)
+    model, _ = _model(cfg, 0)
+    b = to_dev(synth.make_inputs(B, N, M, seed=5))
+    o1 = model.refine(b, n_iter=K)
+    o2 = model.refine(b, n_iter=K)
+    R = o1[f"pose_{K}"][:, :3, :3]
+    assert torch.isfinite(o1[f"pose_{K}"]).all() and torch.isfinite(o1[f"scale_{K}"]).all()
+    assert (R @ R.transpose(1, 2) - torch.eye(3, device=R.device)).abs().max() < 1e-5
+    assert torch.equal(o1[f"pose_{K}"], o2[f"pose_{K}"])
+    half = {k: (v[: B // 2] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in b.items()}
+    assert torch.equal(model.refine(half, n_iter=K)[f"pose_{K}"], o1[f"pose_{K}"][: B // 2])
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "fp32"
+    o32 = model.refine(b, n_iter=K)
+    assert (o32[f"pose_{K}"] - o1[f"pose_{K}"]).abs().max() <= TIGHT
+    assert (o32[f"scale_{K}"] - o1[f"scale_{K}"]).abs().max() <= TIGHT
