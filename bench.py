@@ -177,8 +177,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("refine", "train"), default="refine",
                     help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
-                    help="fp32 (the headline, BASELINE parity bar 1e-4) or bf16 GEMM operands (BASELINE config 5)")
+    ap.add_argument("--dtype", choices=("fp32", "split", "bf16"), default="fp32",
+                    help="fp32: fp32 MFMA everywhere (the headline); split: the three dominant GEMMs as split-bf16 "
+                         "(hi+lo, 3 products) MFMAs, same 2e-5 parity; bf16: bf16 operands (BASELINE config 5)")
     ap.add_argument("--shape", choices=("headline", "config5"), default="headline",
                     help="headline: N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8")
     args = ap.parse_args()
@@ -186,7 +187,9 @@ def main():
     if args.shape == "config5":
         N_PTS, K_ITER = 2048, 8
     bf16 = args.dtype == "bf16"
-    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    split = args.dtype == "split"
+    # split arithmetic spends three bf16 MFMAs per fp32-accurate product: its matrix ceiling is a third of the bf16 peak
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else (BF16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,6 +270,28 @@ def main():
                    "frac": round(nbytes / (avg * 1e-3) / 8e12, 4)}
         del xs, ymax
 
+    # the same batch through the split compute mode (outside the timed region, rank 0 only): throughput and its
+    # deviation from the fp32 kernels' result - reported next to the headline, never as `value`
+    split_extra = None
+    if rank == 0 and args.dtype == "fp32":
+        model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"
+        for _ in range(2):
+            osp = model.refine(batch, n_iter=K_ITER)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            osp = model.refine(batch, n_iter=K_ITER)
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t1
+        model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "fp32"
+        dev_max = max(float((osp[f"pose_{K_ITER}"] - out[f"pose_{K_ITER}"]).abs().max()),
+                      float((osp[f"scale_{K_ITER}"] - out[f"scale_{K_ITER}"]).abs().max()))
+        split_extra = {"what": "same batch, COMPUTE_DTYPE='split': STN conv3 / trunk conv4 / rot-head layer 1 as split-bf16 "
+                               "(hi+lo, 3 products) MFMAs, fp32 accumulation; parity tests hold it to the same 2e-5 as fp32",
+                       "value": round(B_PER_GPU * K_ITER * args.steps / dts, 1), "unit": "object-iterations/s (1 GPU)",
+                       "ms_per_step": round(dts / args.steps * 1e3, 3),
+                       "max_abs_diff_vs_fp32_after_K": dev_max}
+
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,7 +310,8 @@ def main():
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         path_flops = flops_per_object_iteration(N_PTS, M_PTS)
         line = {
-            "metric": f"pose-refine iters/sec (B=256, N={N_PTS}, K={K_ITER})" + (" [bf16 operands]" if bf16 else ""),
+            "metric": f"pose-refine iters/sec (B=256, N={N_PTS}, K={K_ITER})"
+                      + (" [bf16 operands]" if bf16 else (" [split-bf16 GEMMs]" if split else "")),
             "value": round(value, 1),
             "unit": "object-iterations/s",
             "n_gpus": world,
@@ -295,19 +321,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32",
+            "dtype": "bf16" if bf16 else ("f32+bf16x3" if split else "f32"),
             "data": "synthetic",
             "config": {
                 "workload": f"B=256 objects/GPU, N={N_PTS} observed + M={M_PTS} prior points, K={K_ITER} refine iterations, "
                             "forward-only (eval loop of catre_evaluator.py:292-311), "
-                            + ("bf16 MFMA operands / fp32 accumulate" if bf16 else "fp32 MFMA"),
+                            + ("bf16 MFMA operands / fp32 accumulate" if bf16 else
+                               ("fp32 results; STN conv3, trunk conv4 and rot-head layer 1 as split-bf16 (hi+lo, three "
+                                "products) MFMAs, the rest fp32 MFMA" if split else "fp32 MFMA")),
                 "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER,
                 "parallelism": f"batch-sharded x{world} (no data-path collective)",
             },
             "path_tflops": round(value * path_flops / 1e12, 2),
             "path_frac_of_mfma_peak": round(value * path_flops / 1e12 / (mfma_peak * world), 4),
             "roofline": {
-                "kernel": "k_trunk_bf" if bf16 else "k_trunk",
+                "kernel": "k_trunk_bf" if bf16 else ("k_trunk_split" if split else "k_trunk"),
                 "bound": "mfma",
                 "achieved": round(achieved, 2) if achieved else None,
                 "peak": mfma_peak,
@@ -320,6 +348,8 @@ def main():
             },
         }
         line["maxpool_standalone"] = maxpool
+        if split_extra is not None:
+            line["split_mode"] = split_extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg_fn, sd)
         print(json.dumps(line), flush=True)

@@ -868,7 +868,7 @@ struct PackLayout {
   // bf16 fragment packs of the same matrices (catre_bf16.h), offsets in floats
   size_t bf_stn_c2, bf_stn_c3, bf_fstn_c1, bf_fstn_c2, bf_fstn_c3, bf_c2, bf_c3, bf_c4, bf_rot_l0[2], bf_rot_l1[2];
   // hi + lo bf16 fragment packs of the three split-mode layers (catre_split.h), offsets in floats
-  size_t sp_stn_c3, sp_fstn_c3, sp_c4, sp_rot_l1[2];
+  size_t sp_stn_c3, sp_fstn_c3, sp_c3, sp_c4, sp_rot_l0[2], sp_rot_l1[2];
 };
 
 PackLayout pack_layout(int ts_in) {
@@ -906,8 +906,12 @@ PackLayout pack_layout(int ts_in) {
   }
   L.sp_stn_c3 = take(1024 * 128);
   L.sp_fstn_c3 = take(1024 * 128);
+  L.sp_c3 = take(512 * 128);
   L.sp_c4 = take(1024 * 512);
-  for (int h = 0; h < 2; ++h) L.sp_rot_l1[h] = take(256 * 256);
+  for (int h = 0; h < 2; ++h) {
+    L.sp_rot_l0[h] = take(256 * 64);
+    L.sp_rot_l1[h] = take(256 * 256);
+  }
   // everything above is independent of ts_in (the stage entry points rely on that)
   L.ts_w0t = take((size_t)ts_in * 256);
   L.ts_w1t = take(256 * 256);
@@ -1068,15 +1072,18 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     frag_bf(prm[base], PMW, 1024, 256, 64, L.bf_rot_l0[h]);
     frag_bf(prm[base + 4], 256, 0, 256, 256, L.bf_rot_l1[h]);
   }
-  auto frag_sp = [&](const float* src, int ld, int rows, int K, size_t off) {
+  auto frag_sp = [&](const float* src, int ld, int rows, int K, size_t off, int coloff = 0) {
     if (!src) return;
     const int n = rows * K;
-    hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, 0, rows, K,
+    hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
                        reinterpret_cast<unsigned short*>(packed + off));
   };
   frag_sp(prm[CATRE_P_STN_CONV3_W], 128, 1024, 128, L.sp_stn_c3);
   frag_sp(prm[CATRE_P_FSTN_CONV3_W], 128, 1024, 128, L.sp_fstn_c3);
+  frag_sp(prm[CATRE_P_CONV3_W], 128, 512, 128, L.sp_c3);
   frag_sp(prm[CATRE_P_CONV4_W], 512, 1024, 512, L.sp_c4);
+  frag_sp(prm[CATRE_P_ROTX_L0_W], PMW, 256, 64, L.sp_rot_l0[0], 1024);
+  frag_sp(prm[CATRE_P_ROTY_L0_W], PMW, 256, 64, L.sp_rot_l0[1], 1024);
   frag_sp(prm[CATRE_P_ROTX_L0_W + 4], 256, 256, 256, L.sp_rot_l1[0]);
   frag_sp(prm[CATRE_P_ROTY_L0_W + 4], 256, 256, 256, L.sp_rot_l1[1]);
   frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);
@@ -1233,8 +1240,8 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
     if (split)
-      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                         pk4(packed, L.rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
+      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, pointfeat, pkb(packed, L.sp_rot_l0[0]),
+                         pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
                          prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M);
     else
       hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
@@ -1413,7 +1420,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       ProfScope ps(CATRE_K_TRUNK, st);
       hipLaunchKernelGGL(k_trunk_split, dim3(tiles_all), dim3(512), 0, st, *pts, ws + W.trans3, t64,
                          prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],
-                         pk4(packed, PL.c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B], ws + W.pm,
+                         pkb(packed, PL.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B], ws + W.pm,
                          ws + W.pointfeat, B, N, M);
     }
     hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);

@@ -1,5 +1,6 @@
 // catre_split.h - the "split" compute mode: fp32-accurate GEMMs on the bf16 matrix pipe for the three layers that
-// hold 87.5 % of the path's FLOPs (STN conv3 128->1024, trunk conv4 512->1024, rot-head layer 1 256->256).
+// hold 96 % of the path's FLOPs (STN conv3 128->1024, trunk conv3 128->512 and conv4 512->1024, rot-head layers 0
+// 64->256 and 1 256->256).
 // Included by catre_kernels.hip after catre_bf16.h.
 //
 // Every fp32 operand x is written as x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 bits of mantissa.  A product
@@ -133,13 +134,13 @@ __device__ __forceinline__ void store_tile_split(const f32x16 (&acc)[MB][NB], u3
 }
 
 // ------------------------------------------------------------------------------------------
-// trunk: k_trunk with conv3 writing split images and conv4 on GemmPipeS.  512 threads, 160 KiB LDS.
-//   a3 hi [64][512 ch] 64 KiB | a3 lo 64 KiB | a2 [64][128] fp32 32 KiB (swizzled, as k_trunk)
+// trunk: k_trunk with conv3 and conv4 on GemmPipeS (conv2 / conv3 epilogues write split images).  512 threads, 160 KiB.
+//   a3 hi [64][512 ch] 64 KiB | a3 lo 64 KiB | a2 hi [64][128 ch] 16 KiB | a2 lo 16 KiB
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float* __restrict__ trans3,
                                                      const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                      const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
-                                                     const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                                     const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                      const float* __restrict__ b3, const u32x4* __restrict__ wp4,
                                                      const float* __restrict__ b4, float* __restrict__ pm,
                                                      float* __restrict__ pointfeat, int B, int N, int M) {
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   float* pf = smem + TP * LD64 + 4096;   // [64][68]
   u32x4* a3h = reinterpret_cast<u32x4*>(smem);                // [64][64 chunks]
   u32x4* a3l = reinterpret_cast<u32x4*>(smem + TP * 256);     // + 64 KiB
-  float* a2 = smem + TP * 512;           // [64][128] swizzled fp32
+  u32x4* a2h = reinterpret_cast<u32x4*>(smem + TP * 512);     // [64][16 chunks], 16 KiB
+  u32x4* a2l = a2h + TP * 16;                                 // + 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
@@ -192,8 +194,9 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   } else {
     pf = h1;
   }
-  GemmPipe<2, 2, false, true, 16, 3, 1> g3;
-  g3.prefetch(wp3 + (wave * 2 * 16) * 64 + lane, 16 * 64);
+  // conv3 128->512 on the split pipe too (it would otherwise be a third of the kernel's matrix time)
+  GemmPipeS<2, 2, false, 16, 2> g3;
+  g3.prefetch(wp3 + ((wave * 2) * 8) * 64 + lane, 8 * 64, 512 * 128 / 8);
   f32x4 bv3[2][4];
   load_bias_quads<2>(bv3, b3, wave * 64, lane);
   __builtin_amdgcn_sched_barrier(0);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     }
     f32x16 acc[1][1] = {{zero16()}};
     g2.run(acc, pf + nb2 * 32 * LD64, LD64, lane);
-    store_tile_lds_pre<1, 1, true, true>(acc, a2 + nb2 * 32 * 128, 128, mblk2 * 32, bv2, lane);
+    store_tile_split<1, 1, true, 16>(acc, a2h + nb2 * 32 * 16, a2l + nb2 * 32 * 16, mblk2, bv2, lane);
   }
   __syncthreads();
   // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     f32x16 acc3[2][2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) acc3[mb][0] = acc3[mb][1] = zero16();
-    g3.run(acc3, a2, 128, lane);
+    g3.run(acc3, a2h, a2l, lane);
     store_tile_split<2, 2, true, 64>(acc3, a3h, a3l, wave * 2, bv3, lane);
   }
   __syncthreads();
@@ -369,18 +372,19 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
 }
 
 // ------------------------------------------------------------------------------------------
-// rotation head layer 0 (fp32 MFMA, recomputed) -> fused bias+GN affine + GELU -> split image -> layer 1 (256 -> 256,
-// 80 % of the kernel's FLOPs) on GemmPipeS -> y1 + GN1 partials.  Otherwise k_rot_l1.  256 threads, 80 KiB LDS.
+// rotation head: pointfeat tile -> split images -> layer 0 (recomputed) on GemmPipeS -> fused bias+GN affine + GELU ->
+// split image -> layer 1 on GemmPipeS -> y1 + GN1 partials.  Otherwise k_rot_l1.  256 threads, 80 KiB LDS.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict__ pointfeat,
-                                                         const f32x4* __restrict__ wpl0x, const f32x4* __restrict__ wpl0y,
+                                                         const u32x4* __restrict__ wpl0x, const u32x4* __restrict__ wpl0y,
                                                          const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
                                                          const u32x4* __restrict__ wpl1x, const u32x4* __restrict__ wpl1y,
                                                          const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                          float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
                                                          int M) {
   __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
-  float* pf = smem;                                           // [64][64] swizzled fp32
+  u32x4* pfh = reinterpret_cast<u32x4*>(smem);                // [64][8 chunks] hi, 8 KiB
+  u32x4* pfl = pfh + TP * 8;                                  // lo
   u32x4* a0h = reinterpret_cast<u32x4*>(smem + TP * 64);      // [64][32 chunks]
   u32x4* a0l = a0h + TP * 32;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -388,7 +392,16 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
   const RotTile rt = rot_tile(blockIdx.x, B, N, M);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   const int P = N + M;
-  load_pf_tile_swz(pointfeat, rt, pf, tid);
+  for (int i = tid; i < TP * 8; i += 256) {  // pointfeat tile -> split images (chunk = 8 channels in k-slot order)
+    const int row = i >> 3, c = i & 7;
+    const float* src = pointfeat + rt.pf_off + (size_t)min(row, rt.valid - 1) * 64 + 16 * (c >> 1) + 4 * (c & 1);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 8);
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    u32x4 hi, lo;
+    split_bf8(v, hi, lo);
+    pfh[bf_off<8>(row, c)] = hi;
+    pfl[bf_off<8>(row, c)] = lo;
+  }
   __syncthreads();
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll 1
@@ -405,7 +418,11 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
       f32x16 acc[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-      gemm_core<2, 2, false, true, 8, 2>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane);
+      {
+        GemmPipeS<2, 2, false, 8, 2> g0;  // layer 0: 64 -> 256, wave -> m-blocks 2*wave, 2*wave + 1
+        g0.prefetch((hd ? wpl0y : wpl0x) + ((wave * 2) * 4) * 64 + lane, 4 * 64, 256 * 64 / 8);
+        g0.run(acc, pfh, pfl, lane);
+      }
       const int key = bf_key<32>(n);
       float zprev[2][4];
 #pragma unroll
