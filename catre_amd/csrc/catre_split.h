@@ -230,19 +230,21 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   }
   __syncthreads();
   // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16
-  GemmPipeS<2, 2, true, 64, 2> g4a, g4b;
-  g4a.prefetch(wp4 + ((wave * 4) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
-  float bl4[2][2];
-  load_bias_lane<2>(bl4[0], b4, wave * 128, lane);
-  load_bias_lane<2>(bl4[1], b4, wave * 128 + 64, lane);
-  __builtin_amdgcn_sched_barrier(0);
+  GemmPipeS<2, 2, true, 64, 3> g4a, g4b;
   {
     f32x16 acc3[2][2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) acc3[mb][0] = acc3[mb][1] = zero16();
     g3.run(acc3, a2h, a2l, lane);
+    // conv4's first weight fragments are requested once conv3's own ring is dead (register budget), still ahead of
+    // the epilogue and the barrier
+    g4a.prefetch(wp4 + ((wave * 4) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
     store_tile_split<2, 2, true, 64>(acc3, a3h, a3l, wave * 2, bv3, lane);
   }
+  float bl4[2][2];
+  load_bias_lane<2>(bl4[0], b4, wave * 128, lane);
+  load_bias_lane<2>(bl4[1], b4, wave * 128 + 64, lane);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   {
     float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
