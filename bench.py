@@ -286,7 +286,7 @@ def main():
         model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "fp32"
         dev_max = max(float((osp[f"pose_{K_ITER}"] - out[f"pose_{K_ITER}"]).abs().max()),
                       float((osp[f"scale_{K_ITER}"] - out[f"scale_{K_ITER}"]).abs().max()))
-        split_extra = {"what": "same batch, COMPUTE_DTYPE='split': STN conv3, trunk conv3/conv4 and rot-head layers 0/1 as "
+        split_extra = {"what": "same batch, COMPUTE_DTYPE='split': STN conv2/conv3 (+fstn conv1), trunk conv3/conv4 and rot-head layers 0/1 as "
                                "split-bf16 (hi+lo, 3 products) MFMAs with fp32 accumulation, everything else the fp32 "
                                "kernels; the parity tests hold it to the same 2e-5 (contract 1e-4) as the fp32 path",
                        "value": round(B_PER_GPU * K_ITER * args.steps / dts, 1), "unit": "object-iterations/s (1 GPU)",
@@ -328,7 +328,7 @@ def main():
                 "workload": f"B=256 objects/GPU, N={N_PTS} observed + M={M_PTS} prior points, K={K_ITER} refine iterations, "
                             "forward-only (eval loop of catre_evaluator.py:292-311), "
                             + ("bf16 MFMA operands / fp32 accumulate" if bf16 else
-                               ("fp32 results; STN conv3, trunk conv3/conv4 and rot-head layers 0/1 as split-bf16 (hi+lo, "
+                               ("fp32 results; STN conv2/conv3 (+fstn conv1), trunk conv3/conv4 and rot-head layers 0/1 as split-bf16 (hi+lo, "
                                 "three products) MFMAs, the rest fp32 MFMA" if split else "fp32 MFMA")),
                 "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER,
                 "parallelism": f"batch-sharded x{world} (no data-path collective)",

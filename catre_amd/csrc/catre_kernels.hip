@@ -868,7 +868,7 @@ struct PackLayout {
   // bf16 fragment packs of the same matrices (catre_bf16.h), offsets in floats
   size_t bf_stn_c2, bf_stn_c3, bf_fstn_c1, bf_fstn_c2, bf_fstn_c3, bf_c2, bf_c3, bf_c4, bf_rot_l0[2], bf_rot_l1[2];
   // hi + lo bf16 fragment packs of the three split-mode layers (catre_split.h), offsets in floats
-  size_t sp_stn_c3, sp_fstn_c3, sp_c3, sp_c4, sp_rot_l0[2], sp_rot_l1[2];
+  size_t sp_stn_c2, sp_stn_c3, sp_fstn_c1, sp_fstn_c2, sp_fstn_c3, sp_c3, sp_c4, sp_rot_l0[2], sp_rot_l1[2];
 };
 
 PackLayout pack_layout(int ts_in) {
@@ -904,7 +904,10 @@ PackLayout pack_layout(int ts_in) {
     L.bf_rot_l0[h] = take(256 * 64 / 2);
     L.bf_rot_l1[h] = take(256 * 256 / 2);
   }
+  L.sp_stn_c2 = take(128 * 64);
   L.sp_stn_c3 = take(1024 * 128);
+  L.sp_fstn_c1 = take(64 * 64);
+  L.sp_fstn_c2 = take(128 * 64);
   L.sp_fstn_c3 = take(1024 * 128);
   L.sp_c3 = take(512 * 128);
   L.sp_c4 = take(1024 * 512);
@@ -1078,7 +1081,10 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
                        reinterpret_cast<unsigned short*>(packed + off));
   };
+  frag_sp(prm[CATRE_P_STN_CONV2_W], 64, 128, 64, L.sp_stn_c2);
   frag_sp(prm[CATRE_P_STN_CONV3_W], 128, 1024, 128, L.sp_stn_c3);
+  frag_sp(prm[CATRE_P_FSTN_CONV1_W], 64, 64, 64, L.sp_fstn_c1);
+  frag_sp(prm[CATRE_P_FSTN_CONV2_W], 64, 128, 64, L.sp_fstn_c2);
   frag_sp(prm[CATRE_P_FSTN_CONV3_W], 128, 1024, 128, L.sp_fstn_c3);
   frag_sp(prm[CATRE_P_CONV3_W], 128, 512, 128, L.sp_c3);
   frag_sp(prm[CATRE_P_CONV4_W], 512, 1024, 512, L.sp_c4);
@@ -1385,7 +1391,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     {
       ProfScope ps(CATRE_K_STN3D, st);
       hipLaunchKernelGGL(k_stn3d_split, dim3(tiles_all), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
-                         prm[CATRE_P_STN_CONV1_B], pk4(packed, PL.stn_c2), prm[CATRE_P_STN_CONV2_B],
+                         prm[CATRE_P_STN_CONV1_B], pkb(packed, PL.sp_stn_c2), prm[CATRE_P_STN_CONV2_B],
                          pkb(packed, PL.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
     }
     hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
@@ -1401,8 +1407,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       {
         ProfScope ps(CATRE_K_STNKD, st);
         hipLaunchKernelGGL(k_stnkd_split, dim3(tiles_all), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
-                           prm[CATRE_P_CONV1_B], pk4(packed, PL.fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
-                           pk4(packed, PL.fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),
+                           prm[CATRE_P_CONV1_B], pkb(packed, PL.sp_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
+                           pkb(packed, PL.sp_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),
                            prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
       }
       hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);

@@ -1,6 +1,6 @@
 // catre_split.h - the "split" compute mode: fp32-accurate GEMMs on the bf16 matrix pipe for the three layers that
-// hold 96 % of the path's FLOPs (STN conv3 128->1024, trunk conv3 128->512 and conv4 512->1024, rot-head layers 0
-// 64->256 and 1 256->256).
+// hold 98 % of the path's FLOPs (all MFMA layers of the two STNs, trunk conv3 128->512 and conv4 512->1024, rot-head
+// layers 0 64->256 and 1 256->256).
 // Included by catre_kernels.hip after catre_bf16.h.
 //
 // Every fp32 operand x is written as x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 bits of mantissa.  A product
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// STN3d / STNkd: conv2's epilogue writes split images, conv3 (128 -> 1024, 92 % of the kernels' FLOPs) runs on
-// GemmPipeS in four passes of 2 m-blocks per wave.  Otherwise k_stn3d / k_stnkd.
+// STN3d / STNkd: every MFMA layer on GemmPipeS (conv1 3->64 stays on the VALU and writes split images); conv3
+// (128 -> 1024, 92 % of the kernels' FLOPs) in four passes of 2 m-blocks per wave.  Structure of k_stn3d / k_stnkd.
 // ------------------------------------------------------------------------------------------
 template <typename Img>
 __device__ __forceinline__ void stn_conv3_split(const u32x4* __restrict__ wp3, const float* __restrict__ b3, Img a2h,
@@ -296,31 +296,56 @@ __device__ __forceinline__ void stn_conv3_split(const u32x4* __restrict__ wp3, c
   }
 }
 
+// conv 3 -> 16 channels [16*grp, +16) of one point on the VALU (fp32), ReLU -> the two split chunks of k-group grp
+__device__ __forceinline__ void conv3_relu_chunks_split(float x, float y, float z, const float* __restrict__ W,
+                                                        const float* __restrict__ b, int grp, u32x4* rh, u32x4* rl, int key) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = grp * 16 + r;
+    float t = b[ch];
+    t = fmaf(W[ch * 3 + 0], x, t);
+    t = fmaf(W[ch * 3 + 1], y, t);
+    t = fmaf(W[ch * 3 + 2], z, t);
+    v[r] = fmaxf(t, 0.f);
+  }
+  const float c0[8] = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
+  const float c1[8] = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
+  u32x4 hi, lo;
+  split_bf8(c0, hi, lo);
+  rh[(2 * grp) ^ key] = hi;
+  rl[(2 * grp) ^ key] = lo;
+  split_bf8(c1, hi, lo);
+  rh[(2 * grp + 1) ^ key] = hi;
+  rl[(2 * grp + 1) ^ key] = lo;
+}
+
 __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const float* __restrict__ W1,
-                                                        const float* __restrict__ b1, const f32x4* __restrict__ wp2,
+                                                        const float* __restrict__ b1, const u32x4* __restrict__ wp2,
                                                         const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                         const float* __restrict__ b3, float* __restrict__ pm, int B,
                                                         int N, int M) {
-  __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * 128];
-  float* a1 = smem;
-  u32x4* a2h = reinterpret_cast<u32x4*>(smem + TP * LD64);  // [64][16 chunks]
+  __shared__ u32x4 smem[2 * TP * 8 + 2 * TP * 16];  // a1 hi/lo [64][64 ch] 16 KiB + a2 hi/lo [64][128 ch] 32 KiB
+  u32x4* a1h = smem;
+  u32x4* a1l = smem + TP * 8;
+  u32x4* a2h = smem + 2 * TP * 8;
   u32x4* a2l = a2h + TP * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
-  GemmPipe<1, 2, false, false, 8, 3> g2;
-  g2.prefetch(wp2 + (wave * 8) * 64 + lane, 0);
+  GemmPipeS<1, 2, false, 8, 2> g2;  // conv2 64->128: wave -> m-block `wave`
+  g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0, 128 * 64 / 8);
   f32x4 bv2[1][4];
   load_bias_quads<1>(bv2, b2, wave * 32, lane);
   {
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
-    conv3_relu_row<16>(x, y, z, W1, b1, wave * 16, a1 + lane * LD64);
+    conv3_relu_chunks_split(x, y, z, W1, b1, wave, a1h + lane * 8, a1l + lane * 8, bf_key<8>(lane));
   }
   __syncthreads();
   {
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    g2.run(acc, a1, LD64, lane);
+    g2.run(acc, a1h, a1l, lane);
     store_tile_split<1, 2, true, 16>(acc, a2h, a2l, wave, bv2, lane);
   }
   __syncthreads();
@@ -329,44 +354,46 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const fl
 
 __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const float* __restrict__ trans3,
                                                         const float* __restrict__ Wc1, const float* __restrict__ bc1,
-                                                        const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
-                                                        const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
+                                                        const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
+                                                        const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                         const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
                                                         float* __restrict__ pm, int B, int N, int M) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + TP * 128];
-  float* h1 = smem;
-  float* f1 = smem + TP * LD64;
-  u32x4* f2h = reinterpret_cast<u32x4*>(smem + 2 * TP * LD64);
+  __shared__ u32x4 smem[4 * TP * 8 + 2 * TP * 16];  // h1, f1 hi/lo 32 KiB + f2 hi/lo 32 KiB
+  u32x4* h1h = smem;
+  u32x4* h1l = smem + TP * 8;
+  u32x4* f1h = smem + 2 * TP * 8;
+  u32x4* f1l = smem + 3 * TP * 8;
+  u32x4* f2h = smem + 4 * TP * 8;
   u32x4* f2l = f2h + TP * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TileInfo ti = tile_info(blockIdx.x, B, N, M);
   const int mblk1 = wave >> 1, nb1 = wave & 1;
-  GemmPipe<1, 1, false, false, 8, 4> g1;
-  g1.prefetch(wpf1 + (mblk1 * 8) * 64 + lane, 0);
+  GemmPipeS<1, 1, false, 8, 2> g1;  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks
+  g1.prefetch(wpf1 + (mblk1 * 4) * 64 + lane, 0, 64 * 64 / 8);
   f32x4 bv1[1][4];
   load_bias_quads<1>(bv1, bf1, mblk1 * 32, lane);
   {
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
     apply_t3(trans3 + ti.cloud * 9, x, y, z);
-    conv3_relu_row<16>(x, y, z, Wc1, bc1, wave * 16, h1 + lane * LD64);
+    conv3_relu_chunks_split(x, y, z, Wc1, bc1, wave, h1h + lane * 8, h1l + lane * 8, bf_key<8>(lane));
   }
   __syncthreads();
-  GemmPipe<1, 2, false, false, 8, 3> g2;
-  g2.prefetch(wpf2 + (wave * 8) * 64 + lane, 0);
+  GemmPipeS<1, 2, false, 8, 2> g2;
+  g2.prefetch(wpf2 + (wave * 4) * 64 + lane, 0, 128 * 64 / 8);
   f32x4 bv2[1][4];
   load_bias_quads<1>(bv2, bf2, wave * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {
     f32x16 acc[1][1] = {{zero16()}};
-    g1.run(acc, h1 + nb1 * 32 * LD64, LD64, lane);
-    store_tile_lds_pre<1, 1, true, false>(acc, f1 + nb1 * 32 * LD64, LD64, mblk1 * 32, bv1, lane);
+    g1.run(acc, h1h + nb1 * 32 * 8, h1l + nb1 * 32 * 8, lane);
+    store_tile_split<1, 1, true, 8>(acc, f1h + nb1 * 32 * 8, f1l + nb1 * 32 * 8, mblk1, bv1, lane);
   }
   __syncthreads();
   {
     f32x16 acc[1][2] = {{zero16(), zero16()}};
-    g2.run(acc, f1, LD64, lane);
+    g2.run(acc, f1h, f1l, lane);
     store_tile_split<1, 2, true, 16>(acc, f2h, f2l, wave, bv2, lane);
   }
   __syncthreads();

@@ -99,7 +99,7 @@ typedef struct catre_opts {
                                 * bf16 GEMM operands, fp32 accumulation / GroupNorm statistics / SO(3) update          */
 } catre_opts;
 
-/* CATRE_DTYPE_SPLIT: fp32 results from split-bf16 (hi + lo, three products) MFMAs on the three dominant layers;
+/* CATRE_DTYPE_SPLIT: fp32 results from split-bf16 (hi + lo, three products) MFMAs on the layers holding 98 % of the FLOPs;
  * same parity bound as CATRE_DTYPE_F32 */
 enum { CATRE_DTYPE_F32 = 0, CATRE_DTYPE_BF16 = 1, CATRE_DTYPE_SPLIT = 2 };
 
