@@ -170,6 +170,7 @@ __global__ void k_pose_apply(const float* __restrict__ pcl, const float* __restr
 #define LD128 132
 #define LD256 260
 
+template <int RS>
 __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* __restrict__ W1,
                                                const float* __restrict__ b1, const f32x4* __restrict__ wp2,
                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   float* a2 = smem + TP * LD64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
 
   // weights / biases of the first MFMA layer are requested before anything else
   GemmPipe<1, 2, false, false, 8, 3> g2;
@@ -193,12 +195,15 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     conv3_relu_row<16>(x, y, z, W1, b1, wave * 16, a1 + lane * LD64);
   }
   __syncthreads();
-  // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks
-  GemmPipe<4, 2, true, false, 16, 2, 1> g3a, g3b;
-  float bl[2][4];
-  g3a.prefetch(wp3 + ((wave * 8) * 16) * 64 + lane, 16 * 64);
-  load_bias_lane<4>(bl[0], b3, (wave * 8) * 32, lane);
-  load_bias_lane<4>(bl[1], b3, (wave * 8 + 4) * 32, lane);
+  // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks (RS = 1); RS workgroups
+  // per tile: 8/RS m-blocks per wave from mb0 in one pass (see k_trunk)
+  constexpr int MB3 = RS == 4 ? 2 : 4;
+  const int mb0 = part * (32 / RS) + wave * (8 / RS);
+  GemmPipe<MB3, 2, true, false, 16, 2, 1> g3a, g3b;
+  float bl[2][MB3];
+  g3a.prefetch(wp3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<MB3>(bl[0], b3, mb0 * 32, lane);
+  if (RS == 1) load_bias_lane<MB3>(bl[1], b3, (mb0 + 4) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {  // conv2 64->128: wave -> m-block `wave`, both point blocks
     f32x16 acc[1][2] = {{zero16(), zero16()}};
@@ -206,21 +211,21 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     store_tile_lds_pre<1, 2, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
-  float* out = pm + (size_t)blockIdx.x * PMW;
+  float* out = pm + (size_t)tile * PMW;
   {
-    f32x16 acc[4][2];
+    f32x16 acc[MB3][2];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, a2, LD128, lane);
-    g3b.prefetch(wp3 + ((wave * 8 + 4) * 16) * 64 + lane, 16 * 64);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+    if (RS == 1) g3b.prefetch(wp3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
+    max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
-  {
-    f32x16 acc[4][2];
+  if (RS == 1) {
+    f32x16 acc[MB3][2];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, a2, LD128, lane);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+    max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
 // a3+a4: x' = x T3, relu(conv1), STNkd conv stack 64->64->128->1024 (+ReLU), per-tile max
 // (pointnet.py:98-103, 57-61).  256 threads, 2 workgroups per CU.
 // ------------------------------------------------------------------------------------------
+template <int RS>
 __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   float* f2 = smem + 2 * TP * LD64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
 
   const int mblk1 = wave >> 1, nb1 = wave & 1;
   GemmPipe<1, 1, false, false, 8, 4> g1;
@@ -265,11 +272,13 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     store_tile_lds_pre<1, 1, true, false>(acc, f1 + nb1 * 32 * LD64, LD64, mblk1 * 32, bv1, lane);
   }
   __syncthreads();
-  GemmPipe<4, 2, true, false, 16, 2, 1> g3a, g3b;
-  float bl[2][4];
-  g3a.prefetch(wpf3 + ((wave * 8) * 16) * 64 + lane, 16 * 64);
-  load_bias_lane<4>(bl[0], bf3, (wave * 8) * 32, lane);
-  load_bias_lane<4>(bl[1], bf3, (wave * 8 + 4) * 32, lane);
+  constexpr int MB3 = RS == 4 ? 2 : 4;
+  const int mb0 = part * (32 / RS) + wave * (8 / RS);
+  GemmPipe<MB3, 2, true, false, 16, 2, 1> g3a, g3b;
+  float bl[2][MB3];
+  g3a.prefetch(wpf3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<MB3>(bl[0], bf3, mb0 * 32, lane);
+  if (RS == 1) load_bias_lane<MB3>(bl[1], bf3, (mb0 + 4) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {  // fstn.conv2 64->128
     f32x16 acc[1][2] = {{zero16(), zero16()}};
@@ -277,21 +286,21 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     store_tile_lds_pre<1, 2, true, false>(acc, f2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
-  float* out = pm + (size_t)blockIdx.x * PMW;
-  {  // fstn.conv3 128->1024 + max, two passes of 4 m-blocks
-    f32x16 acc[4][2];
+  float* out = pm + (size_t)tile * PMW;
+  {  // fstn.conv3 128->1024 + max, two passes of 4 m-blocks (RS = 1) or one pass of 8/RS
+    f32x16 acc[MB3][2];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, f2, LD128, lane);
-    g3b.prefetch(wpf3 + ((wave * 8 + 4) * 16) * 64 + lane, 16 * 64);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+    if (RS == 1) g3b.prefetch(wpf3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
+    max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
-  {
-    f32x16 acc[4][2];
+  if (RS == 1) {
+    f32x16 acc[MB3][2];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, f2, LD128, lane);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+    max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -302,8 +311,13 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
 // the conv3 input (32 KiB): exactly the 160 KiB of a CU.  conv4 is then ONE K=512 sweep per wave
 // (1024 ch x 64 pts = 128 accumulator VGPRs per lane over 8 waves) with no barrier inside.
 // ------------------------------------------------------------------------------------------
+// Small grids (tiles * RS <= #CUs): RS workgroups share a tile - each repeats the cheap prologue (conv1-conv3, 12 % of
+// the FLOPs) and sweeps 1/RS of conv4's output channels, so a handful of objects still spreads over the chip.  Every
+// output channel sees the same K order for any RS: results do not depend on it.
+// ------------------------------------------------------------------------------------------
 #define TRUNK_SMEM (TP * 512 + TP * 128)
 
+template <int RS>
 __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
 #define TRUNK_STAMP(i)                                                                     \
   do {                                                                                     \
-    if (trace && lane == 0) trace[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
+    if (trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
   // phase-1/2 buffers alias the conv4 input image a3 (dead before a3 is first written)
   float* h1 = smem;                      // [64][68]
@@ -325,7 +339,8 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   float* a2 = smem + TP * 512;           // [64][128] swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
   const bool ft = trans64 != nullptr;
   TRUNK_STAMP(0);
 
@@ -413,11 +428,14 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   }
   __syncthreads();
   TRUNK_STAMP(3);
-  // conv4 512->1024: wave owns out channels [wave*128, +128); first weight chunks + bias requested now
-  GemmPipe<4, 2, true, true, 64, 2, 1> g4;
-  g4.prefetch(wp4 + ((wave * 4) * 64) * 64 + lane, 64 * 64);
-  float bl4[4];
-  load_bias_lane<4>(bl4, b4, wave * 128, lane);
+  // conv4 512->1024: wave owns MB4 m-blocks from mb0 (RS = 1: out channels [wave*128, +128)); first weight chunks +
+  // bias requested now
+  constexpr int MB4 = 4 / RS;
+  const int mb0 = part * (32 / RS) + wave * MB4;
+  GemmPipe<MB4, 2, true, true, 64, RS == 1 ? 2 : 3, 1> g4;
+  g4.prefetch(wp4 + ((size_t)mb0 * 64) * 64 + lane, 64 * 64);
+  float bl4[MB4];
+  load_bias_lane<MB4>(bl4, b4, mb0 * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {
     f32x16 acc3[2][2];
@@ -432,19 +450,19 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   {  // deferred stores of the pointfeat tile (point-major [cloud points][64], coalesced 16 KiB) and its max
     float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
                                             : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
-    if (pf_row < ti.valid) {
+    if (part == 0 && pf_row < ti.valid) {
       f32x4* d = reinterpret_cast<f32x4*>(dstbase + pf_row * 64);
       d[pf_c4] = pf_out0;
       d[pf_c4 + 8] = pf_out1;
     }
-    if (tid < 64) pm[(size_t)blockIdx.x * PMW + 1024 + tid] = pf_max;
+    if (part == 0 && tid < 64) pm[(size_t)tile * PMW + 1024 + tid] = pf_max;
   }
-  f32x16 acc4[4][2];
+  f32x16 acc4[MB4][2];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
+  for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
   g4.run(acc4, a3, 512, lane);
   TRUNK_STAMP(6);
-  max_tile_store_pre<4, 2>(acc4, pm + (size_t)blockIdx.x * PMW, wave * 128, bl4, false, lane);
+  max_tile_store_pre<MB4, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
   TRUNK_STAMP(7);
 #undef TRUNK_STAMP
 }
@@ -970,6 +988,16 @@ inline bool dims_ok(int B, int N, int M) { return B > 0 && N > 0 && M > 0; }
 // the PointNet stages also run on a single cloud per object (M == 0: PointNetfeat.forward on its own)
 inline bool dims_ok1(int B, int N, int M) { return B > 0 && N > 0 && M >= 0; }
 inline int n_clouds(int B, int M) { return M > 0 ? 2 * B : B; }
+// workgroups per 64-point tile of the encoder kernels: small grids split a tile's output channels over 2 or 4
+// workgroups as long as that still fits one wave of workgroups on the 256 CUs
+// RS_DISPATCH(rs, L): expands the launch macro L(RS) for the compile-time RS matching rs
+#define RS_DISPATCH(rs, L) \
+  switch (rs) {            \
+    case 4: L(4); break;   \
+    case 2: L(2); break;   \
+    default: L(1);         \
+  }
+inline int row_split(int tiles) { return tiles * 4 <= 256 ? 4 : tiles * 2 <= 256 ? 2 : 1; }
 
 #define REQUIRE(cond) \
   do {                \
@@ -1138,9 +1166,12 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   {
     ProfScope ps(CATRE_K_STN3D, st);
-  hipLaunchKernelGGL(k_stn3d, dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
-                     pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
-                     ws + W.pm, B, N, M);
+#define LAUNCH_STN3D(RS)                                                                                  \
+  hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],       \
+                     prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B],             \
+                     pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_STN3D)
+#undef LAUNCH_STN3D
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
@@ -1165,9 +1196,12 @@ int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* 
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   {
     ProfScope ps(CATRE_K_STNKD, st);
-  hipLaunchKernelGGL(k_stnkd, dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
-                     pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),
-                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+#define LAUNCH_STNKD(RS)                                                                                       \
+  hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],        \
+                     prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2), \
+                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_STNKD)
+#undef LAUNCH_STNKD
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
@@ -1185,10 +1219,13 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   {
     ProfScope ps(CATRE_K_TRUNK, st);
-  hipLaunchKernelGGL(k_trunk, dim3(tiles), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W],
-                     prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),
-                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
-                     g_trunk_trace);
+#define LAUNCH_TRUNK(RS)                                                                                        \
+  hipLaunchKernelGGL(k_trunk<RS>, dim3(tiles * RS), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W], \
+                     prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),            \
+                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M, \
+                     g_trunk_trace)
+    RS_DISPATCH(row_split(tiles), LAUNCH_TRUNK)
+#undef LAUNCH_TRUNK
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
   return check_launch();
@@ -1390,9 +1427,12 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   if (split) {
     {
       ProfScope ps(CATRE_K_STN3D, st);
-      hipLaunchKernelGGL(k_stn3d_split, dim3(tiles_all), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
-                         prm[CATRE_P_STN_CONV1_B], pkb(packed, PL.sp_stn_c2), prm[CATRE_P_STN_CONV2_B],
-                         pkb(packed, PL.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+#define LAUNCH_(RS)                                                                                                \
+  hipLaunchKernelGGL(k_stn3d_split<RS>, dim3(tiles_all * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
+                     prm[CATRE_P_STN_CONV1_B], pkb(packed, PL.sp_stn_c2), prm[CATRE_P_STN_CONV2_B],                 \
+                     pkb(packed, PL.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
+      RS_DISPATCH(row_split(tiles_all), LAUNCH_)
+#undef LAUNCH_
     }
     hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
     if ((rc = check_launch())) return rc;
@@ -1406,10 +1446,13 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     if (split) {
       {
         ProfScope ps(CATRE_K_STNKD, st);
-        hipLaunchKernelGGL(k_stnkd_split, dim3(tiles_all), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
-                           prm[CATRE_P_CONV1_B], pkb(packed, PL.sp_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
-                           pkb(packed, PL.sp_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),
-                           prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+#define LAUNCH_(RS)                                                                                                  \
+  hipLaunchKernelGGL(k_stnkd_split<RS>, dim3(tiles_all * RS), dim3(256), 0, st, *pts, ws + W.trans3,                  \
+                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pkb(packed, PL.sp_fstn_c1), prm[CATRE_P_FSTN_CONV1_B], \
+                     pkb(packed, PL.sp_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),               \
+                     prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
+        RS_DISPATCH(row_split(tiles_all), LAUNCH_)
+#undef LAUNCH_
       }
       hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
       if ((rc = check_launch())) return rc;
@@ -1424,10 +1467,13 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   if (split) {
     {
       ProfScope ps(CATRE_K_TRUNK, st);
-      hipLaunchKernelGGL(k_trunk_split, dim3(tiles_all), dim3(512), 0, st, *pts, ws + W.trans3, t64,
-                         prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],
-                         pkb(packed, PL.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B], ws + W.pm,
-                         ws + W.pointfeat, B, N, M);
+#define LAUNCH_(RS)                                                                                             \
+  hipLaunchKernelGGL(k_trunk_split<RS>, dim3(tiles_all * RS), dim3(512), 0, st, *pts, ws + W.trans3, t64,        \
+                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],       \
+                     pkb(packed, PL.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B],   \
+                     ws + W.pm, ws + W.pointfeat, B, N, M)
+      RS_DISPATCH(row_split(tiles_all), LAUNCH_)
+#undef LAUNCH_
     }
     hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
     if ((rc = check_launch())) return rc;

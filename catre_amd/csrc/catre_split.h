@@ -137,6 +137,7 @@ __device__ __forceinline__ void store_tile_split(const f32x16 (&acc)[MB][NB], u3
 // trunk: k_trunk with conv3 and conv4 on GemmPipeS (conv2 / conv3 epilogues write split images).  512 threads, 160 KiB.
 //   a3 hi [64][512 ch] 64 KiB | a3 lo 64 KiB | a2 hi [64][128 ch] 16 KiB | a2 lo 16 KiB
 // ------------------------------------------------------------------------------------------
+template <int RS>
 __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float* __restrict__ trans3,
                                                      const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                      const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   u32x4* a2l = a2h + TP * 16;                                 // + 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
   const bool ft = trans64 != nullptr;
 
   const int mblk2 = wave >> 1, nb2 = wave & 1;
@@ -229,8 +231,11 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     store_tile_split<1, 1, true, 16>(acc, a2h + nb2 * 32 * 16, a2l + nb2 * 32 * 16, mblk2, bv2, lane);
   }
   __syncthreads();
-  // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16
-  GemmPipeS<2, 2, true, 64, 3> g4a, g4b;
+  // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16.
+  // RS workgroups per tile: 4/RS m-blocks from mb0 (one pass of 2, or of 1)
+  constexpr int MB4 = RS == 4 ? 1 : 2;
+  const int mb0 = part * (32 / RS) + wave * (4 / RS);
+  GemmPipeS<MB4, 2, true, 64, 3> g4a, g4b;
   {
     f32x16 acc3[2][2];
 #pragma unroll
@@ -238,39 +243,39 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     g3.run(acc3, a2h, a2l, lane);
     // conv4's first weight fragments are requested once conv3's own ring is dead (register budget), still ahead of
     // the epilogue and the barrier
-    g4a.prefetch(wp4 + ((wave * 4) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
+    g4a.prefetch(wp4 + ((size_t)mb0 * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
     store_tile_split<2, 2, true, 64>(acc3, a3h, a3l, wave * 2, bv3, lane);
   }
-  float bl4[2][2];
-  load_bias_lane<2>(bl4[0], b4, wave * 128, lane);
-  load_bias_lane<2>(bl4[1], b4, wave * 128 + 64, lane);
+  float bl4[2][MB4];
+  load_bias_lane<MB4>(bl4[0], b4, mb0 * 32, lane);
+  if (RS == 1) load_bias_lane<MB4>(bl4[1], b4, (mb0 + 2) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   {
     float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
                                             : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
-    if (pf_row < ti.valid) {
+    if (part == 0 && pf_row < ti.valid) {
       f32x4* d = reinterpret_cast<f32x4*>(dstbase + pf_row * 64);
       d[pf_c4] = pf_out0;
       d[pf_c4 + 8] = pf_out1;
     }
-    if (tid < 64) pm[(size_t)blockIdx.x * PMW + 1024 + tid] = pf_max;
+    if (part == 0 && tid < 64) pm[(size_t)tile * PMW + 1024 + tid] = pf_max;
   }
-  float* out = pm + (size_t)blockIdx.x * PMW;
+  float* out = pm + (size_t)tile * PMW;
   {
-    f32x16 acc4[2][2];
+    f32x16 acc4[MB4][2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
+    for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
     g4a.run(acc4, a3h, a3l, lane);
-    g4b.prefetch(wp4 + ((wave * 4 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
-    max_tile_store_pre<2, 2>(acc4, out, wave * 128, bl4[0], false, lane);
+    if (RS == 1) g4b.prefetch(wp4 + ((size_t)(mb0 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
+    max_tile_store_pre<MB4, 2>(acc4, out, mb0 * 32, bl4[0], false, lane);
   }
-  {
-    f32x16 acc4[2][2];
+  if (RS == 1) {
+    f32x16 acc4[MB4][2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
+    for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
     g4b.run(acc4, a3h, a3l, lane);
-    max_tile_store_pre<2, 2>(acc4, out, wave * 128 + 64, bl4[1], false, lane);
+    max_tile_store_pre<MB4, 2>(acc4, out, (mb0 + 2) * 32, bl4[1], false, lane);
   }
 }
 
@@ -278,21 +283,24 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
 // STN3d / STNkd: every MFMA layer on GemmPipeS (conv1 3->64 stays on the VALU and writes split images); conv3
 // (128 -> 1024, 92 % of the kernels' FLOPs) in four passes of 2 m-blocks per wave.  Structure of k_stn3d / k_stnkd.
 // ------------------------------------------------------------------------------------------
-template <typename Img>
+// RS workgroups per tile (small grids, see k_trunk): the wave owns 8/RS m-blocks from mb0 = 4/RS passes.
+template <int RS, typename Img>
 __device__ __forceinline__ void stn_conv3_split(const u32x4* __restrict__ wp3, const float* __restrict__ b3, Img a2h,
-                                                Img a2l, float* __restrict__ out, int wave, int lane) {
+                                                Img a2l, float* __restrict__ out, int part, int wave, int lane) {
+  constexpr int NPS = 4 / RS;
+  const int mb0 = part * (32 / RS) + wave * (8 / RS);
   GemmPipeS<2, 2, true, 16, 2> g[2];
-  g[0].prefetch(wp3 + ((wave * 8) * 8) * 64 + lane, 8 * 64, 1024 * 128 / 8);
+  g[0].prefetch(wp3 + ((size_t)mb0 * 8) * 64 + lane, 8 * 64, 1024 * 128 / 8);
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     float bl[2];
-    load_bias_lane<2>(bl, b3, (wave * 8 + ps * 2) * 32, lane);
+    load_bias_lane<2>(bl, b3, (mb0 + ps * 2) * 32, lane);
     f32x16 acc[2][2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g[ps & 1].run(acc, a2h, a2l, lane);
-    if (ps < 3) g[(ps + 1) & 1].prefetch(wp3 + ((wave * 8 + (ps + 1) * 2) * 8) * 64 + lane, 8 * 64, 1024 * 128 / 8);
-    max_tile_store_pre<2, 2>(acc, out, (wave * 8 + ps * 2) * 32, bl, true, lane);
+    if (ps < NPS - 1) g[(ps + 1) & 1].prefetch(wp3 + ((size_t)(mb0 + (ps + 1) * 2) * 8) * 64 + lane, 8 * 64, 1024 * 128 / 8);
+    max_tile_store_pre<2, 2>(acc, out, (mb0 + ps * 2) * 32, bl, true, lane);
   }
 }
 
@@ -320,6 +328,7 @@ __device__ __forceinline__ void conv3_relu_chunks_split(float x, float y, float 
   rl[(2 * grp + 1) ^ key] = lo;
 }
 
+template <int RS>
 __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, const u32x4* __restrict__ wp2,
                                                         const float* __restrict__ b2, const u32x4* __restrict__ wp3,
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const fl
   u32x4* a2l = a2h + TP * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
   GemmPipeS<1, 2, false, 8, 2> g2;  // conv2 64->128: wave -> m-block `wave`
   g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0, 128 * 64 / 8);
   f32x4 bv2[1][4];
@@ -349,9 +359,10 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const fl
     store_tile_split<1, 2, true, 16>(acc, a2h, a2l, wave, bv2, lane);
   }
   __syncthreads();
-  stn_conv3_split(wp3, b3, a2h, a2l, pm + (size_t)blockIdx.x * PMW, wave, lane);
+  stn_conv3_split<RS>(wp3, b3, a2h, a2l, pm + (size_t)tile * PMW, part, wave, lane);
 }
 
+template <int RS>
 __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const float* __restrict__ trans3,
                                                         const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                         const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
@@ -367,7 +378,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
   u32x4* f2l = f2h + TP * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileInfo ti = tile_info(blockIdx.x, B, N, M);
+  const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
+  const TileInfo ti = tile_info(tile, B, N, M);
   const int mblk1 = wave >> 1, nb1 = wave & 1;
   GemmPipeS<1, 1, false, 8, 2> g1;  // fstn.conv1 64->64: 2 m-blocks x 2 point blocks
   g1.prefetch(wpf1 + (mblk1 * 4) * 64 + lane, 0, 64 * 64 / 8);
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
     store_tile_split<1, 2, true, 16>(acc, f2h, f2l, wave, bv2, lane);
   }
   __syncthreads();
-  stn_conv3_split(wpf3, bf3, f2h, f2l, pm + (size_t)blockIdx.x * PMW, wave, lane);
+  stn_conv3_split<RS>(wpf3, bf3, f2h, f2l, pm + (size_t)tile * PMW, part, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -258,6 +258,26 @@ def test_full_size_properties():
     assert torch.equal(out_b["pose_4"], P), "the path is deterministic (no atomics in reductions)"
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "split"])
+def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtype):
+    """Small grids run 2 or 4 workgroups per 64-point tile of the encoder kernels (each sweeps a share of the output
+    channels, csrc row_split): B=1 -> 4, B=3 -> 2, B=5 -> 1 at N=M=1024.  An object's result must not depend on it -
+    bit for bit."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+
+    cfg = default_cfg()
+    model, _ = build_model(cfg, 0)
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = dtype
+    batch = to_dev(synth.make_inputs(5, 1024, 1024, seed=23))
+    ref = model.refine(batch, n_iter=2)
+    for nb in (1, 3):
+        sub = {k: v[:nb].contiguous() for k, v in batch.items()}
+        out = model.refine(sub, n_iter=2)
+        for key in ("pose_1", "pose_2", "scale_2"):
+            assert torch.equal(out[key], ref[key][:nb]), (dtype, nb, key)
+
+
 def test_errors():
     from catre_amd import hip
     from catre_amd.config import default_cfg
