@@ -1471,7 +1471,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   hipLaunchKernelGGL(k_trunk_split<RS>, dim3(tiles_all * RS), dim3(512), 0, st, *pts, ws + W.trans3, t64,        \
                      prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],       \
                      pkb(packed, PL.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B],   \
-                     ws + W.pm, ws + W.pointfeat, B, N, M)
+                     ws + W.pm, ws + W.pointfeat, B, N, M, g_trunk_trace)
       RS_DISPATCH(row_split(tiles_all), LAUNCH_)
 #undef LAUNCH_
     }

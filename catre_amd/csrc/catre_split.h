@@ -144,7 +144,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
                                                      const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                      const float* __restrict__ b3, const u32x4* __restrict__ wp4,
                                                      const float* __restrict__ b4, float* __restrict__ pm,
-                                                     float* __restrict__ pointfeat, int B, int N, int M) {
+                                                     float* __restrict__ pointfeat, int B, int N, int M,
+                                                     unsigned long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
   float* h1 = smem;                      // [64][68]
   float* t64 = smem + TP * LD64;         // [64][64]
@@ -158,6 +159,11 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
   const TileInfo ti = tile_info(tile, B, N, M);
   const bool ft = trans64 != nullptr;
+#define TRUNKS_STAMP(i)                                                                                    \
+  do {                                                                                                     \
+    if (trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter();     \
+  } while (0)
+  TRUNKS_STAMP(0);
 
   const int mblk2 = wave >> 1, nb2 = wave & 1;
   GemmPipe<1, 1, false, false, 8, 4> g2;
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     }
   }
   __syncthreads();
+  TRUNKS_STAMP(1);
   if (ft) {
     if (wave < 4) {
       const int mblk = wave >> 1, nb = wave & 1;
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   } else {
     pf = h1;
   }
+  TRUNKS_STAMP(2);
   // conv3 128->512 on the split pipe too (it would otherwise be a third of the kernel's matrix time)
   GemmPipeS<2, 2, false, 16, 2> g3;
   g3.prefetch(wp3 + ((wave * 2) * 8) * 64 + lane, 8 * 64, 512 * 128 / 8);
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     store_tile_split<1, 1, true, 16>(acc, a2h + nb2 * 32 * 16, a2l + nb2 * 32 * 16, mblk2, bv2, lane);
   }
   __syncthreads();
+  TRUNKS_STAMP(3);
   // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16.
   // RS workgroups per tile: 4/RS m-blocks from mb0 (one pass of 2, or of 1)
   constexpr int MB4 = RS == 4 ? 1 : 2;
@@ -245,12 +254,14 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     // the epilogue and the barrier
     g4a.prefetch(wp4 + ((size_t)mb0 * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
     store_tile_split<2, 2, true, 64>(acc3, a3h, a3l, wave * 2, bv3, lane);
+    TRUNKS_STAMP(4);
   }
   float bl4[2][MB4];
   load_bias_lane<MB4>(bl4[0], b4, mb0 * 32, lane);
   if (RS == 1) load_bias_lane<MB4>(bl4[1], b4, (mb0 + 2) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  TRUNKS_STAMP(5);
   {
     float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
                                             : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
@@ -269,6 +280,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     g4a.run(acc4, a3h, a3l, lane);
     if (RS == 1) g4b.prefetch(wp4 + ((size_t)(mb0 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
     max_tile_store_pre<MB4, 2>(acc4, out, mb0 * 32, bl4[0], false, lane);
+    TRUNKS_STAMP(6);
   }
   if (RS == 1) {
     f32x16 acc4[MB4][2];
@@ -277,6 +289,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     g4b.run(acc4, a3h, a3l, lane);
     max_tile_store_pre<MB4, 2>(acc4, out, (mb0 + 2) * 32, bl4[1], false, lane);
   }
+  TRUNKS_STAMP(7);
+#undef TRUNKS_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
