@@ -436,8 +436,16 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
                                                          const u32x4* __restrict__ wpl1x, const u32x4* __restrict__ wpl1y,
                                                          const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                          float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
-                                                         int M) {
+                                                         int M, unsigned long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
+  int stamp_i = 0;
+#define ROTS_STAMP()                                                                                     \
+  do {                                                                                                   \
+    if (trace && (threadIdx.x & 63) == 0)                                                                \
+      trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + stamp_i] = __builtin_readcyclecounter(); \
+    ++stamp_i;                                                                                           \
+  } while (0)
+  ROTS_STAMP();
   u32x4* pfh = reinterpret_cast<u32x4*>(smem);                // [64][8 chunks] hi, 8 KiB
   u32x4* pfl = pfh + TP * 8;                                  // lo
   u32x4* a0h = reinterpret_cast<u32x4*>(smem + TP * 64);      // [64][32 chunks]
@@ -458,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
     pfl[bf_off<8>(row, c)] = lo;
   }
   __syncthreads();
+  ROTS_STAMP();
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll 1
   for (int hd = 0; hd < 2; ++hd) {
@@ -478,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         g0.prefetch((hd ? wpl0y : wpl0x) + ((wave * 2) * 4) * 64 + lane, 4 * 64, 256 * 64 / 8);
         g0.run(acc, pfh, pfl, lane);
       }
+      ROTS_STAMP();
       const int key = bf_key<32>(n);
       float zprev[2][4];
 #pragma unroll
@@ -508,7 +518,9 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         }
       }
     }
+    ROTS_STAMP();
     __syncthreads();
+    ROTS_STAMP();
     {
       f32x16 acc[2][2];
 #pragma unroll
@@ -516,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
       GemmPipeS<2, 2, true, 32, 2> g1;
       g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64, 256 * 256 / 8);
       g1.run(acc, a0h, a0l, lane);
+      ROTS_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
@@ -573,6 +586,9 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         }
       }
     }
+    ROTS_STAMP();
     __syncthreads();  // the a0 images are rewritten for the second head
+    ROTS_STAMP();
   }
+#undef ROTS_STAMP
 }

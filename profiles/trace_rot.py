@@ -9,6 +9,7 @@ sd = synth.recipe_state_dict(expected_state_shapes(cfg))
 model.load_state_dict({k:v.cuda() for k,v in sd.items()}); model.eval()
 B=256
 batch = {k:v.cuda() for k,v in synth.make_inputs(B,1024,1024,seed=1).items()}
+model.cfg.MODEL.CATRE.COMPUTE_DTYPE = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
 model.refine(batch, n_iter=1)
 tiles = B*32
 OFF = 1<<24
@@ -17,10 +18,10 @@ hip.load().catre_debug_trunk_trace(ctypes.c_void_p(buf.data_ptr()))
 model.refine(batch, n_iter=1)
 torch.cuda.synchronize()
 hip.load().catre_debug_trunk_trace(None)
-t = buf[OFF:].view(tiles,8,16)[:, :4, :12].cpu().double()
+t = buf[OFF:].view(tiles,8,16)[:, :4, :13].cpu().double()
 t = t[2048:6144]
 d = t[:,:,1:] - t[:,:,:-1]
-names=['load pf+bar','h0 layer0 mfma','h0 gelu+lds','h0 bar','h0 layer1 mfma','h0 store+stats','h0 bar','h1 layer0','h1 gelu','h1 bar','h1 layer1']
+names=['load pf+bar','h0 layer0 mfma','h0 gelu+lds','h0 bar','h0 layer1 mfma','h0 store+stats','h0 bar','h1 layer0','h1 gelu','h1 bar','h1 layer1','h1 store+stats']
 for i,nm in enumerate(names):
     print(f'  {nm:18s} {d[:,:,i].mean():9.0f}  w0 {d[:,0,i].mean():9.0f} w3 {d[:,3,i].mean():9.0f}')
-print('total', (t[:,:,11]-t[:,:,0]).mean().item())
+print('total', (t[:,:,12]-t[:,:,0]).mean().item())
