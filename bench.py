@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--mode", choices=("refine", "train"), default="refine",
                     help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
     ap.add_argument("--dtype", choices=("fp32", "split", "bf16"), default="fp32",
-                    help="fp32: fp32 MFMA everywhere (the headline); split: the three dominant GEMMs as split-bf16 "
+                    help="fp32: fp32 MFMA everywhere (the headline); split: the layers holding 98 %% of the FLOPs as split-bf16 "
                          "(hi+lo, 3 products) MFMAs, same 2e-5 parity; bf16: bf16 operands (BASELINE config 5)")
     ap.add_argument("--shape", choices=("headline", "config5"), default="headline",
                     help="headline: N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8")

@@ -1,5 +1,5 @@
-"""'split' compute mode (catre_amd/csrc/catre_split.h): the three dominant GEMMs (STN conv3, trunk conv4, rot-head
-layer 1 = 87.5 % of the FLOPs) as split-bf16 MFMAs - every fp32 operand as hi + lo bf16, three products, fp32
+"""'split' compute mode (catre_amd/csrc/catre_split.h): the layers holding 98 % of the FLOPs (all MFMA layers of the
+two STNs, trunk conv3/conv4, rot-head layers 0/1) as split-bf16 MFMAs - every fp32 operand as hi + lo bf16, three products, fp32
 accumulation - everything else the fp32 kernels.  It has to meet the SAME bars as the pure fp32 path:
 the reference contract (R, t, s within 1e-4 abs of the reference after K iterations) and our internal 2e-5."""
 import numpy as np
