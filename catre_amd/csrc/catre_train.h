@@ -307,6 +307,148 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gemm_tn on the bf16 matrix pipe.  SPLIT = false: bf16 operands (torch.autocast runs the backward of a bf16 layer
+// in bf16 as well); SPLIT = true: every operand as hi + lo bf16 and three products (fp32-grade gradients).
+// 256 threads, 128 x 128 output tile, wave -> 64 x 64 (2 x 2 blocks: one 16-byte LDS read per MFMA).
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive contraction indices (= rows) per lane, so the 64-row slabs are
+// transposed while they are staged: a thread loads 8 rows x 4 columns (row-major, coalesced), converts, and writes
+// four 16-byte chunks "column c, rows 8g..8g+7".  Slot of (column, chunk) in the image - both the fragment reads (32
+// consecutive columns, one chunk) and the staging writes (columns 4 apart, one chunk) are bank-conflict free:
+//   slot = (c >> 1) * 16 + 8 * ((c ^ (c >> 2)) & 1) + ((chunk ^ (c >> 1) ^ (c >> 4)) & 7)
+// The bias gradient (column sums of dY) is taken from the fp32 values before they are rounded.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_slot(int c, int chunk) {
+  return (c >> 1) * 16 + 8 * ((c ^ (c >> 2)) & 1) + ((chunk ^ (c >> 1) ^ (c >> 4)) & 7);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                       int ldx, float* __restrict__ part, int J, int K, int R,
+                                                       int rows_per_split, float* __restrict__ colpart,
+                                                       const float* __restrict__ ymask, int ldym, size_t pitch) {
+  constexpr int NI = SPLIT ? 2 : 1;
+  __shared__ u32x4 ys[NI][128 * 8];  // [column][8 chunks of 8 rows] bf16, 16 KiB per image
+  __shared__ u32x4 xs[NI][128 * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int row_lo = blockIdx.z * rows_per_split, row_hi = min(R, row_lo + rows_per_split);
+  const int jb0 = 2 * (wave >> 1), kb0 = 2 * (wave & 1);
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) acc[a][0] = acc[a][1] = zero16();
+  const bool do_col = colpart != nullptr && blockIdx.y == 0;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  // staging: thread -> column quad c4 (columns 4 c4 .. +3) and row group g (rows 8g .. 8g+7 of the slab)
+  const int c4 = tid & 31, g = tid >> 5;
+  const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
+  f32x4 vy[8], vx[8];
+  auto fetch = [&](int rs) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gr = rs + g * 8 + u;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      vy[u] = vx[u] = z;
+      if (gr < row_hi) {
+        if (jc < J) {
+          vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+          if (ymask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + (size_t)gr * ldym + jc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
+          }
+        }
+        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
+      }
+    }
+  };
+  auto stage = [&](const f32x4 (&v)[8], u32x4 (&img)[NI][128 * 8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float col[8] = {v[0][q], v[1][q], v[2][q], v[3][q], v[4][q], v[5][q], v[6][q], v[7][q]};
+      const int slot = tn_slot(c4 * 4 + q, g);
+      if (SPLIT) {
+        u32x4 hi, lo;
+        split_bf8(col, hi, lo);
+        img[0][slot] = hi;
+        img[NI - 1][slot] = lo;
+      } else {
+        img[0][slot] = pack_bf8(col);
+      }
+    }
+  };
+  fetch(row_lo);
+  for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
+    __syncthreads();  // the previous slab's fragment reads are done
+    if (do_col) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += vy[u][q];
+        csum[q] += t;
+      }
+    }
+    stage(vy, ys);
+    stage(vx, xs);
+    __syncthreads();
+    if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);  // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < TN_ROWS / 16; ++ks) {
+      u32x4 a[2], b[2], al[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int sa = tn_slot((jb0 + t) * 32 + i, 2 * ks + h), sb = tn_slot((kb0 + t) * 32 + i, 2 * ks + h);
+        a[t] = ys[0][sa];
+        b[t] = xs[0][sb];
+        if (SPLIT) {
+          al[t] = ys[NI - 1][sa];
+          bl[t] = xs[NI - 1][sb];
+        }
+      }
+#pragma unroll
+      for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          if (SPLIT) {
+            acc[ja][kb] = mfma_bf(al[ja], b[kb], acc[ja][kb]);
+            acc[ja][kb] = mfma_bf(a[ja], bl[kb], acc[ja][kb]);
+          }
+          acc[ja][kb] = mfma_bf(a[ja], b[kb], acc[ja][kb]);  // D[j][k]
+        }
+    }
+  }
+  if (do_col) {  // thread (c4, g) holds the sums of its 4 columns over its row groups: merge the 8 groups in order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&ys[0][0]);  // [8 groups][128 columns]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[g * 128 + c4 * 4 + q] = csum[q];
+    __syncthreads();
+    const int j = j0 + tid;
+    if (tid < 128 && j < J) {
+      float t = red[tid];
+#pragma unroll
+      for (int gg = 1; gg < 8; ++gg) t += red[gg * 128 + tid];
+      colpart[(size_t)blockIdx.z * pitch + j] = t;
+    }
+  }
+  float* out = part + (size_t)blockIdx.z * pitch;
+#pragma unroll
+  for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int k = k0 + (kb0 + kb) * 32 + i;
+      if (k >= K) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = j0 + (jb0 + ja) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (j < J) out[(size_t)j * K + k] = acc[ja][kb][reg];
+      }
+    }
+}
+
 // out[i] = sum_s part[s][i]  (fixed order: deterministic)
 __global__ void k_reduce_splits(const float* __restrict__ part, float* __restrict__ out, int n, int splits,
                                 int accumulate) {

@@ -40,15 +40,18 @@ def _pad_cols(t, mult):
 
 # ------------------------------------------------------------------------------------------------- GEMMs
 # Mixed precision: inside torch.autocast (what SOLVER.AMP.ENABLED does to the reference's forward, engine.py:304) the
-# forward and dgrad row GEMMs run with bf16 operands and fp32 accumulation / outputs.  `amp_mode("fp32" | "bf16")`
-# overrides the autocast state (cfg.MODEL.CATRE.COMPUTE_DTYPE).
+# forward, dgrad and wgrad GEMMs run with bf16 operands and fp32 accumulation / outputs (bias gradients stay fp32
+# sums).  `amp_mode("fp32" | "bf16" | "split")` overrides the autocast state (cfg.MODEL.CATRE.COMPUTE_DTYPE); "split"
+# keeps fp32-grade results on the bf16 pipe (hi + lo bf16 operands, three products - DESIGN 5e).
+# The mode is the C ABI's compute_dtype: 0 = CATRE_DTYPE_F32, 1 = CATRE_DTYPE_BF16, 2 = CATRE_DTYPE_SPLIT.
 _AMP_OVERRIDE = [None]
+_MODES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "split": 2}
 
 
 class amp_mode:
     def __init__(self, mode):
-        assert mode in (None, "fp32", "float32", "bf16", "bfloat16"), mode
-        self.mode = None if mode is None else mode in ("bf16", "bfloat16")
+        assert mode is None or mode in _MODES, mode
+        self.mode = None if mode is None else _MODES[mode]
 
     def __enter__(self):
         self.prev, _AMP_OVERRIDE[0] = _AMP_OVERRIDE[0], self.mode if self.mode is not None else _AMP_OVERRIDE[0]
@@ -58,7 +61,7 @@ class amp_mode:
 
 
 def _amp():
-    return torch.is_autocast_enabled() if _AMP_OVERRIDE[0] is None else _AMP_OVERRIDE[0]
+    return int(torch.is_autocast_enabled()) if _AMP_OVERRIDE[0] is None else _AMP_OVERRIDE[0]
 
 
 def _pack_bf16(w, J, K, dev):
@@ -81,7 +84,7 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False):
     dev = x.device
     y = torch.empty(R, J, dtype=torch.float32, device=dev)
     big = _tiled_gemm_ok(R, J, K) and identity_k == 0
-    if big and amp and K in (64, 128, 256, 512):
+    if big and amp == 1 and K in (64, 128, 256, 512):
         wp = _pack_bf16(w, J, K, dev)
         hip.check(lib.catre_op_gemm_rows_bf16(hip.ptr(x), x.stride(0), hip.ptr(xmask),
                                               xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), hip.ptr(bias),
@@ -101,7 +104,7 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False):
     return y
 
 
-def _gemm_tn(dy, x, with_bias=False, ymask=None):
+def _gemm_tn(dy, x, with_bias=False, ymask=None, amp=0):
     """dW[J,K] = dy[R,J]^T x[R,K] (deterministic split reduction); with_bias also returns db[J] = column sums of dy,
     taken from the tiles the kernel stages anyway; with ymask, dy .* (ymask > 0) replaces dy (ReLU backward)."""
     lib = hip.load()
@@ -115,10 +118,10 @@ def _gemm_tn(dy, x, with_bias=False, ymask=None):
     db = buf[J4 * K4:] if with_bias else None  # right behind dW: one split reduction covers both
     need = lib.catre_op_gemm_tn_bias_ws_bytes(J4, K4, R)
     ws = _ws(need, dy.device)
-    hip.check(lib.catre_op_gemm_tn_bias_m(hip.ptr(dy4), dy4.stride(0), hip.ptr(ym4),
-                                          ym4.stride(0) if ym4 is not None else 0, hip.ptr(x4), x4.stride(0), hip.ptr(dw),
-                                          hip.ptr(db), J4, K4, R, 0, hip.ptr(ws), ws.numel(), _st(dy)),
-              "catre_op_gemm_tn_bias_m")
+    hip.check(lib.catre_op_gemm_tn_bias_lp(hip.ptr(dy4), dy4.stride(0), hip.ptr(ym4),
+                                           ym4.stride(0) if ym4 is not None else 0, hip.ptr(x4), x4.stride(0), hip.ptr(dw),
+                                           hip.ptr(db), J4, K4, R, 0, hip.ptr(ws), ws.numel(), int(amp), _st(dy)),
+              "catre_op_gemm_tn_bias_lp")
     if with_bias:
         return dw[:J, :K], db[:J]
     return dw[:J, :K]
@@ -179,10 +182,10 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             kw = min(w2.shape[1], x.shape[1])
             if want_db:
-                dw, db = _gemm_tn(dy, _c(x), with_bias=True, ymask=ymask)
+                dw, db = _gemm_tn(dy, _c(x), with_bias=True, ymask=ymask, amp=ctx.amp)
                 db = _c(db)
             else:
-                dw = _gemm_tn(dy, _c(x), ymask=ymask)
+                dw = _gemm_tn(dy, _c(x), ymask=ymask, amp=ctx.amp)
             dw = dw[:, :kw]
             if kw < w2.shape[1]:
                 dw = F.pad(dw, (0, w2.shape[1] - kw))
@@ -214,7 +217,7 @@ class _LinearMaxPool(torch.autograd.Function):
         xc = _c(x)
         fused = (N % 64 == 0 and M % 64 == 0 and J % 32 == 0 and (J <= 256 or J in (512, 1024))
                  and (K in (64, 128) or K % 256 == 0))
-        if fused and _amp() and K in (64, 128, 256, 512):
+        if fused and _amp() == 1 and K in (64, 128, 256, 512):
             wp = _pack_bf16(w2, J, K, x.device)
             need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)
             ws = _ws(need, x.device)

@@ -250,6 +250,12 @@ int catre_op_gemm_tn_bias(const float* dY, int ldy, const float* X, int ldx, flo
                           int accumulate, void* ws, size_t ws_bytes, void* stream);
 int catre_op_gemm_tn_bias_m(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
                             float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* ... with the products on the matrix pipe compute_dtype names (CATRE_DTYPE_F32 / _BF16: operands rounded to bf16, the
+ * backward of a layer that ran under torch.autocast / _SPLIT: hi + lo bf16 operands, three products); fp32 accumulation
+ * and an fp32 bias gradient in every case */
+int catre_op_gemm_tn_bias_lp(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
+                             float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes,
+                             int compute_dtype, void* stream);
 int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);

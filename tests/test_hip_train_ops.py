@@ -44,6 +44,31 @@ def test_linear_fwd_bwd(R, K, J, relu):
     _cmp(b.grad, br.grad, "db", atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("R,K,J,masked", [(700, 128, 512, True), (1000, 512, 1024, False), (5000, 64, 256, True),
+                                          (333, 256, 64, False), (4096, 1024, 512, False), (520, 132, 36, True)])
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+def test_weight_gradient_on_the_bf16_pipe(mode, R, K, J, masked):
+    """catre_op_gemm_tn_bias_lp: dW = (dY .* mask)^T X with bf16 MFMAs.  'bf16' must equal the product of the
+    bf16-ROUNDED operands (fp32 re-association only); 'split' (hi + lo, three products) must reach the exact product
+    to 2e-5 relative of the largest entry; the bias gradient is an fp32 sum of the unrounded dY in both."""
+    from catre_amd import train_ops as T
+
+    g = _gen(R + K + J)
+    dy = torch.randn(R, J, generator=g)
+    x = torch.randn(R, K, generator=g)
+    ym = torch.randn(R, J, generator=g) if masked else None
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    dw, db = T._gemm_tn(dyd, xd, with_bias=True, ymask=ym.to(DEV) if masked else None, amp=T._MODES[mode])
+    dym = dy * (ym > 0) if masked else dy
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if mode == "bf16" else (lambda t: t.double())
+    want = rnd(dym).t() @ rnd(x)
+    scale = float(want.abs().max())
+    _cmp(dw, want, f"dW {mode}", atol=2e-5 * scale, rtol=0)
+    _cmp(db, dym.double().sum(0), "db", atol=2e-4, rtol=2e-5)
+    dw2, _ = T._gemm_tn(dyd, xd, with_bias=True, ymask=ym.to(DEV) if masked else None, amp=T._MODES[mode])
+    assert torch.equal(dw, dw2), "deterministic"
+
+
 def test_linear_identity_tail():
     from catre_amd import train_ops as T
 
