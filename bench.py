@@ -97,6 +97,9 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
 
     cfg = cfg_fn(str(dev))
     amp = args.dtype == "bf16"
+    split = args.dtype == "split"
+    if split:
+        cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"  # hi + lo bf16 operands, three products: fp32-grade GEMMs on the bf16 pipe
     cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=1e-5, weight_decay=0, clean_grads=True)  # shipped optimiser, fused HIP step
     model, opt = build_model_optimizer(cfg, is_test=False)
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
@@ -152,13 +155,14 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
         print(json.dumps({
-            "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else ""),
+            "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else " [split-bf16 GEMMs]" if split else ""),
             "value": round(value, 1),
             "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if amp else ("f32+bf16x3" if split else "f32"), "data": "synthetic",
             "config": {"workload": "B=256 objects/GPU, N=M=1024, K=4 x (forward + loss + backward + fused Ranger step); "
-                                   + ("bf16-operand forward / dgrad GEMMs under torch.autocast; " if amp else "")
+                                   + ("bf16-operand forward / dgrad / wgrad GEMMs under torch.autocast; " if amp else "")
+                                   + ("forward / dgrad / wgrad GEMMs as split-bf16 (hi+lo, three products) MFMAs, fp32 results; " if split else "")
                                    +
                                    "half the objects y-symmetric with 313 candidate rotations; "
                                    + ("DDP gradient all-reduce over RCCL" if world > 1 else "single rank"),

@@ -36,14 +36,15 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 template <int MB, bool MAXP>
 __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                    const float* __restrict__ mask, int ldm, float* __restrict__ Y,
-                                                   int ldy, int R, int relu, int r0, int nblk, int wave, int lane) {
+                                                   int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
+                                                   int blk_off = 0) {
   const int n = lane & 31, h = lane >> 5;
   if constexpr (MAXP) {
     // D[row = point][col = channel]: lane owns channel blk*32 + n and points (r&3) + 8(r>>2) + 4h + 32nb
     int* amax = reinterpret_cast<int*>(const_cast<float*>(mask));
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int blk = wave + 8 * mb;
+      const int blk = blk_off + wave + 8 * mb;
       if (blk >= nblk) break;
       const int ch = blk * 32 + n;
       const float bv = bias ? bias[ch] : 0.f;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int blk = wave + 8 * mb;
+    const int blk = blk_off + wave + 8 * mb;
     if (blk >= nblk) break;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -210,6 +211,72 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
   gemm_rows_epilogue<MB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+}
+
+// ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
+// at the speed of the bf16 kernels (both are bound by the fp32 activations they stream).  Weights: hi pack, then lo pack
+// (k_op_pack_split); the X tile is split while it is staged.  Wave w owns m-blocks {w + 8 i}; they are swept in passes
+// of two (four accumulator blocks + both fragment rings would not fit 256 VGPRs).
+__global__ void k_op_pack_split(const float* __restrict__ src, int ld, int J, int K, int transpose,
+                                unsigned short* __restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= J * K) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9;
+  const int nkc = K / 16;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 16 + 8 * (lane >> 5) + e;
+  const float v = transpose ? src[(size_t)col * ld + row] : src[(size_t)row * ld + col];
+  const __bf16 hi = (__bf16)v;
+  dst[idx] = __builtin_bit_cast(unsigned short, hi);
+  dst[(size_t)J * K + idx] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hi));
+}
+
+template <int MB, int CP, bool MAXP>
+__global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
+                                                      const float* __restrict__ xmask, int ldxm) {
+  constexpr int NKC = CP / 2;  // K = 8 * CP
+  constexpr int PMB = MB >= 2 ? 2 : 1;
+  __shared__ u32x4 xs[2][TP * CP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * TP;
+  const int nblk = J / 32;
+  for (int i = tid; i < TP * CP; i += 512) {
+    const int row = i / CP, ch = i % CP;
+    const int gr = min(r0 + row, R - 1);
+    const float* src = X + (size_t)gr * ldx + ch * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (xmask) {
+      const float* ms = xmask + (size_t)gr * ldxm + ch * 8;
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(ms), m1 = *reinterpret_cast<const f32x4*>(ms + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = m0[q] > 0.f ? v[q] : 0.f;
+        v[4 + q] = m1[q] > 0.f ? v[4 + q] : 0.f;
+      }
+    }
+    u32x4 hi, lo;
+    split_bf8(v, hi, lo);
+    xs[0][bf_off<CP>(row, ch)] = hi;
+    xs[1][bf_off<CP>(row, ch)] = lo;
+  }
+  __syncthreads();
+  const int lo_off = J * CP;  // u32x4 units: J*K bf16 = J*K/8 chunks, K = 8 CP
+#pragma unroll 1
+  for (int p = 0; p < MB / PMB; ++p) {
+    const int blk0 = 8 * PMB * p;
+    if (blk0 + wave >= nblk) return;
+    f32x16 acc[PMB][2];
+#pragma unroll
+    for (int mb = 0; mb < PMB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    GemmPipeS<PMB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1)> g;
+    g.prefetch(Wp + ((size_t)(blk0 + wave) * NKC) * 64 + lane, 8 * NKC * 64, lo_off);
+    g.run(acc, xs[0], xs[1], lane);
+    gemm_rows_epilogue<PMB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0);
+  }
 }
 
 #define TN_ROWS 64  // rows of dY / X staged per step

@@ -70,6 +70,12 @@ def _pack_bf16(w, J, K, dev):
     return wp
 
 
+def _pack_split(w, J, K, dev):
+    wp = torch.empty(J * K, dtype=torch.float32, device=dev)  # 2*J*K bf16: hi pack, lo pack
+    hip.check(hip.load().catre_op_pack_split(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(w)), "catre_op_pack_split")
+    return wp
+
+
 def _tiled_gemm_ok(R, J, K):
     """Shapes the tiled row kernel (catre_op_gemm_rows) takes."""
     return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= 256
@@ -84,12 +90,12 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False):
     dev = x.device
     y = torch.empty(R, J, dtype=torch.float32, device=dev)
     big = _tiled_gemm_ok(R, J, K) and identity_k == 0
-    if big and amp == 1 and K in (64, 128, 256, 512):
-        wp = _pack_bf16(w, J, K, dev)
-        hip.check(lib.catre_op_gemm_rows_bf16(hip.ptr(x), x.stride(0), hip.ptr(xmask),
-                                              xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), hip.ptr(bias),
-                                              hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R,
-                                              J, K, int(relu), _st(x)), "catre_op_gemm_rows_bf16")
+    if big and amp in (1, 2) and K in (64, 128, 256, 512):
+        wp = (_pack_bf16 if amp == 1 else _pack_split)(w, J, K, dev)
+        fn = lib.catre_op_gemm_rows_bf16 if amp == 1 else lib.catre_op_gemm_rows_split
+        hip.check(fn(hip.ptr(x), x.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0, hip.ptr(wp),
+                     hip.ptr(bias), hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J, K,
+                     int(relu), _st(x)), "catre_op_gemm_rows_bf16" if amp == 1 else "catre_op_gemm_rows_split")
     elif big:
         wp = torch.empty(J * K, dtype=torch.float32, device=dev)
         hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
@@ -217,13 +223,15 @@ class _LinearMaxPool(torch.autograd.Function):
         xc = _c(x)
         fused = (N % 64 == 0 and M % 64 == 0 and J % 32 == 0 and (J <= 256 or J in (512, 1024))
                  and (K in (64, 128) or K % 256 == 0))
-        if fused and _amp() == 1 and K in (64, 128, 256, 512):
-            wp = _pack_bf16(w2, J, K, x.device)
+        amp = _amp()
+        if fused and amp in (1, 2) and K in (64, 128, 256, 512):
+            wp = (_pack_bf16 if amp == 1 else _pack_split)(w2, J, K, x.device)
             need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)
             ws = _ws(need, x.device)
-            hip.check(lib.catre_op_linear_maxpool_bf16(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(b), hip.ptr(g),
-                                                       hip.ptr(idx), J, K, B, N, M, hip.ptr(ws), ws.numel(), _st(x)),
-                      "catre_op_linear_maxpool_bf16")
+            fn = lib.catre_op_linear_maxpool_bf16 if amp == 1 else lib.catre_op_linear_maxpool_split
+            hip.check(fn(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(b), hip.ptr(g), hip.ptr(idx), J, K, B, N, M,
+                         hip.ptr(ws), ws.numel(), _st(x)),
+                      "catre_op_linear_maxpool_bf16" if amp == 1 else "catre_op_linear_maxpool_split")
         elif fused:  # the max / arg-max is the GEMM's epilogue: the [rows, J] matrix never exists
             wp = torch.empty(J * K, dtype=torch.float32, device=x.device)
             hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")

@@ -241,6 +241,13 @@ int catre_op_gemm_rows_bf16(const float* X, int ldx, const float* xmask, int ldx
                             const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
 int catre_op_linear_maxpool_bf16(const float* X, int ldx, const void* Wp, const float* bias, float* out, int* idx, int J,
                                  int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
+/* split mode (hi + lo bf16 operands, three products: fp32-grade results on the bf16 pipe) of the three entry points
+ * above; dst / Wp hold 2 * J * K bf16 (hi pack, then lo pack) */
+int catre_op_pack_split(const float* src, int ld, int J, int K, int transpose, void* dst, void* stream);
+int catre_op_gemm_rows_split(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
+                             const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
+int catre_op_linear_maxpool_split(const float* X, int ldx, const void* Wp, const float* bias, float* out, int* idx, int J,
+                                  int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);

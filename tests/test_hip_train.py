@@ -158,6 +158,58 @@ def test_amp_training_iteration_tracks_fp32():
     assert checked >= 20
 
 
+def test_split_training_iteration_matches_fp32():
+    """COMPUTE_DTYPE='split' in training: the tiled forward / dgrad / wgrad GEMMs run hi + lo bf16 operands with three
+    products (fp32-grade results on the bf16 pipe).  Losses within 1e-5 relative of the fp32 iteration, every gradient
+    within 5e-2 relative L2, the refined pose within 2e-5."""
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from oracle.catre_oracle import y_axis_symmetries
+
+    B, N, M = 8, 256, 192
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.to(DEV) for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()})
+    model.train()
+    b = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=19).items()}
+    batch_updater_test(cfg, b)
+    sym = [y_axis_symmetries(12) if i % 3 == 0 else None for i in range(B)]
+
+    def run(force):
+        model.cfg.MODEL.CATRE.COMPUTE_DTYPE = force
+        model.zero_grad(set_to_none=True)
+        out, ld = model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                        gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                        mean_scales=b["obj_mean_scales"], sym_info=sym, do_loss=True, cur_iter=1)
+        sum(ld.values()).backward()
+        return ({k: float(v) for k, v in ld.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                out["pose_1"].detach().clone())
+
+    l32, g32, p32 = run("fp32")
+    ls, gs, ps = run("split")
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = None
+    assert not torch.equal(ps, p32), "the split kernels did not run"
+    assert (ps - p32).abs().max() < 2e-5
+    for k in l32:
+        assert abs(ls[k] - l32[k]) <= 1e-5 * abs(l32[k]) + 1e-7, (k, ls[k], l32[k])
+    # a 1e-5 perturbation flips a few arg-max / ReLU decisions, which moves single gradient entries of the layers in
+    # front of a max-pool discretely - so gradients are compared in norm: relative L2 error <= 5e-2 (measured ~1e-2 for
+    # the STN's first layers, ~1e-5 behind the pools)
+    worst = 0.0
+    for k, g in g32.items():
+        nrm = float(g.norm())
+        if nrm < 1e-10:
+            continue
+        rel = float((gs[k] - g).norm()) / nrm
+        worst = max(worst, rel)
+        assert rel <= 5e-2, (k, rel)
+        if rel > 1e-3:
+            print(f"  {k}: {rel:.2e}")
+    print(f"worst relative L2 gradient deviation: {worst:.2e}")
+
+
 def test_ddp_world1_wraps_and_steps():
     """The reference wraps the model in DistributedDataParallel(find_unused_parameters=True)
     (core/catre/main_catre.py:154-160); world_size 1 over RCCL exercises the reducer hooks on the HIP gradients."""
