@@ -593,15 +593,31 @@ __global__ void k_rowbias_add(float* __restrict__ Y, int ld, const float* __rest
 }
 
 // dbias[c][j] = sum over the rows of cloud c (object-major row order as above) of dY[r][j]
+// 64 columns x 4 row lanes per workgroup, 8 rows in flight per thread (one thread per column walking the cloud's rows
+// alone was latency-bound: 1.2 TB/s); the four lane sums are merged in lane order
 __global__ __launch_bounds__(256) void k_rowbias_bwd(const float* __restrict__ dY, int ld, float* __restrict__ dbias,
                                                      int J, int B, int N, int M) {
-  const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
-  if (j >= J) return;
+  __shared__ float red[256];
+  const int c = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int obj = c < B ? c : c - B;
   const int r0 = obj * (N + M) + (c < B ? 0 : N), n = c < B ? N : M;
   float s = 0.f;
-  for (int r = 0; r < n; ++r) s += dY[(size_t)(r0 + r) * ld + j];
-  dbias[(size_t)c * J + j] = s;
+  if (j < J) {
+    const float* col = dY + (size_t)r0 * ld + j;
+    int r = rl;
+    for (; r + 28 < n; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + 4 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < n; r += 4) s += col[(size_t)r * ld];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && j < J)
+    dbias[(size_t)c * J + j] = ((red[threadIdx.x] + red[64 + threadIdx.x]) + red[128 + threadIdx.x]) + red[192 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,23 +645,58 @@ __global__ __launch_bounds__(256) void k_maxpool_tiles(const float* __restrict__
   idx[(size_t)c * J + j] = am;
 }
 
+// same shape as k_rowbias_bwd: 64 columns x 4 row lanes, 8 rows in flight; first maximum wins (like torch.max)
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ Y, int ld, float* __restrict__ out,
                                                      int* __restrict__ idx, int J, int B, int N, int M) {
-  const int c = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
-  if (j >= J) return;
+  __shared__ float redm[256];
+  __shared__ int reda[256];
+  const int c = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   int r0, n;
   cloud_rows(c, B, N, M, r0, n);
-  float m = Y[(size_t)r0 * ld + j];
-  int am = 0;
-  for (int r = 1; r < n; ++r) {
-    const float v = Y[(size_t)(r0 + r) * ld + j];
-    if (v > m) {  // first maximum wins, like torch.max
-      m = v;
-      am = r;
+  float m = -INFINITY;
+  int am = n;  // "none yet": loses every tie
+  if (j < J) {
+    const float* col = Y + (size_t)r0 * ld + j;
+    int r = rl;
+    for (; r + 28 < n; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + 4 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] > m) {
+          m = v[u];
+          am = r + 4 * u;
+        }
+    }
+    for (; r < n; r += 4) {
+      const float v = col[(size_t)r * ld];
+      if (v > m) {
+        m = v;
+        am = r;
+      }
     }
   }
-  out[(size_t)c * J + j] = m;
-  idx[(size_t)c * J + j] = r0 + am;
+  redm[threadIdx.x] = m;
+  reda[threadIdx.x] = am;
+  __syncthreads();
+  if (rl == 0 && j < J) {
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+      const float mo = redm[l * 64 + threadIdx.x];
+      const int ao = reda[l * 64 + threadIdx.x];
+      if (mo > m || (mo == m && ao < am)) {
+        m = mo;
+        am = ao;
+      }
+    }
+    if (am >= n) {  // a column of NaNs / -inf: row 0 and its value, like a serial walk
+      am = 0;
+      m = Y[(size_t)r0 * ld + j];
+    }
+    out[(size_t)c * J + j] = m;
+    idx[(size_t)c * J + j] = r0 + am;
+  }
 }
 
 // scatter: dY[idx[c][j]][j] = dout[c][j] on a zeroed dY (dense form, for the narrow pools)
