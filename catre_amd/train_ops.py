@@ -370,7 +370,12 @@ class _RowBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, B, N, M):
         lib = hip.load()
-        y = y.clone()
+        # in place when y is an intermediate nobody else holds (the layer-0 GEMM output: a plain linear does not save
+        # its result) - a [B*(N+M), 256] clone is 1 GiB of traffic per head
+        if y.requires_grad and not y.is_leaf and y.is_contiguous():
+            ctx.mark_dirty(y)
+        else:
+            y = y.clone()
         bias = _c(bias)
         hip.check(lib.catre_op_rowbias_add(hip.ptr(y), y.stride(0), hip.ptr(bias), y.shape[1], B, N, M, _st(y)),
                   "catre_op_rowbias_add")
