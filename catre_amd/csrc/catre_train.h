@@ -886,6 +886,106 @@ __global__ __launch_bounds__(256) void k_cloud_matmul(const float* __restrict__ 
   }
 }
 
+// kd = 64 on the matrix pipe (the VALU form above ran at 0.9 TB/s): 64 rows of one cloud per workgroup, Y^T tile
+// D[j][row] = sum_i T[i][j] X[row][i] with T (or T^T) as the A operand straight from LDS, wave -> (32 channels, 32 rows)
+__global__ __launch_bounds__(256) void k_cloud_matmul64(const float* __restrict__ X, int ldx, const float* __restrict__ T,
+                                                        float* __restrict__ Y, int ldy, int B, int N, int M,
+                                                        int transpose) {
+  __shared__ __attribute__((aligned(16))) float ts[64 * 64];
+  __shared__ __attribute__((aligned(16))) float xs[64 * 68];
+  const int c = blockIdx.y;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const int rb = blockIdx.x * 64;
+  if (rb >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* Tc = T + (size_t)c * 4096;
+  if (transpose) {
+    for (int i = tid; i < 4096; i += 256) ts[i] = Tc[(i & 63) * 64 + (i >> 6)];
+  } else {
+    for (int i = tid; i < 1024; i += 256) reinterpret_cast<f32x4*>(ts)[i] = reinterpret_cast<const f32x4*>(Tc)[i];
+  }
+  {
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    const bool ok = rb + row < n;
+    const float* src = X + (size_t)(r0 + rb + (ok ? row : 0)) * ldx + c0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(src + 4 * u);
+      *reinterpret_cast<f32x4*>(xs + row * 68 + c0 + 4 * u) = v;
+    }
+  }
+  __syncthreads();
+  const int mblk = wave >> 1, nb = wave & 1, nn = lane & 31, h = lane >> 5;
+  f32x16 acc = zero16();
+  const float* xr = xs + (nb * 32 + nn) * 68 + 4 * h;
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) {
+    const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = mfma32(ts[(kc * 8 + 4 * h + q) * 64 + mblk * 32 + nn], bx[q], acc);
+  }
+  const int row = rb + nb * 32 + nn;
+  if (row < n) {
+    float* dst = Y + (size_t)(r0 + row) * ldy + mblk * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+    }
+  }
+}
+
+// dT[c] = X[c]^T dY[c] for kd = 64 on the matrix pipe: one workgroup per cloud, 64-row slabs of both operands staged
+// row-major (the contraction runs over rows, as in k_gemm_tn), wave -> one 32 x 32 block of the 64 x 64 result
+__global__ __launch_bounds__(256) void k_cloud_matmul64_bwd_t(const float* __restrict__ X, int ldx,
+                                                              const float* __restrict__ dY, int ldy,
+                                                              float* __restrict__ dT, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float xs[64 * 64];
+  __shared__ __attribute__((aligned(16))) float ys[64 * 64];
+  const int c = blockIdx.x;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ib = wave >> 1, jb = wave & 1, i = lane & 31, h = lane >> 5;
+  f32x16 acc = zero16();
+  const int row = tid >> 2, c0 = (tid & 3) * 16;
+  f32x4 vx[4], vy[4];
+  auto fetch = [&](int rs) {
+    const bool ok = rs + row < n;
+    const size_t gr = (size_t)(r0 + rs + (ok ? row : 0));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      vx[u] = ok ? *reinterpret_cast<const f32x4*>(X + gr * ldx + c0 + 4 * u) : z;
+      vy[u] = ok ? *reinterpret_cast<const f32x4*>(dY + gr * ldy + c0 + 4 * u) : z;
+    }
+  };
+  fetch(0);
+  for (int rs = 0; rs < n; rs += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      *reinterpret_cast<f32x4*>(xs + row * 64 + c0 + 4 * u) = vx[u];
+      *reinterpret_cast<f32x4*>(ys + row * 64 + c0 + 4 * u) = vy[u];
+    }
+    __syncthreads();
+    if (rs + 64 < n) fetch(rs + 64);
+    const float* xa = xs + h * 64 + ib * 32 + i;
+    const float* yb = ys + h * 64 + jb * 32 + i;
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) acc = mfma32(xa[t * 128], yb[t * 128], acc);  // rows 2t (h = 0), 2t + 1 (h = 1)
+  }
+  // D[row = i][col = j]: lane holds col j = lane&31, rows (reg&3) + 8(reg>>2) + 4h
+  float* out = dT + (size_t)c * 4096;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg)
+    out[(ib * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jb * 32 + i] = acc[reg];
+}
+
 // dT[c][i][j] = sum_r X[r][i] dY[r][j] over the rows of cloud c
 template <int KD>
 __global__ __launch_bounds__(256) void k_cloud_matmul_bwd_t(const float* __restrict__ X, int ldx,
