@@ -52,7 +52,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // fp64) - at 16 VALU ops and one v_rcp instead of the ~45 ops of the two-branch libm erff, which made the
 // rotation head VALU-bound (GELU phase as long as its 256x256 MFMA layer).
 __device__ __forceinline__ float erf_rational(float x) {
-  x = fminf(fmaxf(x, -4.f), 4.f);
+  x = __builtin_amdgcn_fmed3f(x, -4.f, 4.f);  // clamp in one op
   const float x2 = x * x;
   float p = fmaf(x2, -2.72614225801306e-10f, 2.77068142495902e-08f);
   p = fmaf(x2, p, -2.10102402082508e-06f);
@@ -83,7 +83,8 @@ __device__ __forceinline__ f32x2 splat2(float a) {
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 erf_rational2(f32x2 x) {
-  x = __builtin_elementwise_min(__builtin_elementwise_max(x, splat2(-4.f)), splat2(4.f));
+  x[0] = __builtin_amdgcn_fmed3f(x[0], -4.f, 4.f);  // no packed min/max on gfx950: med3 halves the clamp
+  x[1] = __builtin_amdgcn_fmed3f(x[1], -4.f, 4.f);
   const f32x2 x2 = x * x;
   f32x2 p = pk_fma(x2, splat2(-2.72614225801306e-10f), splat2(2.77068142495902e-08f));
   p = pk_fma(x2, p, splat2(-2.10102402082508e-06f));
