@@ -34,6 +34,35 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.catre_version()
 
 
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/catre_hip.h compiles as C99 (no C++, no torch types) and a C program that only
+    includes it links against libcatre_hip.so and can call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+
+    from catre_amd import hip
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = hip.LIB_PATH
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "catre_hip.h"\n'
+        "int main(void) {\n"
+        "  catre_opts o; memset(&o, 0, sizeof o);\n"
+        "  if (sizeof(catre_opts) != 68) return 2;\n"
+        "  if (catre_workspace_bytes(2, 1024, 1024) == 0) return 3;\n"
+        "  if (catre_refine_k(NULL, NULL, NULL, NULL, NULL, NULL, &o, NULL, NULL, NULL, 0, 2, 1024, 1024, 4, NULL) != CATRE_ERR_BAD_ARG) return 4;\n"
+        '  printf("%s %s\\n", catre_version(), catre_status_string(CATRE_ERR_WORKSPACE));\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{root}/include", str(src), "-o", str(exe),
+                    f"-L{os.path.dirname(lib)}", "-lcatre_hip", f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "catre_hip" in out and "workspace" in out.lower()
+
+
 def test_size_queries_without_gpu():
     lib = hip.load()
     assert lib.catre_workspace_bytes(0, 1024, 1024) == 0
