@@ -1327,6 +1327,9 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int k = 0; k < 3; ++k) gR[i * 3 + k] = dp[i * 4 + 0] * p0[k * 4 + 0] + dp[i * 4 + 1] * p0[k * 4 + 1] + dp[i * 4 + 2] * p0[k * 4 + 2];
+  // translation target (needed first: the allo -> ego rotation is a function of it)
+  const float t0[3] = {p0[3], p0[7], p0[11]};
+  float gt[3] = {dp[3], dp[7], dp[11]};
   // recompute x, y, z
   const float a[3] = {rot6d[b * 6 + 0], rot6d[b * 6 + 1], rot6d[b * 6 + 2]};
   const float bb[3] = {rot6d[b * 6 + 3], rot6d[b * 6 + 4], rot6d[b * 6 + 5]};
@@ -1336,6 +1339,78 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
   cross3(x, bb, w);
   const float nw = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
   const float z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};
+  if (o.is_allo) {
+    // ego = A(t') dR with A = quat2mat(axis-angle from the optical axis to t'), core/utils/utils.py:200-231.
+    // gR so far is dL/d ego:  dL/d dR = A^T gR,  dL/dA = gR dR^T -> q -> (angle, axis) -> ray -> t'.
+    const float d0 = dtr[b * 3] * o.delta_t_weight, d1 = dtr[b * 3 + 1] * o.delta_t_weight,
+                d2 = dtr[b * 3 + 2] * o.delta_t_weight;
+    float tt[3];
+    if (!o.delta_t_space_3d) {
+      const float zsrc = t0[2];
+      const float ztgt = o.delta_z_deepim ? zsrc / expf(d2) : d2 * zsrc;
+      const float fx = o.k_aware ? Ks[b * 9 + 0] : 1.f, fy = o.k_aware ? Ks[b * 9 + 4] : 1.f;
+      tt[0] = ztgt * (d0 / fx + t0[0] / zsrc);
+      tt[1] = ztgt * (d1 / fy + t0[1] / zsrc);
+      tt[2] = ztgt;
+    } else {
+      tt[0] = t0[0] + d0;
+      tt[1] = t0[1] + d1;
+      tt[2] = t0[2] + d2;
+    }
+    const float tn = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
+    const float nrm = tn + o.allo_eps;
+    const float ray[3] = {tt[0] / nrm, tt[1] / nrm, tt[2] / nrm};
+    const float angle = acosf(ray[2]);
+    const float axr[2] = {-ray[1], ray[0]};
+    const float axn = sqrtf(axr[0] * axr[0] + axr[1] * axr[1]);
+    const float an = axn + o.allo_eps;
+    const float ax[2] = {axr[0] / an, axr[1] / an};
+    const float sh = sinf(angle * 0.5f), chf = cosf(angle * 0.5f);
+    const float qr[4] = {chf, ax[0] * sh, ax[1] * sh, 0.f};
+    const float qn = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2]);
+    const float qw = qr[0] / qn, qx = qr[1] / qn, qy = qr[2] / qn, qz = 0.f;
+    const float A[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy),
+                        2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx),
+                        2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy)};
+    float yv[3];
+    cross3(z, x, yv);
+    const float dRm[9] = {x[0], yv[0], z[0], x[1], yv[1], z[1], x[2], yv[2], z[2]};  // columns (x, y, z)
+    float gA[9], gD[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gA[r * 3 + c] = gR[r * 3] * dRm[c * 3] + gR[r * 3 + 1] * dRm[c * 3 + 1] + gR[r * 3 + 2] * dRm[c * 3 + 2];
+        gD[r * 3 + c] = A[r] * gR[c] + A[3 + r] * gR[3 + c] + A[6 + r] * gR[6 + c];
+      }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gR[e] = gD[e];
+    // quat2mat backward (q normalised)
+    float gq[4];
+    gq[0] = 2.f * (-qz * gA[1] + qy * gA[2] + qz * gA[3] - qx * gA[5] - qy * gA[6] + qx * gA[7]);
+    gq[1] = 2.f * (qy * gA[1] + qz * gA[2] + qy * gA[3] - 2.f * qx * gA[4] - qw * gA[5] + qz * gA[6] + qw * gA[7] -
+                   2.f * qx * gA[8]);
+    gq[2] = 2.f * (-2.f * qy * gA[0] + qx * gA[1] + qw * gA[2] + qx * gA[3] + qz * gA[5] - qw * gA[6] + qz * gA[7] -
+                   2.f * qy * gA[8]);
+    gq[3] = 2.f * (-2.f * qz * gA[0] - qw * gA[1] + qx * gA[2] + qw * gA[3] - 2.f * qz * gA[4] + qy * gA[5] + qx * gA[6] +
+                   qy * gA[7]);
+    const float qg = qw * gq[0] + qx * gq[1] + qy * gq[2] + qz * gq[3];
+    const float gqr[3] = {(gq[0] - qw * qg) / qn, (gq[1] - qx * qg) / qn, (gq[2] - qy * qg) / qn};
+    const float g_angle = 0.5f * (-sh * gqr[0] + chf * (ax[0] * gqr[1] + ax[1] * gqr[2]));
+    const float gax[2] = {sh * gqr[1], sh * gqr[2]};
+    float gaxr[2] = {gax[0] / an, gax[1] / an};
+    if (axn > 0.f) {
+      const float k = (gax[0] * axr[0] + gax[1] * axr[1]) / (an * an * axn);
+      gaxr[0] -= k * axr[0];
+      gaxr[1] -= k * axr[1];
+    }
+    float gray[3] = {gaxr[1], -gaxr[0], 0.f};
+    const float sz = sqrtf(fmaxf(1.f - ray[2] * ray[2], 0.f));
+    if (sz > 0.f) gray[2] = -g_angle / sz;
+    const float rg = gray[0] * tt[0] + gray[1] * tt[1] + gray[2] * tt[2];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) gt[e] += gray[e] / nrm - (tn > 0.f ? rg * tt[e] / (nrm * nrm * tn) : 0.f);
+  }
   // columns: dR[:,0] = x, dR[:,1] = y = z cross x, dR[:,2] = z
   float gx[3] = {gR[0], gR[3], gR[6]}, gy[3] = {gR[1], gR[4], gR[7]}, gz[3] = {gR[2], gR[5], gR[8]};
   float t[3];
@@ -1366,8 +1441,6 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
   d_rot6d[b * 6 + 4] = gb[1];
   d_rot6d[b * 6 + 5] = gb[2];
   // translation
-  const float gt[3] = {dp[3], dp[7], dp[11]};
-  const float t0[3] = {p0[3], p0[7], p0[11]};
   float gd[3];
   if (!o.delta_t_space_3d) {
     const float d0 = dtr[b * 3] * o.delta_t_weight, d1 = dtr[b * 3 + 1] * o.delta_t_weight,

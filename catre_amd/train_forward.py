@@ -64,8 +64,6 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 
 def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None):
     """p: {state_dict key: live parameter}.  Returns (pose [B,3,4], scale [B,3], aux dict) - autograd-connected."""
-    if opts.is_allo:
-        raise NotImplementedError("training with allo_rot6d: the pose-update backward implements the ego rotation types")
     B, N, M = x.shape[0], x.shape[2], tfd_kps.shape[2]
     hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
     hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)

@@ -24,7 +24,7 @@ def _oracle_grads(g, sd, Gp, Gs, dtype=torch.float64):
 
 
 @pytest.mark.parametrize("name", ["refine_b2_small", "refine_b3_ragged", "refine_b2_kpsfeat_trans", "refine_b2_noft",
-                                  "refine_b2_deepim_noK"])
+                                  "refine_b2_deepim_noK", "refine_b2_allo"])
 def test_forward_train_and_all_param_grads(name):
     from catre_amd.batching import batch_updater_test
     from catre_amd.CATRE_disR_shared import build_model_optimizer

@@ -204,7 +204,8 @@ def test_gn_rows_gelu():
 
 @pytest.mark.parametrize("space,zstyle,ka,stype", [("image", "cosypose", True, "iter_add"), ("image", "deepim", False, "mean_mul"),
                                                    ("3D", "cosypose", True, "iter_add")])
-def test_pose_update_bwd(space, zstyle, ka, stype):
+@pytest.mark.parametrize("allo", [False, True])
+def test_pose_update_bwd(space, zstyle, ka, stype, allo):
     from catre_amd import hip
     from catre_amd import train_ops as T
     from oracle import catre_oracle as O
@@ -223,11 +224,12 @@ def test_pose_update_bwd(space, zstyle, ka, stype):
     o = hip.CatreOpts()
     o.delta_t_space_3d = int(space == "3D"); o.delta_z_deepim = int(zstyle != "cosypose"); o.k_aware = int(ka)
     o.scale_mul = int("add" not in stype); o.scale_base_mean = int("iter" not in stype); o.refine_scale = 1
-    o.delta_t_weight = 0.7; o.allo_eps = 1e-4
+    o.delta_t_weight = 0.7; o.allo_eps = 1e-4; o.is_allo = int(allo)
     pose, scale = T.pose_update_autograd(r6, dt, ds, pose0.to(DEV), s0.to(DEV), ms.to(DEV), K.to(DEV), o)
     Rr, tr, sr = O.pose_scale_from_delta_init(
         O.rot6d_to_mat_batch(r6r), dtr, dsr, R0.double(), t0.double(), (s0 if "iter" in stype else ms).double(),
-        Ks=K.double(), K_aware=ka, delta_T_space=space, delta_T_weight=0.7, delta_z_style=zstyle, scale_type=stype)
+        Ks=K.double(), K_aware=ka, delta_T_space=space, delta_T_weight=0.7, delta_z_style=zstyle, scale_type=stype,
+        is_allo=allo)
     _cmp(pose[:, :, :3], Rr, "R", atol=3e-6)
     _cmp(pose[:, :, 3], tr, "t", atol=3e-6)
     gp = torch.randn(B, 3, 4, generator=g)
