@@ -1646,6 +1646,19 @@ int catre_pcl_sample(const float* depth, const float* K9, const void* workspace,
   return check_launch();
 }
 
+// INPUT.FPS_SAMPLE: sample_idx_out [I][N] = farthest-point order of each instance's tiled candidate list (feed it to
+// catre_pcl_sample).  scratch: I * 4 * slot_cap floats, slot_cap >= the largest tiled list (count doubled until >= N).
+int catre_pcl_fps(const float* depth, const float* K9, const void* workspace, size_t ws_bytes, int I, int H, int W, int N,
+                  float* scratch, int slot_cap, long long* sample_idx_out, void* stream) {
+  REQUIRE(depth && K9 && workspace && scratch && sample_idx_out && I > 0 && H > 0 && W > 0 && N > 0 && slot_cap > 0);
+  const PclWs L = pcl_ws(I, H, W);
+  if (ws_bytes < L.total_ints * sizeof(int)) return CATRE_ERR_WORKSPACE;
+  const int* ws = (const int*)workspace;
+  hipLaunchKernelGGL(k_pcl_fps, dim3(I), dim3(1024), 0, (hipStream_t)stream, depth, pcl_cam(K9), H, W, ws + L.cand,
+                     ws + L.total, N, scratch, slot_cap, sample_idx_out);
+  return check_launch();
+}
+
 // ---- row f1: training loss ---------------------------------------------------------------------------------
 int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,

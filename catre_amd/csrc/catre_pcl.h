@@ -260,3 +260,112 @@ __global__ __launch_bounds__(256) void k_pcl_gather(const float* __restrict__ de
   o[2] = z;
   if (pix_out) pix_out[(size_t)inst * N + i] = pix;
 }
+
+// ------------------------------------------------------------------------------------------------
+// INPUT.FPS_SAMPLE: farthest point sampling of the (tiled) candidate list, as the data loader runs it -
+// crop_ball_from_pts(..., device="cpu", fps_sample=True) -> core/utils/farthest_points_torch.py:6-62 with
+// init_center=True and dist_func = F.pairwise_distance (|| a - b + 1e-6 ||_2):
+//   distances = d(mean(points), points);  N times: c = argmax(distances) (first maximum), distances = min(distances, d(points[c], points)).
+// One 1024-thread workgroup per instance; the tiled candidates' coordinates and running distances live in the
+// caller's scratch (4 floats per slot).  N >= L returns 0 .. L-1 like the reference.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pcl_pdist(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = (ax - bx) + 1e-6f, dy = (ay - by) + 1e-6f, dz = (az - bz) + 1e-6f;
+  return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+}
+
+__global__ __launch_bounds__(1024) void k_pcl_fps(const float* __restrict__ depth, PclCam cam, int H, int W,
+                                                  const int* __restrict__ cand, const int* __restrict__ total, int N,
+                                                  float* __restrict__ scratch, int Lcap,
+                                                  long long* __restrict__ sample_out) {
+  __shared__ float red_v[16];
+  __shared__ int red_i[16];
+  __shared__ float red_s[3][16];
+  __shared__ float cen[3];
+  const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cnt = total[inst];
+  long long* out = sample_out + (size_t)inst * N;
+  unsigned L = cnt > 0 ? (unsigned)cnt : 0u;
+  while (L && L < (unsigned)N) L <<= 1;
+  if (L == 0 || (unsigned)N >= L || L > (unsigned)Lcap) {  // nothing to choose from / everything is chosen
+    for (int i = tid; i < N; i += 1024) out[i] = L ? (long long)((unsigned)i % L) : 0;
+    return;
+  }
+  float* px = scratch + (size_t)inst * 4 * Lcap;
+  float* py = px + Lcap;
+  float* pz = py + Lcap;
+  float* dist = pz + Lcap;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (unsigned j = tid; j < L; j += 1024) {
+    float x, y, z;
+    pcl_point(depth, cand[(size_t)inst * H * W + (j % (unsigned)cnt)], W, cam, x, y, z);
+    px[j] = x;
+    py[j] = y;
+    pz[j] = z;
+    sx += x;
+    sy += y;
+    sz += z;
+  }
+  sx = wave_sum(sx);
+  sy = wave_sum(sy);
+  sz = wave_sum(sz);
+  if (lane == 0) {
+    red_s[0][wave] = sx;
+    red_s[1][wave] = sy;
+    red_s[2][wave] = sz;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red_s[tid][w];
+    cen[tid] = t / (float)L;
+  }
+  __syncthreads();
+  {
+    const float cx = cen[0], cy = cen[1], cz = cen[2];
+    for (unsigned j = tid; j < L; j += 1024) dist[j] = pcl_pdist(cx, cy, cz, px[j], py[j], pz[j]);
+  }
+  for (int it = 0; it < N; ++it) {
+    // arg-max with "first maximum wins": per thread in increasing j, then (value, index) pairs
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (unsigned j = tid; j < L; j += 1024) {
+      const float v = dist[j];
+      if (v > bv) {
+        bv = v;
+        bi = (int)j;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      red_v[wave] = bv;
+      red_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float v = red_v[0];
+      int i = red_i[0];
+      for (int w = 1; w < 16; ++w)
+        if (red_v[w] > v || (red_v[w] == v && red_i[w] < i)) {
+          v = red_v[w];
+          i = red_i[w];
+        }
+      out[it] = i;
+      cen[0] = px[i];
+      cen[1] = py[i];
+      cen[2] = pz[i];
+    }
+    __syncthreads();
+    const float cx = cen[0], cy = cen[1], cz = cen[2];
+    for (unsigned j = tid; j < L; j += 1024) dist[j] = fminf(dist[j], pcl_pdist(cx, cy, cz, px[j], py[j], pz[j]));
+    __syncthreads();
+  }
+}

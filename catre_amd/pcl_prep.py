@@ -35,8 +35,6 @@ def sample_instances(depth, K, masks, poses=None, scales=None, ratio=0.5, num_po
     poses [I,3,4], scales [I,3] -> pcl [I,num_points,3] (+ flat pixel indices [I,num_points] with ``return_pixels``).
     ``use_ball=True`` = ``crop_ball_from_depth_image`` (``INPUT.SAMPLE_DEPTH_FROM_BALL``), ``False`` =
     ``crop_mask_depth_image``."""
-    if fps_sample:
-        raise NotImplementedError("INPUT.FPS_SAMPLE=True (farthest point sampling) is not implemented on the device path")
     if sample not in ("host", "device"):
         raise ValueError(f"sample={sample!r}: expected 'host' or 'device'")
     lib = hip.load()
@@ -68,7 +66,23 @@ def sample_instances(depth, K, masks, poses=None, scales=None, ratio=0.5, num_po
                                        int(bool(use_ball)), I, H, W, hip.ptr(ws), nbytes, hip.ptr(counts), st),
               "catre_pcl_candidates")
     sidx = None
-    if sample == "host":
+    if fps_sample:
+        # INPUT.FPS_SAMPLE: farthest point sampling of the tiled candidate list (cat_data_utils.py:305-306 with
+        # device="cpu" as the data loader passes -> farthest_points_torch.py:6-62), one workgroup per instance
+        cl = counts.cpu().tolist()
+        if min(cl) == 0:
+            raise ValueError("an instance has no masked pixel with depth > 0")
+        cap = 0
+        for c in cl:
+            L = c
+            while L < num_points:
+                L *= 2
+            cap = max(cap, L)
+        scratch = torch.empty(I * 4 * cap, dtype=torch.float32, device=dev)
+        sidx = torch.empty(I, num_points, dtype=torch.int64, device=dev)
+        hip.check(lib.catre_pcl_fps(hip.ptr(depth), k9, hip.ptr(ws), nbytes, I, H, W, num_points, hip.ptr(scratch), cap,
+                                    hip.ptr(sidx), st), "catre_pcl_fps")
+    elif sample == "host":
         rows = []
         for c in counts.cpu().tolist():  # instance order = the data loader's loop order
             if c == 0:

@@ -358,6 +358,12 @@ int catre_pcl_candidates(const float* depth, const float* K9, const unsigned cha
 int catre_pcl_sample(const float* depth, const float* K9, const void* workspace, size_t ws_bytes,
                      const long long* sample_idx, unsigned long long seed, int I, int H, int W, int N, float* pcl_out,
                      int32_t* pix_out, void* stream);
+/* INPUT.FPS_SAMPLE (crop_ball_from_pts(..., fps_sample=True), core/utils/cat_data_utils.py:305-306 ->
+ * core/utils/farthest_points_torch.py:6-62, init_center=True, pairwise_distance): farthest-point order of each
+ * instance's tiled candidate list -> sample_idx_out [I][N] for catre_pcl_sample.  scratch: I * 4 * slot_cap floats
+ * with slot_cap >= the largest tiled list (count doubled until >= N). */
+int catre_pcl_fps(const float* depth, const float* K9, const void* workspace, size_t ws_bytes, int I, int H, int W, int N,
+                  float* scratch, int slot_cap, long long* sample_idx_out, void* stream);
 
 /* ---- the training loss on the device --------------------------------------------------- */
 

@@ -341,6 +341,19 @@ def make_pcl_golden(seed=11, N=96):
             assert np.abs(_np(got) - out[f"{mode}_pcl"][i]).max() < 1e-7, (mode, i)
         out[f"{mode}_counts"] = np.array(cnt, dtype=np.int64)
         out[f"{mode}_sample_idx"] = _np(torch.stack(sidx)).astype(np.int64)
+    # INPUT.FPS_SAMPLE: the reference's ball crop with farthest point sampling (deterministic: no random draw)
+    fps_pcl, fps_idx = [], []
+    for i in range(I):
+        _, pcl, _ = CU.crop_ball_from_depth_image(image, depth_bp, masks[i], poses[i], scales[i], ratio=0.5,
+                                                  cam_intrinsics=K, num_points=N, device="cpu", fps_sample=True)
+        pix, bp = PO.candidates(depth, K, masks[i], poses[i], scales[i], 0.5, use_ball=True)
+        s = PO.fps_sample_idx(pix, bp, N)
+        got, _ = PO.sample(pix, bp, s)
+        assert pcl.shape[0] >= N and np.abs(_np(got) - _np(pcl[:N].to(torch.float32))).max() < 1e-7, ("fps", i)
+        fps_pcl.append(pcl[:N].to(torch.float32))
+        fps_idx.append(s)
+    out["fps_pcl"] = _np(torch.stack(fps_pcl))
+    out["fps_sample_idx"] = _np(torch.stack(fps_idx)).astype(np.int64)
     path = os.path.join(GOLDEN_DIR, "pcl_prep.npz")
     np.savez_compressed(path, **out)
     print(f"pcl: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); ball counts {out['ball_counts']}, mask counts {out['mask_counts']}")

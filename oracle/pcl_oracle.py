@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure only) - restatement of the reference's per-instance point-cloud preparation:
 ``backproject_th`` (``lib/pysixd/misc.py:360-378``), ``sample_bp_depth`` (``core/utils/cat_data_utils.py:209-226``),
 ``crop_ball_from_pts`` (``:289-320``), ``crop_ball_from_depth_image`` (``:380-400``) and ``crop_mask_depth_image``
-(``:352-377``), with the ``torch.randperm`` draw made explicit.  Pinned by ``tests/golden/pcl_prep.npz``."""
+(``:352-377``), with the ``torch.randperm`` draw made explicit, and the farthest point sampling the data loader uses
+with ``INPUT.FPS_SAMPLE`` (``core/utils/farthest_points_torch.py:6-62``).  Pinned by ``tests/golden/pcl_prep.npz``."""
 import torch
 
 
@@ -49,3 +50,27 @@ def sample(pix, bp, sample_idx):
         return torch.zeros(len(sample_idx), 3, dtype=bp.dtype), torch.full((len(sample_idx),), -1, dtype=torch.long)
     sel = pix[sample_idx % len(pix)]
     return bp[sel], sel
+
+
+def farthest_points(points, n):
+    """``farthest_points(data, n_clusters=n, dist_func=F.pairwise_distance, init_center=True)`` of
+    ``core/utils/farthest_points_torch.py:6-62`` as ``crop_ball_from_pts`` calls it with ``device="cpu"``
+    (``cat_data_utils.py:305-306, 331-341``): -> the n centre indices in the order they are picked."""
+    import torch.nn.functional as F
+
+    if n >= points.shape[0]:
+        return torch.arange(points.shape[0], dtype=torch.long)
+    dist = F.pairwise_distance(points.mean(0, keepdim=True).expand(points.shape[0], -1), points)
+    picks = torch.zeros(n, dtype=torch.long)
+    for i in range(n):
+        c = torch.argmax(dist)
+        picks[i] = c
+        dist = torch.min(dist, F.pairwise_distance(points[c].unsqueeze(0).expand(points.shape[0], -1), points))
+    return picks
+
+
+def fps_sample_idx(pix, bp, num_points):
+    """slot indices into the tiled candidate list that ``crop_ball_from_pts(..., fps_sample=True)`` selects."""
+    L = tiled_length(len(pix), num_points)
+    slots = torch.arange(L) % len(pix)
+    return farthest_points(bp[pix[slots]], num_points)

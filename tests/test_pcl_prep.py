@@ -41,6 +41,55 @@ def test_pcl_oracle_matches_reference_functions():
     assert c[1] < c[0] and c[3] == g["mask_counts"][3] and c[4] < N
 
 
+def test_fps_oracle_matches_reference_farthest_point_sampling():
+    """INPUT.FPS_SAMPLE: the golden holds crop_ball_from_depth_image(..., device="cpu", fps_sample=True) of the
+    reference; the scene covers plain lists, lists tiled x2 (61 -> 122) and x16 (11 -> 176: duplicated points, i.e.
+    exact distance ties that only "first maximum wins" resolves like torch.argmax)."""
+    g = _g()
+    depth, K, masks, poses, scales = _scene(g)
+    N = int(g["meta"][0])
+    for i in range(len(masks)):
+        pix, bp = PO.candidates(depth, K, masks[i], poses[i], scales[i], 0.5, use_ball=True)
+        s = PO.fps_sample_idx(pix, bp, N)
+        assert s.tolist() == g["fps_sample_idx"][i].tolist()
+        got, _ = PO.sample(pix, bp, s)
+        assert np.abs(got.numpy() - g["fps_pcl"][i]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_hip_fps_sampling_matches_reference():
+    """Device farthest point sampling (k_pcl_fps) picks the reference's points in the reference's order."""
+    from catre_amd import pcl_prep
+
+    g = _g()
+    depth, K, masks, poses, scales = _scene(g, DEV)
+    N = int(g["meta"][0])
+    pcl, pix, counts = pcl_prep.sample_instances(depth, K, masks, poses, scales, ratio=0.5, num_points=N, use_ball=True,
+                                                 fps_sample=True, return_pixels=True)
+    assert counts.cpu().tolist() == g["ball_counts"].tolist()
+    assert np.abs(pcl.cpu().numpy() - g["fps_pcl"]).max() < 1e-6
+    # the single-instance signature of the reference
+    rgb, pts, nocs = pcl_prep.crop_ball_from_depth_image(None, depth, masks[0], poses[0], scales[0], 0.5, K, num_points=N,
+                                                         fps_sample=True)
+    assert np.abs(pts.cpu().numpy() - g["fps_pcl"][0]).max() < 1e-6
+    # a full-size frame: distinct pixels while the list is long enough, deterministic, and greedy-farthest
+    from catre_amd import synth
+
+    sc = synth.make_depth_scene(seed=5, H=480, W=640, n_inst=3)
+    d, Kb = sc["depth"].to(DEV), sc["K"]
+    m, p, s = sc["masks"].to(DEV), sc["poses"].to(DEV), sc["scales"].to(DEV)
+    a, pa, ca = pcl_prep.sample_instances(d, Kb, m, p, s, num_points=1024, fps_sample=True, return_pixels=True)
+    b, _, _ = pcl_prep.sample_instances(d, Kb, m, p, s, num_points=1024, fps_sample=True, return_pixels=True)
+    assert torch.equal(a, b)
+    for i, c in enumerate(ca.cpu().tolist()):
+        if c >= 1024:
+            assert len(set(pa[i].cpu().tolist())) == 1024
+        pts_i = a[i].cpu().double()
+        # pick k+1 is the farthest remaining point from picks 0..k: its distance to them is >= every later pick's
+        dmin = torch.cdist(pts_i[1:9], pts_i[:1]).min(1)[0]
+        assert dmin[0] >= dmin[1:].max() - 1e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["ball", "mask"])
 def test_hip_pcl_prep_matches_reference_with_its_random_draws(mode):
@@ -143,8 +192,6 @@ def test_hip_device_sampling_properties_and_full_frame():
     pix0, bp = PO.candidates(sc["depth"], Kf, sc["masks"][0], sc["poses"][0], sc["scales"][0], 0.5)
     ref, _ = PO.sample(pix0, bp, torch.randperm(PO.tiled_length(len(pix0), 256))[:256])
     assert np.abs(pts.cpu().numpy() - ref.numpy()).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        pcl_prep.sample_instances(d, Kf, sc["masks"].to(DEV), sc["poses"].to(DEV), sc["scales"].to(DEV), fps_sample=True)
     empty = torch.zeros(1, 480, 640, dtype=torch.bool, device=DEV)
     with pytest.raises(ValueError):
         pcl_prep.sample_instances(d, Kf, empty, sc["poses"][:1].to(DEV), sc["scales"][:1].to(DEV), sample="host")
