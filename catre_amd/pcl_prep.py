@@ -29,6 +29,14 @@ def _k9(K):
     return (ctypes.c_float * 9)(*[float(v) for v in K.reshape(-1)])
 
 
+def _random_sample(n, npoint):
+    """``random_sample`` of the reference (``cat_data_utils.py:322-329``), same random stream."""
+    idx = torch.randperm(n)[:npoint]
+    while len(idx) < npoint:
+        idx = torch.cat((idx, _random_sample(n, npoint - len(idx))), dim=0)
+    return idx
+
+
 def sample_instances(depth, K, masks, poses=None, scales=None, ratio=0.5, num_points=1024, use_ball=True, sample="host",
                      seed=0, fps_sample=False, return_pixels=False):
     """depth [H,W] (device fp32, metres), K 3x3, masks [I,H,W] bool/uint8 (or None: whole frame, I from poses),
@@ -88,12 +96,13 @@ def sample_instances(depth, K, masks, poses=None, scales=None, ratio=0.5, num_po
             if c == 0:
                 # the reference recurses with a 1.2x larger ratio for ever here (cat_data_utils.py:390-393)
                 raise ValueError("an instance has no masked pixel with depth > 0")
-            if not use_ball and c < num_points:
-                raise NotImplementedError("crop_mask_depth_image with fewer masked pixels than NUM_PCL: use sample='device'")
-            L = c
-            while L < num_points:
-                L *= 2
-            rows.append(torch.randperm(L)[:num_points])  # random_sample, cat_data_utils.py:322-329
+            if use_ball:  # the candidate list is tiled until it holds num_points entries, then one permutation
+                L = c
+                while L < num_points:
+                    L *= 2
+                rows.append(torch.randperm(L)[:num_points])  # cat_data_utils.py:301-309, 322-329
+            else:        # crop_mask_depth_image: random_sample tops a short list up with further permutations
+                rows.append(_random_sample(c, num_points))
         sidx = torch.stack(rows).to(dev)
     pcl = torch.empty(I, num_points, 3, dtype=torch.float32, device=dev)
     pix = torch.empty(I, num_points, dtype=torch.int32, device=dev) if return_pixels else None

@@ -321,10 +321,7 @@ def make_pcl_golden(seed=11, N=96):
                 _, pcl, _ = CU.crop_ball_from_depth_image(image, depth_bp, masks[i], poses[i], scales[i], ratio=0.5,
                                                           cam_intrinsics=K, num_points=N, device="cpu", fps_sample=False)
             else:
-                if int((masks[i] & (depth > 0)).sum()) < N:   # the reference recursion draws several permutations here
-                    pcl = torch.zeros(N, 3)
-                else:
-                    _, pcl, _ = CU.crop_mask_depth_image(image, depth_bp, masks[i], num_points=N)
+                _, pcl, _ = CU.crop_mask_depth_image(image, depth_bp, masks[i], num_points=N)
             ref.append(pcl.to(torch.float32))
         out[f"{mode}_pcl"] = _np(torch.stack(ref))
         torch.manual_seed(seed)
@@ -332,10 +329,8 @@ def make_pcl_golden(seed=11, N=96):
         for i in range(I):
             pix, bp = PO.candidates(depth, K, masks[i], poses[i], scales[i], 0.5, use_ball=ball)
             cnt.append(len(pix))
-            if not ball and len(pix) < N:
-                sidx.append(torch.zeros(N, dtype=torch.long))
-                continue
-            s = torch.randperm(PO.tiled_length(len(pix), N))[:N]
+            # ball crop: one permutation of the tiled list; mask crop: random_sample, which tops a short list up
+            s = torch.randperm(PO.tiled_length(len(pix), N))[:N] if ball else PO.random_sample_idx(len(pix), N)
             sidx.append(s)
             got, _ = PO.sample(pix, bp, s)
             assert np.abs(_np(got) - out[f"{mode}_pcl"][i]).max() < 1e-7, (mode, i)

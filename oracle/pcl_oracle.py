@@ -44,6 +44,15 @@ def tiled_length(count, num_points):
     return L
 
 
+def random_sample_idx(n, npoint):
+    """``random_sample`` (``cat_data_utils.py:322-329``): a random permutation cut to npoint; a list shorter than
+    npoint is topped up by further (recursive) draws - each consuming one ``torch.randperm(n)``."""
+    idx = torch.randperm(n)[:npoint]
+    while len(idx) < npoint:
+        idx = torch.cat((idx, random_sample_idx(n, npoint - len(idx))), dim=0)
+    return idx
+
+
 def sample(pix, bp, sample_idx):
     """``idx`` doubled until it holds num_points entries, then ``idx[sample_idx]`` (:309-319)."""
     if len(pix) == 0:
