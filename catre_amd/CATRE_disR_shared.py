@@ -20,7 +20,6 @@ import torch.nn as nn
 from . import hip
 from .model_utils import get_rot_head, get_ts_head
 from .net_factory import PCLNETS
-from .pointnet import _no_grad_only
 from .runtime import HipRuntime, opts_from_cfg
 
 logger = logging.getLogger(__name__)

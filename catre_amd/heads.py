@@ -1,4 +1,7 @@
-"""Residual heads of the CATRE hot path - parameter containers (HIP forward lives in the fused driver).
+"""Residual heads of the CATRE hot path.  Inside ``CATRE_disR_shared.forward`` they are evaluated by the fused
+driver (the concatenated feature tensors are never built); called on their own - the reference's module interface,
+``heads/conv_out_per_rot_head.py:62-71,126-140`` and ``fc_trans_size_head.py:61-70`` on a materialised feature tensor -
+they run layer by layer on the HIP training ops (``catre_amd/train_ops.py``), autograd included.
 
 Mirrors ``core/catre/models/heads/conv_out_per_rot_head.py`` and ``fc_trans_size_head.py``:
 same class names, constructor kwargs, ModuleList indices (``layers.0/1/3/4``, ``linears.0/1/3/4``),
@@ -6,13 +9,6 @@ never-used ``norm`` GroupNorm, and initialisation (N(0, 0.001^2) conv/linear wei
 GN weight 1; ``fc_t``/``fc_s`` N(0, 0.01^2)), so reference checkpoints load ``strict=True``.
 """
 import torch.nn as nn
-
-_FUSED_ONLY = (
-    "{cls}.forward on its own takes the materialised feature tensor ({what}) that the fused MI355X path never "
-    "builds (SURVEY.md a6/a7: the repeated global feature is folded into a per-cloud bias).  It is evaluated "
-    "inside CATRE_disR_shared.forward / catre_rot_head / catre_ts_head."
-)
-
 
 def _normal_init(m, std):
     nn.init.normal_(m.weight, 0.0, std)
@@ -70,7 +66,19 @@ class RotHead(nn.Module):
                 nn.init.constant_(m.bias, 0.0)
 
     def forward(self, x):
-        raise NotImplementedError(_FUSED_ONLY.format(cls="RotHead", what="[B,1088,N+M]"))
+        """x [B,1088,P] -> [B,3]: conv -> GN -> GELU -> conv -> GN -> GELU -> neck -> conv_p over the points."""
+        from . import train_ops as T
+
+        B, C, P = x.shape
+        if P != self.conv_p.in_channels:
+            raise ValueError(f"RotHead was built for {self.conv_p.in_channels} points, got {P}")
+        rows = x.permute(0, 2, 1).reshape(B * P, C)
+        y = T.linear(rows, self.layers[0].weight, self.layers[0].bias)
+        a = T.gn_points_gelu(y, self.layers[1].weight, self.layers[1].bias, B, P)
+        y = T.linear(a, self.layers[3].weight, self.layers[3].bias)
+        a = T.gn_points_gelu(y, self.layers[4].weight, self.layers[4].bias, B, P)
+        y3 = T.linear(a, self.neck[0].weight, self.neck[0].bias)
+        return T.weighted_point_sum(y3, self.conv_p.weight, self.conv_p.bias, B, P)
 
 
 class ConvOutPerRotHead(nn.Module):
@@ -90,7 +98,9 @@ class ConvOutPerRotHead(nn.Module):
         self.num_points = num_points
 
     def forward(self, x):
-        raise NotImplementedError(_FUSED_ONLY.format(cls="ConvOutPerRotHead", what="[B,1088,N+M]"))
+        import torch
+
+        return torch.cat([self.rot_head_x(x), self.rot_head_y(x)], dim=1)  # rot6d [B,6] (:63-66)
 
 
 class FC_TransSizeHead(nn.Module):
@@ -128,4 +138,11 @@ class FC_TransSizeHead(nn.Module):
         _normal_init(self.fc_s, 0.01)
 
     def forward(self, x):
-        raise NotImplementedError(_FUSED_ONLY.format(cls="FC_TransSizeHead", what="[B,1091]"))
+        """x [B,in_dim] -> (trans deltas [B,3], scale deltas [B,3])."""
+        from . import train_ops as T
+
+        h = T.linear(x.flatten(1), self.linears[0].weight, self.linears[0].bias)
+        h = T.gn_rows_gelu(h, self.linears[1].weight, self.linears[1].bias)
+        h = T.linear(h, self.linears[3].weight, self.linears[3].bias)
+        h = T.gn_rows_gelu(h, self.linears[4].weight, self.linears[4].bias)
+        return T.linear(h, self.fc_t.weight, self.fc_t.bias), T.linear(h, self.fc_s.weight, self.fc_s.bias)

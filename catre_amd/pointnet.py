@@ -4,19 +4,14 @@ Mirrors the reference's ``core/catre/models/pointnets/pointnet.py`` surface (cla
 constructor kwargs, sub-module / parameter names, default torch initialisation) so that
 reference checkpoints load with ``strict=True``.  The arithmetic of ``forward`` runs in
 ``libcatre_hip.so``; inside ``CATRE_disR_shared.forward`` these modules are never called -
-the fused refine-iteration driver reads their parameters directly.
+the fused refine-iteration driver reads their parameters directly.  Called on their own they take the fused
+kernels when nothing needs a gradient and the layer-wise HIP training ops (``train_forward.py``) otherwise.
 """
 import torch
 import torch.nn as nn
 
 from . import hip
 from .runtime import HipRuntime
-
-_FUSED_ONLY = (
-    "{cls}.forward on its own consumes an arbitrary [B,{c},N] activation, which the fused MI355X path never "
-    "materialises (it is produced and consumed inside one kernel).  Call PointNetfeat / CATRE_disR_shared instead."
-)
-
 
 class STN3d(nn.Module):
     """Input transform net (reference pointnet.py:13-41)."""
@@ -41,7 +36,8 @@ class STN3d(nn.Module):
         """x [B,3,N] -> [B,3,3] (conv stack + max-pool + FC tail + identity)."""
         if self._rt is None:
             self._rt = HipRuntime(lambda: {f"pcl_net.stn.{k}": v for k, v in self.named_parameters()}, 1, 1, 1)
-        _no_grad_only(self, x)
+        if _needs_grad(self, x):
+            return _stn_rows(self, x, 3)
         lib = hip.load()
         import ctypes
 
@@ -71,19 +67,25 @@ class STNkd(nn.Module):
         self.k = k
 
     def forward(self, x):
-        raise NotImplementedError(_FUSED_ONLY.format(cls="STNkd", c=self.k))
+        """x [B,k,N] -> [B,k,k]: on its own the feature transform net consumes a materialised activation, so it runs
+        layer by layer on the HIP training ops (inside PointNetfeat / the fused path it never sees HBM)."""
+        return _stn_rows(self, x, self.k)
 
 
-def _no_grad_only(module, *tensors):
-    if torch.is_grad_enabled() and (
+def _needs_grad(module, *tensors):
+    return torch.is_grad_enabled() and (
         any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor))
         or any(p.requires_grad for p in module.parameters())
-    ):
-        raise NotImplementedError(
-            "catre_amd round 1 ships the forward (inference) kernels; call under torch.no_grad(). "
-            "Backward kernels are SURVEY.md section 7 step 6 (not built yet) - there is deliberately no autograd "
-            "fallback through PyTorch ops."
-        )
+    )
+
+
+def _stn_rows(module, x, k):
+    from .train_forward import _stn
+
+    B, n = x.shape[0], x.shape[2]
+    hip.require_dev_f32(x, "x", (B, k, n), contiguous=False)
+    rows = x.permute(0, 2, 1).reshape(B * n, k).contiguous()
+    return _stn(rows, {f"m.{name}": v for name, v in module.named_parameters()}, "m", k, B, n, 0)
 
 
 class PointNetfeat(nn.Module):
@@ -118,9 +120,16 @@ class PointNetfeat(nn.Module):
 
     def forward(self, x, **args):
         """x [B,3,n] -> [B,1024] (global_feat) or [B,1088,n] = cat(global repeated, pointfeat)."""
-        _no_grad_only(self, x)
         n_pts = x.shape[2]
-        st = self._runtime().stage_pointnet(x, None, self.feature_transform)
+        if _needs_grad(self, x):
+            from .train_forward import _points_rows, pointnet_rows
+
+            hip.require_dev_f32(x, "x", (x.shape[0], 3, n_pts), contiguous=False)
+            g, pf = pointnet_rows(_points_rows(x), {f"m.{k}": v for k, v in self.named_parameters()}, x.shape[0], n_pts, 0,
+                                  self.feature_transform, prefix="m")
+            st = {"gfeat": g, "pointfeat": pf}
+        else:
+            st = self._runtime().stage_pointnet(x, None, self.feature_transform)
         g = st["gfeat"][:, : self.out_dim]
         if self.global_feat:
             return g.contiguous()

@@ -210,6 +210,52 @@ def test_split_training_iteration_matches_fp32():
     print(f"worst relative L2 gradient deviation: {worst:.2e}")
 
 
+def test_modules_called_on_their_own_run_and_differentiate():
+    """The registry modules keep the reference's module interface: PointNetfeat / STN3d / STNkd / ConvOutPerRotHead /
+    FC_TransSizeHead called directly (materialised feature tensors, grad mode) run on the layer-wise HIP ops and agree
+    with the oracle, values and gradients."""
+    from oracle import catre_oracle as O
+    from tests.test_hip_parity import build_model
+
+    g = load_golden("refine_b2_small")
+    cfg = g["cfg"].__deepcopy__({})
+    cfg.MODEL.DEVICE = DEV
+    model, sd = build_model(cfg, g["salt"])
+    model.train()
+    B, N, M = g["B"], g["N"], g["M"]
+    x, k = O.pose_apply(g["batch"]["pcl"], g["batch"]["obj_kps"], g["batch"]["obj_pose_est"], g["batch"]["obj_scale_est"])
+    sdd = {kk: v.double().requires_grad_(True) for kk, v in sd.items()}
+    # PointNetfeat (grad mode) and the two STNs
+    feat = model.pcl_net(x.to(DEV))
+    want = O.pointnet_feat(x.double(), sdd)
+    assert feat.requires_grad and np.abs(feat.detach().cpu().numpy() - want.detach().numpy()).max() <= 2e-5
+    tr = model.pcl_net.stn(x.to(DEV))
+    wtr, _ = O.stn(x.double(), sdd, "pcl_net.stn", 3)
+    assert np.abs(tr.detach().cpu().numpy() - wtr.detach().numpy()).max() <= 2e-5
+    h = torch.randn(B, 64, N, generator=torch.Generator().manual_seed(1))
+    tf = model.pcl_net.fstn(h.to(DEV))
+    wtf, _ = O.stn(h.double(), sdd, "pcl_net.fstn", 64)
+    assert np.abs(tf.detach().cpu().numpy() - wtf.detach().numpy()).max() <= 2e-5
+    # heads on a materialised [B,1088,N+M] / [B,1091] feature
+    kf = O.pointnet_feat(k.double(), sdd)
+    rot_feat = torch.cat([want, kf], dim=2).detach()
+    r6 = model.rot_head(rot_feat.float().to(DEV))
+    wr6 = O.rot_head(rot_feat, sdd)
+    assert r6.shape == (B, 6) and np.abs(r6.detach().cpu().numpy() - wr6.detach().numpy()).max() <= 2e-5
+    ts_in = torch.randn(B, model.ts_head.in_dim, generator=torch.Generator().manual_seed(2))
+    dt, ds = model.ts_head(ts_in.to(DEV))
+    wdt, wds = O.ts_head(ts_in.double(), sdd)
+    assert np.abs(dt.detach().cpu().numpy() - wdt.detach().numpy()).max() <= 2e-5
+    assert np.abs(ds.detach().cpu().numpy() - wds.detach().numpy()).max() <= 2e-5
+    (r6.sum() + dt.sum() + ds.sum()).backward()
+    (wr6.sum() + wdt.sum() + wds.sum()).backward()
+    for name in ("rot_head.rot_head_x.layers.0.weight", "rot_head.rot_head_y.conv_p.weight", "ts_head.linears.0.weight",
+                 "ts_head.fc_s.bias"):
+        got = dict(model.named_parameters())[name].grad.cpu().double()
+        ref = sdd[name].grad
+        assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, name
+
+
 def test_ddp_world1_wraps_and_steps():
     """The reference wraps the model in DistributedDataParallel(find_unused_parameters=True)
     (core/catre/main_catre.py:154-160); world_size 1 over RCCL exercises the reducer hooks on the HIP gradients."""
