@@ -278,6 +278,25 @@ def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtyp
             assert torch.equal(out[key], ref[key][:nb]), (dtype, nb, key)
 
 
+def test_batches_past_2_to_the_31_elements_index_correctly():
+    """B=2100 at N=M=1024: the rot-head activation buffer holds 2100 x 2 x 2048 x 256 = 2.2e9 floats (> 2^31), the
+    workspace 11.7 GB - offsets must be 64-bit everywhere.  Objects of the big batch equal the same objects run alone,
+    bit for bit."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+
+    cfg = default_cfg()
+    model, _ = build_model(cfg, 0)
+    B = 2100
+    batch = to_dev(synth.make_inputs(B, 1024, 1024, seed=31))
+    out = model.refine(batch, n_iter=1)
+    assert torch.isfinite(out["pose_1"]).all()
+    idx = torch.tensor([0, 1, B // 2, B - 2, B - 1], device=DEV)
+    sub = {k: v[idx].contiguous() for k, v in batch.items()}
+    alone = model.refine(sub, n_iter=1)
+    assert torch.equal(alone["pose_1"], out["pose_1"][idx]) and torch.equal(alone["scale_1"], out["scale_1"][idx])
+
+
 def test_errors():
     from catre_amd import hip
     from catre_amd.config import default_cfg
