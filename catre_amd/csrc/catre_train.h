@@ -31,6 +31,18 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 // gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
 // wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "normal" orientation: 4 consecutive channels/lane.
 // ------------------------------------------------------------------------------------------------
+// optional per-cloud bias of the row GEMMs (rot-head layer 0: the global-feature half of the 1088 -> 256 conv is a bias
+// that depends on the cloud a row belongs to): rows object-major [N observed | M prior] per object, N and M multiples
+// of 64, bias [2B][J].  B == 0: plain bias [J].
+struct CloudBias {
+  int B, N, M;
+};
+__device__ __forceinline__ const float* cloud_bias(const float* bias, CloudBias cb, int r0, int J) {
+  if (cb.B <= 0 || !bias) return bias;
+  const int P = cb.N + cb.M, obj = r0 / P, within = r0 - obj * P;
+  return bias + (size_t)(within < cb.N ? obj : cb.B + obj) * J;
+}
+
 // epilogue shared by the fp32 and bf16-operand row GEMMs: bias / ReLU / output mask -> Y, or (MAXP) the per-tile
 // max / arg-max over the 64 rows
 template <int MB, bool MAXP>
@@ -113,7 +125,7 @@ template <int MB, int NKC, bool MAXP = false>
 __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
-                                                   int relu, const float* __restrict__ xmask, int ldxm) {
+                                                   int relu, const float* __restrict__ xmask, int ldxm, CloudBias cb) {
   constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
   constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
   __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     }
   }
   if (!active) return;
-  gemm_rows_epilogue<MB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,7 +190,7 @@ template <int MB, int CP, bool MAXP>
 __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
-                                                      const float* __restrict__ xmask, int ldxm) {
+                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   __shared__ u32x4 xs[TP * CP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   GemmPipeB<MB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1), 1> g;
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
-  gemm_rows_epilogue<MB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
 }
 
 // ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
@@ -235,7 +247,7 @@ template <int MB, int CP, bool MAXP>
 __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
-                                                      const float* __restrict__ xmask, int ldxm) {
+                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   constexpr int PMB = MB >= 2 ? 2 : 1;
   __shared__ u32x4 xs[2][TP * CP];
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
     GemmPipeS<PMB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1)> g;
     g.prefetch(Wp + ((size_t)(blk0 + wave) * NKC) * 64 + lane, 8 * NKC * 64, lo_off);
     g.run(acc, xs[0], xs[1], lane);
-    gemm_rows_epilogue<PMB, MAXP>(acc, bias, mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0);
+    gemm_rows_epilogue<PMB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0);
   }
 }
 

@@ -53,8 +53,7 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     P = N + M
     W0 = w("layers.0.weight").reshape(256, 1088)
     bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))       # [2B,256]: global half + conv bias
-    y = T.linear(pf_obj, W0[:, 1024:].contiguous(), None)                    # [B*P,256]
-    y = T.rowbias_add(y, bias0, B, N, M)
+    y = T.linear_cloudbias(pf_obj, W0[:, 1024:].contiguous(), bias0, B, N, M)  # [B*P,256], bias per cloud in the epilogue
     a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P)
     y = T.linear(a, w("layers.3.weight"), w("layers.3.bias"))
     a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P)

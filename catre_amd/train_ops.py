@@ -393,6 +393,63 @@ class _RowBias(torch.autograd.Function):
         return dy, db, None, None, None
 
 
+class _LinearCloudBias(torch.autograd.Function):
+    """y = x W^T + bias[cloud(row)] in one kernel (the per-cloud bias is the GEMM's epilogue) - rot-head layer 0, where
+    the global-feature half of the 1088 -> 256 conv is a bias per cloud.  Backward: dbias = per-cloud column sums of dy,
+    dx / dW like a plain linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, B, N, M):
+        lib = hip.load()
+        w2 = _c(w.reshape(w.shape[0], -1))
+        J, K = w2.shape
+        amp = _amp()
+        if amp and K not in (64, 128, 256, 512):
+            amp = 0
+        xc, bc = _c(x), _c(bias)
+        if amp == 1:
+            wp = _pack_bf16(w2, J, K, x.device)
+        elif amp == 2:
+            wp = _pack_split(w2, J, K, x.device)
+        else:
+            wp = torch.empty(J * K, dtype=torch.float32, device=x.device)
+            hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+        y = torch.empty(xc.shape[0], J, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_gemm_rows_cloudbias(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(bc), hip.ptr(y), J, J, K,
+                                                   B, N, M, amp, _st(x)), "catre_op_gemm_rows_cloudbias")
+        ctx.save_for_backward(x, w)
+        ctx.dims, ctx.amp = (B, N, M), amp
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, N, M = ctx.dims
+        lib = hip.load()
+        dy = _c(dy)
+        J = dy.shape[1]
+        w2 = w.reshape(w.shape[0], -1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(2 * B if M > 0 else B, J, dtype=torch.float32, device=dy.device)
+            hip.check(lib.catre_op_rowbias_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(db), J, B, N, M, _st(dy)),
+                      "catre_op_rowbias_bwd")
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_nt(dy, _c(w2.t()), None, False, amp=ctx.amp)
+        if ctx.needs_input_grad[1]:
+            dw = _c(_gemm_tn(dy, _c(x), amp=ctx.amp)).reshape(w.shape)
+        return dx, dw, db, None, None, None
+
+
+def linear_cloudbias(x, w, bias, B, N, M):
+    """x [B*(N+M), K] object-major rows, w [J,K], bias [2B,J] -> x w^T + bias[cloud(row)].  One fused kernel when the
+    tiles cannot straddle clouds (N, M multiples of 64) and the shape is tiled; else linear + rowbias_add."""
+    J, K = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
+    if N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(x.shape[0], J, K) and K % 8 == 0:
+        return _LinearCloudBias.apply(x, w, bias, B, N, M)
+    return rowbias_add(linear(x, w, None), bias, B, N, M)
+
+
 def rowbias_add(y, bias, B, N, M):
     """y [B*(N+M), J] object-major += bias[cloud] (bias [2B, J])."""
     return _RowBias.apply(y, bias, B, N, M)

@@ -248,6 +248,11 @@ int catre_op_gemm_rows_split(const float* X, int ldx, const float* xmask, int ld
                              const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu, void* stream);
 int catre_op_linear_maxpool_split(const float* X, int ldx, const void* Wp, const float* bias, float* out, int* idx, int J,
                                   int K, int B, int N, int M, void* ws, size_t ws_bytes, void* stream);
+/* Y = X Wl^T + bias2d[cloud(row)]: row GEMM with a per-cloud bias (rot-head layer 0: the global-feature half of the
+ * 1088 -> 256 conv, conv_out_per_rot_head.py:126-128, is constant per cloud).  Rows object-major (N observed then M prior
+ * rows per object), N and M multiples of 64, bias2d [2B][J]; Wp packed for compute_dtype (catre_op_pack / _bf16 / _split). */
+int catre_op_gemm_rows_cloudbias(const float* X, int ldx, const void* Wp, const float* bias2d, float* Y, int ldy, int J,
+                                 int K, int B, int N, int M, int compute_dtype, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -124,6 +124,36 @@ def test_linear_maxpool(relu, dims, mode):
     _cmp(b.grad, br.grad, "db", atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "split"])
+@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 192, 0), (3, 100, 60)])
+def test_linear_with_per_cloud_bias(mode, B, N, M):
+    """rot-head layer 0: x W^T + bias[cloud(row)] with the bias in the GEMM epilogue (ragged clouds: linear + add)."""
+    from catre_amd import train_ops as T
+
+    g = _gen(B + N + M)
+    P = N + M
+    x, xr = _leaf(torch.randn(B * P, 64, generator=g))
+    w, wr = _leaf(torch.randn(256, 64, generator=g) / 8)
+    nb = 2 * B if M > 0 else B
+    bias, br = _leaf(torch.randn(nb, 256, generator=g))
+    with T.amp_mode(mode):
+        y = T.linear_cloudbias(x, w, bias, B, N, M)
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if mode == "bf16" else (lambda t: t)
+    bfull = torch.cat([br[:B].unsqueeze(1).expand(B, N, 256)] + ([br[B:].unsqueeze(1).expand(B, M, 256)] if M else []), 1)
+    yr = (rnd(xr.float()).double() if mode == "bf16" else xr) @ (rnd(wr.float()).double() if mode == "bf16" else wr).t()
+    yr = yr + bfull.reshape(B * P, 256)
+    tol = dict(atol=1e-4, rtol=2e-5) if mode != "fp32" else {}
+    _cmp(y, yr, "y", **tol)
+    if mode == "bf16":
+        return
+    dy = torch.randn(B * P, 256, generator=g)
+    y.backward(dy.to(DEV))
+    yr.backward(dy.double())
+    _cmp(x.grad, xr.grad, "dx", **tol)
+    _cmp(w.grad, wr.grad, "dw", atol=2e-3 if mode == "split" else 2e-4, rtol=2e-5)
+    _cmp(bias.grad, br.grad, "dbias", atol=2e-4, rtol=2e-5)
+
+
 def test_maxpool_points_and_cloud_matmul():
     from catre_amd import train_ops as T
 
