@@ -36,6 +36,7 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 // of 64, bias [2B][J].  B == 0: plain bias [J].
 struct CloudBias {
   int B, N, M;
+  float* gn_part;  // optional: per-tile GroupNorm partials of the output [tiles][32][2] (J == 256, no ReLU / mask)
 };
 __device__ __forceinline__ const float* cloud_bias(const float* bias, CloudBias cb, int r0, int J) {
   if (cb.B <= 0 || !bias) return bias;
@@ -49,7 +50,7 @@ template <int MB, bool MAXP>
 __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                    const float* __restrict__ mask, int ldm, float* __restrict__ Y,
                                                    int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
-                                                   int blk_off = 0) {
+                                                   int blk_off = 0, float* __restrict__ gn_part = nullptr) {
   const int n = lane & 31, h = lane >> 5;
   if constexpr (MAXP) {
     // D[row = point][col = channel]: lane owns channel blk*32 + n and points (r&3) + 8(r>>2) + 4h + 32nb
@@ -113,6 +114,30 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
           *reinterpret_cast<f32x4*>(Y + (size_t)r * ldy + ch) = v;
         }
       }
+      if (gn_part) {
+        // GroupNorm(32, 256) partials of this 64-row tile for group blk*4 + g (its 8 channels = this register quad of
+        // both half-waves): (mean, M2) about a shift, merged per object by k_gnp_stats_final in tile order
+        const float shift = __shfl(acc[mb][0][4 * g] + bv[0], 0);
+        float sd = 0.f, sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          if (r0 + nb * 32 + n < R) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float d = (acc[mb][nb][4 * g + q] + bv[q]) - shift;
+              sd += d;
+              sq = fmaf(d, d, sq);
+            }
+          }
+        sd = wave_sum(sd);
+        sq = wave_sum(sq);
+        if (lane == 0) {
+          const float cnt = 8.f * (float)min(TP, R - r0);
+          float* o = gn_part + ((size_t)blockIdx.x * 32 + blk * 4 + g) * 2;
+          o[0] = shift + sd / cnt;
+          o[1] = sq - sd * sd / cnt;
+        }
+      }
     }
   }
 }
@@ -162,7 +187,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     }
   }
   if (!active) return;
-  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
+                               cb.gn_part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +248,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   GemmPipeB<MB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1), 1> g;
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
-  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane);
+  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
+                               cb.gn_part);
 }
 
 // ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
@@ -287,7 +314,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
     GemmPipeS<PMB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1)> g;
     g.prefetch(Wp + ((size_t)(blk0 + wave) * NKC) * 64 + lane, 8 * NKC * 64, lo_off);
     g.run(acc, xs[0], xs[1], lane);
-    gemm_rows_epilogue<PMB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0);
+    gemm_rows_epilogue<PMB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0,
+                                  cb.gn_part);
   }
 }
 
@@ -1101,12 +1129,12 @@ __global__ __launch_bounds__(256) void k_gnp_stats_chunk(const float* __restrict
 }
 
 __global__ __launch_bounds__(64) void k_gnp_stats_final(const float* __restrict__ part, float* __restrict__ stat, int P,
-                                                        int nch) {
+                                                        int nch, int rows_per_chunk) {
   const int obj = blockIdx.x, g = threadIdx.x;
   if (g >= 32) return;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int c = 0; c < nch; ++c) {
-    const float nb = 8.f * (float)(min(P, (c + 1) * GNS_CH) - c * GNS_CH);
+    const float nb = 8.f * (float)(min(P, (c + 1) * rows_per_chunk) - c * rows_per_chunk);
     const float* o = part + (((size_t)obj * nch + c) * 32 + g) * 2;
     const float nn = n + nb, delta = o[0] - mean;
     mean += delta * (nb / nn);

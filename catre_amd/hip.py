@@ -98,6 +98,8 @@ _SIGS = {
     "catre_op_gemm_rows_bf16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "catre_op_linear_maxpool_bf16": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_gemm_rows_cloudbias": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_op_gemm_rows_gn": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "catre_op_gnp_gelu_fwd_pre": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_pack_split": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "catre_op_gemm_rows_split": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "catre_op_linear_maxpool_split": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),

@@ -53,10 +53,11 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     P = N + M
     W0 = w("layers.0.weight").reshape(256, 1088)
     bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))       # [2B,256]: global half + conv bias
-    y = T.linear_cloudbias(pf_obj, W0[:, 1024:].contiguous(), bias0, B, N, M)  # [B*P,256], bias per cloud in the epilogue
-    a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P)
-    y = T.linear(a, w("layers.3.weight"), w("layers.3.bias"))
-    a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P)
+    # [B*P,256]; the per-cloud bias and the GroupNorm tile partials are epilogue work of the GEMMs
+    y, part = T.linear_cloudbias(pf_obj, W0[:, 1024:].contiguous(), bias0, B, N, M, with_gn_partials=True)
+    a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
+    y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
+    a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
     y3 = T.linear(a, w("neck.0.weight"), w("neck.0.bias"))                   # [B*P,3]
     return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)
 

@@ -393,20 +393,21 @@ class _RowBias(torch.autograd.Function):
         return dy, db, None, None, None
 
 
-class _LinearCloudBias(torch.autograd.Function):
-    """y = x W^T + bias[cloud(row)] in one kernel (the per-cloud bias is the GEMM's epilogue) - rot-head layer 0, where
-    the global-feature half of the 1088 -> 256 conv is a bias per cloud.  Backward: dbias = per-cloud column sums of dy,
-    dx / dW like a plain linear."""
+class _RotLinear(torch.autograd.Function):
+    """The rot-head linears in one kernel each: y = x W^T + bias, where the bias is per channel ([J]) or per cloud
+    ([2B,J]: layer 0, whose global-feature half is a bias per cloud), and - J == 256 - the per-64-row-tile GroupNorm
+    partials of y come out of the same epilogue (second, non-differentiable output; gn_points_gelu takes them instead of
+    a statistics pass over y).  Backward: dbias = column sums of dy (per cloud or total), dx / dW like a plain linear."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, B, N, M):
+    def forward(ctx, x, w, bias, per_cloud, B, N, M):
         lib = hip.load()
         w2 = _c(w.reshape(w.shape[0], -1))
         J, K = w2.shape
         amp = _amp()
         if amp and K not in (64, 128, 256, 512):
             amp = 0
-        xc, bc = _c(x), _c(bias)
+        xc, bc = _c(x), (_c(bias) if bias is not None else None)
         if amp == 1:
             wp = _pack_bf16(w2, J, K, x.device)
         elif amp == 2:
@@ -414,15 +415,20 @@ class _LinearCloudBias(torch.autograd.Function):
         else:
             wp = torch.empty(J * K, dtype=torch.float32, device=x.device)
             hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
-        y = torch.empty(xc.shape[0], J, dtype=torch.float32, device=x.device)
-        hip.check(lib.catre_op_gemm_rows_cloudbias(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(bc), hip.ptr(y), J, J, K,
-                                                   B, N, M, amp, _st(x)), "catre_op_gemm_rows_cloudbias")
+        R = xc.shape[0]
+        y = torch.empty(R, J, dtype=torch.float32, device=x.device)
+        part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=x.device) if J == 256 else None
+        hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(bc), int(per_cloud), hip.ptr(y), J,
+                                            J, K, B, N, M, hip.ptr(part), amp, _st(x)), "catre_op_gemm_rows_gn")
         ctx.save_for_backward(x, w)
-        ctx.dims, ctx.amp = (B, N, M), amp
-        return y
+        ctx.dims, ctx.amp, ctx.per_cloud, ctx.has_b = (B, N, M), amp, bool(per_cloud), bias is not None
+        if part is None:
+            part = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart):
         x, w = ctx.saved_tensors
         B, N, M = ctx.dims
         lib = hip.load()
@@ -430,24 +436,48 @@ class _LinearCloudBias(torch.autograd.Function):
         J = dy.shape[1]
         w2 = w.reshape(w.shape[0], -1)
         dx = dw = db = None
-        if ctx.needs_input_grad[2]:
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        if want_db and ctx.per_cloud:
             db = torch.empty(2 * B if M > 0 else B, J, dtype=torch.float32, device=dy.device)
             hip.check(lib.catre_op_rowbias_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(db), J, B, N, M, _st(dy)),
                       "catre_op_rowbias_bwd")
         if ctx.needs_input_grad[0]:
             dx = _gemm_nt(dy, _c(w2.t()), None, False, amp=ctx.amp)
         if ctx.needs_input_grad[1]:
-            dw = _c(_gemm_tn(dy, _c(x), amp=ctx.amp)).reshape(w.shape)
-        return dx, dw, db, None, None, None
+            if want_db and not ctx.per_cloud:
+                dw, db = _gemm_tn(dy, _c(x), with_bias=True, amp=ctx.amp)
+                db = _c(db)
+            else:
+                dw = _gemm_tn(dy, _c(x), amp=ctx.amp)
+            dw = _c(dw).reshape(w.shape)
+        elif want_db and not ctx.per_cloud:
+            db = _colsum(dy)
+        return dx, dw, db, None, None, None, None
 
 
-def linear_cloudbias(x, w, bias, B, N, M):
+def _rot_linear_ok(R, J, K, N, M):
+    return N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(R, J, K) and K % 8 == 0
+
+
+def linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=False):
     """x [B*(N+M), K] object-major rows, w [J,K], bias [2B,J] -> x w^T + bias[cloud(row)].  One fused kernel when the
-    tiles cannot straddle clouds (N, M multiples of 64) and the shape is tiled; else linear + rowbias_add."""
+    tiles cannot straddle clouds (N, M multiples of 64) and the shape is tiled; else linear + rowbias_add.  With
+    with_gn_partials returns (y, partials or None)."""
     J, K = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
-    if N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(x.shape[0], J, K) and K % 8 == 0:
-        return _LinearCloudBias.apply(x, w, bias, B, N, M)
-    return rowbias_add(linear(x, w, None), bias, B, N, M)
+    if _rot_linear_ok(x.shape[0], J, K, N, M):
+        y, part = _RotLinear.apply(x, w, bias, True, B, N, M)
+        return (y, part if part.numel() else None) if with_gn_partials else y
+    y = rowbias_add(linear(x, w, None), bias, B, N, M)
+    return (y, None) if with_gn_partials else y
+
+
+def linear_gn_partials(x, w, bias, B, N, M):
+    """y = x w^T + bias plus the GroupNorm(32,256) tile partials of y from the same kernel -> (y, partials or None)."""
+    J, K = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
+    if J == 256 and _rot_linear_ok(x.shape[0], J, K, N, M):
+        y, part = _RotLinear.apply(x, w, bias, False, B, N, M)
+        return y, part
+    return linear(x, w, bias), None
 
 
 def rowbias_add(y, bias, B, N, M):
@@ -460,13 +490,17 @@ class _GNPointsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) with statistics over the P points of each object (rows object-major)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, B, P):
+    def forward(ctx, y, gamma, beta, B, P, part):
         lib = hip.load()
         y = _c(y)
         a = torch.empty_like(y)
         stat = torch.empty(B, 32, 2, dtype=torch.float32, device=y.device)
-        hip.check(lib.catre_op_gnp_gelu_fwd(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a), hip.ptr(stat), B, P,
-                                            _st(y)), "catre_op_gnp_gelu_fwd")
+        if part is not None and P % 64 == 0:  # statistics from the producing GEMM's tile partials: no pass over y
+            hip.check(lib.catre_op_gnp_gelu_fwd_pre(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a),
+                                                    hip.ptr(stat), B, P, _st(y)), "catre_op_gnp_gelu_fwd_pre")
+        else:
+            hip.check(lib.catre_op_gnp_gelu_fwd(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a), hip.ptr(stat), B, P,
+                                                _st(y)), "catre_op_gnp_gelu_fwd")
         ctx.save_for_backward(y, gamma, beta, stat)
         ctx.dims = (B, P)
         return a
@@ -484,11 +518,13 @@ class _GNPointsGelu(torch.autograd.Function):
         hip.check(lib.catre_op_gnp_gelu_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta),
                                             hip.ptr(dy), hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), ws.numel(), B, P,
                                             _st(y)), "catre_op_gnp_gelu_bwd")
-        return dy, dg, db, None, None
+        return dy, dg, db, None, None, None
 
 
-def gn_points_gelu(y, gamma, beta, B, P):
-    return _GNPointsGelu.apply(y, gamma, beta, B, P)
+def gn_points_gelu(y, gamma, beta, B, P, part=None):
+    """part: optional per-64-row-tile GroupNorm partials of y ([B*P/64, 32, 2], from linear_cloudbias /
+    linear_gn_partials)."""
+    return _GNPointsGelu.apply(y, gamma, beta, B, P, part)
 
 
 class _GNRowsGelu(torch.autograd.Function):

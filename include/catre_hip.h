@@ -253,6 +253,13 @@ int catre_op_linear_maxpool_split(const float* X, int ldx, const void* Wp, const
  * rows per object), N and M multiples of 64, bias2d [2B][J]; Wp packed for compute_dtype (catre_op_pack / _bf16 / _split). */
 int catre_op_gemm_rows_cloudbias(const float* X, int ldx, const void* Wp, const float* bias2d, float* Y, int ldy, int J,
                                  int K, int B, int N, int M, int compute_dtype, void* stream);
+/* The rot-head linears (conv_out_per_rot_head.py:126-134) with two optional epilogue extras: per_cloud != 0 - bias is
+ * [2B][J], indexed by the row's cloud; gn_part != NULL (J == 256) - the per-64-row-tile GroupNorm(32,256) partials
+ * [B*(N+M)/64][32][2] of Y, consumed by catre_op_gnp_gelu_fwd_pre instead of a statistics pass over Y. */
+int catre_op_gemm_rows_gn(const float* X, int ldx, const void* Wp, const float* bias, int per_cloud, float* Y, int ldy,
+                          int J, int K, int B, int N, int M, float* gn_part, int compute_dtype, void* stream);
+int catre_op_gnp_gelu_fwd_pre(const float* Y, const float* part64, const float* gamma, const float* beta, float* A,
+                              float* stat, int B, int P, void* stream);
 size_t catre_op_gemm_tn_ws_bytes(int J, int K, int R);
 int catre_op_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int J, int K, int R,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);

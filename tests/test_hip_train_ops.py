@@ -154,6 +154,49 @@ def test_linear_with_per_cloud_bias(mode, B, N, M):
     _cmp(bias.grad, br.grad, "dbias", atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_groupnorm_statistics_from_the_gemm_epilogue(mode):
+    """linear (+ per-cloud bias) emits per-tile GroupNorm partials; gn_points_gelu fed with them must equal the version
+    that makes its own statistics pass, forward and backward."""
+    from catre_amd import train_ops as T
+
+    g = _gen(77)
+    B, N, M = 3, 128, 64
+    P = N + M
+    x = torch.randn(B * P, 64, generator=g).to(DEV)
+    w0 = (torch.randn(256, 64, generator=g) / 8).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(256, 256, generator=g) / 16).to(DEV).requires_grad_(True)
+    b1 = (torch.randn(256, generator=g) * 0.1 + 3.0).to(DEV).requires_grad_(True)  # a large mean: the shift matters
+    bias = torch.randn(2 * B, 256, generator=g).to(DEV)
+    ga = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    be = (0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    dout = torch.randn(B * P, 256, generator=g).to(DEV)
+
+    def run(fused):
+        for t in (w0, w1, b1, ga, be):
+            t.grad = None
+        with T.amp_mode(mode):
+            if fused:
+                y, part = T.linear_cloudbias(x, w0, bias, B, N, M, with_gn_partials=True)
+                assert part is not None and part.shape == (B * P // 64, 32, 2)
+                a = T.gn_points_gelu(y, ga, be, B, P, part)
+                y, part = T.linear_gn_partials(a, w1, b1, B, N, M)
+                assert part is not None
+                a = T.gn_points_gelu(y, ga, be, B, P, part)
+            else:
+                y = T.rowbias_add(T.linear(x, w0, None), bias, B, N, M)
+                a = T.gn_points_gelu(y, ga, be, B, P)
+                a = T.gn_points_gelu(T.linear(a, w1, b1), ga, be, B, P)
+        (a * dout).sum().backward()
+        return a.detach().clone(), [t.grad.clone() for t in (w0, w1, b1, ga, be)]
+
+    a1, g1 = run(True)
+    a2, g2 = run(False)
+    assert (a1 - a2).abs().max() < 2e-5  # same statistics up to the order of the partial sums
+    for u, v in zip(g1, g2):
+        assert (u - v).abs().max() <= 2e-5 * float(v.abs().max()) + 1e-7
+
+
 def test_maxpool_points_and_cloud_matmul():
     from catre_amd import train_ops as T
 
