@@ -64,15 +64,18 @@ def _amp():
     return int(torch.is_autocast_enabled()) if _AMP_OVERRIDE[0] is None else _AMP_OVERRIDE[0]
 
 
-def _pack_bf16(w, J, K, dev):
+def _pack_bf16(w, J, K, dev, transpose=0):
+    """w [J,K] (transpose: w is the [K,J] source of the [J,K] weight) -> bf16 fragments."""
     wp = torch.empty(J * K // 2, dtype=torch.float32, device=dev)  # J*K bf16
-    hip.check(hip.load().catre_op_pack_bf16(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(w)), "catre_op_pack_bf16")
+    hip.check(hip.load().catre_op_pack_bf16(hip.ptr(w), w.stride(0), J, K, int(transpose), hip.ptr(wp), _st(w)),
+              "catre_op_pack_bf16")
     return wp
 
 
-def _pack_split(w, J, K, dev):
+def _pack_split(w, J, K, dev, transpose=0):
     wp = torch.empty(J * K, dtype=torch.float32, device=dev)  # 2*J*K bf16: hi pack, lo pack
-    hip.check(hip.load().catre_op_pack_split(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(w)), "catre_op_pack_split")
+    hip.check(hip.load().catre_op_pack_split(hip.ptr(w), w.stride(0), J, K, int(transpose), hip.ptr(wp), _st(w)),
+              "catre_op_pack_split")
     return wp
 
 
@@ -81,24 +84,36 @@ def _tiled_gemm_ok(R, J, K):
     return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= 256
 
 
-def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False):
+def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False, wT=None):
     """y[R,J] = act(x[R,K] w[J,K]^T + bias) (zeroed where mask<=0); with xmask the left operand is x .* (xmask > 0).
-    Picks the tiled row kernel when the shape allows, else the one-block-per-32x32 kernel (small R or odd J)."""
+    Picks the tiled row kernel when the shape allows, else the one-block-per-32x32 kernel (small R or odd J).
+    wT (instead of w): the weight is the transpose of this contiguous [K,J] matrix (the dgrad of a linear: x = dy,
+    wT = the layer's own weight) - the fragment pack reads it transposed, no copy."""
     lib = hip.load()
     R, K = x.shape
-    J = w.shape[0]
+    tr = 0
+    if wT is not None:
+        assert w is None and wT.shape[0] == K
+        J = wT.shape[1]
+    else:
+        J = w.shape[0]
     dev = x.device
     y = torch.empty(R, J, dtype=torch.float32, device=dev)
     big = _tiled_gemm_ok(R, J, K) and identity_k == 0
+    if wT is not None:
+        if big:
+            w, tr = wT, 1
+        else:
+            w = _c(wT.t())
     if big and amp in (1, 2) and K in (64, 128, 256, 512):
-        wp = (_pack_bf16 if amp == 1 else _pack_split)(w, J, K, dev)
+        wp = (_pack_bf16 if amp == 1 else _pack_split)(w, J, K, dev, tr)
         fn = lib.catre_op_gemm_rows_bf16 if amp == 1 else lib.catre_op_gemm_rows_split
         hip.check(fn(hip.ptr(x), x.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0, hip.ptr(wp),
                      hip.ptr(bias), hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J, K,
                      int(relu), _st(x)), "catre_op_gemm_rows_bf16" if amp == 1 else "catre_op_gemm_rows_split")
     elif big:
         wp = torch.empty(J * K, dtype=torch.float32, device=dev)
-        hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+        hip.check(lib.catre_op_pack(hip.ptr(w), w.stride(0), J, K, tr, hip.ptr(wp), _st(x)), "catre_op_pack")
         hip.check(lib.catre_op_gemm_rows_m(hip.ptr(x), x.stride(0), hip.ptr(xmask),
                                            xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), hip.ptr(bias),
                                            hip.ptr(mask), mask.stride(0) if mask is not None else 0, hip.ptr(y), J, R, J,
@@ -178,8 +193,11 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
-            wt = _c(_pad_cols(w2.t(), 8))          # [K, J8]
-            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)   # [R, K]
+            if dy.shape[1] % 8 == 0:
+                dx = _gemm_nt(dy, None, None, False, xmask=ymask, amp=ctx.amp, wT=_c(w2))     # [R, K]
+            else:
+                wt = _c(_pad_cols(w2.t(), 8))      # [K, J8]
+                dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)
             if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
                 dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
             elif x.shape[1] < dx.shape[1]:
@@ -442,7 +460,7 @@ class _RotLinear(torch.autograd.Function):
             hip.check(lib.catre_op_rowbias_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(db), J, B, N, M, _st(dy)),
                       "catre_op_rowbias_bwd")
         if ctx.needs_input_grad[0]:
-            dx = _gemm_nt(dy, _c(w2.t()), None, False, amp=ctx.amp)
+            dx = _gemm_nt(dy, None, None, False, amp=ctx.amp, wT=_c(w2))
         if ctx.needs_input_grad[1]:
             if want_db and not ctx.per_cloud:
                 dw, db = _gemm_tn(dy, _c(x), with_bias=True, amp=ctx.amp)
