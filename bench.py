@@ -48,6 +48,76 @@ def flops_per_object_iteration(N, M):
     return 1770258 * (N + M) + 9446400 + 2 * ((2 * 64 * 256 + 2 * 256 * 256 + 2 * 256 * 3 + 6) * (N + M) + 4 * 1024 * 256) + 692736
 
 
+# CATRE_BENCH_DRYRUN=1: no GPU work - the launcher, rendezvous (gloo on CPU), barrier / MAX-over-ranks timing and
+# rank-0 JSON plumbing only (tests/test_bench_launcher.py runs `python bench.py --gpus 2` this way).  The line it
+# prints is marked "dryrun" and carries no throughput.
+DRYRUN = os.environ.get("CATRE_BENCH_DRYRUN", "0") == "1"
+GRAD_ALLREDUCE_BYTES = 4297175 * 4  # trainable-and-used fp32 parameters: one all-reduce per backward
+
+
+def self_launch(n):
+    """Re-run this script as `n` ranks under torch.distributed.run on 127.0.0.1 (free port) and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def rank_stats(dist, dev, dt):
+    """(max dt over ranks, per-rank ms list, number of ranks that took part) - one all_gather on the job's backend."""
+    if dist is None:
+        return dt, [round(dt * 1e3, 3)], 1
+    mine = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
+    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    allv = torch.stack(allv).cpu()
+    return float(allv[:, 0].max()), [round(float(v) * 1e3, 3) for v in allv[:, 0]], int(allv[:, 1].sum())
+
+
+def bench_dryrun(args, world, rank):
+    import torch.distributed as dist
+
+    dev = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist = None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    x = torch.randn(64, 64)
+    for _ in range(args.warmup):
+        x = torch.tanh(x @ x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = torch.tanh(x @ x)
+        if args.mode == "train" and dist is not None:
+            g = torch.zeros(1024)
+            dist.all_reduce(g)  # stands in for DDP's gradient all-reduce
+    barrier()
+    dt, per_rank, seen = rank_stats(dist, dev, time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DRYRUN (launcher / rendezvous plumbing only, no GPU work)", "value": None, "unit": "object-iterations/s",
+            "n_gpus": world, "ranks_seen": seen, "per_rank_ms": per_rank, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "dryrun", "dryrun": True, "mode": args.mode,
+            "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if (args.mode == "train" and world > 1) else 0,
+            "config": {"workload": "dryrun", "backend": "gloo"},
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline(cfg_fn, sd):
     """Oracle (port of the reference's CPU path) on the host cores, bounded sample."""
     from catre_amd import synth
@@ -69,20 +139,34 @@ def cpu_baseline(cfg_fn, sd):
             if best_t is None or t < best_t:
                 best, best_t = th, t
         torch.set_num_threads(best)
-        # bounded sample: aim at ~15 s of CPU work (best_t is 4 object-iterations)
+        # bounded sample: three runs of ~6 s of CPU work each (best_t is 4 object-iterations); the median is reported
         Ks = 4
-        Bs = int(max(4, min(64, 15.0 / max(best_t / 4.0, 1e-3) / Ks)))
+        Bs = int(max(2, min(64, 6.0 / max(best_t / 4.0, 1e-3) / Ks)))
         batch = synth.make_inputs(Bs, N_PTS, M_PTS, seed=123)
-        t0 = time.perf_counter()
-        O.refine_k(batch, sd, cfg, n_iter=Ks)
-        dt = time.perf_counter() - t0
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.refine_k(batch, sd, cfg, n_iter=Ks)
+            runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[1]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": round(Bs * Ks / dt, 3),
         "unit": "object-iterations/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"oracle/catre_oracle.refine_k (torch CPU fp32), B={Bs}, N=M={N_PTS}, K={Ks}, 1 run, {dt:.1f} s, "
-                  f"{torch.get_num_threads()} of {cores} host threads (best of a thread-count calibration)",
+        "cpu_model": model,
+        "runs_s": [round(r, 2) for r in runs],
+        "sample": f"oracle/catre_oracle.refine_k (torch CPU fp32), B={Bs}, N=M={N_PTS}, K={Ks}, median of 3 runs "
+                  f"({dt:.1f} s), {torch.get_num_threads()} of {cores} host threads (best of a thread-count calibration) on {model}",
     }
 
 
@@ -148,13 +232,12 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(last).all()
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
         print(json.dumps({
+            "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms,
+            "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if world > 1 else 0,
             "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else " [split-bf16 GEMMs]" if split else ""),
             "value": round(value, 1),
             "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,13 +278,18 @@ def main():
     # split arithmetic spends three bf16 MFMAs per fp32-accurate product: its matrix ceiling is a third of the bf16 peak
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else (BF16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, like main_catre.py:186-193's
+        # detectron2 `launch`), forward the ranks' exit status
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
+    if DRYRUN:
+        return bench_dryrun(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -297,10 +385,7 @@ def main():
                        "ms_per_step": round(dts / args.steps * 1e3, 3),
                        "max_abs_diff_vs_fp32_after_K": dev_max}
 
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
 
     if rank == 0:
         obj_iters = world * B_PER_GPU * K_ITER * args.steps
@@ -320,6 +405,8 @@ def main():
             "value": round(value, 1),
             "unit": "object-iterations/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,  # ranks that reported through the job's backend (RCCL for N > 1)
+            "per_rank_ms": per_rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
