@@ -36,6 +36,15 @@ class CATRE_disR_shared(nn.Module):
         if getattr(pcl_net, "global_feat", False):
             raise ValueError("CATRE_disR_shared needs per-point features: PCLNET.INIT_CFG.global_feat must be False")
         self._opts = opts_from_cfg(cfg, feature_transform=pcl_net.feature_transform)
+        rot_w = 2 * int(getattr(rot_head, "rot_dim", 3))
+        if rot_w != hip.ROT_DIMS[self._opts.rot_type]:
+            # the reference fails at the first forward instead: get_rot_mat asserts / raises on the width
+            # (pose_utils.py:357, lie_algebra.py:23) - its two-head ConvOutPerRotHead emits 2 x rot_dim values, so only
+            # rot6d (rot_dim=3) and quat (rot_dim=2) can reach get_rot_mat through it
+            raise ValueError(
+                f"ROT_TYPE={cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE!r} needs a {hip.ROT_DIMS[self._opts.rot_type]}-wide rotation "
+                f"residual, the rot head emits 2 x rot_dim = {rot_w}"
+            )
         if int(ts_head.in_dim) != int(self._opts.ts_in_dim):
             raise ValueError(
                 f"TS_HEAD.INIT_CFG.in_dim={ts_head.in_dim} does not match the gathered feature width "
@@ -220,6 +229,7 @@ def expected_state_shapes(cfg):
     """``{state_dict key: shape}`` of the model ``cfg`` describes (SURVEY.md section 8b listing)."""
     net = cfg.MODEL.CATRE
     P = int(net.ROT_HEAD.INIT_CFG.num_points)
+    rd = int(net.ROT_HEAD.INIT_CFG.get("rot_dim", 3))
     ts_in = int(net.TS_HEAD.INIT_CFG.in_dim)
     ft = bool(net.PCLNET.INIT_CFG.get("feature_transform", False))
     s = {}
@@ -242,7 +252,7 @@ def expected_state_shapes(cfg):
         s[f"{p}.layers.1.weight"], s[f"{p}.layers.1.bias"] = (256,), (256,)
         s[f"{p}.layers.3.weight"], s[f"{p}.layers.3.bias"] = (256, 256, 1), (256,)
         s[f"{p}.layers.4.weight"], s[f"{p}.layers.4.bias"] = (256,), (256,)
-        s[f"{p}.neck.0.weight"], s[f"{p}.neck.0.bias"] = (3, 256, 1), (3,)
+        s[f"{p}.neck.0.weight"], s[f"{p}.neck.0.bias"] = (rd, 256, 1), (rd,)
         s[f"{p}.conv_p.weight"], s[f"{p}.conv_p.bias"] = (1, P, 1), (1,)
     s["ts_head.norm.weight"], s["ts_head.norm.bias"] = (256,), (256,)
     s["ts_head.linears.0.weight"], s["ts_head.linears.0.bias"] = (256, ts_in), (256,)

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
                                                     const float* __restrict__ bet1y, const float* __restrict__ neckx,
                                                     const float* __restrict__ necky, const float* __restrict__ wpx,
                                                     const float* __restrict__ wpy, float* __restrict__ rpart, int B,
-                                                    int N, int M) {
+                                                    int N, int M, int rd) {
   __shared__ float red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
     sc[q] = rstd * gam[c0 + q];
     sh[q] = bet[c0 + q] - mean * sc[q];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
+    for (int c = 0; c < 3; ++c) nk[c][q] = c < rd ? neck[c * 256 + c0 + q] : 0.f;
   }
   const unsigned short* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
   float a3[3] = {0.f, 0.f, 0.f};

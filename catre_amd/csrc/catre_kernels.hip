@@ -720,14 +720,14 @@ __device__ __forceinline__ void merge_gn(const float* __restrict__ part /*[T][64
 
 #include "catre_rot.h"
 
-// rot6d[b][hd*3+c] = sum_tiles rpart + neck_b[c] * sum_p w_p + conv_p.bias
+// rot[b][hd*rd+c] = sum_tiles rpart + neck_b[c] * sum_p w_p + conv_p.bias   (rd = RotHead.rot_dim: 3 for rot6d, 2 for quat)
 __global__ void k_rot_finish(const float* __restrict__ rpart, const float* __restrict__ neckbx,
                              const float* __restrict__ neckby, const float* __restrict__ sumwp /*[2]*/,
                              const float* __restrict__ cpbx, const float* __restrict__ cpby, float* __restrict__ rot6d,
-                             int B, int T) {
+                             int B, int T, int rd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * 6) return;
-  const int b = i / 6, hd = (i % 6) / 3, c = i % 3;
+  if (i >= B * 2 * rd) return;
+  const int b = i / (2 * rd), hd = (i % (2 * rd)) / rd, c = i % rd;
   const float* rp = rpart + ((size_t)b * 2 + hd) * T * 4 + c;
   float s = 0.f;
   for (int t = 0; t < T; ++t) s += rp[t * 4];
@@ -741,6 +741,8 @@ __global__ void k_rot_finish(const float* __restrict__ rpart, const float* __res
 // ------------------------------------------------------------------------------------------
 // a10-a12: rot6d -> R (rot_reps.py:46-55), pose/scale update (pose_scale_from_delta_init.py:48-93)
 // ------------------------------------------------------------------------------------------
+#include "catre_so3.h"
+
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
   o[0] = a[1] * b[2] - a[2] * b[1];
   o[1] = a[2] * b[0] - a[0] * b[2];
@@ -765,18 +767,12 @@ __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __re
   if (o.rot_input_is_matrix) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) dR[i] = rot6d[b * 9 + i];
-  } else {
-    float x[3] = {rot6d[b * 6 + 0], rot6d[b * 6 + 1], rot6d[b * 6 + 2]};
-    const float yr[3] = {rot6d[b * 6 + 3], rot6d[b * 6 + 4], rot6d[b * 6 + 5]};
-    float z[3], y[3];
-    normalize3(x);
-    cross3(x, yr, z);
-    normalize3(z);
-    cross3(z, x, y);
-    // columns (x, y, z): torch.stack((x, y, z), dim=-1)
-    dR[0] = x[0]; dR[1] = y[0]; dR[2] = z[0];
-    dR[3] = x[1]; dR[4] = y[1]; dR[5] = z[1];
-    dR[6] = x[2]; dR[7] = y[2]; dR[8] = z[2];
+  } else {  // get_rot_mat, models/model_utils.py:28-40
+    const int rd = catre_rot_dim(o.rot_type);
+    float r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
+    rot_param_to_mat(r, o.rot_type, dR);
   }
 
   const float* p0 = pose0 + b * 12;
@@ -1254,7 +1250,7 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
 
 static int rot_head_impl(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
                          float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st,
-                         bool split = false) {
+                         bool split = false, int rd = 3) {
   const PackLayout L = pack_layout(1);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   float* bias0 = ws + W.bias0;
@@ -1299,11 +1295,33 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
     hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1stat,
                        prm[CATRE_P_ROTX_GN1_W], prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W],
                        prm[CATRE_P_ROTY_GN1_B], prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W],
-                       prm[CATRE_P_ROTX_CONVP_W], prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+                       prm[CATRE_P_ROTX_CONVP_W], prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
   hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
-                     rot6d, B, T);
+                     rot6d, B, T, rd);
+  return check_launch();
+}
+
+int catre_rot_head_dim(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
+                       float* rot, void* workspace, size_t ws_bytes, int B, int N, int M, int rot_dim, void* stream) {
+  REQUIRE(gfeat && pointfeat && prm && packed && rot && workspace && dims_ok(B, N, M) && rot_dim >= 1 && rot_dim <= 3);
+  const WsLayout W = ws_layout(B, N, M);
+  if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  return rot_head_impl(gfeat, pointfeat, prm, packed, rot, (float*)workspace, W, B, N, M, (hipStream_t)stream, false,
+                       rot_dim);
+}
+
+int catre_rot_to_mat(const float* rot, int rot_type, float* R_out, int B, void* stream) {
+  REQUIRE(rot && R_out && B > 0 && rot_type >= CATRE_ROT_6D && rot_type <= CATRE_ROT_LIE_VEC);
+  hipLaunchKernelGGL(k_rot_to_mat, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot, rot_type, R_out, B);
+  return check_launch();
+}
+
+int catre_rot_to_mat_bwd(const float* rot, int rot_type, const float* grad_R, float* grad_rot, int B, void* stream) {
+  REQUIRE(rot && grad_R && grad_rot && B > 0 && rot_type >= CATRE_ROT_6D && rot_type <= CATRE_ROT_LIE_VEC);
+  hipLaunchKernelGGL(k_rot_to_mat_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot, rot_type, grad_R,
+                     grad_rot, B);
   return check_launch();
 }
 
@@ -1321,6 +1339,7 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
   REQUIRE(rot6d && trans_deltas && scale_deltas && init_pose && init_scale && o && pose_out && scale_out && B > 0);
   if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
   if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
+  if (o->rot_type < CATRE_ROT_6D || o->rot_type > CATRE_ROT_LIE_VEC) return CATRE_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, trans_deltas,
                      scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
   return check_launch();
@@ -1334,6 +1353,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                           int N, int M, hipStream_t st) {
   const PackLayout L = pack_layout(1);
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM, tiles = B * T;
+  const int rd = catre_rot_dim(o->rot_type) / 2;
   int rc;
   {
     ProfScope ps(CATRE_K_STN3D, st);
@@ -1396,11 +1416,11 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1stat, prm[CATRE_P_ROTX_GN1_W],
                        prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
                        prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
-                       prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M);
+                       prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
   hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
-                     ws + W.rot6d, B, T);
+                     ws + W.rot6d, B, T, rd);
   if ((rc = check_launch())) return rc;
   return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
                            scale_out, B, (void*)st);
@@ -1417,6 +1437,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  // the two rot heads emit rot_dim values each: only even-width parametrisations can come out of them
+  if (o->rot_type != CATRE_ROT_6D && o->rot_type != CATRE_ROT_QUAT) return CATRE_ERR_UNSUPPORTED;
   if (o->compute_dtype == CATRE_DTYPE_BF16)
     return refine_iter_bf(pts, init_pose, init_scale, mean_scales, Ks, prm, packed, o, pose_out, scale_out, ws, W, B, N, M,
                           st);
@@ -1484,7 +1506,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   }
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, stream)))
     return rc;
-  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split)))
+  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split,
+                          catre_rot_dim(o->rot_type) / 2)))
     return rc;
   return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
                            scale_out, B, stream);

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
                                                  const float* __restrict__ gam1y, const float* __restrict__ bet1y,
                                                  const float* __restrict__ neckx, const float* __restrict__ necky,
                                                  const float* __restrict__ wpx, const float* __restrict__ wpy,
-                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M) {
+                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M,
+                                                 int rd /* neck rows: RotHead.rot_dim <= 3 */) {
   __shared__ float red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
     sc[q] = rstd * gam[c0 + q];
     sh[q] = bet[c0 + q] - mean * sc[q];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nk[c][q] = neck[c * 256 + c0 + q];
+    for (int c = 0; c < 3; ++c) nk[c][q] = c < rd ? neck[c * 256 + c0 + q] : 0.f;
   }
   const float* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
   float a3[3] = {0.f, 0.f, 0.f};

@@ -1349,7 +1349,7 @@ __global__ void k_wsum_bwd(const float* __restrict__ dout, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward of rot6d -> R (rot_reps.py:46-55) and pose_scale_from_delta_init (ego rotation types)
+// backward of get_rot_mat (catre_so3.h) and pose_scale_from_delta_init (ego and allo rotation types)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float* __restrict__ d_scale,
                                   const float* __restrict__ rot6d, const float* __restrict__ dtr,
@@ -1370,15 +1370,11 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
   // translation target (needed first: the allo -> ego rotation is a function of it)
   const float t0[3] = {p0[3], p0[7], p0[11]};
   float gt[3] = {dp[3], dp[7], dp[11]};
-  // recompute x, y, z
-  const float a[3] = {rot6d[b * 6 + 0], rot6d[b * 6 + 1], rot6d[b * 6 + 2]};
-  const float bb[3] = {rot6d[b * 6 + 3], rot6d[b * 6 + 4], rot6d[b * 6 + 5]};
-  const float na = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
-  const float x[3] = {a[0] / na, a[1] / na, a[2] / na};
-  float w[3];
-  cross3(x, bb, w);
-  const float nw = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
-  const float z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};
+  // the rotation residual and its matrix (get_rot_mat)
+  const int rd = catre_rot_dim(o.rot_type);
+  float rp[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rp[i] = i < rd ? rot6d[b * rd + i] : 0.f;
   if (o.is_allo) {
     // ego = A(t') dR with A = quat2mat(axis-angle from the optical axis to t'), core/utils/utils.py:200-231.
     // gR so far is dL/d ego:  dL/d dR = A^T gR,  dL/dA = gR dR^T -> q -> (angle, axis) -> ray -> t'.
@@ -1412,9 +1408,8 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
     const float A[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy),
                         2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx),
                         2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy)};
-    float yv[3];
-    cross3(z, x, yv);
-    const float dRm[9] = {x[0], yv[0], z[0], x[1], yv[1], z[1], x[2], yv[2], z[2]};  // columns (x, y, z)
+    float dRm[9];
+    rot_param_to_mat(rp, o.rot_type, dRm);
     float gA[9], gD[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -1451,35 +1446,13 @@ __global__ void k_pose_update_bwd(const float* __restrict__ d_pose, const float*
 #pragma unroll
     for (int e = 0; e < 3; ++e) gt[e] += gray[e] / nrm - (tn > 0.f ? rg * tt[e] / (nrm * nrm * tn) : 0.f);
   }
-  // columns: dR[:,0] = x, dR[:,1] = y = z cross x, dR[:,2] = z
-  float gx[3] = {gR[0], gR[3], gR[6]}, gy[3] = {gR[1], gR[4], gR[7]}, gz[3] = {gR[2], gR[5], gR[8]};
-  float t[3];
-  // y = z x x : dz += x cross gy ; dx += gy cross z
-  cross3(x, gy, t);
-  gz[0] += t[0];
-  gz[1] += t[1];
-  gz[2] += t[2];
-  cross3(gy, z, t);
-  gx[0] += t[0];
-  gx[1] += t[1];
-  gx[2] += t[2];
-  // z = w/|w|
-  const float zg = z[0] * gz[0] + z[1] * gz[1] + z[2] * gz[2];
-  const float gw[3] = {(gz[0] - z[0] * zg) / nw, (gz[1] - z[1] * zg) / nw, (gz[2] - z[2] * zg) / nw};
-  // w = x cross b : dx += b cross gw ; db = gw cross x
-  cross3(bb, gw, t);
-  gx[0] += t[0];
-  gx[1] += t[1];
-  gx[2] += t[2];
-  float gb[3];
-  cross3(gw, x, gb);
-  const float xg = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
-  d_rot6d[b * 6 + 0] = (gx[0] - x[0] * xg) / na;
-  d_rot6d[b * 6 + 1] = (gx[1] - x[1] * xg) / na;
-  d_rot6d[b * 6 + 2] = (gx[2] - x[2] * xg) / na;
-  d_rot6d[b * 6 + 3] = gb[0];
-  d_rot6d[b * 6 + 4] = gb[1];
-  d_rot6d[b * 6 + 5] = gb[2];
+  {
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    rot_param_to_mat_bwd(rp, o.rot_type, gR, g);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i < rd) d_rot6d[b * rd + i] = g[i];
+  }
   // translation
   float gd[3];
   if (!o.delta_t_space_3d) {

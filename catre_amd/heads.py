@@ -37,10 +37,12 @@ class RotHead(nn.Module):
                  act="leaky_relu", num_classes=1, kernel_size=1, num_points=1, norm_input=False, dropout=False,
                  point_bias=True):
         super().__init__()
-        if (in_dim, feat_dim, num_layers, rot_dim, num_classes, kernel_size, num_gn_groups) != (1088, 256, 2, 3, 1, 1, 32):
+        if (in_dim, feat_dim, num_layers, num_classes, kernel_size, num_gn_groups) != (1088, 256, 2, 1, 1, 32) or not (
+                1 <= int(rot_dim) <= 3):
             raise NotImplementedError(
-                "HIP rot head is built for in_dim=1088, feat_dim=256, num_layers=2, rot_dim=3, kernel_size=1, "
-                f"num_gn_groups=32, num_classes=1; got {(in_dim, feat_dim, num_layers, rot_dim, num_classes, kernel_size, num_gn_groups)}"
+                "HIP rot head is built for in_dim=1088, feat_dim=256, num_layers=2, rot_dim in {1,2,3} (3: rot6d, 2: quat), "
+                "kernel_size=1, num_gn_groups=32, num_classes=1; got "
+                f"{(in_dim, feat_dim, num_layers, rot_dim, num_classes, kernel_size, num_gn_groups)}"
             )
         if norm_input or dropout:
             raise NotImplementedError("norm_input / dropout are not used by the shipped configs")
@@ -66,7 +68,8 @@ class RotHead(nn.Module):
                 nn.init.constant_(m.bias, 0.0)
 
     def forward(self, x):
-        """x [B,1088,P] -> [B,3]: conv -> GN -> GELU -> conv -> GN -> GELU -> neck -> conv_p over the points."""
+        """x [B,1088,P] -> (r [B,rot_dim], feat [B,rot_dim,P]) like the reference (``:126-140``): conv -> GN -> GELU ->
+        conv -> GN -> GELU -> neck = feat -> conv_p over the points."""
         from . import train_ops as T
 
         B, C, P = x.shape
@@ -77,8 +80,26 @@ class RotHead(nn.Module):
         a = T.gn_points_gelu(y, self.layers[1].weight, self.layers[1].bias, B, P)
         y = T.linear(a, self.layers[3].weight, self.layers[3].bias)
         a = T.gn_points_gelu(y, self.layers[4].weight, self.layers[4].bias, B, P)
-        y3 = T.linear(a, self.neck[0].weight, self.neck[0].bias)
-        return T.weighted_point_sum(y3, self.conv_p.weight, self.conv_p.bias, B, P)
+        y3 = neck_rows(a, self.neck[0].weight, self.neck[0].bias)             # [B*P,3], columns >= rot_dim are zero
+        r = T.weighted_point_sum(y3, self.conv_p.weight, self.conv_p.bias, B, P)
+        rd = self.rot_dim
+        feat = y3.view(B, P, 3)[:, :, :rd].permute(0, 2, 1)                      # the reference's `feat = x.clone()` (:132)
+        return r[:, :rd], feat  # a padded column only carries conv_p.bias: sliced away
+
+
+def neck_rows(a, weight, bias):
+    """neck Conv1d(256 -> rot_dim, k=1) on point rows, zero-padded to the 3 columns the point-sum kernels are built for
+    (pure data movement on [rot_dim,256] / [rot_dim]; gradients of the padding rows are dropped by autograd)."""
+    import torch.nn.functional as F
+
+    from . import train_ops as T
+
+    rd = weight.shape[0]
+    w = weight.reshape(rd, -1)
+    if rd < 3:
+        w = F.pad(w, (0, 0, 0, 3 - rd))
+        bias = F.pad(bias, (0, 3 - rd)) if bias is not None else None
+    return T.linear(a, w, bias)
 
 
 class ConvOutPerRotHead(nn.Module):
@@ -88,19 +109,23 @@ class ConvOutPerRotHead(nn.Module):
                  num_classes=1, kernel_size=1, num_points=1, per_rot_sup=False, norm_input=False, dropout=False,
                  point_bias=True, **args):
         super().__init__()
-        if per_rot_sup:
-            raise NotImplementedError("per_rot_sup=True is not used by the shipped configs")
         self.per_rot_sup = per_rot_sup
         mk = lambda: RotHead(in_dim, feat_dim, num_layers, rot_dim, norm, num_gn_groups, act, num_classes, kernel_size,
                              num_points, norm_input, dropout, point_bias)
         self.rot_head_x = mk()
         self.rot_head_y = mk()
         self.num_points = num_points
+        self.rot_dim = rot_dim
 
     def forward(self, x):
         import torch
 
-        return torch.cat([self.rot_head_x(x), self.rot_head_y(x)], dim=1)  # rot6d [B,6] (:63-66)
+        rx, feat_x = self.rot_head_x(x)
+        ry, feat_y = self.rot_head_y(x)
+        r_pred = torch.cat((rx, ry), dim=1)            # [B, 2*rot_dim] (:63-66)
+        if self.per_rot_sup:
+            return r_pred, torch.cat((feat_x, feat_y), dim=1)   # (:68-69)
+        return r_pred
 
 
 class FC_TransSizeHead(nn.Module):

@@ -52,10 +52,21 @@ class CatreOpts(ctypes.Structure):
         ("ts_in_dim", ctypes.c_int32),
         ("rot_input_is_matrix", ctypes.c_int32),
         ("compute_dtype", ctypes.c_int32),
+        ("rot_type", ctypes.c_int32),
     ]
 
 
 DTYPE_F32, DTYPE_BF16, DTYPE_SPLIT = 0, 1, 2
+ROT_6D, ROT_QUAT, ROT_LOG_QUAT, ROT_LIE_VEC = 0, 1, 2, 3
+ROT_DIMS = {ROT_6D: 6, ROT_QUAT: 4, ROT_LOG_QUAT: 3, ROT_LIE_VEC: 3}
+
+
+def rot_type_id(rot_type):
+    """'{ego,allo}_{rot6d,quat,log_quat,lie_vec}' -> CATRE_ROT_* (reference models/model_utils.py:11-40)."""
+    for suffix, v in (("_rot6d", ROT_6D), ("_log_quat", ROT_LOG_QUAT), ("_quat", ROT_QUAT), ("_lie_vec", ROT_LIE_VEC)):
+        if rot_type in ("ego" + suffix, "allo" + suffix):
+            return v
+    raise ValueError(f"Unknown rot_type: {rot_type}")  # model_utils.py:24
 
 
 class CatreLossCfg(ctypes.Structure):
@@ -85,6 +96,9 @@ _SIGS = {
     "catre_trunk": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_ts_head": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "catre_rot_head": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_rot_head_dim": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_rot_to_mat": (_I, [_P, _I, _P, _I, _P]),
+    "catre_rot_to_mat_bwd": (_I, [_P, _I, _P, _P, _I, _P]),
     "catre_pose_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),

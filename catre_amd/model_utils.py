@@ -1,6 +1,9 @@
 """Head builders - same names/returns as reference ``core/catre/models/model_utils.py:66-89,144-167``."""
 import copy
 
+import torch
+
+from . import hip
 from .net_factory import HEADS, PCLNETS  # noqa: F401
 
 
@@ -13,6 +16,41 @@ def get_rot_dim(rot_type):
     if rot_type in ["allo_rot6d", "ego_rot6d"]:
         return 6
     raise ValueError(f"Unknown rot_type: {rot_type}")
+
+
+class _RotToMat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rot, type_id):
+        from .runtime import rot_to_mat
+
+        rot = rot.contiguous()
+        ctx.save_for_backward(rot)
+        ctx.type_id = type_id
+        return rot_to_mat(rot, type_id)
+
+    @staticmethod
+    def backward(ctx, grad_R):
+        from .runtime import rot_to_mat_bwd
+
+        (rot,) = ctx.saved_tensors
+        return rot_to_mat_bwd(rot, ctx.type_id, grad_R), None
+
+
+def get_rot_mat(rot, rot_type):
+    """reference model_utils.py:28-40: [B,d] residual -> [B,3,3] rotation matrix for ``{ego,allo}_{quat,log_quat,lie_vec,
+    rot6d}`` - ``quat2mat_torch`` (pose_utils.py:349-412), ``quat2mat_torch(qexp(.))`` (quaternion_lf.py:294-317),
+    ``lie_vec_to_rot`` (lie_algebra.py:7-77), ``rot6d_to_mat_batch`` (rot_reps.py:34-55) - one HIP launch
+    (``catre_rot_to_mat``), autograd-connected (``catre_rot_to_mat_bwd``)."""
+    try:
+        type_id = hip.rot_type_id(rot_type)
+    except ValueError:
+        raise ValueError(f"Wrong pred_rot type: {rot_type}") from None  # model_utils.py:39
+    d = hip.ROT_DIMS[type_id]
+    if type_id == hip.ROT_QUAT:
+        assert rot.ndim == 2 and rot.shape[1] == 4, rot.shape  # pose_utils.py:357
+    elif rot.shape[-1] != d:
+        raise ValueError(f"Input size must be a (*, {d}) tensor. Got {tuple(rot.shape)}")  # lie_algebra.py:23
+    return _RotToMat.apply(rot.reshape(-1, d), type_id)
 
 
 def _build_head(cfg, head_cfg, num_classes):

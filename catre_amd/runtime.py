@@ -20,11 +20,7 @@ def opts_from_cfg(cfg, feature_transform=True):
     ``core/catre/models/CATRE_disR_shared.py:57-120``) into ``catre_opts``."""
     net = cfg.MODEL.CATRE
     rh, th = net.ROT_HEAD, net.TS_HEAD
-    if rh.ROT_TYPE not in ("ego_rot6d", "allo_rot6d"):
-        raise NotImplementedError(
-            f"ROT_TYPE={rh.ROT_TYPE!r}: the HIP path implements the rot6d heads of the shipped configs "
-            "(ConvOutPerRotHead emits 3+3 values, reference heads/conv_out_per_rot_head.py:62-66)"
-        )
+    rot_type = hip.rot_type_id(rh.ROT_TYPE)  # ValueError on an unknown name, like get_rot_dim (model_utils.py:24)
     if rh.get("CLASS_AWARE", False):
         # the reference branch itself is unreachable: it dereferences the non-existent self.pose_head
         # (CATRE_disR_shared.py:90-95)
@@ -47,6 +43,7 @@ def opts_from_cfg(cfg, feature_transform=True):
     o.delta_t_weight = float(rh.DELTA_T_WEIGHT)
     o.allo_eps = 1e-4  # CATRE_disR_shared.py:112
     o.ts_in_dim = 1088 * (2 if o.with_kps_feature else 1) + 3 * o.with_init_scale + 3 * o.with_init_trans
+    o.rot_type = rot_type
     return o
 
 
@@ -232,19 +229,21 @@ class HipRuntime:
         prm, packed = self.params(dev)
         dt = torch.empty(B, 3, dtype=torch.float32, device=dev)
         ds = torch.empty(B, 3, dtype=torch.float32, device=dev)
-        hip.check(lib.catre_ts_head(hip.ptr(gfeat), hip.ptr(init_pose.contiguous()), hip.ptr(init_scale.contiguous()),
+        init_pose, init_scale = init_pose.contiguous(), init_scale.contiguous()  # bound: must outlive the enqueue
+        hip.check(lib.catre_ts_head(hip.ptr(gfeat), hip.ptr(init_pose), hip.ptr(init_scale),
                                     prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(dt), hip.ptr(ds), B,
                                     hip.stream_ptr(dev)), "catre_ts_head")
         return dt, ds
 
-    def stage_rot_head(self, gfeat, pointfeat, B, N, M):
+    def stage_rot_head(self, gfeat, pointfeat, B, N, M, rot_dim=3):
         lib = hip.load()
         dev = gfeat.device
         prm, packed = self.params(dev)
         ws = self.workspace(B, N, M, dev)
-        rot6d = torch.empty(B, 6, dtype=torch.float32, device=dev)
-        hip.check(lib.catre_rot_head(hip.ptr(gfeat), hip.ptr(pointfeat), prm, hip.ptr(packed), hip.ptr(rot6d),
-                                     hip.ptr(ws), ws.numel(), B, N, M, hip.stream_ptr(dev)), "catre_rot_head")
+        rot6d = torch.empty(B, 2 * rot_dim, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_rot_head_dim(hip.ptr(gfeat), hip.ptr(pointfeat), prm, hip.ptr(packed), hip.ptr(rot6d),
+                                         hip.ptr(ws), ws.numel(), B, N, M, int(rot_dim), hip.stream_ptr(dev)),
+                  "catre_rot_head_dim")
         return rot6d
 
 
@@ -271,11 +270,12 @@ def pose_update(rot6d, trans_deltas, scale_deltas, init_pose, init_scale, mean_s
     dev = rot6d.device
     pose_out = torch.empty(B, 3, 4, dtype=torch.float32, device=dev)
     scale_out = torch.empty(B, 3, dtype=torch.float32, device=dev)
-    c = lambda t: t.contiguous() if t is not None else None
-    hip.check(lib.catre_pose_update(hip.ptr(c(rot6d)), hip.ptr(c(trans_deltas)), hip.ptr(c(scale_deltas)),
-                                    hip.ptr(c(init_pose)), hip.ptr(c(init_scale)), hip.ptr(c(mean_scales)),
-                                    hip.ptr(c(Ks)), ctypes.byref(opts), hip.ptr(pose_out), hip.ptr(scale_out), B,
+    # contiguous copies stay bound until the launch is enqueued (a temporary's block would be recycled by the next copy)
+    keep = [t.contiguous() if t is not None else None
+            for t in (rot6d, trans_deltas, scale_deltas, init_pose, init_scale, mean_scales, Ks)]
+    hip.check(lib.catre_pose_update(*[hip.ptr(t) for t in keep], ctypes.byref(opts), hip.ptr(pose_out), hip.ptr(scale_out), B,
                                     hip.stream_ptr(dev)), "catre_pose_update")
+    del keep
     return pose_out, scale_out
 
 
@@ -287,3 +287,27 @@ def colmax(x):
     out = torch.empty(B, C, dtype=torch.float32, device=x.device)
     hip.check(lib.catre_colmax(hip.ptr(x), hip.ptr(out), B, C, N, hip.stream_ptr(x.device)), "catre_colmax")
     return out
+
+
+def rot_to_mat(rot, rot_type_id):
+    """``get_rot_mat`` on the device (reference models/model_utils.py:28-40): rot [B,d] -> R [B,3,3]."""
+    lib = hip.load()
+    d = hip.ROT_DIMS[rot_type_id]
+    rot = hip.require_dev_f32(rot.contiguous(), "rot", (None, d))
+    B = rot.shape[0]
+    R = torch.empty(B, 3, 3, dtype=torch.float32, device=rot.device)
+    if B:
+        hip.check(lib.catre_rot_to_mat(hip.ptr(rot), int(rot_type_id), hip.ptr(R), B, hip.stream_ptr(rot.device)),
+                  "catre_rot_to_mat")
+    return R
+
+
+def rot_to_mat_bwd(rot, rot_type_id, grad_R):
+    lib = hip.load()
+    rot = rot.contiguous()
+    grad_R = hip.require_dev_f32(grad_R.contiguous(), "grad_R", (rot.shape[0], 3, 3))
+    g = torch.empty_like(rot)
+    if rot.shape[0]:
+        hip.check(lib.catre_rot_to_mat_bwd(hip.ptr(rot), int(rot_type_id), hip.ptr(grad_R), hip.ptr(g), rot.shape[0],
+                                           hip.stream_ptr(rot.device)), "catre_rot_to_mat_bwd")
+    return g

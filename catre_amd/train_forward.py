@@ -58,8 +58,11 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
-    y3 = T.linear(a, w("neck.0.weight"), w("neck.0.bias"))                   # [B*P,3]
-    return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)
+    from .heads import neck_rows
+
+    rd = w("neck.0.weight").shape[0]
+    y3 = neck_rows(a, w("neck.0.weight"), w("neck.0.bias"))                  # [B*P,3] (columns >= rot_dim are zero)
+    return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
 
 
 def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None):

@@ -629,11 +629,13 @@ class _PoseUpdate(torch.autograd.Function):
         lib = hip.load()
         B = rot6d.shape[0]
         g6, gt, gs = torch.empty_like(rot6d), torch.empty_like(dt), torch.empty_like(ds)
-        c = lambda t: _c(t) if t is not None else None
-        hip.check(lib.catre_op_pose_update_bwd(hip.ptr(c(d_pose)), hip.ptr(c(d_scale)), hip.ptr(c(rot6d)), hip.ptr(c(dt)),
-                                               hip.ptr(c(ds)), hip.ptr(c(init_pose)), hip.ptr(c(init_scale)),
-                                               hip.ptr(c(mean_scales)), hip.ptr(c(Ks)), ctypes.byref(ctx.opts), hip.ptr(g6),
+        # contiguous copies are bound to names: a temporary would be returned to the caching allocator (and its block
+        # handed to the next copy) before the kernel that reads it is even enqueued
+        keep = [_c(t) if t is not None else None
+                for t in (d_pose, d_scale, rot6d, dt, ds, init_pose, init_scale, mean_scales, Ks)]
+        hip.check(lib.catre_op_pose_update_bwd(*[hip.ptr(t) for t in keep], ctypes.byref(ctx.opts), hip.ptr(g6),
                                                hip.ptr(gt), hip.ptr(gs), B, _st(rot6d)), "catre_op_pose_update_bwd")
+        del keep
         return g6, gt, gs, None, None, None, None, None
 
 

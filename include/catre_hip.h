@@ -97,7 +97,15 @@ typedef struct catre_opts {
   int32_t compute_dtype;       /* catre_refine_iter / catre_refine_k: CATRE_DTYPE_F32 (default) or CATRE_DTYPE_BF16 -
                                 * what torch.cuda.amp.autocast selects in the reference (engine.py:304, TEST.AMP_TEST):
                                 * bf16 GEMM operands, fp32 accumulation / GroupNorm statistics / SO(3) update          */
+  int32_t rot_type;            /* parametrisation of the rotation residual, the part of ROT_HEAD.ROT_TYPE after ego_/allo_
+                                * (get_rot_mat, core/catre/models/model_utils.py:28-40): CATRE_ROT_6D (default, [B,6]),
+                                * CATRE_ROT_QUAT ([B,4]), CATRE_ROT_LOG_QUAT ([B,3]), CATRE_ROT_LIE_VEC ([B,3]).  The fused
+                                * drivers take the two rot heads' concatenated output [B, 2*rot_dim], so they accept the
+                                * types whose width is even: 6D (rot_dim 3) and QUAT (rot_dim 2) - exactly the ones the
+                                * reference's ConvOutPerRotHead can feed to get_rot_mat                                 */
 } catre_opts;
+
+enum { CATRE_ROT_6D = 0, CATRE_ROT_QUAT = 1, CATRE_ROT_LOG_QUAT = 2, CATRE_ROT_LIE_VEC = 3 };
 
 /* CATRE_DTYPE_SPLIT: fp32 results from split-bf16 (hi + lo, three products) MFMAs on the layers holding 98 % of the FLOPs;
  * same parity bound as CATRE_DTYPE_F32 */
@@ -167,10 +175,23 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
 int catre_rot_head(const float* gfeat, const float* pointfeat, const float* const* params,
                    const float* packed, float* rot6d, void* workspace, size_t ws_bytes,
                    int B, int N, int M, void* stream);
+/* Same with neck width rot_dim in {1,2,3} per head (RotHead's `rot_dim` constructor argument,
+ * conv_out_per_rot_head.py:80,109) -> rot [B, 2*rot_dim]. */
+int catre_rot_head_dim(const float* gfeat, const float* pointfeat, const float* const* params,
+                       const float* packed, float* rot, void* workspace, size_t ws_bytes,
+                       int B, int N, int M, int rot_dim, void* stream);
+
+/* a10 on its own: get_rot_mat (core/catre/models/model_utils.py:28-40): rot [B,d] -> R [B,3,3] for
+ * rot_type in CATRE_ROT_* (d = 6 / 4 / 3 / 3): rot6d_to_mat_batch (core/utils/rot_reps.py:34-55), quat2mat_torch
+ * (core/utils/pose_utils.py:349-412), quat2mat_torch(qexp(.)) (core/utils/quaternion_lf.py:294-317), lie_vec_to_rot
+ * (core/utils/lie_algebra.py:7-77); and its backward grad_R [B,3,3] -> grad_rot [B,d]. */
+int catre_rot_to_mat(const float* rot, int rot_type, float* R_out, int B, void* stream);
+int catre_rot_to_mat_bwd(const float* rot, int rot_type, const float* grad_R, float* grad_rot, int B, void* stream);
 
 /* a10+a11+a12: rot6d_to_mat_batch (core/utils/rot_reps.py:34-55) and pose_scale_from_delta_init
  * (core/catre/models/pose_scale_from_delta_init.py:8-95).  Ks / mean_scales may be NULL when unused.
- * rot6d is [B,6], or [B,3,3] rotation matrices when opts->rot_input_is_matrix.
+ * rot6d is [B,d] in the parametrisation opts->rot_type names (d = 6 / 4 / 3 / 3), or [B,3,3] rotation matrices when
+ * opts->rot_input_is_matrix.
  * -> pose_out [B,3,4], scale_out [B,3]. */
 int catre_pose_update(const float* rot6d, const float* trans_deltas, const float* scale_deltas,
                       const float* init_pose, const float* init_scale, const float* mean_scales,

@@ -221,10 +221,57 @@ def allo_to_ego_mat_torch(translation, rot_allo, eps=1e-4):
     return torch.matmul(quat2mat_torch(q), rot_allo)
 
 
+def qexp(q, eps=1e-8):
+    """``core/utils/quaternion_lf.py:294-317`` (``is_normalized=False``): exponent of (s; v), or of the pure quaternion
+    (0; v) when ``q`` is [B,3]."""
+    if q.shape[1] == 4:
+        s, v = torch.split(q, (1, 3), dim=-1)
+    else:
+        s = torch.zeros_like(q[:, :1])
+        v = q
+    theta = torch.norm(v, dim=-1, keepdim=True)
+    exp_s = torch.exp(s)
+    w = torch.cos(theta)
+    xyz = 1.0 / theta.clamp(min=eps) * torch.sin(theta) * v
+    return exp_s * torch.cat((w, xyz), dim=-1)
+
+
+def lie_vec_to_rot(angle_axis):
+    """``core/utils/lie_algebra.py:7-77``: Rodrigues with the axis ``v / (theta + 1e-6)``; first-order matrix where
+    ``theta^2 <= 1e-6``."""
+    if not angle_axis.shape[-1] == 3:
+        raise ValueError("Input size must be a (*, 3) tensor. Got {}".format(angle_axis.shape))
+    eps = 1e-6
+    theta2 = (angle_axis * angle_axis).sum(1, keepdim=True)  # matmul(v, v^T) (:56-58)
+    theta = torch.sqrt(theta2)
+    wxyz = angle_axis / (theta + eps)
+    wx, wy, wz = torch.chunk(wxyz, 3, dim=1)
+    c, sn = torch.cos(theta), torch.sin(theta)
+    r00 = c + wx * wx * (1.0 - c)
+    r10 = wz * sn + wx * wy * (1.0 - c)
+    r20 = -wy * sn + wx * wz * (1.0 - c)
+    r01 = wx * wy * (1.0 - c) - wz * sn
+    r11 = c + wy * wy * (1.0 - c)
+    r21 = wx * sn + wy * wz * (1.0 - c)
+    r02 = wy * sn + wx * wz * (1.0 - c)
+    r12 = -wx * sn + wy * wz * (1.0 - c)
+    r22 = c + wz * wz * (1.0 - c)
+    normal = torch.cat([r00, r01, r02, r10, r11, r12, r20, r21, r22], dim=1).view(-1, 3, 3)
+    rx, ry, rz = torch.chunk(angle_axis, 3, dim=1)
+    one = torch.ones_like(rx)
+    taylor = torch.cat([one, -rz, ry, rz, one, -rx, -ry, rx, one], dim=1).view(-1, 3, 3)
+    mask = (theta2 > eps).view(-1, 1, 1)
+    return mask.type_as(theta2) * normal + (mask == False).type_as(theta2) * taylor  # noqa: E712
+
+
 def get_rot_mat(rot, rot_type):
-    """``core/catre/models/model_utils.py:28-40`` (rot6d and quat branches)."""
+    """``core/catre/models/model_utils.py:28-40``."""
     if rot_type in ["ego_quat", "allo_quat"]:
         return quat2mat_torch(rot)
+    if rot_type in ["ego_log_quat", "allo_log_quat"]:
+        return quat2mat_torch(qexp(rot))
+    if rot_type in ["ego_lie_vec", "allo_lie_vec"]:
+        return lie_vec_to_rot(rot)
     if rot_type in ["ego_rot6d", "allo_rot6d"]:
         return rot6d_to_mat_batch(rot)
     raise ValueError(f"Wrong pred_rot type: {rot_type}")

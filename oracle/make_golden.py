@@ -136,6 +136,11 @@ CASES = {
     "refine_b1_n2048_k8": (1, 2048, 1024, 8, 9, 0, None, {}),
     # PointNet without the feature transform (PCLNET.INIT_CFG.feature_transform=False, pointnet.py:105)
     "refine_b2_noft": (2, 192, 128, 2, 10, 0, None, {"MODEL.CATRE.PCLNET.INIT_CFG.feature_transform": False}),
+    # quaternion residual: two rot heads of width rot_dim=2 -> [B,4] -> quat2mat_torch (model_utils.py:29-30)
+    "refine_b2_quat": (2, 256, 128, 3, 12, 0, None, {
+        "MODEL.CATRE.ROT_HEAD.ROT_TYPE": "ego_quat", "MODEL.CATRE.ROT_HEAD.INIT_CFG.rot_dim": 2}),
+    "refine_b2_allo_quat": (2, 128, 256, 2, 13, 1, None, {
+        "MODEL.CATRE.ROT_HEAD.ROT_TYPE": "allo_quat", "MODEL.CATRE.ROT_HEAD.INIT_CFG.rot_dim": 2}),
     "refine_b2_kpsfeat_trans": (2, 256, 256, 2, 8, 0, None, {
         "MODEL.CATRE.TS_HEAD.WITH_KPS_FEATURE": True, "MODEL.CATRE.TS_HEAD.WITH_INIT_TRANS": True,
         "MODEL.CATRE.TS_HEAD.INIT_CFG.in_dim": 1088 * 2 + 3 + 3}),
@@ -394,6 +399,57 @@ def make_ranger_golden():
     print(f"ranger_steps: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def make_rot_mats_golden(seed=41, B=24):
+    """a10: the reference's ``get_rot_mat`` (models/model_utils.py:28-40) for every rotation type on seeded residuals
+    (O(1) values, small-angle rows on both sides of the reference's thresholds, one exact zero), its autograd gradient
+    for a fixed upstream G, and ``pose_scale_from_delta_init`` fed with those matrices (ego and allo)."""
+    ref_shim.install()
+    from core.catre.models.model_utils import get_rot_mat
+    from core.catre.models.pose_scale_from_delta_init import pose_scale_from_delta_init
+
+    g = torch.Generator().manual_seed(seed)
+    arrays = {}
+    G = torch.randn(B, 3, 3, generator=g)
+    arrays["upstream"] = _np(G)
+    R0 = None
+    for name, d in (("rot6d", 6), ("quat", 4), ("log_quat", 3), ("lie_vec", 3)):
+        r = torch.randn(B, d, generator=g)
+        if d == 3:  # rows 0-5: small angles around the 1e-3 (theta^2 = 1e-6) switch of lie_vec / tiny log-quats
+            r[0] *= 2e-4
+            r[1] *= 5e-4
+            r[2] *= 9e-4 / r[2].norm()
+            r[3] *= 1.1e-3 / r[3].norm()
+            r[4] *= 1e-6
+            r[5] = 0.0
+        if d == 4:
+            r[0] *= 1e-3  # quat2mat_torch normalises: scale-invariant
+            r[1] *= 50.0
+        rr = r.clone().requires_grad_(True)
+        R = get_rot_mat(rr, f"ego_{name}")
+        (R * G).sum().backward()
+        arrays[f"{name}_in"], arrays[f"{name}_R"], arrays[f"{name}_grad"] = _np(r), _np(R), _np(rr.grad)
+        if R0 is None:
+            R0 = R.detach()
+        # the update with this residual, ego and allo (pose_scale_from_delta_init.py:87-93)
+        t0 = torch.tensor([0.05, -0.03, 0.9]) + 0.05 * torch.randn(B, 3, generator=g)
+        dt = torch.tensor([0.0, 0.0, 1.0]) + 0.02 * torch.randn(B, 3, generator=g)
+        ds = 0.01 * torch.randn(B, 3, generator=g)
+        s0 = 0.1 + 0.05 * torch.rand(B, 3, generator=g)
+        K = torch.tensor([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]]).expand(B, 3, 3).contiguous()
+        arrays[f"{name}_t0"], arrays[f"{name}_dt"], arrays[f"{name}_ds"], arrays[f"{name}_s0"] = map(_np, (t0, dt, ds, s0))
+        for allo in (False, True):
+            Rt, tt, st = pose_scale_from_delta_init(
+                R.detach(), dt, ds, R0, t0, s0, Ks=K, K_aware=True, delta_T_space="image", delta_T_weight=1.0,
+                delta_z_style="cosypose", eps=1e-4, is_allo=allo, scale_type="iter_add")
+            tag = f"{name}_{'allo' if allo else 'ego'}"
+            arrays[f"{tag}_R"], arrays[f"{tag}_t"], arrays[f"{tag}_s"] = _np(Rt), _np(tt), _np(st)
+    arrays["R0"], arrays["K"] = _np(R0), _np(K)
+    path = os.path.join(GOLDEN_DIR, "rot_mats.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"rot_mats: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); NaN grads: "
+          + ", ".join(f"{k}={int(np.isnan(v).sum())}" for k, v in arrays.items() if k.endswith("_grad")))
+
+
 def bottle_prior():
     """The reference's data file for category 'bottle' (config 1 of BASELINE.json)."""
     import pickle
@@ -416,6 +472,9 @@ def main(argv=None):
     if "aug" in names:
         make_aug_golden()
         names = [n for n in names if n != "aug"]
+    if "rot_mats" in names:
+        make_rot_mats_golden()
+        names = [n for n in names if n != "rot_mats"]
     if "amp" in names:
         make_amp_golden()
         names = [n for n in names if n != "amp"]
@@ -425,6 +484,7 @@ def main(argv=None):
         make_amp_golden()
         make_aug_golden()
         make_pcl_golden()
+        make_rot_mats_golden()
     for name in names:
         if name in TRAIN_CASES:
             make_train_golden(name)

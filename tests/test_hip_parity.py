@@ -376,3 +376,36 @@ def test_input_layouts_and_streams():
         s.synchronize()
         assert torch.equal(alt, ref)
     assert np.abs(ref.cpu().numpy() - g["ref"]["pose_1"]).max() <= TIGHT
+
+
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """INTEGRATION.md section 2 is the binding a maintainer would copy: extract the code block, execute it as is and
+    check its refine_k against the reference golden (a wrong struct layout there reads past catre_opts)."""
+    import ctypes
+    import os
+    import re
+
+    from catre_amd import hip
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    sect = md[md.index("## 2. Binding the C ABI directly"):md.index("## 3. Entry points")]
+    code = re.search(r"```python\n(.*?)```", sect, flags=re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)  # the stub opens "catre_amd/csrc/libcatre_hip.so" relative to the checkout
+    try:
+        exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    assert ctypes.sizeof(ns["catre_opts"]) == ctypes.sizeof(hip.CatreOpts)
+    assert [f[0] for f in ns["catre_opts"]._fields_] == [f[0] for f in hip.CatreOpts._fields_]
+    g = load_golden("refine_b2_small")
+    sd = {k: v.to(DEV).contiguous() for k, v in recipe_sd(g["cfg"], g["salt"]).items()}
+    b = to_dev(g["batch"])
+    poses, scales = ns["refine_k"](sd, hip.PARAM_KEYS, b["pcl"], b["obj_kps"], b["obj_pose_est"], b["obj_scale_est"],
+                                   b["K"], g["K"])
+    torch.cuda.synchronize()
+    for i in range(g["K"] + 1):
+        assert np.abs(poses[i].cpu().numpy() - g["ref"][f"pose_{i}"]).max() <= TIGHT
+        assert np.abs(scales[i].cpu().numpy() - g["ref"][f"scale_{i}"]).max() <= TIGHT

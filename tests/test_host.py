@@ -51,7 +51,7 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
         '#include <stdio.h>\n#include <string.h>\n#include "catre_hip.h"\n'
         "int main(void) {\n"
         "  catre_opts o; memset(&o, 0, sizeof o);\n"
-        "  if (sizeof(catre_opts) != 68) return 2;\n"
+        "  if (sizeof(catre_opts) != 72) return 2;\n"
         "  if (catre_workspace_bytes(2, 1024, 1024) == 0) return 3;\n"
         "  if (catre_refine_k(NULL, NULL, NULL, NULL, NULL, NULL, &o, NULL, NULL, NULL, 0, 2, 1024, 1024, 4, NULL) != CATRE_ERR_BAD_ARG) return 4;\n"
         '  printf("%s %s\\n", catre_version(), catre_status_string(CATRE_ERR_WORKSPACE));\n'
@@ -71,7 +71,7 @@ def test_size_queries_without_gpu():
     assert 0 < small < big
     assert lib.catre_packed_floats(1024, 1024, 1091) > 1024 * 512
     assert lib.catre_status_string(-2).decode().startswith("workspace")
-    assert ctypes.sizeof(hip.CatreOpts) == 68 and ctypes.sizeof(hip.CatrePoints) == 64
+    assert ctypes.sizeof(hip.CatreOpts) == 72 and ctypes.sizeof(hip.CatrePoints) == 64
 
 
 def test_param_enum_matches_header():
@@ -140,8 +140,13 @@ def test_opts_from_cfg_flag_mapping():
     with pytest.raises(ValueError):
         opts_from_cfg(cfg)
     cfg = default_cfg(device="cpu")
-    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_quat"
-    with pytest.raises(NotImplementedError):
+    for rt, want in (("ego_quat", hip.ROT_QUAT), ("allo_log_quat", hip.ROT_LOG_QUAT), ("ego_lie_vec", hip.ROT_LIE_VEC),
+                     ("allo_rot6d", hip.ROT_6D)):
+        cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = rt
+        o = opts_from_cfg(cfg)
+        assert o.rot_type == want and o.is_allo == int(rt.startswith("allo"))
+    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_euler"
+    with pytest.raises(ValueError, match="Unknown rot_type"):  # model_utils.py:24
         opts_from_cfg(cfg)
     # in_dim inconsistent with the gathered features is caught at construction
     cfg = default_cfg(device="cpu")
@@ -221,3 +226,24 @@ def test_empty_batch_returns_empty_outputs_without_touching_the_device():
     out = model.refine({"pcl": z(0, 64, 3), "obj_kps": z(0, 32, 3), "obj_pose_est": z(0, 3, 4), "obj_scale_est": z(0, 3),
                         "K": z(0, 3, 3)})
     assert sorted(out) == ["pose_0", "pose_1", "pose_2", "scale_0", "scale_1", "scale_2"] and out["pose_2"].shape == (0, 3, 4)
+
+
+def test_integration_md_stub_struct_matches_the_header():
+    """The ctypes stub in INTEGRATION.md section 2 declares catre_opts field for field like include/catre_hip.h (a shorter
+    struct would make the library read past it)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sect = md[md.index("## 2. Binding the C ABI directly"):md.index("## 3. Entry points")]
+    code = re.search(r"```python\n(.*?)```", sect, flags=re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    assert [(n, t) for n, t in ns["catre_opts"]._fields_] == [(n, t) for n, t in hip.CatreOpts._fields_]
+    src = open(os.path.join(ROOT, "include", "catre_hip.h")).read()
+    body = src[src.index("typedef struct catre_opts {"):src.index("} catre_opts;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(?:int32_t|float)\s+(\w+);", body)
+    assert fields == [n for n, _ in hip.CatreOpts._fields_]
