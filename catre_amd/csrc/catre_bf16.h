@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
   __shared__ u32x4 smem[TP * 64 + TP * 16];
 #define TRUNKB_STAMP(i)                                                                                    \
   do {                                                                                                     \
-    if (trace && (threadIdx.x & 63) == 0)                                                                  \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                                  \
       trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter();      \
   } while (0)
   u32x4* a3 = smem;
@@ -601,24 +601,38 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
       g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64);
       g1.run(acc, a0, lane);
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
+      int valid_h = rt.valid - 4 * h;
+      asm volatile("" : "+v"(valid_h));
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
         const float bb = (hd ? b1y : b1x)[ch];
         unsigned short* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
+        unsigned short* dh = dst + (size_t)(4 * h) * 256;
+        if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = acc[mb][nb][r] + bb;
-            acc[mb][nb][r] = v;
-            if (pt < rt.valid) {
-              dst[(size_t)pt * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mb][nb][r] + bb;
+              acc[mb][nb][r] = v;
+              dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
               s += v;
             }
-          }
+        } else {  // ragged tile: see k_rot_l1
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mb][nb][r] + bb;
+              acc[mb][nb][r] = v;
+              if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
+                dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                s += v;
+              }
+            }
+        }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
@@ -629,9 +643,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float d = acc[mb][nb][r] - mean;
-            m2 += pt < rt.valid ? d * d : 0.f;
+            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
           }
         m2 += __shfl_xor(m2, 1);
         m2 += __shfl_xor(m2, 2);

@@ -26,6 +26,14 @@
 
 #define TP 64  // points per tile
 
+// Per-phase cycle stamps (profiles/trace_*.py) are compiled into the instrumented library only
+// (`make TRACE=1` -> libcatre_hip_trace.so); in the product library the stamp macros fold to nothing.
+#ifdef CATRE_DEBUG_TRACE
+#define CATRE_TRACE_ON 1
+#else
+#define CATRE_TRACE_ON 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

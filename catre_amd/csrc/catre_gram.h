@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
         t = fmaf(s4[2], w[k4 * 4 + 2], t);
         t = fmaf(s4[3], w[k4 * 4 + 3], t);
       }
-      quad = fmaf(w[r], t, quad);
+      quad = fmaf(wrow[r], t, quad);  // (a runtime index into w[] would put the whole array in scratch)
     }
     qpart[cl][rq][cq] = quad;
   }

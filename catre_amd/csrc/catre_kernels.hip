@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
 #define TRUNK_STAMP(i)                                                                     \
   do {                                                                                     \
-    if (trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
+    if (CATRE_TRACE_ON && trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
   // phase-1/2 buffers alias the conv4 input image a3 (dead before a3 is first written)
   float* h1 = smem;                      // [64][68]
@@ -1544,8 +1544,13 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
 
 
 int catre_debug_trunk_trace(void* device_buffer) {
+#ifdef CATRE_DEBUG_TRACE
   g_trunk_trace = (unsigned long long*)device_buffer;
   return CATRE_OK;
+#else
+  (void)device_buffer;
+  return CATRE_ERR_UNSUPPORTED;  // product build: no stamps in the kernels (make TRACE=1 builds the instrumented library)
+#endif
 }
 
 int catre_profile_enable(int kernel_id, int max_records) {

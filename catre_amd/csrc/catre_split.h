@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   const bool ft = trans64 != nullptr;
 #define TRUNKS_STAMP(i)                                                                                    \
   do {                                                                                                     \
-    if (trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter();     \
+    if (CATRE_TRACE_ON && trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter();     \
   } while (0)
   TRUNKS_STAMP(0);
 
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
   int stamp_i = 0;
 #define ROTS_STAMP()                                                                                     \
   do {                                                                                                   \
-    if (trace && (threadIdx.x & 63) == 0)                                                                \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                                \
       trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + stamp_i] = __builtin_readcyclecounter(); \
     ++stamp_i;                                                                                           \
   } while (0)
@@ -530,6 +530,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
       g1.run(acc, a0h, a0l, lane);
       ROTS_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
+      int valid_h = rt.valid - 4 * h;  // point (r, nb) of this half-wave is real iff its in-tile index < valid_h
+      asm volatile("" : "+v"(valid_h));
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
@@ -548,15 +550,18 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
               s += v;
             }
         } else {
+          // ragged tile (rare): same base pointer + compile-time offsets as above; the row bound is re-materialised per
+          // head so that hipcc does not hoist 32 loop-invariant predicates / addresses out of the head loop (that cost
+          // 24-34 spilled SGPRs here and 6 VGPRs + scratch in the split variant)
+          float* dh = dst + (size_t)(4 * h) * 256;
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
               const float v = acc[mb][nb][r] + bb;
               acc[mb][nb][r] = v;
-              if (pt < rt.valid) {
-                dst[(size_t)pt * 256] = v;
+              if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
+                dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
                 s += v;
               }
             }
@@ -571,9 +576,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int pt = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float d = acc[mb][nb][r] - mean;
-            m2 += pt < rt.valid ? d * d : 0.f;
+            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
           }
         m2 += __shfl_xor(m2, 1);
         m2 += __shfl_xor(m2, 2);

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     __syncthreads();
     if (active) {
       // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
-      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 ? 2 : 1), 1> g;
+      // two weight chunks in flight, except the widest instance (4 m-blocks x K-chunk 256): 32 MFMAs per chunk cover
+      // one chunk's L2 round trip, and the third ring slot would not fit 256 VGPRs (2 spills)
+      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;
       // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
       g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
       g.run(acc, xs, LDX, lane);
@@ -304,8 +306,12 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
   }
   __syncthreads();
   const int lo_off = J * CP;  // u32x4 units: J*K bf16 = J*K/8 chunks, K = 8 CP
+  // the pass count is hidden from the optimiser: with a visible trip count of 1 (MB == 2) the sweep is merged with the
+  // staging code above and the K = 512 variant spills 72 VGPRs; as a real loop it fits like the MB == 4 instances do
+  int passes = MB / PMB;
+  asm volatile("" : "+s"(passes));
 #pragma unroll 1
-  for (int p = 0; p < MB / PMB; ++p) {
+  for (int p = 0; p < passes; ++p) {
     const int blk0 = 8 * PMB * p;
     if (blk0 + wave >= nblk) return;
     f32x16 acc[PMB][2];

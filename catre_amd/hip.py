@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcatre_hip.so")
+# CATRE_HIP_LIB selects another build of the same ABI (the instrumented `make TRACE=1` library for profiles/trace_*.py)
+LIB_PATH = os.environ.get("CATRE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcatre_hip.so")
 
 # state_dict keys in the order of `enum catre_param` (include/catre_hip.h)
 PARAM_KEYS = (

@@ -1,0 +1,41 @@
+"""No kernel of the product library may use scratch memory or spill vector registers (four kernels
+did while DESIGN.md said none).  `make -C catre_amd/csrc` records hipcc's -Rpass-analysis=kernel-resource-usage remarks
+next to the library on every build; this test parses them."""
+import os
+
+from catre_amd import hip, resusage
+
+
+def _rows():
+    if not os.path.exists(resusage.RAW) or not os.path.exists(hip.LIB_PATH) or \
+            os.path.getmtime(resusage.RAW) + 120 < os.path.getmtime(hip.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return resusage.parse()
+
+
+def test_no_kernel_uses_scratch_or_spills_vgprs():
+    rows = _rows()
+    assert len(rows) >= 150, len(rows)
+    bad = [(r["kernel"], r["scratch"], r["vgpr_spill"]) for r in rows if r["scratch"] or r["vgpr_spill"]]
+    assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
+    assert all(r["vgpr"] + r["agpr"] <= 512 for r in rows)
+
+
+def test_headline_kernels_keep_their_occupancy_shape():
+    """The workgroup shapes DESIGN.md section 3 relies on: LDS bytes and registers allow the stated workgroups per CU."""
+    by = {r["kernel"]: r for r in _rows()}
+    t = by["k_trunk<1>"]
+    assert t["lds"] == 160 * 1024 and t["vgpr"] <= 256           # one 512-thread workgroup per CU
+    for k in ("k_stn3d<1>", "k_stnkd<1>", "k_rot_l1", "k_rot_l1_split"):
+        assert by[k]["lds"] <= 80 * 1024 and by[k]["vgpr"] <= 256, k  # two 256-thread workgroups per CU
+
+
+def test_committed_table_lists_every_kernel_of_the_build():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r02_resource_usage.txt")
+    text = open(path).read()
+    names = {ln[:72].strip() for ln in text.splitlines()[1:]}
+    missing = [r["kernel"][:72] for r in _rows() if r["kernel"][:72].strip() not in names]
+    assert not missing, f"profiles/r02_resource_usage.txt is stale (python -m catre_amd.resusage --out ...): {missing[:5]}"
