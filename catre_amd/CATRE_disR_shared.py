@@ -129,19 +129,26 @@ class CATRE_disR_shared(nn.Module):
         # under torch.autocast (SOLVER.AMP.ENABLED in the reference's loop) the row GEMMs take bf16 operands;
         # cfg.MODEL.CATRE.COMPUTE_DTYPE forces either precision
         with amp_mode(self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)):
-            pose, scale, _ = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
-                                           K_zoom, mean_scales)
+            pose, scale, aux = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
+                                             K_zoom, mean_scales)
         out_dict = {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
         if not do_loss:
             return out_dict
         assert gt_ego_rot is not None and (gt_trans is not None)
-        from .losses import catre_loss
+        from .losses import VisScalars, catre_loss
 
-        loss_dict = catre_loss(self.cfg, out_rot=pose[:, :3, :3], out_trans=pose[:, :3, 3], out_scale=scale,
-                               gt_rot=gt_ego_rot, gt_trans=gt_trans, gt_scale=gt_scale, obj_kps=obj_kps,
-                               sym_info=sym_info)
-        # the reference also pushes ~15 `.item()` scalars per call into detectron2's EventStorage
-        # (CATRE_disR_shared.py:127-164): logging, deliberately left out - each one is a host sync.
+        loss_dict, vis = catre_loss(self.cfg, out_rot=pose[:, :3, :3], out_trans=pose[:, :3, 3], out_scale=scale,
+                                    gt_rot=gt_ego_rot, gt_trans=gt_trans, gt_scale=gt_scale, obj_kps=obj_kps,
+                                    sym_info=sym_info, trans_deltas=aux["trans_deltas"], return_vis=True)
+        # The reference pushes 14 `.item()` scalars per call into detectron2's EventStorage (:127-164: vis/error_R,
+        # vis/error_t, object 0's translation / deltas / ground truth).  Here the loss kernels write them into ONE device
+        # tensor; `self.vis_scalars` exposes it (no copy until read) and, when an EventStorage is active, the same keys
+        # are written with a single 14-float copy - never while the step is being captured into a HIP graph.
+        self.vis_scalars = VisScalars(vis, cur_iter)
+        storage = _active_event_storage()
+        if storage is not None and self.cfg.MODEL.CATRE.get("LOG_VIS_SCALARS", True) \
+                and not torch.cuda.is_current_stream_capturing():
+            storage.put_scalars(**self.vis_scalars.as_dict())
         return out_dict, loss_dict
 
     def catre_loss(self, out_rot, out_trans, out_scale, gt_rot=None, gt_trans=None, gt_scale=None, obj_kps=None,
@@ -178,23 +185,79 @@ class CATRE_disR_shared(nn.Module):
         return out
 
 
+def _active_event_storage():
+    """detectron2's current ``EventStorage`` if the caller opened one (``engine.py:266``), else None (detectron2 absent or
+    no storage context: nothing to log into)."""
+    try:
+        from detectron2.utils.events import get_event_storage
+
+        return get_event_storage()
+    except Exception:  # ImportError, or detectron2's AssertionError outside a `with EventStorage(...)` block
+        return None
+
+
+def _maybe_add_gradient_clipping(cfg, optimizer):
+    """``lib/torch_utils/solver/grad_clip_d2.py:80-120``: with ``SOLVER.CLIP_GRADIENTS.ENABLED`` the optimizer's class is
+    replaced by a subclass whose ``step`` clips first - ``CLIP_TYPE`` "value" / "norm" per parameter, "full_model" (the
+    default) over all parameters at once."""
+    clip = cfg.SOLVER.get("CLIP_GRADIENTS", None)
+    if not clip or not clip.get("ENABLED", False):
+        return optimizer
+    clip_value, norm_type = float(clip.get("CLIP_VALUE", 1.0)), float(clip.get("NORM_TYPE", 2.0))
+    clip_type = clip.get("CLIP_TYPE", "full_model")
+    if clip_type not in ("value", "norm", "full_model"):
+        raise ValueError(f"'{clip_type}' is not a valid GradientClipType")
+    base = type(optimizer)
+
+    def step(self, closure=None):
+        groups = [[p for p in g["params"] if p.grad is not None] for g in self.param_groups]
+        if clip_type == "full_model":
+            torch.nn.utils.clip_grad_norm_([p for g in groups for p in g], clip_value, norm_type)
+        else:
+            for p in (p for g in groups for p in g):
+                if clip_type == "value":
+                    torch.nn.utils.clip_grad_value_(p, clip_value)
+                else:
+                    torch.nn.utils.clip_grad_norm_(p, clip_value, norm_type)
+        return base.step(self, closure)
+
+    optimizer.__class__ = type(base.__name__ + "WithGradientClip", (base,), {"step": step})
+    return optimizer
+
+
 def _build_optimizer(cfg, params_lr_list):
-    """Stand-in for ``core/utils/solver_utils.build_optimizer_with_params`` (reference ``:75-87``): the
-    shipped config's Ranger is ``catre_amd.ranger.Ranger`` (one fused multi-tensor HIP step); other
-    types resolve to ``torch.optim``."""
-    ocfg = dict(cfg.SOLVER.get("OPTIMIZER_CFG", {}) or {})
-    typ = ocfg.pop("type", "Adam")
-    lr = ocfg.pop("lr", float(cfg.SOLVER.BASE_LR))
-    wd = ocfg.pop("weight_decay", float(cfg.SOLVER.get("WEIGHT_DECAY", 0.0)))
+    """``core/utils/solver_utils.build_optimizer_with_params`` (reference ``:75-87``): ``OPTIMIZER_CFG`` (a dict, or the
+    string form the reference ``eval``s) names the optimizer and carries its keyword arguments; the shipped config's
+    Ranger is ``catre_amd.ranger.Ranger`` (one fused multi-tensor HIP step); ``torch.optim`` types get every
+    keyword; then ``maybe_add_gradient_clipping``."""
+    ocfg = cfg.SOLVER.get("OPTIMIZER_CFG", "")
+    if isinstance(ocfg, str):
+        if ocfg == "":
+            raise RuntimeError("please provide cfg.SOLVER.OPTIMIZER_CFG to build optimizer")  # solver_utils.py:77
+        ocfg = eval(ocfg, {"__builtins__": {}}, {"dict": dict})  # "dict(type='Ranger', lr=1e-4, ...)" (:79)
+    ocfg = dict(ocfg)
+    typ = ocfg.pop("type")
     groups = [dict(params=list(g["params"]), lr=g["lr"]) for g in params_lr_list]
-    if typ == "Ranger":  # the shipped config (…_120e.py:49): fused multi-tensor HIP step, SURVEY.md 8f-4
+    if typ == "Ranger":  # the shipped config (…_120e.py:49)
         from .ranger import Ranger
 
-        return Ranger(groups, lr=lr, weight_decay=wd, **ocfg)
-    if hasattr(torch.optim, typ):
-        return getattr(torch.optim, typ)(groups, lr=lr, weight_decay=wd)
-    logger.warning("optimizer %s is not part of the hot path; using torch.optim.RAdam with the same param groups", typ)
-    return torch.optim.RAdam(groups, lr=lr, weight_decay=wd)
+        opt = Ranger(groups, **ocfg)
+    elif hasattr(torch.optim, typ):
+        opt = getattr(torch.optim, typ)(groups, **ocfg)
+    else:
+        # Ranger21 / Lamb / MADGRAD / NAdamW / AdaBelief / SGDP / AdamP / SGD_GC of solver_utils.py:30-72 are generic
+        # third-party optimizers outside the hot path
+        raise ValueError(f"Unknown optimizer name: {typ} (available: 'Ranger' and every torch.optim class)")
+    return _maybe_add_gradient_clipping(cfg, opt)
+
+
+def _load_pretrained_pcl_net(model, path):
+    """``PCLNET.PRETRAINED`` = a checkpoint file (reference ``:342-346``, mmcv ``load_checkpoint(..., strict=False)``)."""
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt.get("state_dict", ckpt.get("model", ckpt)) if isinstance(ckpt, dict) else ckpt
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    missing, unexpected = model.pcl_net.load_state_dict(sd, strict=False)
+    logger.info("load pcl_net weights from: %s (missing %d, unexpected %d keys)", path, len(missing), len(unexpected))
 
 
 def build_model_optimizer(cfg, is_test=False):
@@ -219,8 +282,14 @@ def build_model_optimizer(cfg, is_test=False):
 
     model = CATRE_disR_shared(cfg, pcl_net, rot_head, ts_head)
     optimizer = None if is_test else _build_optimizer(cfg, params_lr_list)
-    if cfg.MODEL.get("WEIGHTS", "") == "":
-        logger.warning("Randomly initialize weights for pcl_net!")
+    if cfg.MODEL.get("WEIGHTS", "") == "":  # reference :328-346
+        pretrained = pcl_net_cfg.get("PRETRAINED", "")
+        if pretrained == "":
+            logger.warning("Randomly initialize weights for pcl_net!")
+        elif pretrained in ("timm", "internal"):
+            logger.info("Check if the pcl_net has been initialized with its own method!")
+        else:
+            _load_pretrained_pcl_net(model, pretrained)
     model.to(torch.device(cfg.MODEL.DEVICE))
     return model, optimizer
 

@@ -1691,14 +1691,15 @@ int catre_pcl_fps(const float* depth, const float* K9, const void* workspace, si
 int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
                    const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
-                   float* losses, int B, int M, int S1, void* stream) {
+                   float* losses, const float* trans_deltas, int B, int M, int S1, void* stream) {
   REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && part_ws && losses && B > 0 &&
           S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && valid && M > 0));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, st, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid,
                      is_sym, *cfg, best, part_ws, B, M, S1);
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M);
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M,
+                     pose, gt_trans, trans_deltas);
   return check_launch();
 }
 

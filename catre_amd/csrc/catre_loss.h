@@ -8,8 +8,11 @@
 
 typedef catre_loss_cfg LossCfg;  // include/catre_hip.h
 
-// per-object partial sums: 0 PM |est - tgt|, 1 rot (non-sym), 2 y-axis (sym), 3 trans xy (or xyz), 4 trans z, 5 scale
+// per-object partial sums: 0 PM |est - tgt|, 1 rot (non-sym), 2 y-axis (sym), 3 trans xy (or xyz), 4 trans z, 5 scale,
+// 6 rotation error re() in degrees, 7 translation error te() (lib/pysixd/pose_error.py:359-374,406-417) - the last
+// two feed the forward-side logging scalars of CATRE_disR_shared.forward (reference :127-164)
 #define LOSS_NP 8
+#define LOSS_NVIS 14
 
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wave_sum(v);
@@ -129,10 +132,23 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
         }
       } else {
         float s = 0.f;
+        if (cfg.yaxis_smooth >= 2) {  // 2: L2Loss (l2_loss.py:5-28, per-object norm); 3: angular_distance_vec (rot_loss.py:33-42)
+          float dd = 0.f, pg = 0.f, pp = 0.f, gg = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float d = P[i * 3 + 1] - G[i * 3 + 1];
-          s += cfg.yaxis_smooth ? smooth_l1(d) : fabsf(d);
+          for (int i = 0; i < 3; ++i) {
+            const float p = P[i * 3 + 1], g = G[i * 3 + 1];
+            dd += (p - g) * (p - g);
+            pg += p * g;
+            pp += p * p;
+            gg += g * g;
+          }
+          s = cfg.yaxis_smooth == 2 ? sqrtf(dd) : (1.f - pg / (sqrtf(pp) * sqrtf(gg))) * 0.5f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float d = P[i * 3 + 1] - G[i * 3 + 1];
+            s += cfg.yaxis_smooth ? smooth_l1(d) : fabsf(d);
+          }
         }
         out[2] = s;
       }
@@ -141,8 +157,12 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
       const float d[3] = {t[0] - gt_trans[b * 3], t[1] - gt_trans[b * 3 + 1], t[2] - gt_trans[b * 3 + 2]};
       float f[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) f[i] = cfg.trans_mse ? d[i] * d[i] : fabsf(d[i]);
-      out[3] = cfg.trans_split ? f[0] + f[1] : f[0] + f[1] + f[2];
+      for (int i = 0; i < 3; ++i) f[i] = cfg.trans_mse == 1 ? d[i] * d[i] : fabsf(d[i]);
+      if (cfg.trans_mse == 2) {  // L2Loss: per-object Euclidean norm
+        out[3] = sqrtf(cfg.trans_split ? d[0] * d[0] + d[1] * d[1] : d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      } else {
+        out[3] = cfg.trans_split ? f[0] + f[1] : f[0] + f[1] + f[2];
+      }
       out[4] = f[2];
     }
     if (cfg.scale_on) {
@@ -152,7 +172,16 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
         const float d = scale[b * 3 + i] - gt_scale[b * 3 + i];
         s += cfg.scale_mse ? d * d : fabsf(d);
       }
-      out[5] = s;
+      out[5] = cfg.scale_mse == 2 ? sqrtf(s) : s;
+    }
+    {  // compute_mean_re_te (models/model_utils.py:226-238): re against the plain ground truth, te
+      float tr = 0.f;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) tr = fmaf(P[e], G[e], tr);  // trace(R_est R_gt^T)
+      tr = fminf(tr, 3.0f);
+      out[6] = acosf(fminf(1.0f, fmaxf(-1.0f, 0.5f * (tr - 1.0f)))) * 57.29577951308232f;
+      const float d0 = gt_trans[b * 3] - t[0], d1 = gt_trans[b * 3 + 1] - t[1], d2 = gt_trans[b * 3 + 2] - t[2];
+      out[7] = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     }
 #pragma unroll
     for (int i = 0; i < LOSS_NP; ++i) part[(size_t)b * LOSS_NP + i] = out[i];
@@ -162,9 +191,29 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
 // losses[6] = PM_R, rot, yaxis_rot, trans_xy (or trans), trans_z, scale: objects summed in order, then normalised
 // counts[2] = {objects with symmetry info, without}: taken from is_sym on the device, so a captured graph stays valid
 // when the mix of objects changes from batch to batch
+// losses[6 .. 6+14) = the reference's vis/ scalars in its own order: error_R [deg], error_t [cm], |t_pred - t_gt| of
+// object 0 [cm] x3, t_pred x3, trans_deltas x3 (0 when no deltas are passed), t_gt x3 - all of object 0 like the
+// reference (`pred_trans[0, 0]` ...)
 __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
-                              float* __restrict__ losses, int* __restrict__ counts, int B, int M) {
+                              float* __restrict__ losses, int* __restrict__ counts, int B, int M,
+                              const float* __restrict__ pose, const float* __restrict__ gt_trans,
+                              const float* __restrict__ trans_deltas) {
   const int i = threadIdx.x;
+  if (i >= 6 && i < 6 + LOSS_NVIS) {
+    const int k = i - 6;
+    float v;
+    if (k < 2) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += part[(size_t)b * LOSS_NP + 6 + k];
+      v = s / (float)B * (k == 1 ? 100.f : 1.f);
+    } else {
+      const int c = (k - 2) % 3, what = (k - 2) / 3;
+      const float tp = pose[c * 4 + 3], tg = gt_trans[c];
+      v = what == 0 ? fabsf(tp - tg) * 100.f : what == 1 ? tp : what == 2 ? (trans_deltas ? trans_deltas[c] : 0.f) : tg;
+    }
+    losses[i] = v;
+    return;
+  }
   if (i >= 6) return;
   int n_sym = 0;
   for (int b = 0; b < B; ++b) n_sym += is_sym[b] != 0;
@@ -179,10 +228,10 @@ __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restr
   switch (i) {
     case 0: v = 3.f * (s / ((float)B * M * 3.f)) * cfg.pm_lw; break;
     case 1: v = n_nonsym > 0 ? s / ((float)n_nonsym * (cfg.rot_l2 ? 9.f : 1.f)) * cfg.rot_lw : 0.f; break;
-    case 2: v = n_sym > 0 ? s / ((float)n_sym * 3.f) * cfg.rot_lw : 0.f; break;
-    case 3: v = s / ((float)B * (cfg.trans_split ? 2.f : 3.f)) * cfg.trans_lw; break;
+    case 2: v = n_sym > 0 ? s / ((float)n_sym * (cfg.yaxis_smooth >= 2 ? 1.f : 3.f)) * cfg.rot_lw : 0.f; break;
+    case 3: v = s / ((float)B * (cfg.trans_mse == 2 ? 1.f : cfg.trans_split ? 2.f : 3.f)) * cfg.trans_lw; break;
     case 4: v = s / (float)B * cfg.trans_lw; break;
-    case 5: v = s / ((float)B * 3.f) * cfg.scale_lw; break;
+    case 5: v = s / ((float)B * (cfg.scale_mse == 2 ? 1.f : 3.f)) * cfg.scale_lw; break;
   }
   losses[i] = v;
 }
@@ -252,6 +301,26 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
           for (int e = 0; e < 9; ++e) dR[e] += c * G[e];
         }
       }
+    } else if (n_sym > 0 && cfg.yaxis_smooth >= 2) {
+      const float c = up[2] * cfg.rot_lw / (float)n_sym;
+      float dd = 0.f, pg = 0.f, pp = 0.f, gg = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float p = P[i * 3 + 1], g = G[i * 3 + 1];
+        dd += (p - g) * (p - g);
+        pg += p * g;
+        pp += p * p;
+        gg += g * g;
+      }
+      if (cfg.yaxis_smooth == 2) {
+        const float nrm = sqrtf(dd);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dR[i * 3 + 1] += nrm > 0.f ? c * (P[i * 3 + 1] - G[i * 3 + 1]) / nrm : 0.f;
+      } else {
+        const float np_ = sqrtf(pp), ng = sqrtf(gg), cs = pg / (np_ * ng);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dR[i * 3 + 1] += -0.5f * c * (G[i * 3 + 1] / (np_ * ng) - cs * P[i * 3 + 1] / pp);
+      }
     } else if (n_sym > 0) {
       const float c = up[2] * cfg.rot_lw / ((float)n_sym * 3.f);
 #pragma unroll
@@ -270,21 +339,32 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
     const float d[3] = {t[0] - gt_trans[b * 3], t[1] - gt_trans[b * 3 + 1], t[2] - gt_trans[b * 3 + 2]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const float gd = cfg.trans_mse ? 2.f * d[i] : (d[i] > 0.f ? 1.f : (d[i] < 0.f ? -1.f : 0.f));
+      const float sg = d[i] > 0.f ? 1.f : (d[i] < 0.f ? -1.f : 0.f);
+      float gd = cfg.trans_mse == 1 ? 2.f * d[i] : sg;
       float c;
-      if (cfg.trans_split)
+      if (cfg.trans_mse == 2) {  // d ||d|| / d d_i = d_i / ||d|| over the components the norm spans
+        const bool in_norm = !cfg.trans_split || i < 2;
+        const float nrm = sqrtf(cfg.trans_split ? d[0] * d[0] + d[1] * d[1] : d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        gd = in_norm ? (nrm > 0.f ? d[i] / nrm : 0.f) : sg;
+        c = (in_norm ? up[3] : up[4]) * cfg.trans_lw / (float)B;
+      } else if (cfg.trans_split) {
         c = i < 2 ? up[3] * cfg.trans_lw / ((float)B * 2.f) : up[4] * cfg.trans_lw / (float)B;
-      else
+      } else {
         c = up[3] * cfg.trans_lw / ((float)B * 3.f);
+      }
       dt[i] = c * gd;
     }
   }
   if (cfg.scale_on) {
-    const float c = up[5] * cfg.scale_lw / ((float)B * 3.f);
+    const float c = up[5] * cfg.scale_lw / ((float)B * (cfg.scale_mse == 2 ? 1.f : 3.f));
+    const float d3[3] = {scale[b * 3] - gt_scale[b * 3], scale[b * 3 + 1] - gt_scale[b * 3 + 1],
+                         scale[b * 3 + 2] - gt_scale[b * 3 + 2]};
+    const float nrm = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const float d = scale[b * 3 + i] - gt_scale[b * 3 + i];
-      ds[i] += c * (cfg.scale_mse ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+      const float d = d3[i];
+      ds[i] += c * (cfg.scale_mse == 2 ? (nrm > 0.f ? d / nrm : 0.f)
+                                       : cfg.scale_mse == 1 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
     }
   }
   float* o = dpose + b * 12;

@@ -1533,9 +1533,10 @@ struct RangerTensor {
 static_assert(sizeof(RangerTensor) == 72, "host packs this struct with the same layout");
 
 __device__ __forceinline__ float ranger_clean(float g, int clean, float lim) {
+  // torch.nan_to_num(g, nan=0, posinf=lim, neginf=-lim) (engine.py:351-353): finite values pass unchanged
   if (!clean) return g;
   if (g != g) return 0.f;
-  return fminf(fmaxf(g, -lim), lim);
+  return g == INFINITY ? lim : (g == -INFINITY ? -lim : g);
 }
 
 // one wave per (tensor, row): mean of the (cleaned) gradient row

@@ -153,7 +153,7 @@ _SIGS = {
     "catre_pcl_candidates": (_I, [_P, _P, _P, _P, _P, ctypes.c_float, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "catre_pcl_sample": (_I, [_P, _P, _P, _SZ, _P, ctypes.c_uint64, _I, _I, _I, _I, _P, _P, _P]),
     "catre_pcl_fps": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P, _I, _P, _P]),
-    "catre_loss_fwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
+    "catre_loss_fwd": (_I, [_P] * 15 + [_I, _I, _I, _P]),
     "catre_loss_bwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),

@@ -47,6 +47,11 @@ def _sym_tensor(sym_infos, device, dtype):
     return out
 
 
+# loss-type names of the reference (CATRE_disR_shared.py:232-285) -> the enums of catre_loss_cfg
+_YAXIS_TYPES = {"L1": 0, "smoothL1": 1, "L2": 2, "angular": 3}
+_NORM_TYPES = {"L1": 0, "MSE": 1, "L2": 2}
+
+
 def _loss_cfg_struct(cfg):
     lc = cfg.MODEL.CATRE.LOSS_CFG
     c = hip.CatreLossCfg()
@@ -57,44 +62,46 @@ def _loss_cfg_struct(cfg):
     c.rot_on = int(lc.ROT_LW > 0)
     if c.rot_on:
         if lc.ROT_LOSS_TYPE not in ("angular", "L2"):
-            raise ValueError(f"Unknown rot loss type: {lc.ROT_LOSS_TYPE}")
-        if lc.ROT_YAXIS_LOSS_TYPE not in ("L1", "smoothL1"):
-            raise ValueError(f"Unknown rot yaxis loss type: {lc.ROT_YAXIS_LOSS_TYPE}")
-    c.rot_l2, c.yaxis_smooth = int(lc.ROT_LOSS_TYPE == "L2"), int(lc.ROT_YAXIS_LOSS_TYPE == "smoothL1")
+            raise ValueError(f"Unknown rot loss type: {lc.ROT_LOSS_TYPE}")  # CATRE_disR_shared.py:228
+        if lc.ROT_YAXIS_LOSS_TYPE not in _YAXIS_TYPES:
+            raise ValueError(f"Unknown rot yaxis loss type: {lc.ROT_YAXIS_LOSS_TYPE}")  # :243
+    c.rot_l2, c.yaxis_smooth = int(lc.ROT_LOSS_TYPE == "L2"), _YAXIS_TYPES.get(lc.ROT_YAXIS_LOSS_TYPE, 0)
     c.trans_on = int(lc.TRANS_LW > 0)
-    if c.trans_on and lc.TRANS_LOSS_TYPE not in ("L1", "MSE"):
-        raise ValueError(f"Unknown trans loss type: {lc.TRANS_LOSS_TYPE}")
-    c.trans_mse, c.trans_split = int(lc.TRANS_LOSS_TYPE == "MSE"), int(bool(lc.TRANS_LOSS_DISENTANGLE))
+    if c.trans_on and lc.TRANS_LOSS_TYPE not in _NORM_TYPES:
+        raise ValueError(f"Unknown trans loss type: {lc.TRANS_LOSS_TYPE}")  # :259,269
+    c.trans_mse, c.trans_split = _NORM_TYPES.get(lc.TRANS_LOSS_TYPE, 0), int(bool(lc.TRANS_LOSS_DISENTANGLE))
     c.scale_on = int(lc.SCALE_LW > 0)
     if c.scale_on:
         assert cfg.MODEL.REFINE_SCLAE
-        if lc.SCALE_LOSS_TYPE not in ("L1", "MSE"):
-            raise ValueError(f"Unknown scale loss type: {lc.SCALE_LOSS_TYPE}")
-    c.scale_mse = int(lc.SCALE_LOSS_TYPE == "MSE")
+        if lc.SCALE_LOSS_TYPE not in _NORM_TYPES:
+            raise ValueError(f"Unknown scale loss type: {lc.SCALE_LOSS_TYPE}")  # :283
+    c.scale_mse = _NORM_TYPES.get(lc.SCALE_LOSS_TYPE, 0)
     c.pm_lw, c.rot_lw, c.trans_lw, c.scale_lw = float(lc.PM_LW), float(lc.ROT_LW), float(lc.TRANS_LW), float(lc.SCALE_LW)
     return c
 
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, lcfg):
+    def forward(ctx, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, lcfg, trans_deltas):
         lib = hip.load()
         B, M, S1 = pose.shape[0], (kps.shape[1] if kps is not None else 0), cands.shape[1]
         dev = pose.device
         best = torch.empty(B, dtype=torch.int32, device=dev)
         counts = torch.empty(2, dtype=torch.int32, device=dev)
         part = torch.empty(B * 8, dtype=torch.float32, device=dev)
-        losses = torch.empty(6, dtype=torch.float32, device=dev)
+        buf = torch.empty(6 + N_VIS, dtype=torch.float32, device=dev)
         hip.check(lib.catre_loss_fwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
                                      hip.ptr(kps), hip.ptr(cands), hip.ptr(valid), hip.ptr(is_sym), ctypes.byref(lcfg),
-                                     hip.ptr(best), hip.ptr(counts), hip.ptr(part), hip.ptr(losses), B, M, S1,
-                                     hip.stream_ptr(dev)), "catre_loss_fwd")
+                                     hip.ptr(best), hip.ptr(counts), hip.ptr(part), hip.ptr(buf), hip.ptr(trans_deltas),
+                                     B, M, S1, hip.stream_ptr(dev)), "catre_loss_fwd")
         ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts)
         ctx.lcfg, ctx.dims = lcfg, (B, M, S1)
-        return losses
+        losses, vis = buf[:6], buf[6:]
+        ctx.mark_non_differentiable(vis)
+        return losses, vis
 
     @staticmethod
-    def backward(ctx, up):
+    def backward(ctx, up, _up_vis):
         pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts = ctx.saved_tensors
         B, M, S1 = ctx.dims
         lib = hip.load()
@@ -104,7 +111,7 @@ class _FusedLoss(torch.autograd.Function):
                                      hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(counts), hip.ptr(up),
                                      ctypes.byref(ctx.lcfg), hip.ptr(dpose), hip.ptr(dscale), B, M, S1,
                                      hip.stream_ptr(pose.device)), "catre_loss_bwd")
-        return dpose, dscale, None, None, None, None, None, None, None, None
+        return dpose, dscale, None, None, None, None, None, None, None, None, None
 
 
 class SymTensors:
@@ -127,8 +134,34 @@ class SymTensors:
         return cls(cands, valid, is_sym)
 
 
-def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info):
-    """-> the reference's loss dict (same keys, same values).  Gradients flow to out_rot / out_trans / out_scale."""
+N_VIS = 14
+VIS_KEYS = ("error_R", "error_t", "error_tx", "error_ty", "error_tz", "tx_pred", "ty_pred", "tz_pred", "tx_delta", "ty_delta",
+            "tz_delta", "tx_gt", "ty_gt", "tz_gt")
+
+
+class VisScalars:
+    """The per-iteration logging scalars of the reference's training forward (``CATRE_disR_shared.py:127-164``: mean
+    rotation error [deg], mean translation error [cm], object 0's translation / deltas / ground truth) as ONE device
+    tensor written by the loss kernels.  Nothing is copied until a value is asked for: ``as_dict()`` does a single
+    14-float device->host copy and returns the reference's ``vis/<name>_<cur_iter>`` keys."""
+
+    def __init__(self, tensor, cur_iter):
+        self.tensor, self.cur_iter = tensor, cur_iter
+        self._host = None
+
+    def tolist(self):
+        if self._host is None:
+            self._host = self.tensor.detach().tolist()  # the only host sync
+        return self._host
+
+    def as_dict(self):
+        return {f"vis/{k}_{self.cur_iter}": v for k, v in zip(VIS_KEYS, self.tolist())}
+
+
+def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info, trans_deltas=None,
+               return_vis=False):
+    """-> the reference's loss dict (same keys, same values).  Gradients flow to out_rot / out_trans / out_scale.
+    ``return_vis``: also return the 14 logging scalars (device tensor, see :class:`VisScalars`)."""
     lc = cfg.MODEL.CATRE.LOSS_CFG
     B = out_rot.shape[0]
     dev = out_rot.device
@@ -146,8 +179,9 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
     pose = torch.cat([out_rot, out_trans.unsqueeze(-1)], -1).contiguous()
     f32 = lambda t: hip.require_dev_f32(t.contiguous(), "loss input") if t is not None else None
     gs = f32(gt_scale) if gt_scale is not None else torch.zeros(B, 3, dtype=torch.float32, device=dev)
-    losses = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
-                              f32(obj_kps), cands, valid, is_sym, lcfg)
+    td = f32(trans_deltas.detach()) if trans_deltas is not None else None
+    losses, vis = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
+                                   f32(obj_kps), cands, valid, is_sym, lcfg, td)
     ld = {}
     if lcfg.pm_on:
         ld["loss_PM_R"] = losses[0]
@@ -163,4 +197,4 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
             ld["loss_trans_LPnP"] = losses[3]
     if lcfg.scale_on:
         ld["loss_scale"] = losses[5]
-    return ld
+    return (ld, vis) if return_vis else ld

@@ -21,18 +21,31 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_batch(batch, rank, world):
-    """Slice every per-object tensor / list of a reference-style batch dict."""
+# per-object entries of the reference's batch dicts (engine/batch_test.py:10-60,63-99; engine/batching.py:9-146): first
+# dimension = the object.  Per-IMAGE entries ("img", "depth_obs", "roi_img", ...) and scalars are never sliced, whatever
+# their length happens to be.
+PER_OBJECT_KEYS = frozenset((
+    "obj_cls", "obj_bbox", "obj_pose", "obj_scale", "obj_pose_est", "obj_scale_est", "obj_mean_points", "obj_mean_scales",
+    "obj_fps_points", "obj_kps", "im_id", "inst_id", "K", "sym_info", "pcl", "x", "tfd_kps",
+    "gt_rot", "gt_trans", "gt_scale", "obj_pose_gt", "obj_scale_gt", "nocs_scale",
+))
+
+
+def shard_batch(batch, rank, world, extra_keys=()):
+    """Slice the per-object tensors / lists of a reference-style batch dict (``PER_OBJECT_KEYS`` + ``extra_keys``);
+    everything else is passed through untouched."""
     B = batch["pcl"].shape[0]
     lo, hi = shard_bounds(B, rank, world)
+    keys = PER_OBJECT_KEYS | frozenset(extra_keys)
     out = {}
     for k, v in batch.items():
-        if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == B:
-            out[k] = v[lo:hi].contiguous()
-        elif isinstance(v, (list, tuple)) and len(v) == B:
-            out[k] = v[lo:hi]
-        else:
+        if k not in keys:
             out[k] = v
+            continue
+        n = v.shape[0] if isinstance(v, torch.Tensor) else len(v)
+        if n != B:
+            raise ValueError(f"batch[{k!r}] is a per-object entry but holds {n} rows for {B} objects")
+        out[k] = v[lo:hi].contiguous() if isinstance(v, torch.Tensor) else v[lo:hi]
     return out
 
 

@@ -404,13 +404,19 @@ int catre_pcl_fps(const float* depth, const float* K9, const void* workspace, si
  * (core/catre/models/CATRE_disR_shared.py:168-288; PyPMLoss core/catre/losses/pm_loss.py:85-194, L1 / R-only form). */
 typedef struct catre_loss_cfg {
   int32_t pm_on, pm_sym, pm_with_scale;     /* PM_LW > 0, PM_LOSS_SYM, PM_WITH_SCALE                              */
-  int32_t rot_on, rot_l2, yaxis_smooth;     /* ROT_LW > 0, ROT_LOSS_TYPE == "L2" (else angular), ROT_YAXIS "smoothL1" */
-  int32_t trans_on, trans_mse, trans_split; /* TRANS_LW > 0, TRANS_LOSS_TYPE == "MSE" (else L1), TRANS_LOSS_DISENTANGLE */
-  int32_t scale_on, scale_mse;
+  int32_t rot_on, rot_l2, yaxis_smooth;     /* ROT_LW > 0, ROT_LOSS_TYPE == "L2" (else angular), ROT_YAXIS_LOSS_TYPE: 0 "L1",
+                                             * 1 "smoothL1", 2 "L2", 3 "angular" (CATRE_disR_shared.py:232-243)           */
+  int32_t trans_on, trans_mse, trans_split; /* TRANS_LW > 0, TRANS_LOSS_TYPE: 0 "L1", 1 "MSE", 2 "L2" (L2Loss,
+                                             * core/catre/losses/l2_loss.py:5-28), TRANS_LOSS_DISENTANGLE                 */
+  int32_t scale_on, scale_mse;              /* SCALE_LW > 0, SCALE_LOSS_TYPE: 0 "L1", 1 "MSE", 2 "L2"                      */
   float pm_lw, rot_lw, trans_lw, scale_lw;
 } catre_loss_cfg;
 
-/* losses[6] = {loss_PM_R, loss_rot, loss_yaxis_rot, loss_trans_xy (or loss_trans_LPnP), loss_trans_z, loss_scale}.
+/* losses[20]: [0..6) = {loss_PM_R, loss_rot, loss_yaxis_rot, loss_trans_xy (or loss_trans_LPnP), loss_trans_z,
+ * loss_scale}; [6..20) = the scalars CATRE_disR_shared.forward logs per training iteration
+ * (core/catre/models/CATRE_disR_shared.py:127-164, compute_mean_re_te models/model_utils.py:226-238), in its order:
+ * error_R [deg], error_t [cm], |t_pred - t_gt| x,y,z of object 0 [cm], t_pred x,y,z, trans_deltas x,y,z
+ * (trans_deltas [B,3] may be NULL -> 0), t_gt x,y,z - computed with the loss, so logging costs no launch and one copy.
  * pose [B,3,4] = [R|t] estimate, scale [B,3]; cands [B,S1,3,3] = symmetry rotations per object with the identity
  * first, valid [B,S1] bytes, is_sym [B]; the ground-truth rotation closest to the estimate among R_gt S_k
  * (get_closest_rot_batch, core/utils/pose_utils.py:472-528) is chosen on the device, its index kept in best [B] for
@@ -419,7 +425,7 @@ typedef struct catre_loss_cfg {
 int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
                    const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
-                   float* losses, int B, int M, int S1, void* stream);
+                   float* losses, const float* trans_deltas, int B, int M, int S1, void* stream);
 /* dpose [B,3,4], dscale [B,3] = gradient of sum_i upstream[i] * losses[i] (upstream: 6 floats on the device) */
 int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                    const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,

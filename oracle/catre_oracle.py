@@ -426,6 +426,18 @@ def get_closest_rot_batch(pred_rots, gt_rots, sym_infos):
     return out
 
 
+def l2_loss(pred, target):
+    """``L2Loss(reduction="mean")``, ``core/catre/losses/l2_loss.py:5-28``: mean over the batch of per-sample L2 norms."""
+    bs = pred.size(0)
+    return torch.norm((pred - target).view(bs, -1), p=2, dim=1, keepdim=True).mean()
+
+
+def angular_distance_vec(v1, v2):
+    """``core/catre/losses/rot_loss.py:33-42``."""
+    cos = torch.bmm(v1.unsqueeze(1), v2.unsqueeze(2)).squeeze() / (torch.norm(v1, dim=1) * torch.norm(v2, dim=1))
+    return ((1 - cos) / 2).mean()
+
+
 def catre_loss(out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info, loss_cfg):
     """``CATRE_disR_shared.catre_loss`` (``core/catre/models/CATRE_disR_shared.py:168-288``) with ``PyPMLoss``
     (``core/catre/losses/pm_loss.py:85-194``) for the shipped loss types (L1 PM / angular rot / L1 y-axis / L1 t,s)."""
@@ -448,17 +460,18 @@ def catre_loss(out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kp
                 assert loss_cfg.ROT_LOSS_TYPE == "L2"
                 ld["loss_rot"] = torch.pow(out_rot[ns] - gt_rot[ns], 2).mean() * loss_cfg.ROT_LW
         if len(sy) > 0:
-            fn = {"L1": F.l1_loss, "smoothL1": F.smooth_l1_loss}[loss_cfg.ROT_YAXIS_LOSS_TYPE]
+            fn = {"L1": F.l1_loss, "smoothL1": F.smooth_l1_loss, "L2": l2_loss,
+                  "angular": angular_distance_vec}[loss_cfg.ROT_YAXIS_LOSS_TYPE]  # :232-243
             ld["loss_yaxis_rot"] = fn(out_rot[sy][:, :, 1], gt_rot[sy][:, :, 1]) * loss_cfg.ROT_LW
     if loss_cfg.TRANS_LW > 0:
-        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}[loss_cfg.TRANS_LOSS_TYPE]
+        fn = {"L1": F.l1_loss, "MSE": F.mse_loss, "L2": l2_loss}[loss_cfg.TRANS_LOSS_TYPE]
         if loss_cfg.TRANS_LOSS_DISENTANGLE:
             ld["loss_trans_xy"] = fn(out_trans[:, :2], gt_trans[:, :2]) * loss_cfg.TRANS_LW
             ld["loss_trans_z"] = fn(out_trans[:, 2], gt_trans[:, 2]) * loss_cfg.TRANS_LW
         else:
             ld["loss_trans_LPnP"] = fn(out_trans, gt_trans) * loss_cfg.TRANS_LW
     if loss_cfg.SCALE_LW > 0:
-        fn = {"L1": F.l1_loss, "MSE": F.mse_loss}[loss_cfg.SCALE_LOSS_TYPE]
+        fn = {"L1": F.l1_loss, "MSE": F.mse_loss, "L2": l2_loss}[loss_cfg.SCALE_LOSS_TYPE]
         ld["loss_scale"] = fn(out_scale, gt_scale) * loss_cfg.SCALE_LW
     return ld
 

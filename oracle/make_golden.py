@@ -171,14 +171,31 @@ def run_reference_train(cfg, batch, sym_info, salt=0):
     model.load_state_dict(sd, strict=True)
     b = {k: (v.clone() if isinstance(v, torch.Tensor) else copy.deepcopy(v)) for k, v in batch.items()}
     batch_updater_test(cfg, b, device="cpu")
-    out_dict, loss_dict = model(
-        b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
-        obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
-        obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1,
-    )
+    # the scalars the reference's forward pushes into detectron2's EventStorage (CATRE_disR_shared.py:127-164)
+    import core.catre.models.CATRE_disR_shared as ref_mod
+
+    logged = {}
+
+    class _Storage:
+        def put_scalars(self, **kw):
+            logged.update(kw)
+
+    saved = ref_mod.get_event_storage
+    ref_mod.get_event_storage = lambda: _Storage()
+    try:
+        out_dict, loss_dict = model(
+            b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+            obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
+            obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1,
+        )
+    finally:
+        ref_mod.get_event_storage = saved
     losses = sum(loss_dict.values())
     losses.backward()
     out = {"pose_1": _np(out_dict["pose_1"]), "scale_1": _np(out_dict["scale_1"])}
+    assert len(logged) == 14, sorted(logged)
+    for k, v in logged.items():
+        out["vis__" + k.replace("/", "__")] = np.array([float(v)], dtype=np.float64)
     for k, v in loss_dict.items():
         out[f"loss__{k}"] = _np(v.reshape(1))
     for k, p in model.named_parameters():

@@ -315,8 +315,15 @@ def test_errors():
         model(b["pcl"].permute(0, 2, 1), b["obj_kps"].permute(0, 2, 1), b["obj_pose_est"], b["obj_scale_est"],
               K_zoom=b["K"], do_loss=True)
     cfg = default_cfg()
-    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_quat"
+    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_quat"  # with rot_dim=3 heads: 6 values for a 4-wide quaternion
     from catre_amd.CATRE_disR_shared import build_model_optimizer
+    with pytest.raises(ValueError, match="rot head emits"):
+        build_model_optimizer(cfg, is_test=True)
+    cfg.MODEL.CATRE.ROT_HEAD.ROT_TYPE = "ego_euler"
+    with pytest.raises(ValueError, match="Unknown rot_type"):
+        build_model_optimizer(cfg, is_test=True)
+    cfg = default_cfg()
+    cfg.MODEL.CATRE.ROT_HEAD.CLASS_AWARE = True
     with pytest.raises(NotImplementedError):
         build_model_optimizer(cfg, is_test=True)
 

@@ -100,6 +100,13 @@ def test_module_training_step_matches_reference_golden():
         np.testing.assert_allclose(float(got.norm()), nrm, rtol=1e-3, atol=1e-9, err_msg=k)
         np.testing.assert_allclose(got.reshape(-1)[:64].numpy(), ref[f"gradhead__{k}"], atol=1e-3 * nrm + 1e-9, rtol=0,
                                    err_msg=k)
+    # the scalars the reference's forward logs (CATRE_disR_shared.py:127-164), written by the loss kernels into one
+    # device tensor: same keys, same values
+    vis = model.vis_scalars.as_dict()
+    want = {k[5:].replace("__", "/"): float(v[0]) for k, v in ref.items() if k.startswith("vis__")}
+    assert set(vis) == set(want) and len(vis) == 14
+    for k in want:
+        np.testing.assert_allclose(vis[k], want[k], rtol=2e-4, atol=2e-5, err_msg=k)
     # an optimizer step runs on the HIP-computed gradients and changes the next forward (weights are re-packed)
     before = model.refine(b, n_iter=1)["pose_1"].clone()
     opt.step()
@@ -295,6 +302,9 @@ def test_ddp_world1_wraps_and_steps():
     {"TRANS_LOSS_TYPE": "MSE", "SCALE_LOSS_TYPE": "MSE"},
     {"TRANS_LOSS_DISENTANGLE": False, "PM_LOSS_SYM": False},
     {"PM_LW": 0.0, "ROT_LW": 2.0, "TRANS_LW": 0.5},
+    # the reference's L2Loss (per-object norm, losses/l2_loss.py) and angular_distance_vec variants (:232-285)
+    {"TRANS_LOSS_TYPE": "L2", "SCALE_LOSS_TYPE": "L2", "ROT_YAXIS_LOSS_TYPE": "L2"},
+    {"TRANS_LOSS_TYPE": "L2", "TRANS_LOSS_DISENTANGLE": False, "ROT_YAXIS_LOSS_TYPE": "angular"},
 ])
 def test_fused_loss_matches_oracle_values_and_gradients(variant):
     """catre_loss_fwd / catre_loss_bwd (row f1) vs fp64 autograd through the oracle's restatement of
@@ -404,3 +414,85 @@ def test_graphed_train_step_replays_the_eager_iteration():
     assert all(st["step"] == 4 for st in opt_g.state.values() if "step" in st)
     with pytest.raises(ValueError):
         step(x=torch.zeros(B + 1, 3, N, device=DEV))
+
+
+def test_vis_scalars_reach_an_active_event_storage(monkeypatch):
+    """With detectron2's EventStorage active (engine.py:266) the forward writes the reference's 14 vis/ keys - one copy
+    of one device tensor; without a storage nothing is copied."""
+    import sys
+    import types
+
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+    from tests.util import load_train_golden
+
+    g = load_train_golden("train_b4")
+    cfg = g["cfg"].__deepcopy__({})
+    cfg.MODEL.DEVICE = DEV
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.to(DEV) for k, v in recipe_sd(cfg, g["salt"]).items()}, strict=True)
+    b = {k: v.to(DEV) for k, v in g["batch"].items()}
+    batch_updater_test(cfg, b)
+    logged = {}
+
+    class Storage:
+        def put_scalars(self, **kw):
+            logged.update(kw)
+
+    events = types.ModuleType("detectron2.utils.events")
+    events.get_event_storage = lambda: Storage()
+    for name in ("detectron2", "detectron2.utils"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "detectron2.utils.events", events)
+    call = lambda it: model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                            gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"], obj_kps=b["obj_kps"],
+                            mean_scales=b["obj_mean_scales"], sym_info=g["sym_info"], do_loss=True, cur_iter=it)
+    call(3)
+    assert len(logged) == 14 and all(k.endswith("_3") and k.startswith("vis/") for k in logged)
+    np.testing.assert_allclose(logged["vis/error_R_3"], float(g["ref"]["vis__vis__error_R_1"][0]), rtol=2e-4)
+    logged.clear()
+    model.cfg.MODEL.CATRE.LOG_VIS_SCALARS = False
+    call(1)
+    assert not logged and model.vis_scalars._host is None  # nothing copied until asked for
+    assert abs(model.vis_scalars.as_dict()["vis/error_t_1"] - float(g["ref"]["vis__vis__error_t_1"][0])) < 1e-3
+
+
+def test_pose_update_backward_with_expanded_gradients():
+    """`(pose.sum() + scale.sum()).backward()` hands stride-0 expanded gradients to the pose-update backward: the
+    contiguous copies must stay alive until the kernel is enqueued (two temporaries shared one block)."""
+    from catre_amd import hip
+    from catre_amd import synth
+    from catre_amd import train_ops as T
+    from catre_amd.config import default_cfg
+    from catre_amd.runtime import opts_from_cfg
+
+    B = 9
+    o = opts_from_cfg(default_cfg(device=DEV))
+    inp = synth.make_inputs(B, 8, 8, seed=3)
+    g = torch.Generator().manual_seed(1)
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * 0.3).to(DEV)
+    rot, dt, ds = mk(B, 6) + 1.0, mk(B, 3) + torch.tensor([0, 0, 1.0], device=DEV), mk(B, 3) * 0.05
+    pose0, scale0, K = inp["obj_pose_est"].to(DEV), inp["obj_scale_est"].to(DEV), inp["K"].to(DEV)
+
+    def grads(expanded):
+        leaves = [t.clone().requires_grad_(True) for t in (rot, dt, ds)]
+        pose, scale = T.pose_update_autograd(*leaves, pose0, scale0, None, K, o)
+        if expanded:
+            (pose.sum() + scale.sum()).backward()              # both upstream gradients are expanded scalars
+        else:
+            torch.autograd.backward([pose, scale], [torch.ones_like(pose), torch.ones_like(scale)])
+        return [t.grad.clone() for t in leaves]
+
+    for a, b_ in zip(grads(True), grads(False)):
+        assert torch.equal(a, b_)
+    # forward with non-contiguous inputs (a strided mean_scales view next to a strided K)
+    from catre_amd.runtime import pose_update
+
+    o2 = hip.CatreOpts.from_buffer_copy(o)
+    o2.scale_base_mean = 1
+    ms_wide = torch.rand(B, 6, device=DEV) + 0.1
+    K_wide = torch.zeros(B, 3, 6, device=DEV)
+    K_wide[:, :, ::2] = K
+    p1, s1 = pose_update(rot, dt, ds, pose0, scale0, ms_wide[:, ::2], K_wide[:, :, ::2], o2)
+    p2, s2 = pose_update(rot, dt, ds, pose0, scale0, ms_wide[:, ::2].contiguous(), K, o2)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)

@@ -247,3 +247,82 @@ def test_integration_md_stub_struct_matches_the_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"(?:int32_t|float)\s+(\w+);", body)
     assert fields == [n for n, _ in hip.CatreOpts._fields_]
+
+
+def test_shard_batch_slices_only_per_object_entries():
+    from catre_amd.sharding import shard_batch
+
+    B = 4
+    batch = {"pcl": torch.zeros(B, 8, 3), "obj_cls": torch.arange(B), "sym_info": [None] * B,
+             "img": torch.zeros(B, 3, 2, 2),      # per IMAGE: happens to have B entries, must not be sliced
+             "depth_obs": torch.zeros(B, 2, 2), "note": "x"}
+    s = shard_batch(batch, 1, 2)
+    assert s["pcl"].shape[0] == 2 and s["obj_cls"].tolist() == [2, 3] and len(s["sym_info"]) == 2
+    assert s["img"].shape[0] == B and s["depth_obs"].shape[0] == B and s["note"] == "x"
+    assert shard_batch(batch, 0, 2, extra_keys=("img",))["img"].shape[0] == 2
+    with pytest.raises(ValueError, match="per-object entry"):
+        shard_batch(dict(batch, obj_cls=torch.arange(3)), 0, 2)
+
+
+def test_optimizer_factory_follows_the_reference_builder():
+    """build_optimizer_with_params (core/utils/solver_utils.py:75-87): dict or string OPTIMIZER_CFG, every keyword reaches
+    the optimizer, unknown names raise, gradient clipping wraps step()."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    cfg = default_cfg(device="cpu")
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="SGD", lr=3e-3, momentum=0.85, nesterov=True, weight_decay=1e-4)
+    _, opt = build_model_optimizer(cfg, is_test=False)
+    assert isinstance(opt, torch.optim.SGD)
+    g = opt.param_groups[0]
+    assert (g["momentum"], g["nesterov"], g["weight_decay"]) == (0.85, True, 1e-4)
+    assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12  # per-group lr (BASE_LR) overrides the default, as in the reference
+    cfg.SOLVER.OPTIMIZER_CFG = "dict(type='AdamW', lr=1e-4, betas=(0.8, 0.9), weight_decay=0.01)"
+    _, opt = build_model_optimizer(cfg, is_test=False)
+    assert isinstance(opt, torch.optim.AdamW) and opt.param_groups[0]["betas"] == (0.8, 0.9)
+    cfg.SOLVER.OPTIMIZER_CFG = ""
+    with pytest.raises(RuntimeError, match="OPTIMIZER_CFG"):
+        build_model_optimizer(cfg, is_test=False)
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="NoSuchOpt", lr=1.0)
+    with pytest.raises(ValueError, match="Unknown optimizer name"):
+        build_model_optimizer(cfg, is_test=False)
+    # SOLVER.CLIP_GRADIENTS (lib/torch_utils/solver/grad_clip_d2.py): full-model norm clip before the step
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="SGD", lr=1.0)
+    cfg.SOLVER.CLIP_GRADIENTS = dict(ENABLED=True, CLIP_TYPE="full_model", CLIP_VALUE=0.5, NORM_TYPE=2.0)
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    assert type(opt).__name__ == "SGDWithGradientClip" and isinstance(opt, torch.optim.SGD)
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    total = torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters()))
+    assert abs(float(total) - 0.5) < 1e-4
+
+
+def test_pretrained_pcl_net_checkpoint_is_loaded(tmp_path):
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    cfg = default_cfg(device="cpu")
+    ref, _ = build_model_optimizer(cfg, is_test=True)
+    path = str(tmp_path / "pcl.pth")
+    torch.save({"state_dict": {"module." + k: v + 1.0 for k, v in ref.pcl_net.state_dict().items()}}, path)
+    cfg.MODEL.CATRE.PCLNET.PRETRAINED = path
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    a, b = ref.pcl_net.state_dict(), model.pcl_net.state_dict()
+    assert all(torch.equal(a[k] + 1.0, b[k]) for k in a)
+
+
+def test_loss_type_names_of_the_reference_are_accepted():
+    from catre_amd.losses import _loss_cfg_struct
+
+    cfg = default_cfg(device="cpu")
+    lc = cfg.MODEL.CATRE.LOSS_CFG
+    lc.TRANS_LOSS_TYPE, lc.SCALE_LOSS_TYPE, lc.ROT_YAXIS_LOSS_TYPE = "L2", "L2", "angular"
+    c = _loss_cfg_struct(cfg)
+    assert (c.trans_mse, c.scale_mse, c.yaxis_smooth) == (2, 2, 3)
+    lc.ROT_YAXIS_LOSS_TYPE = "L2"
+    assert _loss_cfg_struct(cfg).yaxis_smooth == 2
+    for field, msg in (("TRANS_LOSS_TYPE", "Unknown trans loss type"), ("SCALE_LOSS_TYPE", "Unknown scale loss type"),
+                       ("ROT_YAXIS_LOSS_TYPE", "Unknown rot yaxis loss type"), ("ROT_LOSS_TYPE", "Unknown rot loss type")):
+        cfg2 = default_cfg(device="cpu")
+        cfg2.MODEL.CATRE.LOSS_CFG[field] = "huber"
+        with pytest.raises(ValueError, match=msg):
+            _loss_cfg_struct(cfg2)
