@@ -146,7 +146,7 @@ def test_bf16_ragged_and_full_size_properties():
         for key in ("pose_1", "scale_1"):
             assert np.abs(out[key].cpu().numpy() - emu[key].numpy()).max() <= EMU_TOL, (B, N, M, key)
 
-    B, N, M, K = 64, 2048, 1024, 8
+    B, N, M, K = 256, 2048, 1024, 8  # BASELINE.json config 5 at its full per-GPU batch
     cfg5 = cfg.__deepcopy__({})
     cfg5.INPUT.NUM_PCL, cfg5.INPUT.NUM_KPS = N, M
     cfg5.MODEL.CATRE.ROT_HEAD.INIT_CFG.num_points = N + M
