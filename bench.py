@@ -170,19 +170,19 @@ def cpu_baseline(cfg_fn, sd):
     }
 
 
-def bench_train(args, world, rank, dev, dist, cfg_fn):
+def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup):
     """BASELINE.json configs 3/4: one step = the reference's train loop body for one data batch
     (core/catre/engine/engine.py:293-355): K_ITER x (pose-apply, forward + loss, backward, optimizer step), the fed-back
     pose detached.  With N > 1 the model is wrapped in DistributedDataParallel exactly like
-    core/catre/main_catre.py:154-160 and gradients are all-reduced over RCCL (17.19 MB per backward)."""
+    core/catre/main_catre.py:154-160 and gradients are all-reduced over RCCL (17.19 MB per backward).
+    -> seconds for `steps` steps on this rank (barrier + synchronize on both sides)."""
     from catre_amd import synth
     from catre_amd.batching import batch_updater_test
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 
     cfg = cfg_fn(str(dev))
-    amp = args.dtype == "bf16"
-    split = args.dtype == "split"
-    if split:
+    amp = dtype == "bf16"
+    if dtype == "split":
         cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"  # hi + lo bf16 operands, three products: fp32-grade GEMMs on the bf16 pipe
     cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=1e-5, weight_decay=0, clean_grads=True)  # shipped optimiser, fused HIP step
     model, opt = build_model_optimizer(cfg, is_test=False)
@@ -223,15 +223,22 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = one_step()
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(last).all()
+    return dt
+
+
+def bench_train(args, world, rank, dev, dist, cfg_fn):
+    amp = args.dtype == "bf16"
+    split = args.dtype == "split"
+    dt = run_train(cfg_fn, dev, dist, rank, args.dtype, args.steps, args.warmup)
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
@@ -262,6 +269,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-extra", action="store_true", help="skip the bounded fp32 training measurement of the default line")
     ap.add_argument("--mode", choices=("refine", "train"), default="refine",
                     help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
     ap.add_argument("--dtype", choices=("fp32", "split", "bf16"), default="fp32",
@@ -385,6 +393,18 @@ def main():
                        "ms_per_step": round(dts / args.steps * 1e3, 3),
                        "max_abs_diff_vs_fp32_after_K": dev_max}
 
+    # BASELINE.json config 3 next to the headline (outside the timed region, rank 0 of a 1-GPU run only): the training
+    # step of engine.py:293-355 at the same batch, fp32, a few steps - so the driver's record carries a train number too
+    train_extra = None
+    if rank == 0 and world == 1 and args.dtype == "fp32" and args.shape == "headline" and not args.no_train_extra:
+        tsteps = 3
+        tdt = run_train(cfg_fn, dev, None, 0, "fp32", tsteps, 1)
+        train_extra = {"what": "BASELINE config 3: K=4 x (pose-apply, forward + device-side loss, backward, fused Ranger step) of "
+                               "the same B=256, N=M=1024 batch, fp32 kernels, half the objects y-symmetric (313 candidates), "
+                               "DDP world 1; 1 warm-up + 3 timed steps",
+                       "value": round(B_PER_GPU * K_ITER * tsteps / tdt, 1), "unit": "training object-iterations/s (1 GPU)",
+                       "ms_per_step": round(tdt / tsteps * 1e3, 3), "ms_per_iteration": round(tdt / tsteps / K_ITER * 1e3, 3)}
+
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
 
     if rank == 0:
@@ -442,6 +462,8 @@ def main():
         line["maxpool_standalone"] = maxpool
         if split_extra is not None:
             line["split_mode"] = split_extra
+        if train_extra is not None:
+            line["train_fp32"] = train_extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg_fn, sd)
         print(json.dumps(line), flush=True)
