@@ -159,10 +159,20 @@ struct GemmPipe {
   __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const float* x, int ld, int lane) {
     const int n = lane & 31, h = lane >> 5, sw = lane & 15;
     const float* xrow = x + n * ld;
-    auto issue_b = [&](int kc) {
-      const int coff = SWZ ? (((2 * kc + h) ^ sw) << 2) : (kc * 8 + 4 * h);
+    // Swizzled image: chunk c = 2 kc + h of row r sits at chunk c ^ (r & 15).  The XOR only touches the low four bits, so
+    // c ^ sw = (c & ~15) | ((c & 15) ^ sw): eight per-lane row pointers (kc & 7) cover the sweep and the rest of the
+    // offset, 64 floats per 8 chunks, is a compile-time immediate of the ds_read - no address VALU inside the K loop
+    // (every VALU instruction costs the fp32 MFMA stream ~4 cycles: profiles/ubench/mfma_valu.hip).
+    constexpr int NLOW = SWZ ? (NKC < 8 ? NKC : 8) : 1;
+    const float* xlow[NLOW];
+    if (SWZ) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b[kc % RB][nb] = *reinterpret_cast<const f32x4*>(xrow + nb * 32 * ld + coff);
+      for (int j = 0; j < NLOW; ++j) xlow[j] = xrow + (((2 * j + h) ^ sw) << 2);
+    }
+    auto issue_b = [&](int kc) {
+      const float* src = SWZ ? xlow[kc % NLOW] + (kc / 8) * 64 : xrow + (kc * 8 + 4 * h);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[kc % RB][nb] = *reinterpret_cast<const f32x4*>(src + nb * 32 * ld);
     };
 #pragma unroll
     for (int d = 0; d < PFB; ++d) issue_b(d);

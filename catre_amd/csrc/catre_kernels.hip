@@ -970,7 +970,7 @@ WsLayout ws_layout(int B, int N, int M) {
   L.aff0 = take(b * 2 * 2 * 2 * 256);
   L.gn1stat = take(b * 2 * 64);
   {  // y1 [b][2][P][256]; before it is written the region holds the pointfeat moments (catre_gram.h)
-    const size_t y1n = b * 2 * P * 256, mom = b * T * (4096 + 64) + b * 2 * (4096 + 64);
+    const size_t y1n = b * 2 * P * 256, mom = b * 2 * (4096 + 64 + 64);
     L.y1 = take(y1n > mom ? y1n : mom);
   }
   L.rpart = take(b * 2 * T * 4);
@@ -1262,17 +1262,13 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   }
   // GN0 statistics from second moments of pointfeat (catre_gram.h); the moment buffers borrow y1, which is only
   // written by k_rot_l1 afterwards
-  float* gram = ws + W.y1;
-  float* tmean = gram + (size_t)B * T * 4096;
-  float* Scl = tmean + (size_t)B * T * 64;
-  float* mucl = Scl + (size_t)B * 2 * 4096;
+  float* Gc = ws + W.y1;
+  float* s1c = Gc + (size_t)2 * B * 4096;
+  float* shc = s1c + (size_t)2 * B * 64;
   {
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
-    const int TNc = (N + TP - 1) / TP, TMc = (M + TP - 1) / TP;
-    hipLaunchKernelGGL(k_pf_gram<false>, dim3(B * T), dim3(256), 0, st, (const void*)pointfeat, gram, tmean, B, N, M);
-    hipLaunchKernelGGL(k_gram_merge, dim3(B, 2, 4), dim3(256), (size_t)(TNc > TMc ? TNc : TMc) * 64 * sizeof(float), st, gram,
-                       tmean, Scl, mucl, B, N, M);
-    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Scl, mucl, prm[CATRE_P_ROTX_L0_W],
+    hipLaunchKernelGGL(k_pf_moments, dim3(2 * B), dim3(256), 0, st, pointfeat, Gc, s1c, shc, B, N, M);
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
                        prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   }

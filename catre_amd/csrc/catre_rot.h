@@ -136,10 +136,15 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
     __syncthreads();
     ROT_STAMP();
     {
-      // layer 1 (256->256), "swapped": lane owns channels wave*64 + mb*32 + n and 32 of the tile's points
+      // layer 1 (256->256), "swapped": lane owns channels wave*64 + mb*32 + n and 32 of the tile's points.  The
+      // accumulators start at the lane's channel bias (one value per lane in this orientation): no bias add afterwards.
       f32x16 acc[2][2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      for (int mb = 0; mb < 2; ++mb) {
+        const float bb = (hd ? b1y : b1x)[wave * 64 + mb * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = acc[mb][1][r] = bb;
+      }
       gemm_core<2, 2, true, true, 32, 2>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane);
       ROT_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
@@ -148,7 +153,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
-        const float bb = (hd ? b1y : b1x)[ch];
         float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
         if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
@@ -157,8 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
+              const float v = acc[mb][nb][r];
               dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
               s += v;
             }
@@ -171,8 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
+              const float v = acc[mb][nb][r];
               if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
                 dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
                 s += v;
@@ -186,13 +188,23 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
         s += __shfl_xor(s, 32);
         const float mean = s * inv_cnt;
         float m2 = 0.f;
+        if (rt.valid == TP) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[mb][nb][r] - mean;
-            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
+            }
+        }
         m2 += __shfl_xor(m2, 1);
         m2 += __shfl_xor(m2, 2);
         m2 += __shfl_xor(m2, 4);

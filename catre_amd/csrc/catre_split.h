@@ -522,9 +522,13 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
     __syncthreads();
     ROTS_STAMP();
     {
-      f32x16 acc[2][2];
+      f32x16 acc[2][2];  // start at the lane's channel bias ("swapped" orientation: one channel per lane)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      for (int mb = 0; mb < 2; ++mb) {
+        const float bb = (hd ? b1y : b1x)[wave * 64 + mb * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = acc[mb][1][r] = bb;
+      }
       GemmPipeS<2, 2, true, 32, 2> g1;
       g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64, 256 * 256 / 8);
       g1.run(acc, a0h, a0l, lane);
@@ -535,7 +539,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
-        const float bb = (hd ? b1y : b1x)[ch];
         float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
         if (rt.valid == TP) {
@@ -544,8 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
+              const float v = acc[mb][nb][r];
               dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
               s += v;
             }
@@ -558,8 +560,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
+              const float v = acc[mb][nb][r];
               if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
                 dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
                 s += v;
@@ -572,13 +573,23 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         s += __shfl_xor(s, 32);
         const float mean = s * inv_cnt;
         float m2 = 0.f;
+        if (rt.valid == TP) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[mb][nb][r] - mean;
-            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
+            }
+        }
         m2 += __shfl_xor(m2, 1);
         m2 += __shfl_xor(m2, 2);
         m2 += __shfl_xor(m2, 4);
