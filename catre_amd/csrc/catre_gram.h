@@ -25,9 +25,15 @@
 // so that  mu = c + s1 / n  and the centred scatter  S = G' - s1 s1^T / n  (applied by k_gn0_from_moments while it loads
 // G').  Replaces the per-tile Gram kernel + merge kernel of round 1 (136 MB of per-tile moments written and re-read).
 // Fixed summation order: deterministic.
-__global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ pointfeat, float* __restrict__ Gc /*[2B][4096]*/,
-                                                    float* __restrict__ s1c /*[2B][64]*/, float* __restrict__ shc /*[2B][64]*/,
-                                                    int B, int N, int M) {
+// The cloud's tiles are always summed in PF_NG = 4 contiguous groups, each into its own partial (G', s1): with
+// gridDim.y == 1 one workgroup sweeps all four groups, with gridDim.y == 4 (small batches: a handful of clouds would
+// leave the chip idle) four workgroups take one group each.  The consumer adds the four partials in a fixed order, so
+// an object's result does not depend on how many objects share its batch.
+#define PF_NG 4
+__global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ pointfeat,
+                                                    float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
+                                                    float* __restrict__ s1c /*[2B][PF_NG][64]*/,
+                                                    float* __restrict__ shc /*[2B][64]*/, int B, int N, int M) {
   __shared__ __attribute__((aligned(16))) float pf[2][TP * LD64];
   __shared__ float part[4][64];
   __shared__ float shift[64];
@@ -36,7 +42,7 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
   const int cloud = blockIdx.x;
   const int n = cloud < B ? N : M;
   const float* src = pointfeat + (cloud < B ? (size_t)cloud * N : (size_t)B * N + (size_t)(cloud - B) * M) * 64;
-  const int nt = (n + TP - 1) / TP;
+  const int nt = (n + TP - 1) / TP, tpg = (nt + PF_NG - 1) / PF_NG;  // tiles per group
   // staging map: thread -> rows {r0, r0+16, r0+32, r0+48}, float4 column c4 (coalesced 256 B per row)
   const int r0 = tid >> 4, c4 = tid & 15;
   f32x4 nxt[4];
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
     }
   };
   fetch(0);
-  {  // tile 0 as it is -> buffer 1 (scratch use), column means of its valid points = the shift
+  {  // the cloud's first tile as it is -> buffer 1 (scratch use); column means of its valid points = the shift
 #pragma unroll
     for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(pf[1] + (r0 + 16 * u) * LD64 + c4 * 4) = nxt[u];
     __syncthreads();
@@ -57,55 +63,63 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
     for (int p = q * 16; p < q * 16 + 16; ++p) s += p < v0 ? pf[1][p * LD64 + ch] : 0.f;
     part[q][ch] = s;
     __syncthreads();
-    if (tid < 64) shift[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / (float)v0;
+    if (tid < 64) {
+      const float m = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / (float)v0;
+      shift[tid] = m;
+      if (blockIdx.y == 0) shc[(size_t)cloud * 64 + tid] = m;
+    }
     __syncthreads();
   }
   const f32x4 sh4 = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
   const int bi = wave >> 1, bj = wave & 1, i = lane & 31, h = lane >> 5;
-  f32x16 acc = zero16();
-  float colsum = 0.f;  // thread (channel tid & 63, point quarter tid >> 6)
-  for (int t = 0; t < nt; ++t) {
-    float* buf = pf[t & 1];
-    {  // shifted tile -> LDS, rows past the cloud's end as zeros (they then add nothing to G' or s1)
+  const int g_lo = gridDim.y == 1 ? 0 : blockIdx.y, g_hi = gridDim.y == 1 ? PF_NG : blockIdx.y + 1;
+#pragma unroll 1
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int t_lo = min(g * tpg, nt), t_hi = min(t_lo + tpg, nt);
+    f32x16 acc = zero16();
+    float colsum = 0.f;  // thread (channel tid & 63, point quarter tid >> 6)
+    if (t_lo < t_hi && !(g == g_lo && t_lo == 0)) fetch(t_lo);  // (tile 0 is still in registers for the first group)
+    for (int t = t_lo; t < t_hi; ++t) {
+      float* buf = pf[t & 1];
+      {  // shifted tile -> LDS, rows past the cloud's end as zeros (they then add nothing to G' or s1)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = t * TP + r0 + 16 * u < n;
-        f32x4 v = nxt[u] - sh4;
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(buf + (r0 + 16 * u) * LD64 + c4 * 4) = v;
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = t * TP + r0 + 16 * u < n;
+          f32x4 v = nxt[u] - sh4;
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(buf + (r0 + 16 * u) * LD64 + c4 * 4) = v;
+        }
       }
-    }
-    __syncthreads();  // also orders the previous iteration's reads of the other buffer before its next overwrite
-    if (t + 1 < nt) fetch(t + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const float* col = buf + (tid >> 6) * 16 * LD64 + (tid & 63);
+      __syncthreads();  // also orders the previous tile's reads of the other buffer before its next overwrite
+      if (t + 1 < t_hi) fetch(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const float* col = buf + (tid >> 6) * 16 * LD64 + (tid & 63);
 #pragma unroll
-      for (int p = 0; p < 16; ++p) colsum += col[p * LD64];
-    }
-    const float* pa = buf + h * LD64 + bi * 32 + i;
-    const float* pb = buf + h * LD64 + bj * 32 + i;
+        for (int p = 0; p < 16; ++p) colsum += col[p * LD64];
+      }
+      const float* pa = buf + h * LD64 + bi * 32 + i;
+      const float* pb = buf + h * LD64 + bj * 32 + i;
 #pragma unroll 8
-    for (int k = 0; k < TP / 2; ++k) acc = mfma32(pa[2 * k * LD64], pb[2 * k * LD64], acc);  // lane half h: point 2k + h
-  }
-  float* out = Gc + (size_t)cloud * 4096;
+      for (int k = 0; k < TP / 2; ++k) acc = mfma32(pa[2 * k * LD64], pb[2 * k * LD64], acc);  // lane half h: point 2k + h
+    }
+    float* out = Gc + ((size_t)cloud * PF_NG + g) * 4096;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = bi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    out[row * 64 + bj * 32 + i] = acc[reg];
-  }
-  __syncthreads();
-  part[tid >> 6][tid & 63] = colsum;
-  __syncthreads();
-  if (tid < 64) {
-    s1c[(size_t)cloud * 64 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    shc[(size_t)cloud * 64 + tid] = shift[tid];
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = bi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      out[row * 64 + bj * 32 + i] = acc[reg];
+    }
+    __syncthreads();  // every wave is done with both tile buffers and with `part`
+    part[tid >> 6][tid & 63] = colsum;
+    __syncthreads();
+    if (tid < 64)
+      s1c[((size_t)cloud * PF_NG + g) * 64 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
   }
 }
 
 // aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256], as k_gn0_affine.  One workgroup per (object, head,
 // 64 channels); thread = (channel, quarter of the rows of S) so that small batches still fill some of the chip.
-__global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restrict__ Gc /*[2B][4096]*/,
+__global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
                                                           const float* __restrict__ s1c, const float* __restrict__ shc,
                                                           const float* __restrict__ w0x, const float* __restrict__ w0y,
                                                           int ldw, int coloff, const float* __restrict__ bias0,
@@ -121,18 +135,19 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
   if (tid < 128) {
     const int cl = tid >> 6, k = tid & 63;
     const size_t cloud = cl ? (size_t)B + obj : obj;
-    const float v = s1c[cloud * 64 + k];
+    const float* sp = s1c + cloud * PF_NG * 64 + k;
+    const float v = (sp[0] + sp[64]) + (sp[128] + sp[192]);  // the four tile groups, fixed order
     s1[cl][k] = v;
     mu[cl][k] = shc[cloud * 64 + k] + v / (float)(cl ? M : N);
   }
   __syncthreads();
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl) {  // S = G' - s1 s1^T / n while loading
-    const f32x4* src = reinterpret_cast<const f32x4*>(Gc + (cl ? (size_t)B + obj : (size_t)obj) * 4096);
+    const f32x4* src = reinterpret_cast<const f32x4*>(Gc + (cl ? (size_t)B + obj : (size_t)obj) * PF_NG * 4096);
     const float inv_n = 1.0f / (float)(cl ? M : N);
     for (int e4 = tid; e4 < 1024; e4 += 256) {
       const int r = e4 >> 4, c0 = (e4 & 15) * 4;
-      f32x4 g = src[e4];
+      f32x4 g = (src[e4] + src[1024 + e4]) + (src[2048 + e4] + src[3072 + e4]);
       const float sr = s1[cl][r] * inv_n;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = fmaf(-sr, s1[cl][c0 + q], g[q]);

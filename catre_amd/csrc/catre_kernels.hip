@@ -40,6 +40,33 @@ __device__ __forceinline__ TileInfo tile_info(int bid, int B, int N, int M) {
   return ti;
 }
 
+// a1, one point: x = pcl - t (observed; only when ZERO_CENTER_INPUT) / tfd_kps = R (kps * s) (+ t otherwise)
+// (engine/batch_test.py:81-97, lib/pysixd/misc.py:1014-1026).  Shared by k_pose_apply and the on-the-fly form in
+// load_point, so both produce the same bits.
+__device__ __forceinline__ void pose_apply_point(const float* __restrict__ p, const float* __restrict__ sc, int is_obs,
+                                                 int zero_center, float& x, float& y, float& z) {
+  if (is_obs) {
+    if (zero_center) {
+      x -= p[3];
+      y -= p[7];
+      z -= p[11];
+    }
+  } else {
+    const float sx = x * sc[0], sy = y * sc[1], sz = z * sc[2];      // misc.py:1017
+    float ox = p[0] * sx + p[1] * sy + p[2] * sz;                   // misc.py:1021 (row . column)
+    float oy = p[4] * sx + p[5] * sy + p[6] * sz;
+    float oz = p[8] * sx + p[9] * sy + p[10] * sz;
+    if (!zero_center) {
+      ox += p[3];
+      oy += p[7];
+      oz += p[11];
+    }
+    x = ox;
+    y = oy;
+    z = oz;
+  }
+}
+
 __device__ __forceinline__ void load_point(const catre_points& P, const TileInfo& ti, int p, float& x, float& y,
                                            float& z) {
   const int pi = ti.p0 + min(p, ti.valid - 1);  // clamp: duplicates never change a max-pool
@@ -55,6 +82,7 @@ __device__ __forceinline__ void load_point(const catre_points& P, const TileInfo
   x = base[0];
   y = base[sc];
   z = base[2 * sc];
+  if (P.apply_pose) pose_apply_point(P.pose + ti.obj * 12, P.scale + ti.obj * 3, ti.is_obs, P.zero_center, x, y, z);
 }
 
 // out[ch] = relu(W[ch][0..2] . (x,y,z) + b[ch]) for NCH consecutive channels starting at ch0 (wave-uniform)
@@ -126,40 +154,16 @@ __global__ void k_pose_apply(const float* __restrict__ pcl, const float* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int total_obs = B * N, total = B * (N + M);
   if (i >= total) return;
-  if (i < total_obs) {
-    const int b = i / N;
-    const float* p = pose + b * 12;
-    const float* s = pcl + (size_t)i * 3;
-    float x = s[0], y = s[1], z = s[2];
-    if (zero_center) {
-      x -= p[3];
-      y -= p[7];
-      z -= p[11];
-    }
-    float* o = xo + (size_t)i * 3;
-    o[0] = x;
-    o[1] = y;
-    o[2] = z;
-  } else {
-    const int j = i - total_obs;
-    const int b = j / M;
-    const float* p = pose + b * 12;
-    const float* sc = scale + b * 3;
-    const float* s = kps + (size_t)j * 3;
-    const float x = s[0] * sc[0], y = s[1] * sc[1], z = s[2] * sc[2];  // misc.py:1017
-    float ox = p[0] * x + p[1] * y + p[2] * z;                         // misc.py:1021 (row . column)
-    float oy = p[4] * x + p[5] * y + p[6] * z;
-    float oz = p[8] * x + p[9] * y + p[10] * z;
-    if (!zero_center) {
-      ox += p[3];
-      oy += p[7];
-      oz += p[11];
-    }
-    float* o = ko + (size_t)j * 3;
-    o[0] = ox;
-    o[1] = oy;
-    o[2] = oz;
-  }
+  const bool obs = i < total_obs;
+  const int j = obs ? i : i - total_obs;
+  const int b = obs ? j / N : j / M;
+  const float* s = (obs ? pcl : kps) + (size_t)j * 3;
+  float x = s[0], y = s[1], z = s[2];
+  pose_apply_point(pose + b * 12, scale + b * 3, obs, zero_center, x, y, z);
+  float* o = (obs ? xo : ko) + (size_t)j * 3;
+  o[0] = x;
+  o[1] = y;
+  o[2] = z;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,17 +474,25 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
 // ------------------------------------------------------------------------------------------
 // tile partial maxima -> per-cloud max:  out[cloud][c] = max_t pm[row(cloud,t)][c]
 // ------------------------------------------------------------------------------------------
-__global__ void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ out, int ldo, int C, int B, int N,
-                            int M) {
+__global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ out, int ldo, int C,
+                                                   int B, int N, int M) {
+  // grid (clouds, C / 256): one thread per (cloud, channel), so that a single object still spreads over several CUs
   const int cloud = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
   const int nt = cloud < B ? TN : TM;
   const size_t row0 = cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float m = pm[row0 * PMW + c];
-    for (int t = 1; t < nt; ++t) m = fmaxf(m, pm[(row0 + t) * PMW + c]);
-    out[(size_t)cloud * ldo + c] = m;
+  const float* src = pm + row0 * PMW + c;
+  float m = src[0];
+  int t = 1;
+  for (; t + 3 < nt; t += 4) {  // four loads in flight
+    const float a = src[(size_t)t * PMW], b = src[(size_t)(t + 1) * PMW], d = src[(size_t)(t + 2) * PMW],
+                e = src[(size_t)(t + 3) * PMW];
+    m = fmaxf(fmaxf(m, fmaxf(a, b)), fmaxf(d, e));
   }
+  for (; t < nt; ++t) m = fmaxf(m, src[(size_t)t * PMW]);
+  out[(size_t)cloud * ldo + c] = m;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -756,11 +768,19 @@ __device__ __forceinline__ void normalize3(float* v) {  // F.normalize(p=2, eps=
   v[2] /= nrm;
 }
 
+// The tail of the rotation heads (what k_rot_finish computes) can be taken in by the pose update itself: one launch less
+// per refine iteration.  rpart == nullptr: the residual is read from `rot6d`.
+struct RotTail {
+  const float* rpart;                 // [B][2][T][4] per-tile partial sums of k_rot_out
+  const float *neckbx, *neckby, *sumwp, *cpbx, *cpby;
+  int T;
+};
+
 __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __restrict__ dtr,
                               const float* __restrict__ dsr, const float* __restrict__ pose0,
                               const float* __restrict__ scale0, const float* __restrict__ mean_scales,
                               const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
-                              float* __restrict__ scale_out, int B) {
+                              float* __restrict__ scale_out, int B, RotTail rtl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float dR[9];
@@ -770,8 +790,25 @@ __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __re
   } else {  // get_rot_mat, models/model_utils.py:28-40
     const int rd = catre_rot_dim(o.rot_type);
     float r[6];
+    if (rtl.rpart) {  // same arithmetic, same order as k_rot_finish
+      const int hrd = rd >> 1;  // values per head
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
+      for (int i = 0; i < 6; ++i) {
+        const int hd = i >= hrd ? 1 : 0, c = i - hd * hrd;
+        float s = 0.f;
+        if (i < rd) {
+          const float* rp = rtl.rpart + ((size_t)b * 2 + hd) * rtl.T * 4 + c;
+          for (int t = 0; t < rtl.T; ++t) s += rp[t * 4];
+          s = fmaf((hd ? rtl.neckby : rtl.neckbx)[c], rtl.sumwp[hd], s);
+          const float* cpb = hd ? rtl.cpby : rtl.cpbx;
+          if (cpb) s += cpb[0];
+        }
+        r[i] = s;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
+    }
     rot_param_to_mat(r, o.rot_type, dR);
   }
 
@@ -970,7 +1007,7 @@ WsLayout ws_layout(int B, int N, int M) {
   L.aff0 = take(b * 2 * 2 * 2 * 256);
   L.gn1stat = take(b * 2 * 64);
   {  // y1 [b][2][P][256]; before it is written the region holds the pointfeat moments (catre_gram.h)
-    const size_t y1n = b * 2 * P * 256, mom = b * 2 * (4096 + 64 + 64);
+    const size_t y1n = b * 2 * P * 256, mom = b * 2 * (4 * (4096 + 64) + 64);  // PF_NG partial moments per cloud
     L.y1 = take(y1n > mom ? y1n : mom);
   }
   L.rpart = take(b * 2 * T * 4);
@@ -1169,7 +1206,7 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
     RS_DISPATCH(row_split(tiles), LAUNCH_STN3D)
 #undef LAUNCH_STN3D
   }
-  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
 
@@ -1199,7 +1236,7 @@ int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* 
     RS_DISPATCH(row_split(tiles), LAUNCH_STNKD)
 #undef LAUNCH_STNKD
   }
-  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
 
@@ -1223,7 +1260,7 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
     RS_DISPATCH(row_split(tiles), LAUNCH_TRUNK)
 #undef LAUNCH_TRUNK
   }
-  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M)), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
   return check_launch();
 }
 
@@ -1250,7 +1287,7 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
 
 static int rot_head_impl(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
                          float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st,
-                         bool split = false, int rd = 3) {
+                         bool split = false, int rd = 3, bool finish = true) {
   const PackLayout L = pack_layout(1);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   float* bias0 = ws + W.bias0;
@@ -1263,11 +1300,13 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   // GN0 statistics from second moments of pointfeat (catre_gram.h); the moment buffers borrow y1, which is only
   // written by k_rot_l1 afterwards
   float* Gc = ws + W.y1;
-  float* s1c = Gc + (size_t)2 * B * 4096;
-  float* shc = s1c + (size_t)2 * B * 64;
+  float* s1c = Gc + (size_t)2 * B * PF_NG * 4096;
+  float* shc = s1c + (size_t)2 * B * PF_NG * 64;
   {
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
-    hipLaunchKernelGGL(k_pf_moments, dim3(2 * B), dim3(256), 0, st, pointfeat, Gc, s1c, shc, B, N, M);
+    // a handful of clouds: the four tile groups of a cloud on four workgroups (same partial sums, same result)
+    hipLaunchKernelGGL(k_pf_moments, dim3(2 * B, 2 * B * PF_NG <= 256 ? PF_NG : 1), dim3(256), 0, st, pointfeat, Gc, s1c,
+                       shc, B, N, M);
     hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
                        prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
@@ -1279,23 +1318,27 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
                          pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
                          prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
                          g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
-    else
-      hipLaunchKernelGGL(k_rot_l1, dim3(B * T), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
-                         pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),
-                         prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
-                         g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
+    else {
+#define LAUNCH_ROT_L1(RS)                                                                                               \
+  hipLaunchKernelGGL(k_rot_l1<RS>, dim3(B * T * RS), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),               \
+                     pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),         \
+                     prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,                     \
+                     g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr)
+      RS_DISPATCH(row_split(B * T), LAUNCH_ROT_L1)
+#undef LAUNCH_ROT_L1
+    }
   }
-  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
   {
     ProfScope ps(CATRE_K_ROT_OUT, st);
-    hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1stat,
+    hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1,
                        prm[CATRE_P_ROTX_GN1_W], prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W],
                        prm[CATRE_P_ROTY_GN1_B], prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W],
                        prm[CATRE_P_ROTX_CONVP_W], prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
-  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
-                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
-                     rot6d, B, T, rd);
+  if (finish)  // the stage entry points return the residual itself; the fused drivers fold this into the pose update
+    hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                       prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
+                       rot6d, B, T, rd);
   return check_launch();
 }
 
@@ -1337,7 +1380,24 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
   if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
   if (o->rot_type < CATRE_ROT_6D || o->rot_type > CATRE_ROT_LIE_VEC) return CATRE_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, trans_deltas,
-                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
+                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B, RotTail{});
+  return check_launch();
+}
+
+// pose update fed by the per-tile partials of the rotation heads (the fused drivers: no k_rot_finish launch)
+static int pose_update_from_rpart(const float* ws_rpart, const float* const* prm, const float* packed, int T,
+                                  const float* trans_deltas, const float* scale_deltas, const float* init_pose,
+                                  const float* init_scale, const float* mean_scales, const float* Ks, const catre_opts* o,
+                                  float* pose_out, float* scale_out, int B, hipStream_t st) {
+  if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
+  if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
+  const PackLayout L = pack_layout(1);
+  RotTail rtl{ws_rpart, prm[CATRE_P_ROTX_NECK_B], prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B],
+              prm[CATRE_P_ROTY_CONVP_B], T};
+  catre_opts oo = *o;
+  oo.rot_input_is_matrix = 0;
+  hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)nullptr, trans_deltas, scale_deltas,
+                     init_pose, init_scale, mean_scales, Ks, oo, pose_out, scale_out, B, rtl);
   return check_launch();
 }
 
@@ -1357,7 +1417,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                        prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
                        pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
   }
-  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
   if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
     return rc;
   const float* t64 = nullptr;
@@ -1369,7 +1429,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                          pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
                          prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
     }
-    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
     if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
       return rc;
     t64 = ws + W.trans64;
@@ -1382,7 +1442,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                        prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
                        g_trunk_trace);
   }
-  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
+  hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, (void*)st)))
     return rc;
   float* bias0 = ws + W.bias0;
@@ -1406,20 +1466,17 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                        pkb(packed, L.bf_rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], y1, ws + W.gn1, B,
                        N, M);
   }
-  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(64), 0, st, ws + W.gn1, ws + W.gn1stat, N, M);
   {
     ProfScope ps(CATRE_K_ROT_OUT, st);
-    hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1stat, prm[CATRE_P_ROTX_GN1_W],
+    hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1, prm[CATRE_P_ROTX_GN1_W],
                        prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
                        prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
                        prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
-  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
-                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
-                     ws + W.rot6d, B, T, rd);
   if ((rc = check_launch())) return rc;
-  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
-                           scale_out, B, (void*)st);
+  (void)rd;
+  return pose_update_from_rpart(ws + W.rpart, prm, packed, T, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks,
+                                o, pose_out, scale_out, B, st);
 }
 
 int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
@@ -1453,7 +1510,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       RS_DISPATCH(row_split(tiles_all), LAUNCH_)
 #undef LAUNCH_
     }
-    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
     if ((rc = check_launch())) return rc;
   } else if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) {
     return rc;
@@ -1473,7 +1530,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
         RS_DISPATCH(row_split(tiles_all), LAUNCH_)
 #undef LAUNCH_
       }
-      hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
+      hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
       if ((rc = check_launch())) return rc;
     } else if ((rc = catre_stnkd_pool(pts, ws + W.trans3, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M,
                                       stream))) {
@@ -1494,7 +1551,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       RS_DISPATCH(row_split(tiles_all), LAUNCH_)
 #undef LAUNCH_
     }
-    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
+    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
     if ((rc = check_launch())) return rc;
   } else if ((rc = catre_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.gfeat, ws + W.pointfeat, workspace, ws_bytes,
                                B, N, M, stream))) {
@@ -1503,10 +1560,10 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, stream)))
     return rc;
   if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split,
-                          catre_rot_dim(o->rot_type) / 2)))
+                          catre_rot_dim(o->rot_type) / 2, /*finish=*/false)))
     return rc;
-  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
-                           scale_out, B, stream);
+  return pose_update_from_rpart(ws + W.rpart, prm, packed, (N + TP - 1) / TP + (M + TP - 1) / TP, ws + W.dt, ws + W.ds,
+                                init_pose, init_scale, mean_scales, Ks, o, pose_out, scale_out, B, st);
 }
 
 int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,
@@ -1516,23 +1573,26 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
-  catre_points pts;
-  pts.obs = ws + W.xbuf;
+  (void)ws;
+  catre_points pts;  // the raw clouds; the pose-apply of batch_updater_test happens as the encoder kernels load a point
+  pts.obs = pcl;
   pts.obs_sb = (int64_t)N * 3;
   pts.obs_sn = 3;
   pts.obs_sc = 1;
-  pts.kps = ws + W.kbuf;
+  pts.kps = kps;
   pts.kps_sb = (int64_t)M * 3;
   pts.kps_sn = 3;
   pts.kps_sc = 1;
+  pts.apply_pose = 1;
+  pts.zero_center = o->zero_center;
   for (int i = 1; i <= n_iter; ++i) {
     const float* pose_in = poses + (size_t)(i - 1) * B * 12;
     // batch_test.py:74-75: the scale estimate is only fed back when REFINE_SCLAE
     const float* scale_in = scales + (size_t)(o->refine_scale ? i - 1 : 0) * B * 3;
-    int rc = catre_pose_apply(pcl, kps, pose_in, scale_in, ws + W.xbuf, ws + W.kbuf, B, N, M, o->zero_center, stream);
-    if (rc) return rc;
-    rc = catre_refine_iter(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
-                           scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream);
+    pts.pose = pose_in;
+    pts.scale = scale_in;
+    const int rc = catre_refine_iter(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
+                                     scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream);
     if (rc) return rc;
   }
   return CATRE_OK;

@@ -65,6 +65,10 @@ __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ point
   }
 }
 
+// Small grids (tiles * RS <= #CUs, like the encoder kernels): RS = 2 puts the two heads of a tile on two workgroups,
+// RS = 4 additionally halves layer 1's output channels (each workgroup repeats layer 0 + GELU, 20 % of the MFMAs, and
+// sweeps 128 of the 256 layer-1 channels: one m-block per wave).  Every output sees the same K order for any RS.
+template <int RS>
 __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
                                                    const f32x4* __restrict__ wpl0y,
                                                    const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
   float* a0 = smem + TP * 64;  // [64][256] swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  const int part = blockIdx.x % RS;
+  const RotTile rt = rot_tile(blockIdx.x / RS, B, N, M);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   const int P = N + M;
   ROT_STAMP();
@@ -92,8 +97,11 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
   __syncthreads();
   ROT_STAMP();
   const int n = lane & 31, h = lane >> 5;
+  constexpr int MB1 = RS == 4 ? 1 : 2;                       // layer-1 m-blocks per wave
+  const int mblk1 = RS == 4 ? (part >> 1) * 4 + wave : wave * 2;  // first of them
+  const int hd_lo = RS == 1 ? 0 : (part & 1), hd_hi = RS == 1 ? 2 : hd_lo + 1;
 #pragma unroll 1
-  for (int hd = 0; hd < 2; ++hd) {
+  for (int hd = hd_lo; hd < hd_hi; ++hd) {
     {
       // layer 0 recompute: wave -> channels [wave*64, +64), "normal" orientation.  The fused bias+GN affine
       // of this (object, head, cloud) is requested before the GEMM so the epilogue never waits on HBM/L2.
@@ -138,21 +146,22 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
     {
       // layer 1 (256->256), "swapped": lane owns channels wave*64 + mb*32 + n and 32 of the tile's points.  The
       // accumulators start at the lane's channel bias (one value per lane in this orientation): no bias add afterwards.
-      f32x16 acc[2][2];
+      f32x16 acc[MB1][2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float bb = (hd ? b1y : b1x)[wave * 64 + mb * 32 + n];
+      for (int mb = 0; mb < MB1; ++mb) {
+        const float bb = (hd ? b1y : b1x)[(mblk1 + mb) * 32 + n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][0][r] = acc[mb][1][r] = bb;
       }
-      gemm_core<2, 2, true, true, 32, 2>(acc, (hd ? wpl1y : wpl1x) + (wave * 2 * 32) * 64 + lane, 32 * 64, a0, 256, lane);
+      gemm_core<MB1, 2, true, true, 32, 2>(acc, (hd ? wpl1y : wpl1x) + ((size_t)mblk1 * 32) * 64 + lane, 32 * 64, a0, 256,
+                                          lane);
       ROT_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
       int valid_h = rt.valid - 4 * h;  // point (r, nb) of this half-wave is real iff its in-tile index < valid_h
       asm volatile("" : "+v"(valid_h));
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const int ch = wave * 64 + mb * 32 + n;
+      for (int mb = 0; mb < MB1; ++mb) {
+        const int ch = (mblk1 + mb) * 32 + n;
         float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
         if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 }
 
 // GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
-__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1stat,
+__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1part,
                                                  const float* __restrict__ gam1x, const float* __restrict__ bet1x,
                                                  const float* __restrict__ gam1y, const float* __restrict__ bet1y,
                                                  const float* __restrict__ neckx, const float* __restrict__ necky,
@@ -241,8 +250,17 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
   const float* bet = hd ? bet1y : bet1x;
   const float* neck = hd ? necky : neckx;
   const float* wp = hd ? wpy : wpx;
-  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
-  const float mean = st[0], rstd = st[1];
+  // GN1 statistics of this (object, head): the per-tile (mean, M2) partials of k_rot_l1 merged in tile order by the
+  // first 32 threads (Chan's formula, deterministic; 8 KiB of L2-resident partials) - no separate finalize launch
+  __shared__ float gst[64];
+  if (tid < 32) {
+    float mean_g, rstd_g;
+    merge_gn(gn1part + ((size_t)rt.obj * 2 + hd) * T * 64, tid, T, (N + TP - 1) / TP, N, M, mean_g, rstd_g);
+    gst[tid * 2] = mean_g;
+    gst[tid * 2 + 1] = rstd_g;
+  }
+  __syncthreads();
+  const float mean = gst[(c0 >> 3) * 2], rstd = gst[(c0 >> 3) * 2 + 1];
   f32x4 sc, sh;
   float nk[3][4];
 #pragma unroll

@@ -80,6 +80,7 @@ class CatrePoints(ctypes.Structure):
     _fields_ = [
         ("obs", ctypes.c_void_p), ("obs_sb", ctypes.c_int64), ("obs_sn", ctypes.c_int64), ("obs_sc", ctypes.c_int64),
         ("kps", ctypes.c_void_p), ("kps_sb", ctypes.c_int64), ("kps_sn", ctypes.c_int64), ("kps_sc", ctypes.c_int64),
+        ("pose", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("apply_pose", ctypes.c_int32), ("zero_center", ctypes.c_int32),
     ]
 
 

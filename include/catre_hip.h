@@ -139,6 +139,12 @@ int catre_pose_apply(const float* pcl, const float* kps, const float* pose /*[B,
 typedef struct catre_points {
   const float* obs;  int64_t obs_sb, obs_sn, obs_sc;   /* observed cloud  x        [B,N,3] */
   const float* kps;  int64_t kps_sb, kps_sn, kps_sc;   /* transformed prior tfd_kps [B,M,3] */
+  /* apply_pose != 0: obs / kps describe the RAW batch["pcl"] / batch["obj_kps"] and the pose-apply of
+   * batch_updater_test (engine/batch_test.py:81-97: x = pcl - t, tfd_kps = R (kps * s) [+ t]) is done on the fly as
+   * the points are loaded, with pose [B,3,4] / scale [B,3] - what catre_refine_k does instead of materialising x and
+   * tfd_kps every iteration.  0 (and NULL pointers): the arrays already hold x / tfd_kps. */
+  const float* pose;  const float* scale;
+  int32_t apply_pose, zero_center;
 } catre_points;
 
 /* a2: STN3d conv stack + max-pool (core/catre/models/pointnets/pointnet.py:24-29).

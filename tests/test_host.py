@@ -71,7 +71,7 @@ def test_size_queries_without_gpu():
     assert 0 < small < big
     assert lib.catre_packed_floats(1024, 1024, 1091) > 1024 * 512
     assert lib.catre_status_string(-2).decode().startswith("workspace")
-    assert ctypes.sizeof(hip.CatreOpts) == 72 and ctypes.sizeof(hip.CatrePoints) == 64
+    assert ctypes.sizeof(hip.CatreOpts) == 72 and ctypes.sizeof(hip.CatrePoints) == 88
 
 
 def test_param_enum_matches_header():
