@@ -679,15 +679,8 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
   const float* bet = hd ? bet1y : bet1x;
   const float* neck = hd ? necky : neckx;
   const float* wp = hd ? wpy : wpx;
-  __shared__ float gst[64];  // GN1 statistics merged from the per-tile partials here (see k_rot_out)
-  if (tid < 32) {
-    float mean_g, rstd_g;
-    merge_gn(gn1stat + ((size_t)rt.obj * 2 + hd) * T * 64, tid, T, (N + TP - 1) / TP, N, M, mean_g, rstd_g);
-    gst[tid * 2] = mean_g;
-    gst[tid * 2 + 1] = rstd_g;
-  }
-  __syncthreads();
-  const float mean = gst[(c0 >> 3) * 2], rstd = gst[(c0 >> 3) * 2 + 1];
+  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
+  const float mean = st[0], rstd = st[1];
   f32x4 sc, sh;
   float nk[3][4];
 #pragma unroll

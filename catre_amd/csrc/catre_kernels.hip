@@ -53,9 +53,10 @@ __device__ __forceinline__ void pose_apply_point(const float* __restrict__ p, co
     }
   } else {
     const float sx = x * sc[0], sy = y * sc[1], sz = z * sc[2];      // misc.py:1017
-    float ox = p[0] * sx + p[1] * sy + p[2] * sz;                   // misc.py:1021 (row . column)
-    float oy = p[4] * sx + p[5] * sy + p[6] * sz;
-    float oz = p[8] * sx + p[9] * sy + p[10] * sz;
+    // misc.py:1021 (row . column); explicit fma chain so that every caller contracts it the same way
+    float ox = fmaf(p[2], sz, fmaf(p[1], sy, p[0] * sx));
+    float oy = fmaf(p[6], sz, fmaf(p[5], sy, p[4] * sx));
+    float oz = fmaf(p[10], sz, fmaf(p[9], sy, p[8] * sx));
     if (!zero_center) {
       ox += p[3];
       oy += p[7];
@@ -503,7 +504,16 @@ __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm,
 __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restrict__ X, int ldx,
                                                             const float* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, float* __restrict__ Y,
-                                                            int ldy, int R, int J, int K, int relu, int iden_k) {
+                                                            int ldy, int R, int J, int K, int relu, int iden_k,
+                                                            const float* __restrict__ W_z1 = nullptr,
+                                                            const float* __restrict__ bias_z1 = nullptr,
+                                                            float* __restrict__ Y_z1 = nullptr) {
+  // gridDim.z == 2: a second (W, bias, Y) on the same X in the same launch (the two rotation heads' global halves)
+  if (blockIdx.z == 1) {
+    W = W_z1;
+    bias = bias_z1;
+    Y = Y_z1;
+  }
   // 8 waves split K (interleaved 8-wide chunks), each with up to 8 chunk pairs in flight - the kernel is a chain of
   // L2 round trips, so the trip count (K/8/8/8 = 2 for K = 1024) is what sets its time; partial 32x32 blocks are
   // summed through LDS in wave order (deterministic).
@@ -579,26 +589,21 @@ __device__ __forceinline__ float group8_norm_gelu(float v, float gamma, float be
   return gelu_erf(fmaf(v, sc, beta - mean * sc));
 }
 
-__global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfeat, const float* __restrict__ pose,
-                                                 const float* __restrict__ scale, const float* __restrict__ W0T,
-                                                 const float* __restrict__ b0, const float* __restrict__ g0,
-                                                 const float* __restrict__ be0, const float* __restrict__ W1T,
-                                                 const float* __restrict__ b1, const float* __restrict__ g1,
-                                                 const float* __restrict__ be1, const float* __restrict__ Wt,
-                                                 const float* __restrict__ bt, const float* __restrict__ Ws,
-                                                 const float* __restrict__ bs, float* __restrict__ dt,
-                                                 float* __restrict__ ds, int B, int in_dim, int with_kps,
-                                                 int with_scale, int with_trans) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* feat = sm;                          // [TS_OB][in_dim]
-  float* hbuf = sm + TS_OB * in_dim;         // [TS_OB][256]
-  float* kpart = hbuf + TS_OB * 256;         // [4][TS_OB][256] K-slice partial sums
-  // 1024 threads: 4 K-slices x 256 output channels; slice partials are merged in slice order
-  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+// Layer 0 (in_dim -> 256) split over TS_KS workgroups per group of TS_OB objects: each gathers its K slice of
+// ts_feat and writes a partial sum per (object, slice, channel).  With one workgroup the layer is a serial chain of
+// ~1100 L2 round trips (33 us for a single object); eight slices cut it to ~140 and put 8x as many CUs to work.
+#define TS_KS 8
+__global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, const float* __restrict__ pose,
+                                               const float* __restrict__ scale, const float* __restrict__ W0T,
+                                               float* __restrict__ part /*[B][TS_KS][256]*/, int B, int in_dim, int with_kps,
+                                               int with_scale, int with_trans) {
+  extern __shared__ __attribute__((aligned(16))) float feat[];  // [TS_OB][slice length]
+  const int tid = threadIdx.x, ks = blockIdx.y;
   const int b0i = blockIdx.x * TS_OB;
+  const int k0 = (in_dim * ks) / TS_KS, k1 = (in_dim * (ks + 1)) / TS_KS, len = k1 - k0;
   for (int o = 0; o < TS_OB; ++o) {
     const int b = min(b0i + o, B - 1);
-    for (int k = threadIdx.x; k < in_dim; k += 1024) {
+    for (int k = k0 + tid; k < k1; k += 256) {
       int kk = k;
       float v;
       if (kk < PMW) {
@@ -617,31 +622,45 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ gfea
           }
         }
       }
-      feat[o * in_dim + k] = v;
+      feat[o * len + k - k0] = v;
     }
   }
   __syncthreads();
   float acc[TS_OB];
-  {
-    const int k0 = (in_dim * ks) / 4, k1 = (in_dim * (ks + 1)) / 4;
 #pragma unroll
-    for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
+  for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
 #pragma unroll 16
-    for (int k = k0; k < k1; ++k) {
-      const float w = W0T[(size_t)k * 256 + tid];
+  for (int k = 0; k < len; ++k) {
+    const float w = W0T[(size_t)(k0 + k) * 256 + tid];
 #pragma unroll
-      for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * in_dim + k], w, acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < TS_OB; ++o) kpart[(ks * TS_OB + o) * 256 + tid] = acc[o];
+    for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * len + k], w, acc[o]);
   }
-  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < TS_OB; ++o)
+    if (b0i + o < B) part[((size_t)(b0i + o) * TS_KS + ks) * 256 + tid] = acc[o];
+}
+
+__global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ l0part /*[B][TS_KS][256]*/,
+                                                 const float* __restrict__ b0, const float* __restrict__ g0,
+                                                 const float* __restrict__ be0, const float* __restrict__ W1T,
+                                                 const float* __restrict__ b1, const float* __restrict__ g1,
+                                                 const float* __restrict__ be1, const float* __restrict__ Wt,
+                                                 const float* __restrict__ bt, const float* __restrict__ Ws,
+                                                 const float* __restrict__ bs, float* __restrict__ dt,
+                                                 float* __restrict__ ds, int B) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* hbuf = sm;                          // [TS_OB][256]
+  float* kpart = hbuf + TS_OB * 256;         // [4][TS_OB][256] K-slice partial sums
+  // 1024 threads: 4 K-slices x 256 output channels; slice partials are merged in slice order
+  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  const int b0i = blockIdx.x * TS_OB;
+  float acc[TS_OB];
   if (ks == 0) {
     const float ga = g0[tid], be = be0[tid], bb = b0[tid];
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) {
-      const float v = bb + (((kpart[o * 256 + tid] + kpart[(TS_OB + o) * 256 + tid]) +
-                             kpart[(2 * TS_OB + o) * 256 + tid]) + kpart[(3 * TS_OB + o) * 256 + tid]);
+      const float* p = l0part + (size_t)min(b0i + o, B - 1) * TS_KS * 256 + tid;
+      const float v = bb + (((p[0] + p[256]) + (p[512] + p[768])) + ((p[1024] + p[1280]) + (p[1536] + p[1792])));
       hbuf[o * 256 + tid] = group8_norm_gelu(v, ga, be);
     }
   }
@@ -768,19 +787,11 @@ __device__ __forceinline__ void normalize3(float* v) {  // F.normalize(p=2, eps=
   v[2] /= nrm;
 }
 
-// The tail of the rotation heads (what k_rot_finish computes) can be taken in by the pose update itself: one launch less
-// per refine iteration.  rpart == nullptr: the residual is read from `rot6d`.
-struct RotTail {
-  const float* rpart;                 // [B][2][T][4] per-tile partial sums of k_rot_out
-  const float *neckbx, *neckby, *sumwp, *cpbx, *cpby;
-  int T;
-};
-
 __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __restrict__ dtr,
                               const float* __restrict__ dsr, const float* __restrict__ pose0,
                               const float* __restrict__ scale0, const float* __restrict__ mean_scales,
                               const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
-                              float* __restrict__ scale_out, int B, RotTail rtl) {
+                              float* __restrict__ scale_out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float dR[9];
@@ -790,25 +801,8 @@ __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __re
   } else {  // get_rot_mat, models/model_utils.py:28-40
     const int rd = catre_rot_dim(o.rot_type);
     float r[6];
-    if (rtl.rpart) {  // same arithmetic, same order as k_rot_finish
-      const int hrd = rd >> 1;  // values per head
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int hd = i >= hrd ? 1 : 0, c = i - hd * hrd;
-        float s = 0.f;
-        if (i < rd) {
-          const float* rp = rtl.rpart + ((size_t)b * 2 + hd) * rtl.T * 4 + c;
-          for (int t = 0; t < rtl.T; ++t) s += rp[t * 4];
-          s = fmaf((hd ? rtl.neckby : rtl.neckbx)[c], rtl.sumwp[hd], s);
-          const float* cpb = hd ? rtl.cpby : rtl.cpbx;
-          if (cpb) s += cpb[0];
-        }
-        r[i] = s;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
-    }
+    for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
     rot_param_to_mat(r, o.rot_type, dR);
   }
 
@@ -974,7 +968,7 @@ PackLayout pack_layout(int ts_in) {
 }
 
 struct WsLayout {
-  size_t xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, aff0, gn1stat, y1, rpart,
+  size_t tspart, xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, aff0, gn1stat, y1, rpart,
       total;  // offsets in floats
 };
 
@@ -988,6 +982,7 @@ WsLayout ws_layout(int B, int N, int M) {
     o += align_up(n, 64);
     return r;
   };
+  L.tspart = take(b * 8 * 256);  // first: catre_ts_head finds it without knowing N, M (TS_KS = 8 layer-0 partials)
   L.xbuf = take(b * N * 3);
   L.kbuf = take(b * M * 3);
   L.pm = take(b * T * PMW);
@@ -1265,38 +1260,40 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
 }
 
 int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_scale, const float* const* prm,
-                  const float* packed, const catre_opts* o, float* trans_deltas, float* scale_deltas, int B,
-                  void* stream) {
+                  const float* packed, const catre_opts* o, float* trans_deltas, float* scale_deltas, void* workspace,
+                  size_t ws_bytes, int B, void* stream) {
   REQUIRE(gfeat && init_pose && init_scale && prm && packed && o && trans_deltas && scale_deltas && B > 0);
   const int expect = PMW * (o->with_kps_feature ? 2 : 1) + (o->with_init_scale ? 3 : 0) + (o->with_init_trans ? 3 : 0);
   if (o->ts_in_dim != expect) return CATRE_ERR_BAD_ARG;
   const PackLayout L = pack_layout(o->ts_in_dim);
-  const size_t smem = (size_t)TS_OB * (o->ts_in_dim + 256 + 4 * 256) * sizeof(float);
-  if (smem > 64 * 1024) return CATRE_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (!workspace || ws_bytes < (size_t)B * TS_KS * 256 * sizeof(float)) return CATRE_ERR_WORKSPACE;
+  float* l0part = (float*)workspace;  // WsLayout::tspart sits at offset 0 for every (N, M)
+  const int groups = (B + TS_OB - 1) / TS_OB;
   {
-    ProfScope ps(CATRE_K_TS_HEAD, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_ts_head, dim3((B + TS_OB - 1) / TS_OB), dim3(1024), smem, (hipStream_t)stream, gfeat, init_pose,
-                     init_scale, packed + L.ts_w0t, prm[CATRE_P_TS_L0_B], prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B],
-                     packed + L.ts_w1t, prm[CATRE_P_TS_L1_B], prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B],
-                     prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B], prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B],
-                     trans_deltas, scale_deltas, B, o->ts_in_dim, o->with_kps_feature, o->with_init_scale,
-                     o->with_init_trans);
+    ProfScope ps(CATRE_K_TS_HEAD, st);
+    const size_t smem0 = (size_t)TS_OB * (o->ts_in_dim / TS_KS + 2) * sizeof(float);
+    hipLaunchKernelGGL(k_ts_l0, dim3(groups, TS_KS), dim3(256), smem0, st, gfeat, init_pose, init_scale, packed + L.ts_w0t,
+                       l0part, B, o->ts_in_dim, o->with_kps_feature, o->with_init_scale, o->with_init_trans);
+    const size_t smem = (size_t)TS_OB * (256 + 4 * 256) * sizeof(float);
+    hipLaunchKernelGGL(k_ts_head, dim3(groups), dim3(1024), smem, st, (const float*)l0part, prm[CATRE_P_TS_L0_B],
+                       prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B], packed + L.ts_w1t, prm[CATRE_P_TS_L1_B],
+                       prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B], prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B],
+                       prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B], trans_deltas, scale_deltas, B);
   }
   return check_launch();
 }
 
 static int rot_head_impl(const float* gfeat, const float* pointfeat, const float* const* prm, const float* packed,
                          float* rot6d, float* ws, const WsLayout& W, int B, int N, int M, hipStream_t st,
-                         bool split = false, int rd = 3, bool finish = true) {
+                         bool split = false, int rd = 3) {
   const PackLayout L = pack_layout(1);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   float* bias0 = ws + W.bias0;
   // global-feature half of layer 0 for every cloud: bias0[hd][cloud][:] = W0[:, :1024] g_cloud + b0
-  for (int hd = 0; hd < 2; ++hd) {
-    const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
-    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, gfeat, PMW, prm[base], PMW,
-                       prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
-  }
+  hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32, 2), dim3(64 * LIN_WAVES), 0, st, gfeat, PMW,
+                     prm[CATRE_P_ROTX_L0_W], PMW, prm[CATRE_P_ROTX_L0_W + 1], bias0, 256, 2 * B, 256, 1024, 0, 0,
+                     prm[CATRE_P_ROTY_L0_W], prm[CATRE_P_ROTY_L0_W + 1], bias0 + (size_t)2 * B * 256);
   // GN0 statistics from second moments of pointfeat (catre_gram.h); the moment buffers borrow y1, which is only
   // written by k_rot_l1 afterwards
   float* Gc = ws + W.y1;
@@ -1328,17 +1325,18 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
 #undef LAUNCH_ROT_L1
     }
   }
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(256), (size_t)T * 64 * sizeof(float), st, ws + W.gn1, ws + W.gn1stat,
+                     N, M);
   {
     ProfScope ps(CATRE_K_ROT_OUT, st);
-    hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1,
+    hipLaunchKernelGGL(k_rot_out, dim3(B * T, 2), dim3(256), 0, st, ws + W.y1, ws + W.gn1stat,
                        prm[CATRE_P_ROTX_GN1_W], prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W],
                        prm[CATRE_P_ROTY_GN1_B], prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W],
                        prm[CATRE_P_ROTX_CONVP_W], prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
-  if (finish)  // the stage entry points return the residual itself; the fused drivers fold this into the pose update
-    hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
-                       prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
-                       rot6d, B, T, rd);
+  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
+                     rot6d, B, T, rd);
   return check_launch();
 }
 
@@ -1380,24 +1378,7 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
   if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
   if (o->rot_type < CATRE_ROT_6D || o->rot_type > CATRE_ROT_LIE_VEC) return CATRE_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, trans_deltas,
-                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B, RotTail{});
-  return check_launch();
-}
-
-// pose update fed by the per-tile partials of the rotation heads (the fused drivers: no k_rot_finish launch)
-static int pose_update_from_rpart(const float* ws_rpart, const float* const* prm, const float* packed, int T,
-                                  const float* trans_deltas, const float* scale_deltas, const float* init_pose,
-                                  const float* init_scale, const float* mean_scales, const float* Ks, const catre_opts* o,
-                                  float* pose_out, float* scale_out, int B, hipStream_t st) {
-  if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
-  if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
-  const PackLayout L = pack_layout(1);
-  RotTail rtl{ws_rpart, prm[CATRE_P_ROTX_NECK_B], prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B],
-              prm[CATRE_P_ROTY_CONVP_B], T};
-  catre_opts oo = *o;
-  oo.rot_input_is_matrix = 0;
-  hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)nullptr, trans_deltas, scale_deltas,
-                     init_pose, init_scale, mean_scales, Ks, oo, pose_out, scale_out, B, rtl);
+                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
   return check_launch();
 }
 
@@ -1443,14 +1424,13 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                        g_trunk_trace);
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
-  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, (void*)st)))
+  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, ws,
+                          W.total * sizeof(float), B, (void*)st)))
     return rc;
   float* bias0 = ws + W.bias0;
-  for (int hd = 0; hd < 2; ++hd) {
-    const int base = hd ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
-    hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, ws + W.gfeat, PMW, prm[base], PMW,
-                       prm[base + 1], bias0 + (size_t)hd * 2 * B * 256, 256, 2 * B, 256, 1024, 0, 0);
-  }
+  hipLaunchKernelGGL(k_linear, dim3((2 * B + 31) / 32, 256 / 32, 2), dim3(64 * LIN_WAVES), 0, st, ws + W.gfeat, PMW,
+                     prm[CATRE_P_ROTX_L0_W], PMW, prm[CATRE_P_ROTX_L0_W + 1], bias0, 256, 2 * B, 256, 1024, 0, 0,
+                     prm[CATRE_P_ROTY_L0_W], prm[CATRE_P_ROTY_L0_W + 1], bias0 + (size_t)2 * B * 256);
   {
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
     hipLaunchKernelGGL(k_rot_l0_stats_bf, dim3(B * T), dim3(512), 0, st, pointfeat, pkb(packed, L.bf_rot_l0[0]),
@@ -1466,17 +1446,21 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                        pkb(packed, L.bf_rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], y1, ws + W.gn1, B,
                        N, M);
   }
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(256), (size_t)T * 64 * sizeof(float), st, ws + W.gn1, ws + W.gn1stat,
+                     N, M);
   {
     ProfScope ps(CATRE_K_ROT_OUT, st);
-    hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1, prm[CATRE_P_ROTX_GN1_W],
+    hipLaunchKernelGGL(k_rot_out_bf, dim3(B * T, 2), dim3(256), 0, st, y1, ws + W.gn1stat, prm[CATRE_P_ROTX_GN1_W],
                        prm[CATRE_P_ROTX_GN1_B], prm[CATRE_P_ROTY_GN1_W], prm[CATRE_P_ROTY_GN1_B],
                        prm[CATRE_P_ROTX_NECK_W], prm[CATRE_P_ROTY_NECK_W], prm[CATRE_P_ROTX_CONVP_W],
                        prm[CATRE_P_ROTY_CONVP_W], ws + W.rpart, B, N, M, rd);
   }
+  hipLaunchKernelGGL(k_rot_finish, dim3((B * 6 + 255) / 256), dim3(256), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
+                     ws + W.rot6d, B, T, rd);
   if ((rc = check_launch())) return rc;
-  (void)rd;
-  return pose_update_from_rpart(ws + W.rpart, prm, packed, T, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks,
-                                o, pose_out, scale_out, B, st);
+  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                           scale_out, B, (void*)st);
 }
 
 int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
@@ -1557,13 +1541,14 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
                                B, N, M, stream))) {
     return rc;
   }
-  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, B, stream)))
+  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, workspace, ws_bytes, B,
+                          stream)))
     return rc;
   if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split,
-                          catre_rot_dim(o->rot_type) / 2, /*finish=*/false)))
+                          catre_rot_dim(o->rot_type) / 2)))
     return rc;
-  return pose_update_from_rpart(ws + W.rpart, prm, packed, (N + TP - 1) / TP + (M + TP - 1) / TP, ws + W.dt, ws + W.ds,
-                                init_pose, init_scale, mean_scales, Ks, o, pose_out, scale_out, B, st);
+  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                           scale_out, B, stream);
 }
 
 int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,

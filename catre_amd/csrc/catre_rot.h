@@ -11,14 +11,21 @@
 // 80 KiB of LDS (pointfeat tile 16 KiB + a0 image 64 KiB, both XOR-swizzled instead of padded).
 #pragma once
 
-// (mean, M2) partials [rows][T][32][2] -> (mean, rstd) [rows][32][2]; one wave per row (row = object*2+head)
-__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ part, float* __restrict__ stat, int N,
-                                                    int M) {
+// (mean, M2) partials [rows][T][32][2] -> (mean, rstd) [rows][32][2]; one workgroup per row (row = object*2+head): the
+// row's partials are staged in LDS with coalesced loads, then 32 threads merge them in tile order (the merge is a serial
+// chain per group - from LDS it costs ~1 us instead of T dependent L2 round trips).  (Tried: merging inside k_rot_out
+// instead of a separate launch - every one of its 16 k workgroups then waits on the chain: 190 -> 297 us at B = 256.)
+__global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ part, float* __restrict__ stat, int N,
+                                                     int M) {
+  extern __shared__ float sp[];  // [T][64]
   const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
+  const float* src = part + (size_t)blockIdx.x * T * 64;
+  for (int i = threadIdx.x; i < T * 64; i += 256) sp[i] = src[i];
+  __syncthreads();
   const int g = threadIdx.x;
   if (g >= 32) return;
   float mean, rstd;
-  merge_gn(part + (size_t)blockIdx.x * T * 64, g, T, TN, N, M, mean, rstd);
+  merge_gn(sp, g, T, TN, N, M, mean, rstd);
   stat[((size_t)blockIdx.x * 32 + g) * 2] = mean;
   stat[((size_t)blockIdx.x * 32 + g) * 2 + 1] = rstd;
 }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 }
 
 // GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
-__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1part,
+__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1stat,
                                                  const float* __restrict__ gam1x, const float* __restrict__ bet1x,
                                                  const float* __restrict__ gam1y, const float* __restrict__ bet1y,
                                                  const float* __restrict__ neckx, const float* __restrict__ necky,
@@ -250,17 +257,8 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
   const float* bet = hd ? bet1y : bet1x;
   const float* neck = hd ? necky : neckx;
   const float* wp = hd ? wpy : wpx;
-  // GN1 statistics of this (object, head): the per-tile (mean, M2) partials of k_rot_l1 merged in tile order by the
-  // first 32 threads (Chan's formula, deterministic; 8 KiB of L2-resident partials) - no separate finalize launch
-  __shared__ float gst[64];
-  if (tid < 32) {
-    float mean_g, rstd_g;
-    merge_gn(gn1part + ((size_t)rt.obj * 2 + hd) * T * 64, tid, T, (N + TP - 1) / TP, N, M, mean_g, rstd_g);
-    gst[tid * 2] = mean_g;
-    gst[tid * 2 + 1] = rstd_g;
-  }
-  __syncthreads();
-  const float mean = gst[(c0 >> 3) * 2], rstd = gst[(c0 >> 3) * 2 + 1];
+  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
+  const float mean = st[0], rstd = st[1];
   f32x4 sc, sh;
   float nk[3][4];
 #pragma unroll

@@ -96,7 +96,7 @@ _SIGS = {
     "catre_linear": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_stnkd_pool": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_trunk": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
-    "catre_ts_head": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "catre_ts_head": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
     "catre_rot_head": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_rot_head_dim": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_rot_to_mat": (_I, [_P, _I, _P, _I, _P]),

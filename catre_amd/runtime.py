@@ -230,9 +230,10 @@ class HipRuntime:
         dt = torch.empty(B, 3, dtype=torch.float32, device=dev)
         ds = torch.empty(B, 3, dtype=torch.float32, device=dev)
         init_pose, init_scale = init_pose.contiguous(), init_scale.contiguous()  # bound: must outlive the enqueue
+        ws = self.workspace(B, self.N, self.M, dev)
         hip.check(lib.catre_ts_head(hip.ptr(gfeat), hip.ptr(init_pose), hip.ptr(init_scale),
-                                    prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(dt), hip.ptr(ds), B,
-                                    hip.stream_ptr(dev)), "catre_ts_head")
+                                    prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(dt), hip.ptr(ds), hip.ptr(ws),
+                                    ws.numel(), B, hip.stream_ptr(dev)), "catre_ts_head")
         return dt, ds
 
     def stage_rot_head(self, gfeat, pointfeat, B, N, M, rot_dim=3):

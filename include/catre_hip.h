@@ -174,7 +174,7 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
  * heads/fc_trans_size_head.py:61-70).  -> trans_deltas [B,3], scale_deltas [B,3]. */
 int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_scale,
                   const float* const* params, const float* packed, const catre_opts* opts,
-                  float* trans_deltas, float* scale_deltas, int B, void* stream);
+                  float* trans_deltas, float* scale_deltas, void* workspace, size_t ws_bytes, int B, void* stream);
 
 /* a7+a9: ConvOutPerRotHead.forward on cat(pcl_feat,kps_feat,dim=2) without materialising it
  * (CATRE_disR_shared.py:86-88, heads/conv_out_per_rot_head.py:62-71,126-140). -> rot6d [B,6]. */
