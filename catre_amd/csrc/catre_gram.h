@@ -162,12 +162,22 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[k4 * 4 + q] = v[q];
   }
+  // the 16 entries of w that multiply this thread's rows, loaded together (indexing w[] with the runtime row would put
+  // the array in scratch; loading them one by one inside the loop serialises 32 L2 round trips)
+  float wr[16];
+#pragma unroll
+  for (int u4 = 0; u4 < 4; ++u4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + rq * 16 + u4 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[u4 * 4 + q] = v[q];
+  }
   __syncthreads();
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl) {  // this thread's 16 rows of w^T S w
     float quad = 0.f;
-#pragma unroll 4
-    for (int r = rq * 16; r < rq * 16 + 16; ++r) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = rq * 16 + u;
       const f32x4* Sr = reinterpret_cast<const f32x4*>(S[cl] + r * 64);
       float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;  // four independent chains (fixed association)
 #pragma unroll
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
         t3 = fmaf(s4[3], w[k4 * 4 + 3], t3);
       }
       const float t = (t0 + t1) + (t2 + t3);
-      quad = fmaf(wrow[r], t, quad);  // (a runtime index into w[] would put the whole array in scratch)
+      quad = fmaf(wr[u], t, quad);
     }
     qpart[cl][rq][cq] = quad;
   }

@@ -629,9 +629,22 @@ __global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, 
   float acc[TS_OB];
 #pragma unroll
   for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
-#pragma unroll 16
-  for (int k = 0; k < len; ++k) {
-    const float w = W0T[(size_t)(k0 + k) * 256 + tid];
+  // 16 weight rows requested together, then used: left to itself hipcc waits for every row before asking for the next
+  // (one L2 round trip, ~150 ns, per row - measured 24 us for 137 rows)
+  const float* wcol = W0T + (size_t)k0 * 256 + tid;
+  int k = 0;
+  for (; k + 16 <= len; k += 16) {
+    float w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = wcol[(size_t)(k + u) * 256];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * len + k + u], w[u], acc[o]);
+  }
+  for (; k < len; ++k) {
+    const float w = wcol[(size_t)k * 256];
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(feat[o * len + k], w, acc[o]);
   }
@@ -668,11 +681,16 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ l0pa
   {
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) acc[o] = 0.f;
-#pragma unroll 16
-    for (int k = ks * 64; k < ks * 64 + 64; ++k) {
-      const float w = W1T[k * 256 + tid];
+#pragma unroll 1
+    for (int kb = ks * 64; kb < ks * 64 + 64; kb += 16) {  // 16 rows of W1T in flight (see k_ts_l0)
+      float w[16];
 #pragma unroll
-      for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(hbuf[o * 256 + k], w, acc[o]);
+      for (int u = 0; u < 16; ++u) w[u] = W1T[(kb + u) * 256 + tid];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int o = 0; o < TS_OB; ++o) acc[o] = fmaf(hbuf[o * 256 + kb + u], w[u], acc[o]);
     }
 #pragma unroll
     for (int o = 0; o < TS_OB; ++o) kpart[(ks * TS_OB + o) * 256 + tid] = acc[o];
@@ -688,14 +706,20 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ l0pa
     }
   }
   __syncthreads();
-  if (ks != 0) return;
-  if (tid < TS_OB * 6) {
-    const int o = tid / 6, c = tid % 6;
+  // fc_t / fc_s: 32 lanes per output (object, coordinate): lane j takes k = j, j + 32, ... and a fixed shuffle tree adds
+  // the 32 partials (a serial 256-term chain per output took most of this kernel's time)
+  const int grp = threadIdx.x >> 5, j = threadIdx.x & 31;
+  if (grp < TS_OB * 6) {
+    const int o = grp / 6, c = grp % 6;
     const int b = b0i + o;
-    if (b < B) {
-      const float* w = c < 3 ? Wt + c * 256 : Ws + (c - 3) * 256;
-      float s = c < 3 ? bt[c] : bs[c - 3];
-      for (int k = 0; k < 256; ++k) s = fmaf(hbuf[o * 256 + k], w[k], s);
+    const float* w = c < 3 ? Wt + c * 256 : Ws + (c - 3) * 256;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = fmaf(hbuf[o * 256 + j + 32 * u], w[j + 32 * u], s);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (j == 0 && b < B) {
+      s += c < 3 ? bt[c] : bs[c - 3];
       if (c < 3)
         dt[b * 3 + c] = s;
       else
