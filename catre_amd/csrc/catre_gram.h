@@ -145,9 +145,16 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
   for (int cl = 0; cl < 2; ++cl) {  // S = G' - s1 s1^T / n while loading
     const f32x4* src = reinterpret_cast<const f32x4*>(Gc + (cl ? (size_t)B + obj : (size_t)obj) * PF_NG * 4096);
     const float inv_n = 1.0f / (float)(cl ? M : N);
-    for (int e4 = tid; e4 < 1024; e4 += 256) {
-      const int r = e4 >> 4, c0 = (e4 & 15) * 4;
-      f32x4 g = (src[e4] + src[1024 + e4]) + (src[2048 + e4] + src[3072 + e4]);
+    f32x4 gp[4][PF_NG];  // all 16 loads of this thread in flight before the first use
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int p = 0; p < PF_NG; ++p) gp[u][p] = src[p * 1024 + tid + 256 * u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = tid + 256 * u, r = e4 >> 4, c0 = (e4 & 15) * 4;
+      f32x4 g = (gp[u][0] + gp[u][1]) + (gp[u][2] + gp[u][3]);
       const float sr = s1[cl][r] * inv_n;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = fmaf(-sr, s1[cl][c0 + q], g[q]);
