@@ -1,6 +1,8 @@
 // catre_kernels.hip - hand-written gfx950 kernels for CATRE's pose-refine hot path + their C ABI.
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see Makefile).
 // Reference citations (file:line) are relative to the CATRE tree; see include/catre_hip.h.
+#include <mutex>
+
 #include "catre_device.h"
 
 #include "../../include/catre_hip.h"
@@ -1083,19 +1085,33 @@ struct ProfState {
 ProfState g_prof;
 unsigned long long* g_trunk_trace = nullptr;  // catre_debug_trunk_trace
 
+// The measurement hooks are the library's only process-global mutable state.  They are fenced: compiled out entirely
+// with -DCATRE_NO_PROFILING (catre_profile_* then return CATRE_ERR_UNSUPPORTED), off unless catre_profile_enable was
+// called, and the record table is guarded by a mutex so that concurrent callers of the data path cannot corrupt it.
+#ifndef CATRE_NO_PROFILING
+std::mutex g_prof_mu;
 struct ProfScope {
   hipStream_t st;
   int slot = -1;
   ProfScope(int kernel_id, hipStream_t s) : st(s) {
+    if (g_prof.kernel != kernel_id) return;  // the common case: one relaxed read, no lock
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.kernel == kernel_id && g_prof.n < g_prof.cap) {
       slot = g_prof.n++;
       (void)hipEventRecord(g_prof.ev[2 * slot], st);
     }
   }
   ~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < g_prof.cap) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
   }
 };
+#else
+struct ProfScope {
+  ProfScope(int, hipStream_t) {}
+};
+#endif
 
 }  // namespace
 
@@ -1618,7 +1634,12 @@ int catre_debug_trunk_trace(void* device_buffer) {
 #endif
 }
 
+#ifdef CATRE_NO_PROFILING
+int catre_profile_enable(int, int) { return CATRE_ERR_UNSUPPORTED; }
+int catre_profile_collect(float*, int, int*) { return CATRE_ERR_UNSUPPORTED; }
+#else
 int catre_profile_enable(int kernel_id, int max_records) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
   delete[] g_prof.ev;
   g_prof = ProfState();
@@ -1634,6 +1655,7 @@ int catre_profile_enable(int kernel_id, int max_records) {
 
 int catre_profile_collect(float* ms_out, int max_out, int* n_out) {
   REQUIRE(n_out && (ms_out || max_out == 0));
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   int n = g_prof.n < max_out ? g_prof.n : max_out;
   for (int i = 0; i < n; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return CATRE_ERR_LAUNCH;
@@ -1643,6 +1665,7 @@ int catre_profile_collect(float* ms_out, int max_out, int* n_out) {
   g_prof.n = 0;
   return CATRE_OK;
 }
+#endif
 
 int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream) {
   REQUIRE(x && out && B > 0 && C > 0 && N > 0);

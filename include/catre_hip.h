@@ -226,7 +226,13 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
 /* torch.max(x, 2)[0] for x [B,C,N] contiguous -> out [B,C]  (pointnet.py:28,61,115). */
 int catre_colmax(const float* x, float* out, int B, int C, int N, void* stream);
 
-/* ---- opt-in kernel timing (measurement aid for bench.py; process-global, not re-entrant) -------- */
+/* ---- opt-in kernel timing: a MEASUREMENT AID for bench.py, fenced off from the data path's contract ---------------
+ * Everything above keeps no state between calls and is re-entrant.  The two functions below are the exception and are
+ * kept apart for that reason: they hold one process-global record table (mutex-guarded), do nothing unless
+ * catre_profile_enable was called, and a product build may drop them altogether (-DCATRE_NO_PROFILING: both return
+ * CATRE_ERR_UNSUPPORTED and the launch hooks compile to nothing).  catre_debug_trunk_trace (per-phase cycle stamps) only
+ * works in the instrumented library (`make TRACE=1` -> libcatre_hip_trace.so); the product library returns
+ * CATRE_ERR_UNSUPPORTED and its kernels carry no stamp code. */
 typedef enum catre_kernel_id {
   CATRE_K_STN3D = 0, CATRE_K_STNKD, CATRE_K_TRUNK, CATRE_K_TS_HEAD, CATRE_K_ROT_L0_STATS, CATRE_K_ROT_L1,
   CATRE_K_ROT_OUT, CATRE_K_COLMAX, CATRE_K_COUNT
