@@ -169,6 +169,31 @@ __global__ void k_pose_apply(const float* __restrict__ pcl, const float* __restr
   o[2] = z;
 }
 
+// Experiment knob of the instrumented build (make TRACE=1; catre_debug_knob): the co-resident workgroups of the first
+// dispatch round can be started `g_dephase_cycles` apart, to test whether pairs that begin in lock step keep stalling
+// in their load / thin-layer prologues at the same time.  Product build: no code.
+#ifdef CATRE_DEBUG_TRACE
+__device__ int g_dephase_cycles = 0;
+__device__ __forceinline__ void debug_dephase(int first_round_blocks) {
+  const int cyc = g_dephase_cycles;
+  if (cyc <= 0 || (int)blockIdx.x >= first_round_blocks) return;
+  __shared__ int odd_slot;
+  if (threadIdx.x == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    odd_slot = hw & 1;  // wave slot on the SIMD: the two co-resident workgroups' first waves sit in different slots
+  }
+  __syncthreads();
+  if (odd_slot) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while ((long long)(__builtin_readcyclecounter() - t0) < cyc) __builtin_amdgcn_s_sleep(32);
+  }
+  __syncthreads();
+}
+#else
+__device__ __forceinline__ void debug_dephase(int) {}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // a2: STN3d conv stack 3->64->128->1024 (+ReLU) and per-tile max  (pointnet.py:24-28)
 // 256 threads = 4 waves, 2 workgroups per CU.
@@ -190,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
   const TileInfo ti = tile_info(tile, B, N, M);
+  debug_dephase(512);
 
   // weights / biases of the first MFMA layer are requested before anything else
   GemmPipe<1, 2, false, false, 8, 3> g2;
@@ -255,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
   const TileInfo ti = tile_info(tile, B, N, M);
+  debug_dephase(512);
 
   const int mblk1 = wave >> 1, nb1 = wave & 1;
   GemmPipe<1, 1, false, false, 8, 4> g1;
@@ -1623,6 +1650,17 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   return CATRE_OK;
 }
 
+
+int catre_debug_knob(int id, int value) {
+#ifdef CATRE_DEBUG_TRACE
+  if (id == 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_dephase_cycles), &value, sizeof(int)) == hipSuccess ? CATRE_OK : CATRE_ERR_LAUNCH;
+  return CATRE_ERR_BAD_ARG;
+#else
+  (void)id;
+  (void)value;
+  return CATRE_ERR_UNSUPPORTED;
+#endif
+}
 
 int catre_debug_trunk_trace(void* device_buffer) {
 #ifdef CATRE_DEBUG_TRACE

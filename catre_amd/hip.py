@@ -159,6 +159,7 @@ _SIGS = {
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),
+    "catre_debug_knob": (_I, [_I, _I]),
     "catre_status_string": (ctypes.c_char_p, [_I]),
     "catre_version": (ctypes.c_char_p, []),
 }

@@ -241,6 +241,9 @@ typedef enum catre_kernel_id {
 /* Record a HIP event pair around every launch of `kernel_id` on its launch stream (up to max_records).
  * kernel_id < 0 or max_records <= 0 disables and frees the events. */
 int catre_profile_enable(int kernel_id, int max_records);
+/* Experiment knobs of the instrumented library (id 0: start offset in cycles between the co-resident workgroups of the
+ * STN kernels' first dispatch round); CATRE_ERR_UNSUPPORTED in the product library. */
+int catre_debug_knob(int id, int value);
 /* Wait for the recorded events, write per-launch durations (ms) and reset the record counter. */
 int catre_profile_collect(float* ms_out, int max_out, int* n_out);
 
