@@ -413,11 +413,17 @@ def main():
         trunk_avg_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
         trunk_flops = B_PER_GPU * (N_PTS + M_PTS) * TRUNK_FLOPS_PER_POINT  # all points of both clouds per launch
         achieved = trunk_flops / (trunk_avg_ms * 1e-3) / 1e12 if trunk_ms else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_trunk_hbm_bytes.json")
+        # HBM bytes of the dominant kernel cannot be counted inside this run (PMC passes serialise the kernels and need
+        # rocprofv3): the figure is the one collected from this build by profiles/pmc.sh (separate --pmc passes, gfx950
+        # FETCH_SIZE x2 correction) and committed next to its summary; `traffic_source` says so in the line itself
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_trunk_hbm_bytes.json")
         if os.path.exists(pmc) and args.dtype == "fp32" and args.shape == "headline":
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/r02_trunk_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "build (profiles/pmc.sh, profiles/r02_pmc_summary.csv), not measured in this run; algorithmic "
+                              f"bytes per launch = {B_PER_GPU * (N_PTS + M_PTS) * 12}")
         path_flops = flops_per_object_iteration(N_PTS, M_PTS)
         line = {
             "metric": f"pose-refine iters/sec (B=256, N={N_PTS}, K={K_ITER})"
@@ -454,6 +460,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / mfma_peak, 4) if achieved else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": round(trunk_avg_ms, 4),
                 "launches_timed": len(trunk_ms),
                 "flops_per_launch": trunk_flops,
