@@ -130,7 +130,7 @@ class CATRE_disR_shared(nn.Module):
         # cfg.MODEL.CATRE.COMPUTE_DTYPE forces either precision
         with amp_mode(self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)):
             pose, scale, aux = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
-                                             K_zoom, mean_scales)
+                                             K_zoom, mean_scales, rt=self._runtime())
         out_dict = {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}
         if not do_loss:
             return out_dict

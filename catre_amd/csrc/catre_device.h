@@ -340,3 +340,51 @@ __device__ __forceinline__ void max_tile_store_pre(const f32x16 (&acc)[MB][NB], 
   }
 }
 
+
+// ---- training forward of the fused encoder kernels (SAVE variants): what the layer-wise backward needs ----------------
+// LDS activation image [TP][ld] (point-major) -> global rows dst[TP][C], coalesced float4 stores by all NT threads
+template <int C, int NT, bool SWZ>
+__device__ __forceinline__ void save_tile_rows(const float* __restrict__ img, int ld, float* __restrict__ dst, int tid) {
+  constexpr int F4 = C / 4;
+#pragma unroll
+  for (int u = 0; u < TP * F4 / NT; ++u) {
+    const int i = tid + NT * u, row = i / F4, c4 = i % F4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(img + (SWZ ? swz_off(row, c4, ld) : row * ld + c4 * 4));
+    *reinterpret_cast<f32x4*>(dst + (size_t)row * C + c4 * 4) = v;
+  }
+}
+
+// "swapped"-orientation epilogue with the arg-max: per channel the maximum of (acc + bias) over the tile's 64 points
+// and the ROW it came from (row0 + point; the first maximum wins, like torch.max) - the forward of linear + max-pool
+// for training, where the backward gathers / scatters at exactly these rows.
+template <int MB, int NB>
+__device__ __forceinline__ void argmax_tile_store(const f32x16 (&acc)[MB][NB], float* __restrict__ pmax,
+                                                  int* __restrict__ pidx, int ch0, const float (&bl)[MB], int row0,
+                                                  int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // increasing point order inside a half-wave: strict > keeps the first
+        const float v = acc[mb][nb][r] + bl[mb];
+        if (v > m) {
+          m = v;
+          am = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        }
+      }
+    const float mo = __shfl_xor(m, 32);
+    const int ao = __shfl_xor(am, 32);
+    if (mo > m || (mo == m && ao < am)) {
+      m = mo;
+      am = ao;
+    }
+    if (h == 0) {
+      pmax[ch0 + mb * 32 + n] = m;
+      pidx[ch0 + mb * 32 + n] = row0 + am;
+    }
+  }
+}

@@ -202,12 +202,21 @@ __device__ __forceinline__ void debug_dephase(int) {}
 #define LD128 132
 #define LD256 260
 
-template <int RS>
+// SAVE (training forward, RS == 1, N and M multiples of 64): additionally writes what the layer-wise backward reads -
+// the activation images as point rows (cloud-major: B*N observed rows, then B*M prior rows) and, instead of the tile
+// maxima alone, the per-tile (max, arg-max row) pairs of the pooled layer (pitch 1024, merged by k_maxpool_tiles).
+struct TrainSave {
+  float *s1, *s2, *s3, *s4, *s5;  // kernel-specific activation rows (see the launchers)
+  float* pmax;                    // [tiles][1024]
+  int* pidx;                      // [tiles][1024]
+};
+
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* __restrict__ W1,
                                                const float* __restrict__ b1, const f32x4* __restrict__ wp2,
                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
                                                const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
-                                               int M) {
+                                               int M, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * LD128];
   float* a1 = smem;
   float* a2 = smem + TP * LD64;
@@ -228,6 +237,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     conv3_relu_row<16>(x, y, z, W1, b1, wave * 16, a1 + lane * LD64);
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows<64, 256, false>(a1, LD64, sv.s1 + row0 * 64, tid);
   // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks (RS = 1); RS workgroups
   // per tile: 8/RS m-blocks per wave from mb0 in one pass (see k_trunk)
   constexpr int MB3 = RS == 4 ? 2 : 4;
@@ -244,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     store_tile_lds_pre<1, 2, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows<128, 256, false>(a2, LD128, sv.s2 + row0 * 128, tid);
   float* out = pm + (size_t)tile * PMW;
   {
     f32x16 acc[MB3][2];
@@ -251,14 +263,22 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, a2, LD128, lane);
     if (RS == 1) g3b.prefetch(wp3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
-    max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
+    if (SAVE)
+      argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl[0],
+                                (int)row0, lane);
+    else
+      max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
   if (RS == 1) {
     f32x16 acc[MB3][2];
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, a2, LD128, lane);
-    max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
+    if (SAVE)
+      argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, (mb0 + 4) * 32, bl[1],
+                                (int)row0, lane);
+    else
+      max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -266,13 +286,14 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
 // a3+a4: x' = x T3, relu(conv1), STNkd conv stack 64->64->128->1024 (+ReLU), per-tile max
 // (pointnet.py:98-103, 57-61).  256 threads, 2 workgroups per CU.
 // ------------------------------------------------------------------------------------------
-template <int RS>
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                const f32x4* __restrict__ wpf3, const float* __restrict__ bf3,
-                                               float* __restrict__ pm, int B, int N, int M) {
+                                               float* __restrict__ pm, int B, int N, int M,
+                                               TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + TP * LD128];
   float* h1 = smem;
   float* f1 = smem + TP * LD64;
@@ -306,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     store_tile_lds_pre<1, 1, true, false>(acc, f1 + nb1 * 32 * LD64, LD64, mblk1 * 32, bv1, lane);
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows<64, 256, false>(f1, LD64, sv.s1 + row0 * 64, tid);
   constexpr int MB3 = RS == 4 ? 2 : 4;
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
   GemmPipe<MB3, 2, true, false, 16, 2, 1> g3a, g3b;
@@ -320,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     store_tile_lds_pre<1, 2, true, false>(acc, f2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows<128, 256, false>(f2, LD128, sv.s2 + row0 * 128, tid);
   float* out = pm + (size_t)tile * PMW;
   {  // fstn.conv3 128->1024 + max, two passes of 4 m-blocks (RS = 1) or one pass of 8/RS
     f32x16 acc[MB3][2];
@@ -327,14 +351,22 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, f2, LD128, lane);
     if (RS == 1) g3b.prefetch(wpf3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
-    max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
+    if (SAVE)
+      argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl[0],
+                                (int)row0, lane);
+    else
+      max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
   if (RS == 1) {
     f32x16 acc[MB3][2];
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, f2, LD128, lane);
-    max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
+    if (SAVE)
+      argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, (mb0 + 4) * 32, bl[1],
+                                (int)row0, lane);
+    else
+      max_tile_store_pre<MB3, 2>(acc, out, (mb0 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -351,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
 // ------------------------------------------------------------------------------------------
 #define TRUNK_SMEM (TP * 512 + TP * 128)
 
-template <int RS>
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
                                                const float* __restrict__ b3, const f32x4* __restrict__ wp4,
                                                const float* __restrict__ b4, float* __restrict__ pm,
                                                float* __restrict__ pointfeat, int B, int N, int M,
-                                               unsigned long long* __restrict__ trace) {
+                                               unsigned long long* __restrict__ trace, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
 #define TRUNK_STAMP(i)                                                                     \
   do {                                                                                     \
@@ -389,6 +421,11 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
     apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    if (SAVE && wave == 0) {  // x' = x T3 as a zero-padded 8-wide row: the input of the conv1 row GEMM in the backward
+      float* xr = sv.s1 + ((ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0 + lane) * 8;
+      *reinterpret_cast<f32x4*>(xr) = f32x4{x, y, z, 0.f};
+      *reinterpret_cast<f32x4*>(xr + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     conv3_relu_row<8>(x, y, z, Wc1, bc1, wave * 8, h1 + lane * LD64);
     if (ft) {
       const f32x4* src = reinterpret_cast<const f32x4*>(trans64 + (size_t)ti.cloud * 4096);
@@ -399,6 +436,8 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   }
   __syncthreads();
   TRUNK_STAMP(1);
+  const size_t trow0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows<64, 512, false>(h1, LD64, sv.s2 + trow0 * 64, tid);
   if (ft) {
     if (wave < 4) {  // pointfeat[j][n] = sum_i T64[i][j] h1[i][n]  (pointnet.py:107-109); A operand from LDS
       const int mblk = wave >> 1, nb = wave & 1;
@@ -462,6 +501,7 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   }
   __syncthreads();
   TRUNK_STAMP(3);
+  if (SAVE) save_tile_rows<128, 512, true>(a2, 128, sv.s3 + trow0 * 128, tid);
   // conv4 512->1024: wave owns MB4 m-blocks from mb0 (RS = 1: out channels [wave*128, +128)); first weight chunks +
   // bias requested now
   constexpr int MB4 = 4 / RS;
@@ -491,12 +531,17 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     }
     if (part == 0 && tid < 64) pm[(size_t)tile * PMW + 1024 + tid] = pf_max;
   }
+  if (SAVE) save_tile_rows<512, 512, true>(a3, 512, sv.s4 + trow0 * 512, tid);
   f32x16 acc4[MB4][2];
 #pragma unroll
   for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
   g4.run(acc4, a3, 512, lane);
   TRUNK_STAMP(6);
-  max_tile_store_pre<MB4, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
+  if (SAVE)
+    argmax_tile_store<MB4, 2>(acc4, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl4,
+                              (int)trow0, lane);
+  else
+    max_tile_store_pre<MB4, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
   TRUNK_STAMP(7);
 #undef TRUNK_STAMP
 }
@@ -1169,11 +1214,18 @@ size_t catre_packed_floats(int N, int M, int ts_in_dim) {
 
 int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* packed, size_t packed_floats,
                        void* stream) {
+  return catre_pack_weights_sel(prm, N, M, ts_in, packed, packed_floats, CATRE_PACK_ALL, stream);
+}
+
+int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, float* packed, size_t packed_floats, int sel,
+                           void* stream) {
   REQUIRE(prm && packed && N > 0 && M > 0 && ts_in > 0);
   const PackLayout L = pack_layout(ts_in);
   if (packed_floats < L.total) return CATRE_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   // a NULL source is skipped, so a sub-module (e.g. PointNetfeat alone) can pack just its own layers
+  const bool enc32 = sel & CATRE_PACK_F32_ENCODER, head32 = sel & CATRE_PACK_F32_HEADS, bf = sel & CATRE_PACK_BF16,
+             sp = sel & CATRE_PACK_SPLIT;
   auto frag = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
     if (!src) return;
     const int n = rows * K;
@@ -1185,6 +1237,7 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     hipLaunchKernelGGL(k_pack_frag_bf, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
                        reinterpret_cast<unsigned short*>(packed + off));
   };
+  if (bf) {
   frag_bf(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.bf_stn_c2);
   frag_bf(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.bf_stn_c3);
   frag_bf(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.bf_fstn_c1);
@@ -1198,12 +1251,14 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
     frag_bf(prm[base], PMW, 1024, 256, 64, L.bf_rot_l0[h]);
     frag_bf(prm[base + 4], 256, 0, 256, 256, L.bf_rot_l1[h]);
   }
+  }
   auto frag_sp = [&](const float* src, int ld, int rows, int K, size_t off, int coloff = 0) {
     if (!src) return;
     const int n = rows * K;
     hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
                        reinterpret_cast<unsigned short*>(packed + off));
   };
+  if (sp) {
   frag_sp(prm[CATRE_P_STN_CONV2_W], 64, 128, 64, L.sp_stn_c2);
   frag_sp(prm[CATRE_P_STN_CONV3_W], 128, 1024, 128, L.sp_stn_c3);
   frag_sp(prm[CATRE_P_FSTN_CONV1_W], 64, 64, 64, L.sp_fstn_c1);
@@ -1215,6 +1270,8 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
   frag_sp(prm[CATRE_P_ROTY_L0_W], PMW, 256, 64, L.sp_rot_l0[1], 1024);
   frag_sp(prm[CATRE_P_ROTX_L0_W + 4], 256, 256, 256, L.sp_rot_l1[0]);
   frag_sp(prm[CATRE_P_ROTY_L0_W + 4], 256, 256, 256, L.sp_rot_l1[1]);
+  }
+  if (enc32) {
   frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);
   frag(prm[CATRE_P_STN_CONV3_W], 128, 0, 1024, 128, L.stn_c3);
   frag(prm[CATRE_P_FSTN_CONV1_W], 64, 0, 64, 64, L.fstn_c1);
@@ -1223,14 +1280,15 @@ int catre_pack_weights(const float* const* prm, int N, int M, int ts_in, float* 
   frag(prm[CATRE_P_CONV2_W], 64, 0, 128, 64, L.c2);
   frag(prm[CATRE_P_CONV3_W], 128, 0, 512, 128, L.c3);
   frag(prm[CATRE_P_CONV4_W], 512, 0, 1024, 512, L.c4);
-  for (int h = 0; h < 2; ++h) {
+  }
+  for (int h = 0; h < 2 && head32; ++h) {
     const int base = h ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
     frag(prm[base], PMW, 1024, 256, 64, L.rot_l0[h]);  // W0[:, 1024:1088]
     frag(prm[base + 4], 256, 0, 256, 256, L.rot_l1[h]);
     if (prm[base + 10])
       hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, prm[base + 10], N + M, packed + L.sumwp + h);
   }
-  if (prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
+  if (head32 && prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
     int n = ts_in * 256;
     hipLaunchKernelGGL(k_pack_transpose, dim3((n + 255) / 256), dim3(256), 0, st, prm[CATRE_P_TS_L0_W], 256, ts_in,
                        packed + L.ts_w0t);

@@ -58,6 +58,7 @@ class CatreOpts(ctypes.Structure):
 
 
 DTYPE_F32, DTYPE_BF16, DTYPE_SPLIT = 0, 1, 2
+PACK_F32_ENCODER, PACK_F32_HEADS, PACK_BF16, PACK_SPLIT, PACK_ALL = 1, 2, 4, 8, 15
 ROT_6D, ROT_QUAT, ROT_LOG_QUAT, ROT_LIE_VEC = 0, 1, 2, 3
 ROT_DIMS = {ROT_6D: 6, ROT_QUAT: 4, ROT_LOG_QUAT: 3, ROT_LIE_VEC: 3}
 
@@ -91,6 +92,10 @@ _SIGS = {
     "catre_workspace_bytes": (_SZ, [_I, _I, _I]),
     "catre_packed_floats": (_SZ, [_I, _I, _I]),
     "catre_pack_weights": (_I, [_P, _I, _I, _I, _P, _SZ, _P]),
+    "catre_pack_weights_sel": (_I, [_P, _I, _I, _I, _P, _SZ, _I, _P]),
+    "catre_train_stn3d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_train_stnkd_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "catre_train_trunk_fwd": (_I, [_P] * 12 + [_P, _SZ, _I, _I, _I, _P]),
     "catre_pose_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "catre_stn3d_pool": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_linear": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

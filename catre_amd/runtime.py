@@ -58,6 +58,7 @@ class HipRuntime:
         self._param_arr = None
         self._param_keep = None
         self._packed = None
+        self._packed_sel = 0
         self._ws = None
 
     # ------------------------------------------------------------------ weights
@@ -65,11 +66,17 @@ class HipRuntime:
         named = self._named_params()
         return [named.get(k) for k in hip.PARAM_KEYS]
 
-    def params(self, device):
-        """(param pointer array, packed weights) - re-packed on the current stream if stale."""
+    def params(self, device, sel=hip.PACK_ALL):
+        """(param pointer array, packed weights) - re-packed on the current stream if stale.  ``sel``: the packs the
+        caller needs (``hip.PACK_*``); a training step, which re-packs after every optimizer step, asks for the fp32
+        encoder image only."""
         lib = hip.load()
         tensors = self._live_params()
         fp = (hip.param_epoch(),) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        if fp == self._fingerprint and self._packed is not None and self._packed.device == device \
+                and (sel & ~self._packed_sel):
+            sel |= self._packed_sel  # same weights, more packs wanted: redo with the union
+            self._fingerprint = None
         if fp != self._fingerprint or self._packed is None or self._packed.device != device:
             for k, t in zip(hip.PARAM_KEYS, tensors):
                 if t is not None and t.device != device:
@@ -81,11 +88,12 @@ class HipRuntime:
             if self._packed is None or self._packed.numel() < n or self._packed.device != device:
                 self._packed = torch.empty(n, dtype=torch.float32, device=device)
             hip.check(
-                lib.catre_pack_weights(self._param_arr, self.N, self.M, self.ts_in_dim, hip.ptr(self._packed),
-                                       self._packed.numel(), hip.stream_ptr(device)),
-                "catre_pack_weights",
+                lib.catre_pack_weights_sel(self._param_arr, self.N, self.M, self.ts_in_dim, hip.ptr(self._packed),
+                                           self._packed.numel(), int(sel), hip.stream_ptr(device)),
+                "catre_pack_weights_sel",
             )
             self._fingerprint = fp
+            self._packed_sel = int(sel)
         return self._param_arr, self._packed
 
     # ------------------------------------------------------------------ workspace
@@ -162,6 +170,40 @@ class HipRuntime:
             raise ValueError(
                 f"got N+M={N + M} points but the rotation head was built for num_points={self.N + self.M}"
             )
+
+    # ------------------------------------------------------------------ training forward on the fused encoder kernels
+    def train_encoder_buffers(self, B, N, M, device):
+        R, C = B * (N + M), 2 * B
+        e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=device)
+        return dict(
+            a1=e(R, 64), a2=e(R, 128), g_stn=e(C, 1024), i_stn=e(C, 1024, dt=torch.int32),
+            f1=e(R, 64), f2=e(R, 128), g_fstn=e(C, 1024), i_fstn=e(C, 1024, dt=torch.int32),
+            x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128), c3=e(R, 512), g=e(C, 1024), i=e(C, 1024, dt=torch.int32))
+
+    def train_stn3d(self, pts, buf, B, N, M, device):
+        lib = hip.load()
+        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        ws = self.workspace(B, N, M, device)
+        hip.check(lib.catre_train_stn3d_fwd(ctypes.byref(pts), prm, hip.ptr(packed), hip.ptr(buf["a1"]), hip.ptr(buf["a2"]),
+                                            hip.ptr(buf["g_stn"]), hip.ptr(buf["i_stn"]), hip.ptr(ws), ws.numel(), B, N, M,
+                                            hip.stream_ptr(device)), "catre_train_stn3d_fwd")
+
+    def train_stnkd(self, pts, trans3, buf, B, N, M, device):
+        lib = hip.load()
+        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        ws = self.workspace(B, N, M, device)
+        hip.check(lib.catre_train_stnkd_fwd(ctypes.byref(pts), hip.ptr(trans3), prm, hip.ptr(packed), hip.ptr(buf["f1"]),
+                                            hip.ptr(buf["f2"]), hip.ptr(buf["g_fstn"]), hip.ptr(buf["i_fstn"]), hip.ptr(ws),
+                                            ws.numel(), B, N, M, hip.stream_ptr(device)), "catre_train_stnkd_fwd")
+
+    def train_trunk(self, pts, trans3, trans64, buf, B, N, M, device):
+        lib = hip.load()
+        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        ws = self.workspace(B, N, M, device)
+        hip.check(lib.catre_train_trunk_fwd(ctypes.byref(pts), hip.ptr(trans3), hip.ptr(trans64), prm, hip.ptr(packed),
+                                            hip.ptr(buf["x1"]), hip.ptr(buf["h1"]), hip.ptr(buf["pf"]), hip.ptr(buf["c2"]),
+                                            hip.ptr(buf["c3"]), hip.ptr(buf["g"]), hip.ptr(buf["i"]), hip.ptr(ws),
+                                            ws.numel(), B, N, M, hip.stream_ptr(device)), "catre_train_trunk_fwd")
 
     # ------------------------------------------------------------------ single stages (tests, sub-modules)
     def stage_linear(self, x, W, bias, relu=False, add_identity_k=0):

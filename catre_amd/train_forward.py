@@ -18,16 +18,43 @@ def _points_rows(x):
     return x.permute(0, 2, 1).reshape(-1, 3).contiguous()
 
 
-def _stn(rows, p, prefix, k, B, N, M):
-    """STN3d / STNkd on cloud-major rows [R, k] -> [C, k, k]  (pointnet.py:24-41 / 57-78)."""
+def _stn(rows, p, prefix, k, B, N, M, pre=None):
+    """STN3d / STNkd on cloud-major rows [R, k] -> [C, k, k]  (pointnet.py:24-41 / 57-78).  ``pre``: (conv1 out, conv2
+    out, pooled maxima, arg-max rows) already computed by the fused forward kernel - the nodes then only build the graph."""
     w = lambda n: p[f"{prefix}.{n}"]
-    h = T.linear(rows, w("conv1.weight"), w("conv1.bias"), relu=True)
-    h = T.linear(h, w("conv2.weight"), w("conv2.bias"), relu=True)
-    g = T.linear_maxpool(h, w("conv3.weight"), w("conv3.bias"), True, B, N, M)  # relu(conv3) then max
+    p1, p2, pg = (pre[0], pre[1], (pre[2], pre[3])) if pre is not None else (None, None, None)
+    h = T.linear(rows, w("conv1.weight"), w("conv1.bias"), relu=True, pre=p1)
+    h = T.linear(h, w("conv2.weight"), w("conv2.bias"), relu=True, pre=p2)
+    g = T.linear_maxpool(h, w("conv3.weight"), w("conv3.bias"), True, B, N, M, pre=pg)  # relu(conv3) then max
     h = T.linear(g, w("fc1.weight"), w("fc1.bias"), relu=True)
     h = T.linear(h, w("fc2.weight"), w("fc2.bias"), relu=True)
     t = T.linear(h, w("fc3.weight"), w("fc3.bias"), identity_k=k)
     return t.view(-1, k, k)
+
+
+def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net"):
+    """The same graph as :func:`pointnet_rows` (feature_transform=True), but the three conv stacks run as the FUSED encoder
+    kernels with extra stores (``catre_train_{stn3d,stnkd,trunk}_fwd``): one launch per block instead of a row GEMM per
+    layer.  Every layer op becomes a graph node around an output that exists already (``pre=``); the backward is the
+    layer-wise one, unchanged.  fp32 only; N, M multiples of 64."""
+    w = lambda n: p[f"{prefix}.{n}"]
+    dev = pts.device
+    buf = rt.train_encoder_buffers(B, N, M, dev)
+    rt.train_stn3d(desc, buf, B, N, M, dev)
+    trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M, pre=(buf["a1"], buf["a2"], buf["g_stn"], buf["i_stn"]))
+    trans3 = trans.detach().reshape(-1, 9).contiguous()
+    # x1 / h1 are written by the trunk kernel further down (same stream, before anything reads them)
+    x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8, pre=buf["x1"])
+    h1 = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True, pre=buf["h1"])
+    rt.train_stnkd(desc, trans3, buf, B, N, M, dev)
+    trans_feat = _stn(h1, p, f"{prefix}.fstn", 64, B, N, M, pre=(buf["f1"], buf["f2"], buf["g_fstn"], buf["i_fstn"]))
+    trans64 = trans_feat.detach().reshape(-1, 4096).contiguous()
+    rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev)
+    pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
+    h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
+    h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
+    g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
+    return g, pf
 
 
 def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
@@ -65,13 +92,18 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
 
 
-def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None):
-    """p: {state_dict key: live parameter}.  Returns (pose [B,3,4], scale [B,3], aux dict) - autograd-connected."""
+def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None, rt=None):
+    """p: {state_dict key: live parameter}.  Returns (pose [B,3,4], scale [B,3], aux dict) - autograd-connected.
+    ``rt``: the model's :class:`~catre_amd.runtime.HipRuntime`; with it the fp32 encoder forward takes the fused kernels."""
     B, N, M = x.shape[0], x.shape[2], tfd_kps.shape[2]
     hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
     hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)
     pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
-    g, pf = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform))
+    if rt is not None and T._amp() == 0 and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
+            and N + M == rt.N + rt.M:
+        g, pf = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M)
+    else:
+        g, pf = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform))
     pfmax = T.maxpool_points(pf, B, N, M)                                     # max_n pointfeat (flat_pcl_feat tail)
 
     feats = [g[:B], pfmax[:B]]

@@ -162,12 +162,17 @@ class _Linear(torch.autograd.Function):
     """y = act(x W^T + b); W may be a Conv1d weight [J,K,1].  identity_k adds vec(I_k) (STN tails)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, identity_k):
+    def forward(ctx, x, w, b, relu, identity_k, pre):
         w2 = w.reshape(w.shape[0], -1)
         K = w2.shape[1]
-        xk, wk = _c(_pad_cols(x, 8)), _c(_pad_cols(w2, 8))
         amp = _amp()
-        y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k, amp=amp)
+        if pre is not None:
+            # the output already exists (or is about to be written on this stream by a fused forward kernel,
+            # catre_train_*_fwd): this node only ties it into the graph; the backward below is the layer's own
+            y = pre
+        else:
+            xk, wk = _c(_pad_cols(x, 8)), _c(_pad_cols(w2, 8))
+            y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k, amp=amp)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.K, ctx.has_b, ctx.amp = relu, K, b is not None, amp
         return y
@@ -218,11 +223,11 @@ class _Linear(torch.autograd.Function):
             if ymask is not None:
                 dy = dy * (ymask > 0)
             db = _colsum(dy)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, relu=False, identity_k=0):
-    return _Linear.apply(x, w, b, relu, identity_k)
+def linear(x, w, b=None, relu=False, identity_k=0, pre=None):
+    return _Linear.apply(x, w, b, relu, identity_k, pre)
 
 
 # ------------------------------------------------------------------------------------------------- linear + max-pool
@@ -231,18 +236,23 @@ class _LinearMaxPool(torch.autograd.Function):
     pre-pool activation only lives inside forward; backward is sparse (gather / scatter at the argmax rows)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, B, N, M):
+    def forward(ctx, x, w, b, relu, B, N, M, pre):
         lib = hip.load()
         w2 = _c(w.reshape(w.shape[0], -1))
         J, K = w2.shape
         C = 2 * B if M > 0 else B
-        g = torch.empty(C, J, dtype=torch.float32, device=x.device)
-        idx = torch.empty(C, J, dtype=torch.int32, device=x.device)
+        if pre is not None:  # (pooled maxima with the bias added, arg-max rows) from a fused forward kernel
+            g, idx = pre
+        else:
+            g = torch.empty(C, J, dtype=torch.float32, device=x.device)
+            idx = torch.empty(C, J, dtype=torch.int32, device=x.device)
         xc = _c(x)
         fused = (N % 64 == 0 and M % 64 == 0 and J % 32 == 0 and (J <= 256 or J in (512, 1024))
                  and (K in (64, 128) or K % 256 == 0))
         amp = _amp()
-        if fused and amp in (1, 2) and K in (64, 128, 256, 512):
+        if pre is not None:
+            pass
+        elif fused and amp in (1, 2) and K in (64, 128, 256, 512):
             wp = (_pack_bf16 if amp == 1 else _pack_split)(w2, J, K, x.device)
             need = lib.catre_op_linear_maxpool_ws_bytes(xc.shape[0], J)
             ws = _ws(need, x.device)
@@ -295,7 +305,7 @@ class _LinearMaxPool(torch.autograd.Function):
                 dx = torch.zeros_like(xc)
                 hip.check(lib.catre_op_maxlin_bwd_x(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx), dx.stride(0), C,
                                                     J, K, _st(x)), "catre_op_maxlin_bwd_x")
-        return dx, dw.reshape(w.shape), db, None, None, None, None
+        return dx, dw.reshape(w.shape), db, None, None, None, None, None
 
 
 class _Relu:
@@ -308,8 +318,8 @@ class _Relu:
         return out
 
 
-def linear_maxpool(x, w, b, relu, B, N, M):
-    return _LinearMaxPool.apply(x, w, b, relu, B, N, M)
+def linear_maxpool(x, w, b, relu, B, N, M, pre=None):
+    return _LinearMaxPool.apply(x, w, b, relu, B, N, M, pre)
 
 
 class _MaxPool(torch.autograd.Function):
@@ -348,15 +358,18 @@ class _CloudMatmul(torch.autograd.Function):
     """y[r,:] = x[r,:kd] T[cloud(r)]; output has `out_cols` columns (zero beyond kd) so it can feed the MFMA GEMM."""
 
     @staticmethod
-    def forward(ctx, x, T, B, N, M, out_cols):
+    def forward(ctx, x, T, B, N, M, out_cols, pre):
         lib = hip.load()
         kd = T.shape[-1]
         x, T = _c(x), _c(T)
         R = x.shape[0]
-        y = torch.zeros(R, out_cols, dtype=torch.float32, device=x.device) if out_cols != kd else \
-            torch.empty(R, kd, dtype=torch.float32, device=x.device)
-        hip.check(lib.catre_op_cloud_matmul(hip.ptr(x), x.stride(0), hip.ptr(T), hip.ptr(y), out_cols, kd, B, N, M, 0,
-                                            _st(x)), "catre_op_cloud_matmul")
+        if pre is not None:
+            y = pre
+        else:
+            y = torch.zeros(R, out_cols, dtype=torch.float32, device=x.device) if out_cols != kd else \
+                torch.empty(R, kd, dtype=torch.float32, device=x.device)
+            hip.check(lib.catre_op_cloud_matmul(hip.ptr(x), x.stride(0), hip.ptr(T), hip.ptr(y), out_cols, kd, B, N, M, 0,
+                                                _st(x)), "catre_op_cloud_matmul")
         ctx.save_for_backward(x, T)
         ctx.dims = (B, N, M, kd)
         return y
@@ -376,11 +389,11 @@ class _CloudMatmul(torch.autograd.Function):
             dT = torch.empty_like(T)
             hip.check(lib.catre_op_cloud_matmul_bwd_t(hip.ptr(x), x.stride(0), hip.ptr(dy), dy.stride(0), hip.ptr(dT), kd,
                                                       B, N, M, _st(x)), "catre_op_cloud_matmul_bwd_t")
-        return dx, dT, None, None, None, None
+        return dx, dT, None, None, None, None, None
 
 
-def cloud_matmul(x, T, B, N, M, out_cols=None):
-    return _CloudMatmul.apply(x, T, B, N, M, T.shape[-1] if out_cols is None else out_cols)
+def cloud_matmul(x, T, B, N, M, out_cols=None, pre=None):
+    return _CloudMatmul.apply(x, T, B, N, M, T.shape[-1] if out_cols is None else out_cols, pre)
 
 
 # ------------------------------------------------------------------------------------------------- per-cloud bias

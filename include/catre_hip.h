@@ -125,6 +125,12 @@ size_t catre_packed_floats(int N, int M, int ts_in_dim);
 int catre_pack_weights(const float* const* params, int N, int M, int ts_in_dim,
                        float* packed, size_t packed_floats, void* stream);
 
+/* Same, restricted to the packs a caller needs (a training step that re-packs after every optimizer step only needs
+ * the fp32 encoder image): OR of CATRE_PACK_*. */
+enum { CATRE_PACK_F32_ENCODER = 1, CATRE_PACK_F32_HEADS = 2, CATRE_PACK_BF16 = 4, CATRE_PACK_SPLIT = 8, CATRE_PACK_ALL = 15 };
+int catre_pack_weights_sel(const float* const* params, int N, int M, int ts_in_dim, float* packed, size_t packed_floats,
+                           int sel, void* stream);
+
 /* ---- single stages (each also usable on its own; tests check them one by one) ---------- */
 
 /* a1: batch_updater_test core (core/catre/engine/batch_test.py:81-97) with
@@ -346,6 +352,23 @@ int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const fl
                              const float* scale_deltas, const float* init_pose, const float* init_scale,
                              const float* mean_scales, const float* Ks, const catre_opts* opts, float* d_rot6d,
                              float* d_dt, float* d_ds, int B, void* stream);
+
+/* Training forward of the three encoder blocks on the FUSED kernels (the inference kernels with extra stores): the
+ * pooled feature g [2B,1024] (bias added, no activation) with its arg-max rows idx [2B,1024], plus the activations the
+ * layer-wise backward ops above read, as cloud-major point rows (B*N observed rows, then B*M prior rows):
+ *   stn3d: a1 = relu(stn.conv1) [R,64], a2 = relu(stn.conv2) [R,128]            (pointnet.py:24-28)
+ *   stnkd: f1 = relu(fstn.conv1) [R,64], f2 = relu(fstn.conv2) [R,128]           (pointnet.py:57-61)
+ *   trunk: x1 = x T3 [R,8] (zero-padded), h1 = relu(conv1) [R,64], pf = h1 T64 [R,64], a2 = relu(conv2) [R,128],
+ *          a3 = relu(conv3) [R,512]                                               (pointnet.py:98-116)
+ * N and M multiples of 64; fp32 packs (CATRE_PACK_F32_ENCODER) in `packed`; `workspace` as catre_workspace_bytes. */
+int catre_train_stn3d_fwd(const catre_points* pts, const float* const* params, const float* packed, float* a1, float* a2,
+                          float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+int catre_train_stnkd_fwd(const catre_points* pts, const float* trans3, const float* const* params, const float* packed,
+                          float* f1, float* f2, float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N,
+                          int M, void* stream);
+int catre_train_trunk_fwd(const catre_points* pts, const float* trans3, const float* trans64, const float* const* params,
+                          const float* packed, float* x1, float* h1, float* pf, float* a2, float* a3, float* g,
+                          int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
 
 /* f4: one fused multi-tensor Ranger step = RAdam + Lookahead + gradient centralization
  * (lib/torch_utils/solver/ranger.py:102-202) with the train loop's grad nan_to_num folded in

@@ -26,9 +26,9 @@ def test_no_kernel_uses_scratch_or_spills_vgprs():
 def test_headline_kernels_keep_their_occupancy_shape():
     """The workgroup shapes DESIGN.md section 3 relies on: LDS bytes and registers allow the stated workgroups per CU."""
     by = {r["kernel"]: r for r in _rows()}
-    t = by["k_trunk<1>"]
+    t = by["k_trunk<1, false>"]
     assert t["lds"] == 160 * 1024 and t["vgpr"] <= 256           # one 512-thread workgroup per CU
-    for k in ("k_stn3d<1>", "k_stnkd<1>", "k_rot_l1<1>", "k_rot_l1_split"):
+    for k in ("k_stn3d<1, false>", "k_stnkd<1, false>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1>", "k_rot_l1_split"):
         assert by[k]["lds"] <= 80 * 1024 and by[k]["vgpr"] <= 256, k  # two 256-thread workgroups per CU
 
 
