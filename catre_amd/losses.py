@@ -182,6 +182,7 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
     td = f32(trans_deltas.detach()) if trans_deltas is not None else None
     losses, vis = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
                                    f32(obj_kps), cands, valid, is_sym, lcfg, td)
+    losses = losses.unbind(0)  # six 0-dim views; their backward is one stack instead of six zero-fill + index + add chains
     ld = {}
     if lcfg.pm_on:
         ld["loss_PM_R"] = losses[0]

@@ -122,7 +122,7 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
     # rot head input in object-major order: [N observed | M prior] per object (CATRE_disR_shared.py:86)
-    pf_obj = torch.cat([pf[: B * N].view(B, N, 64), pf[B * N:].view(B, M, 64)], 1).reshape(B * (N + M), 64)
+    pf_obj = T.object_major(pf, B, N, M)
     rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
     ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
     rot6d = torch.cat([rx, ry], 1)

@@ -396,6 +396,29 @@ def cloud_matmul(x, T, B, N, M, out_cols=None, pre=None):
     return _CloudMatmul.apply(x, T, B, N, M, T.shape[-1] if out_cols is None else out_cols, pre)
 
 
+# ------------------------------------------------------------------------------------------------- row re-ordering
+class _ObjectMajor(torch.autograd.Function):
+    """cloud-major rows (B*N observed, then B*M prior) -> object-major rows ([N observed | M prior] per object): the
+    order the rotation heads want (``cat(pcl_feat, kps_feat, dim=2)``, CATRE_disR_shared.py:86).  One gather copy each
+    way - autograd's own slice / cat backward would zero-fill and accumulate two full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, x, B, N, M):
+        C = x.shape[1]
+        ctx.dims = (B, N, M, C)
+        return torch.cat([x[: B * N].view(B, N, C), x[B * N:].view(B, M, C)], 1).reshape(B * (N + M), C)
+
+    @staticmethod
+    def backward(ctx, d):
+        B, N, M, C = ctx.dims
+        d = d.view(B, N + M, C)
+        return torch.cat([d[:, :N].reshape(B * N, C), d[:, N:].reshape(B * M, C)], 0), None, None, None
+
+
+def object_major(x, B, N, M):
+    return _ObjectMajor.apply(x, B, N, M)
+
+
 # ------------------------------------------------------------------------------------------------- per-cloud bias
 class _RowBias(torch.autograd.Function):
     @staticmethod
