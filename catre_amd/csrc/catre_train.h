@@ -391,11 +391,25 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
     }
     const float* ya = ys + h * 128 + jb * 32 + i;
     const float* xb = xs + h * 128 + kb0 * 32 + i;
-#pragma unroll 8
-    for (int t = 0; t < TN_ROWS / 2; ++t) {  // MFMA t contracts rows 2t (h = 0) and 2t + 1 (h = 1)
-      const float a = ya[t * 256];
-      acc[0] = mfma32(a, xb[t * 256], acc[0]);  // D[j][k]
-      acc[1] = mfma32(a, xb[t * 256 + 32], acc[1]);
+    // MFMA step t contracts rows 2t (h = 0) and 2t + 1 (h = 1); operands two steps ahead of their use, pinned
+    float an[3], x0n[3], x1n[3];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      an[d] = ya[d * 256];
+      x0n[d] = xb[d * 256];
+      x1n[d] = xb[d * 256 + 32];
+    }
+#pragma unroll
+    for (int t = 0; t < TN_ROWS / 2; ++t) {
+      if (t + 2 < TN_ROWS / 2) {
+        an[(t + 2) % 3] = ya[(t + 2) * 256];
+        x0n[(t + 2) % 3] = xb[(t + 2) * 256];
+        x1n[(t + 2) % 3] = xb[(t + 2) * 256 + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma32(an[t % 3], x0n[t % 3], acc[0]);  // D[j][k]
+      acc[1] = mfma32(an[t % 3], x1n[t % 3], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (do_col) {
@@ -420,104 +434,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   }
 }
 
-// Wide-tile form for the big weight gradients (J a multiple of 256, K of 128): 256 x (128 KT) outputs per workgroup,
-// wave = 64 x (64 KT) = 2 x (2 KT) blocks.  With 128 x 128 tiles every 64-row slab costs 64 KiB of operand reads for 512
-// MFMAs - chip-wide 4.7 TB/s at the matrix rate, i.e. the kernel sits on the HBM roofline and the matrix pipe waits;
-// a 256 x 256 tile reads each operand once (1.2 TB/s at the matrix rate) and halves the LDS reads per MFMA.
-template <int KT>
-__global__ __launch_bounds__(512) void k_gemm_tn_wide(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
-                                                      int ldx, float* __restrict__ part, int J, int K, int R,
-                                                      int rows_per_split, float* __restrict__ colpart,
-                                                      const float* __restrict__ ymask, int ldym, size_t pitch) {
-  constexpr int KW = 128 * KT, KBW = 2 * KT, NX = 4 * KT;
-  __shared__ __attribute__((aligned(16))) float ys[TN_ROWS * 256];
-  __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * KW];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j0 = blockIdx.x * 256, k0 = blockIdx.y * KW;
-  const int row_lo = blockIdx.z * rows_per_split, row_hi = min(R, row_lo + rows_per_split);
-  const int jg = wave >> 1, kg = wave & 1;  // wave -> j-blocks {2 jg, 2 jg + 1}, k-blocks kg * KBW ...
-  f32x16 acc[2][KBW];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < KBW; ++b) acc[a][b] = zero16();
-  const int i = lane & 31, h = lane >> 5;
-  const bool do_col = colpart != nullptr && blockIdx.y == 0;
-  float csum = 0.f;
-  f32x4 vy[8], vx[NX];
-  auto fetch = [&](int rs) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {  // dY slab: 64 rows x 64 float4
-      const int e = tid + 512 * u, row = e >> 6, c4 = e & 63, gr = rs + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gr < row_hi) {
-        v = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + j0 + c4 * 4);
-        if (ymask) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + (size_t)gr * ldym + j0 + c4 * 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
-        }
-      }
-      vy[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < NX; ++u) {  // X slab: 64 rows x 32 KT float4
-      const int e = tid + 512 * u, row = e / (32 * KT), c4 = e % (32 * KT), gr = rs + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gr < row_hi) v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + k0 + c4 * 4);
-      vx[u] = v;
-    }
-  };
-  fetch(row_lo);
-  for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(ys + (tid + 512 * u) * 4) = vy[u];
-#pragma unroll
-    for (int u = 0; u < NX; ++u) *reinterpret_cast<f32x4*>(xs + (tid + 512 * u) * 4) = vx[u];
-    __syncthreads();
-    if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);
-    if (do_col) {  // thread = column tid & 255, half of the slab's rows
-      const float* yc = ys + (tid >> 8) * 32 * 256 + (tid & 255);
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < 32; ++r) t += yc[r * 256];
-      csum += t;
-    }
-    const float* ya = ys + h * 256 + jg * 64 + i;
-    const float* xb = xs + h * KW + kg * KBW * 32 + i;
-#pragma unroll 4
-    for (int t = 0; t < TN_ROWS / 2; ++t) {  // MFMA t contracts rows 2t (h = 0) and 2t + 1 (h = 1)
-      const float a0 = ya[t * 512], a1 = ya[t * 512 + 32];
-#pragma unroll
-      for (int b = 0; b < KBW; ++b) {
-        const float x = xb[t * 2 * KW + b * 32];
-        acc[0][b] = mfma32(a0, x, acc[0][b]);
-        acc[1][b] = mfma32(a1, x, acc[1][b]);
-      }
-    }
-  }
-  if (do_col) {
-    __syncthreads();
-    ys[tid] = csum;  // [2 row halves][256 columns]
-    __syncthreads();
-    if (tid < 256) colpart[(size_t)blockIdx.z * pitch + j0 + tid] = ys[tid] + ys[256 + tid];
-  }
-  float* out = part + (size_t)blockIdx.z * pitch;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < KBW; ++b) {
-      const int k = k0 + (kg * KBW + b) * 32 + i;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int j = j0 + (jg * 2 + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        out[(size_t)j * K + k] = acc[a][b][reg];
-      }
-    }
-}
-
+// (Tried in round 2: 256 x 256 / 256 x 128 output tiles per workgroup for the big layers - each operand read once instead
+// of twice, half the LDS reads per MFMA: 0.72 ms for the 256 x 256 x 524 k weight gradient either way, no gain.)
 // ------------------------------------------------------------------------------------------------
 // k_gemm_tn on the bf16 matrix pipe.  SPLIT = false: bf16 operands (torch.autocast runs the backward of a bf16 layer
 // in bf16 as well); SPLIT = true: every operand as hi + lo bf16 and three products (fp32-grade gradients).
