@@ -166,16 +166,50 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     if (c) __syncthreads();
     // stage X[r0..r0+64, c*KC .. +KC) : coalesced float4 along K, swizzled rows
     constexpr int F4 = KC / 4;
-    for (int i = tid; i < TP * F4; i += 512) {
-      const int row = i / F4, ch = i % F4;
-      const int gr = min(r0 + row, R - 1);
-      f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
-      if (xmask) {  // ReLU backward folded into the operand load: X .* (xmask > 0)
-        const f32x4 m = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
+    constexpr int NU = (TP * F4 + 511) / 512;
+    // all of this thread's loads are requested before the first LDS store: as a plain loop hipcc waits for every load
+    // before issuing the next (up to 8 HBM round trips in a row per workgroup - the row GEMMs were latency-bound on it)
+    // (the instances with 128 accumulator registers have no room for it and keep the plain loop)
+    constexpr int G = NU;
+    if constexpr (MB >= 4) {
+      for (int i = tid; i < TP * F4; i += 512) {
+        const int row = i / F4, ch = i % F4;
+        const int gr = min(r0 + row, R - 1);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+        if (xmask) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
+          for (int q = 0; q < 4; ++q) v1[q] = m[q] > 0.f ? v1[q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v1;
       }
-      *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v;
+    } else
+#pragma unroll
+    for (int u0 = 0; u0 < NU; u0 += G) {
+      f32x4 v[G], mk[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int i = tid + 512 * (u0 + u);
+        if (u0 + u < NU && i < TP * F4) {
+          const int row = i / F4, ch = i % F4;
+          const int gr = min(r0 + row, R - 1);
+          v[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
+          if (xmask) mk[u] = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int i = tid + 512 * (u0 + u);
+        if (u0 + u < NU && i < TP * F4) {
+          const int row = i / F4, ch = i % F4;
+          if (xmask) {  // ReLU backward folded into the operand load: X .* (xmask > 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = mk[u][q] > 0.f ? v[u][q] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(xs + swz_off(row, ch, LDX)) = v[u];
+        }
+      }
     }
     __syncthreads();
     if (active) {

@@ -416,3 +416,23 @@ def test_integration_md_ctypes_stub_runs_verbatim():
     for i in range(g["K"] + 1):
         assert np.abs(poses[i].cpu().numpy() - g["ref"][f"pose_{i}"]).max() <= TIGHT
         assert np.abs(scales[i].cpu().numpy() - g["ref"][f"scale_{i}"]).max() <= TIGHT
+
+
+def test_fused_loop_with_on_the_fly_pose_apply_equals_the_materialised_loop_bitwise():
+    """catre_refine_k applies the pose while the encoder kernels load a point (catre_points.apply_pose); the module loop
+    materialises x / tfd_kps with k_pose_apply first.  Same arithmetic (one shared device function): same bits."""
+    from catre_amd.batching import batch_updater_test
+
+    g = load_golden("refine_b3_ragged")
+    model, _ = build_model(g["cfg"], g["salt"])
+    batch = to_dev(g["batch"])
+    fused = model.refine(batch, n_iter=g["K"])
+    b = dict(batch)
+    poses_est = scales_est = None
+    with torch.no_grad():
+        for i in range(1, g["K"] + 1):
+            batch_updater_test(model.cfg, b, poses_est=poses_est, scales_est=scales_est)
+            o = model(b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                      mean_scales=b["obj_mean_scales"], do_loss=False, cur_iter=i)
+            poses_est, scales_est = o[f"pose_{i}"], o[f"scale_{i}"]
+            assert torch.equal(poses_est, fused[f"pose_{i}"]) and torch.equal(scales_est, fused[f"scale_{i}"]), i
