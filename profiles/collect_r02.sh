@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything the round-2 docs quote, collected on one GPU box from the build of this commit (run from the repo root):
+#   profiles/collect_r02.sh      -> gpurun_out/r02_*   (copy the summaries into profiles/)
+o=gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $o/r02_gputest.log
+python bench.py > $o/r02_bench_n1.json 2> $o/r02_bench_n1.err
+{ python bench.py --dtype split --no-cpu-baseline; python bench.py --dtype bf16 --no-cpu-baseline;
+  python bench.py --shape config5 --no-cpu-baseline --steps 5; python bench.py --shape config5 --dtype bf16 --no-cpu-baseline --steps 5;
+  python bench.py --shape config5 --dtype split --no-cpu-baseline --steps 5; } 2>/dev/null | grep '^{' > $o/r02_modes_bench.jsonl
+{ python bench.py --mode train --steps 4 --warmup 1; python bench.py --mode train --dtype bf16 --steps 4 --warmup 1;
+  python bench.py --mode train --dtype split --steps 4 --warmup 1; } 2>/dev/null | grep '^{' > $o/r02_train_bench.jsonl
+python profiles/small_batch.py 2>/dev/null | grep '^{' > $o/r02_other_configs.jsonl
+python profiles/train_step.py 16 64 256 2>/dev/null | grep '^{' > $o/r02_train_step.jsonl
+profiles/prof.sh $o/r02_kernel_stats.csv python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra
+profiles/prof.sh $o/r02_train_kernel_stats.csv python $PWD/bench.py --mode train --steps 3 --warmup 1
+profiles/prof.sh $o/r02_b1_kernel_stats.csv python $PWD/profiles/b1_profile.py 1 50
+profiles/pmc.sh $o/pmc_r02 > /dev/null 2>&1
+python profiles/summarize_pmc.py $o/pmc_r02 $o/r02_pmc_summary.csv r02 > /dev/null
+rm -rf $o/pmc_r02
+cat $o/r02_gputest.log
