@@ -1683,24 +1683,35 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
-  (void)ws;
-  catre_points pts;  // the raw clouds; the pose-apply of batch_updater_test happens as the encoder kernels load a point
-  pts.obs = pcl;
+  // Small batches (latency-bound: every launch counts): the raw clouds go straight to the encoder kernels and the
+  // pose-apply of batch_updater_test happens as they load a point.  Large batches: x / tfd_kps are materialised once per
+  // iteration (5 us) - three kernels x eight waves re-deriving every point's transform costs more than that there.
+  // Same device function either way: same bits.
+  const bool on_the_fly = (size_t)B * (N + M) <= (size_t)64 * 1024;
+  catre_points pts;
+  pts.obs = on_the_fly ? pcl : ws + W.xbuf;
   pts.obs_sb = (int64_t)N * 3;
   pts.obs_sn = 3;
   pts.obs_sc = 1;
-  pts.kps = kps;
+  pts.kps = on_the_fly ? kps : ws + W.kbuf;
   pts.kps_sb = (int64_t)M * 3;
   pts.kps_sn = 3;
   pts.kps_sc = 1;
-  pts.apply_pose = 1;
+  pts.apply_pose = on_the_fly ? 1 : 0;
   pts.zero_center = o->zero_center;
+  pts.pose = pts.scale = nullptr;
   for (int i = 1; i <= n_iter; ++i) {
     const float* pose_in = poses + (size_t)(i - 1) * B * 12;
     // batch_test.py:74-75: the scale estimate is only fed back when REFINE_SCLAE
     const float* scale_in = scales + (size_t)(o->refine_scale ? i - 1 : 0) * B * 3;
-    pts.pose = pose_in;
-    pts.scale = scale_in;
+    if (on_the_fly) {
+      pts.pose = pose_in;
+      pts.scale = scale_in;
+    } else {
+      const int rc0 =
+          catre_pose_apply(pcl, kps, pose_in, scale_in, ws + W.xbuf, ws + W.kbuf, B, N, M, o->zero_center, stream);
+      if (rc0) return rc0;
+    }
     const int rc = catre_refine_iter(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
                                      scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream);
     if (rc) return rc;
