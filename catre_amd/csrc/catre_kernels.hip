@@ -1687,7 +1687,10 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   // pose-apply of batch_updater_test happens as they load a point.  Large batches: x / tfd_kps are materialised once per
   // iteration (5 us) - three kernels x eight waves re-deriving every point's transform costs more than that there.
   // Same device function either way: same bits.
-  const bool on_the_fly = (size_t)B * (N + M) <= (size_t)64 * 1024;
+#ifndef CATRE_OTF_POINTS
+#define CATRE_OTF_POINTS (64 * 1024)
+#endif
+  const bool on_the_fly = (size_t)B * (N + M) <= (size_t)CATRE_OTF_POINTS;
   catre_points pts;
   pts.obs = on_the_fly ? pcl : ws + W.xbuf;
   pts.obs_sb = (int64_t)N * 3;

@@ -2,7 +2,7 @@
 # Everything the round-2 docs quote, collected on one GPU box from the build of this commit (run from the repo root):
 #   profiles/collect_r02.sh      -> gpurun_out/r02_*   (copy the summaries into profiles/)
 o=gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $o/r02_gputest.log
+python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -5 > $o/r02_gputest.log
 python bench.py > $o/r02_bench_n1.json 2> $o/r02_bench_n1.err
 { python bench.py --dtype split --no-cpu-baseline; python bench.py --dtype bf16 --no-cpu-baseline;
   python bench.py --shape config5 --no-cpu-baseline --steps 5; python bench.py --shape config5 --dtype bf16 --no-cpu-baseline --steps 5;

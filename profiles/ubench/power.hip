@@ -1,0 +1,99 @@
+// Micro-benchmark (MI355X): which property of the fp32 K-sweep makes the chip drop its clock?  The GemmPipe sweep of
+// gemmpipe.hip with the knobs varied one at a time: register blocking (MB x NB: L2 weight bytes vs LDS bytes per MFMA),
+// waves per SIMD, prefetch depths, and forced pipe bubbles (workgroup barrier + s_sleep every chunk).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../catre_amd/csrc -o power power.hip && ./power
+// Columns: wall time, TFLOP/s, core cycles per MFMA per SIMD (64 = saturated), clock = cycles / wall.
+#include "catre_device.h"
+#include <cstdio>
+#include <vector>
+
+template <int MB, int NB, int NKC, int PFD, int PFB, int WAVES, int BUBBLE>
+__global__ __launch_bounds__(WAVES * 64) void k(const f32x4* __restrict__ wp, float* out, int reps, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int LD = 8 * NKC;
+  for (int i = tid; i < 32 * NB * LD; i += WAVES * 64) lds[i] = 0.001f * (i & 255);
+  __syncthreads();
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) {
+    GemmPipe<MB, NB, true, true, NKC, PFD, PFB> g;
+    const f32x4* w = wp + ((size_t)((wave * MB + r % 3) * NKC)) * 64 + lane;
+    asm volatile("" : "+v"(w));
+    g.prefetch(w, NKC * 64);
+    g.run(acc, lds, LD, lane);
+    if (BUBBLE) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_sleep(BUBBLE);
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) s += acc[mb][0][0] + acc[mb][NB - 1][5];
+  if (s == 12345.678f) out[tid] = s;
+  if (lane == 0) cyc[blockIdx.x * WAVES + wave] = t1 - t0;
+}
+
+template <int MB, int NB, int NKC, int PFD, int PFB, int WAVES, int BUBBLE>
+void run(const char* name, int wg_per_cu, size_t lds_bytes, int reps = 64) {
+  f32x4* wp;
+  float* out;
+  unsigned long long* cyc;
+  const size_t wfloats = (size_t)(WAVES * MB + 4) * NKC * 64 * 4 + 4096;
+  hipMalloc(&wp, wfloats * 4);
+  hipMemset(wp, 0, wfloats * 4);
+  hipMalloc(&out, 1 << 16);
+  const int grid = 256 * wg_per_cu;
+  hipMalloc(&cyc, grid * WAVES * 8);
+  auto fn = k<MB, NB, NKC, PFD, PFB, WAVES, BUBBLE>;
+  hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  // long enough (tens of ms, back-to-back launches) for the power controller to settle; the last launch is timed
+  const int launches = 6;
+  for (int i = 0; i < launches; ++i) {
+    if (i == launches - 1) hipEventRecord(e0);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(WAVES * 64), lds_bytes, 0, wp, out, reps, cyc);
+  }
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(grid * WAVES);
+  hipMemcpy(h.data(), cyc, grid * WAVES * 8, hipMemcpyDeviceToHost);
+  double c = 0;
+  for (auto v : h) c += v;
+  c /= h.size();
+  const double mf = (double)reps * NKC * 4 * MB * NB;  // MFMAs per wave
+  const double waves_per_simd = WAVES * wg_per_cu / 4.0;
+  printf("%-66s %7.3f ms %6.1f TFLOP/s %6.1f cyc/MFMA/SIMD  %5.2f GHz\n", name, ms,
+         mf * grid * WAVES * 4096 / (ms * 1e-3) / 1e12, c / mf / waves_per_simd, c / (ms * 1e-3) / 1e9);
+  hipFree(wp);
+  hipFree(out);
+  hipFree(cyc);
+}
+
+int main() {
+  const size_t L = 160 * 1024;
+  run<4, 2, 64, 2, 1, 8, 0>("8 waves MB4xNB2 K512 (trunk conv4 as shipped)", 1, L);
+  run<4, 2, 64, 2, 1, 8, 1>("  + barrier + s_sleep 1 per 256-MFMA rep", 1, L);
+  run<4, 2, 64, 2, 1, 8, 4>("  + barrier + s_sleep 4", 1, L);
+  run<4, 2, 64, 2, 1, 8, 16>("  + barrier + s_sleep 16", 1, L);
+  run<4, 2, 64, 2, 1, 8, 48>("  + barrier + s_sleep 48", 1, L);
+  run<4, 2, 64, 2, 1, 4, 0>("4 waves (1 per SIMD) MB4xNB2 K512", 1, L);
+  run<4, 2, 64, 3, 2, 4, 0>("4 waves MB4xNB2, 3 weight + 2 LDS chunks in flight", 1, L);
+  run<8, 2, 64, 2, 1, 4, 0>("4 waves MB8xNB2 (256 accumulators): half the LDS reads per MFMA", 1, L);
+  run<8, 2, 64, 3, 2, 4, 0>("4 waves MB8xNB2, 3 + 2 in flight", 1, L);
+  run<4, 4, 32, 2, 1, 4, 0>("4 waves MB4xNB4 K256 (128-row tile): half the L2 weight bytes per MFMA", 1, L);
+  run<2, 4, 32, 2, 1, 8, 0>("8 waves MB2xNB4 K256 (128-row tile)", 1, L);
+  run<2, 2, 64, 2, 1, 8, 0>("8 waves MB2xNB2 K512: twice the L2 weight bytes per MFMA", 1, L);
+  run<4, 2, 64, 2, 1, 8, 0>("8 waves MB4xNB2 K512 again (drift check)", 1, L);
+  return 0;
+}
