@@ -147,7 +147,7 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
 // arg-max rows [tiles][J]).  Uses the "swapped" MFMA orientation so that a lane owns a channel and the reduction is
 // in-register; the first maximum wins, like torch.max.
 template <int MB, int NKC, bool MAXP = false>
-__global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
+__global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
                                                    int relu, const float* __restrict__ xmask, int ldxm, CloudBias cb) {
@@ -170,7 +170,11 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
     // all of this thread's loads are requested before the first LDS store: as a plain loop hipcc waits for every load
     // before issuing the next (up to 8 HBM round trips in a row per workgroup - the row GEMMs were latency-bound on it)
     // (the instances with 128 accumulator registers have no room for it and keep the plain loop)
-    constexpr int G = NU;
+    constexpr int G = NU > 4 ? 4 : NU;  // eight loads + eight masks at once do not fit 128 VGPRs next to the sweep
+    // opaque zero, new in every chunk: keeps hipcc from hoisting the 2 x NU 64-bit row addresses out of the chunk loop
+    // (32 VGPRs held across the MFMA sweep - the K-chunk-256 instance then needs 158 and only one workgroup fits a CU)
+    int rz = 0;
+    asm volatile("" : "+v"(rz));  // eight at once would push the K-chunk-256 instance over 128 VGPRs (one workgroup per CU)
     if constexpr (MB >= 4) {
       for (int i = tid; i < TP * F4; i += 512) {
         const int row = i / F4, ch = i % F4;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows(const float* __restrict__ X, 
         const int i = tid + 512 * (u0 + u);
         if (u0 + u < NU && i < TP * F4) {
           const int row = i / F4, ch = i % F4;
-          const int gr = min(r0 + row, R - 1);
+          const int gr = min(r0 + row + rz, R - 1);
           v[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + c * KC + ch * 4);
           if (xmask) mk[u] = *reinterpret_cast<const f32x4*>(xmask + (size_t)gr * ldxm + c * KC + ch * 4);
         }
@@ -464,6 +468,79 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
     for (int reg = 0; reg < 16; ++reg) {
       const int j = j0 + jb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
       if (j < J) out[(size_t)j * K + k] = acc[kb][reg];
+    }
+  }
+}
+
+// The same partials for a SKINNY right operand (K <= 8: the layers fed by 3-d points - conv1 of the STN and of the
+// trunk).  On the 128 x 128 MFMA tile above 97 % of the products are padding and the launch is bound by them (0.23 ms
+// for a 64 x 3 gradient whose operands stream in 0.02 ms); here a thread owns four dY columns, 256 / (J/4) row lanes
+// share the rows, the X row is a uniform 16/32-byte load, and four rows per lane are requested together.
+template <int KS>
+__global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                        int ldx, float* __restrict__ part, int J, int K, int R,
+                                                        int rows_per_split, float* __restrict__ colpart,
+                                                        const float* __restrict__ ymask, int ldym, size_t pitch) {
+  extern __shared__ float red[];  // [row lane][column quad][4 * KS products + 4 column sums]
+  constexpr int E = 4 * KS + 4;
+  const int JQ = J >> 2, RL = 256 / JQ;
+  const int tid = threadIdx.x, q = tid % JQ, rl = tid / JQ;
+  const int lo = blockIdx.x * rows_per_split, hi = min(R, lo + rows_per_split);
+  float acc[4][KS], cs[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cs[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc[c][k] = 0.f;
+  }
+  if (rl < RL) {
+    for (int r = lo + rl; r < hi; r += 4 * RL) {
+      f32x4 d[4], m[4], xa[4], xb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = min(r + u * RL, hi - 1);
+        d[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)rr * ldy + 4 * q);
+        if (ymask) m[u] = *reinterpret_cast<const f32x4*>(ymask + (size_t)rr * ldym + 4 * q);
+        xa[u] = *reinterpret_cast<const f32x4*>(X + (size_t)rr * ldx);
+        if (KS == 8) xb[u] = *reinterpret_cast<const f32x4*>(X + (size_t)rr * ldx + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * RL < hi) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float dv = (ymask && !(m[u][c] > 0.f)) ? 0.f : d[u][c];
+            cs[c] += dv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[c][k] = fmaf(dv, xa[u][k], acc[c][k]);
+            if (KS == 8) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[c][4 + k] = fmaf(dv, xb[u][k], acc[c][4 + k]);
+            }
+          }
+        }
+      }
+    }
+    float* o = red + (size_t)(rl * JQ + q) * E;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) o[c * KS + k] = acc[c][k];
+      o[4 * KS + c] = cs[c];
+    }
+  }
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * pitch;
+  for (int e = tid; e < JQ * E; e += 256) {
+    float sum = 0.f;
+    for (int l = 0; l < RL; ++l) sum += red[(size_t)l * JQ * E + e];  // fixed order
+    const int qq = e / E, i = e % E;
+    if (i < 4 * KS) {
+      const int c = i / KS, k = i % KS;
+      if (k < K) out[(size_t)(4 * qq + c) * K + k] = sum;
+    } else if (colpart) {
+      colpart[(size_t)blockIdx.x * pitch + 4 * qq + (i - 4 * KS)] = sum;
     }
   }
 }
@@ -1319,6 +1396,162 @@ __global__ void k_gnp_bwd_apply(const float* __restrict__ dA, const float* __res
     const float sc = rstd * ga[q];
     const float xh = (y[q] - mean) * rstd;
     const float dxh = da[q] * gelu_grad(fmaf(y[q], sc, be[q] - mean * sc)) * ga[q];
+    o[q] = rstd * (dxh - m1 - xh * m2);
+  }
+  reinterpret_cast<f32x4*>(dY)[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm + GELU + neck (Conv1d 256 -> rot_dim <= 3, conv_out_per_rot_head.py:134-137) as ONE op for training: the
+// [R,256] activation between them is never written and its gradient never exists - d a[r][c] = sum_k dY3[r][k] Wn[k][c]
+// is rebuilt from the three floats of its row wherever it is needed.  Per head that removes a 0.5 GiB store + three
+// 0.5 GiB loads forward and backward, and the two padded GEMMs (a 3 x 256 weight gradient on 128 x 128 MFMA tiles).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gelu_both(float v, float& g, float& dg) {
+  const float e = erf_rational(v * 0.70710678118654752440f);
+  const float hv = 0.5f * v;
+  g = fmaf(hv, e, hv);  // the operation sequences of gelu_erf / gelu_grad on one erf evaluation
+  dg = fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), 0.5f * (1.0f + e));
+}
+
+// workgroup = 64 consecutive rows of one object (P % 64 == 0); wave = row, lane = 4 channels; Y3 [R][3]
+__global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd(const float* __restrict__ Y, const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ Wn, const float* __restrict__ bn,
+                                                           float* __restrict__ Y3, int P) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t r0 = (size_t)blockIdx.x * 64;
+  const int obj = (int)(r0 / P), c0 = lane * 4;
+  const float* st = stat + ((size_t)obj * 32 + (c0 >> 3)) * 2;
+  const float mean = st[0], rstd = st[1];
+  f32x4 sc, sh;
+  float nk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * gamma[c0 + q];
+    sh[q] = beta[c0 + q] - mean * sc[q];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nk[k][q] = Wn[k * 256 + c0 + q];
+  }
+  const float b0 = bn ? bn[0] : 0.f, b1 = bn ? bn[1] : 0.f, b2 = bn ? bn[2] : 0.f;
+  const float* src = Y + (r0 + wave) * 256 + c0;
+  // four rows of this wave per step: the loads are requested together, the 12 row sums share one butterfly
+  for (int it = 0; it < 4; ++it) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(16 * it + 4 * u) * 256));
+    float t[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float z[4];
+      gelu_affine4(v[u][0], v[u][1], v[u][2], v[u][3], sc, sh, z);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float a = nk[k][0] * z[0];
+        a = fmaf(nk[k][1], z[1], a);
+        a = fmaf(nk[k][2], z[2], a);
+        t[u][k] = fmaf(nk[k][3], z[3], a);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[u][k] = wave_sum(t[u][k]);
+    if (lane < 4) {
+      // lane u stores row u of the step (wave_sum leaves the totals in every lane)
+      float o0 = t[0][0], o1 = t[0][1], o2 = t[0][2];
+#pragma unroll
+      for (int u = 1; u < 4; ++u)
+        if (lane == u) {
+          o0 = t[u][0];
+          o1 = t[u][1];
+          o2 = t[u][2];
+        }
+      float* dst = Y3 + (r0 + wave + 16 * it + 4 * lane) * 3;
+      dst[0] = o0 + b0;
+      dst[1] = o1 + b1;
+      dst[2] = o2 + b2;
+    }
+  }
+}
+
+// backward pass 1: k_gnp_bwd_sums with d a rebuilt from dY3, plus the neck's weight-gradient partials.
+// dgb_part [slot][5][256] = dgamma, dbeta, dWn[0..2] of the chunk.
+__global__ __launch_bounds__(256) void k_gnp_neck_bwd_sums(const float* __restrict__ dY3, const float* __restrict__ Y,
+                                                           const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ Wn,
+                                                           float* __restrict__ sums_part, float* __restrict__ dgb_part,
+                                                           int P) {
+  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, ch = threadIdx.x, g = ch >> 3;
+  const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
+  const float ga = gamma[ch], be = beta[ch];
+  const float sc = rstd * ga, sh = be - mean * sc;
+  const float w0 = Wn[ch], w1 = Wn[256 + ch], w2 = Wn[512 + ch];
+  float s1 = 0.f, s2 = 0.f, dga = 0.f, dbe = 0.f, dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
+  const float* y = Y + (size_t)obj * P * 256 + ch;
+  const float* d3 = dY3 + (size_t)obj * P * 3;
+  for (int p = p0; p < p1; ++p) {
+    const float d0 = d3[p * 3], d1 = d3[p * 3 + 1], d2 = d3[p * 3 + 2];  // uniform over the workgroup
+    const float yv = y[(size_t)p * 256];
+    const float xh = (yv - mean) * rstd;
+    float a, dg;
+    gelu_both(fmaf(yv, sc, sh), a, dg);
+    const float da = fmaf(w2, d2, fmaf(w1, d1, w0 * d0));
+    const float dyh = da * dg;
+    dga = fmaf(dyh, xh, dga);
+    dbe += dyh;
+    const float dxh = dyh * ga;
+    s1 += dxh;
+    s2 = fmaf(dxh, xh, s2);
+    dw0 = fmaf(d0, a, dw0);
+    dw1 = fmaf(d1, a, dw1);
+    dw2 = fmaf(d2, a, dw2);
+  }
+  s1 += __shfl_xor(s1, 1);
+  s1 += __shfl_xor(s1, 2);
+  s1 += __shfl_xor(s1, 4);
+  s2 += __shfl_xor(s2, 1);
+  s2 += __shfl_xor(s2, 2);
+  s2 += __shfl_xor(s2, 4);
+  const size_t slot = (size_t)obj * nch + chunk;
+  if ((ch & 7) == 0) {
+    sums_part[(slot * 32 + g) * 2] = s1;
+    sums_part[(slot * 32 + g) * 2 + 1] = s2;
+  }
+  float* o = dgb_part + slot * 5 * 256 + ch;
+  o[0] = dga;
+  o[256] = dbe;
+  o[512] = dw0;
+  o[768] = dw1;
+  o[1024] = dw2;
+}
+
+// backward pass 2: dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat)) with d a rebuilt from dY3
+__global__ void k_gnp_neck_bwd_apply(const float* __restrict__ dY3, const float* __restrict__ Y,
+                                     const float* __restrict__ stat, const float* __restrict__ sums,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ Wn, float* __restrict__ dY, int P, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = i & 63;
+  const size_t row = i >> 6;
+  const int obj = row / P, g = c4 >> 1;
+  const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + g) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + g) * 2 + 1] * inv_m;
+  const f32x4 y = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + i);
+  const float d0 = dY3[row * 3], d1 = dY3[row * 3 + 1], d2 = dY3[row * 3 + 2];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
+  const f32x4 w0 = reinterpret_cast<const f32x4*>(Wn)[c4], w1 = reinterpret_cast<const f32x4*>(Wn)[64 + c4],
+              w2 = reinterpret_cast<const f32x4*>(Wn)[128 + c4];
+  f32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float sc = rstd * ga[q];
+    const float xh = (y[q] - mean) * rstd;
+    const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
+    const float dxh = da * gelu_grad(fmaf(y[q], sc, be[q] - mean * sc)) * ga[q];
     o[q] = rstd * (dxh - m1 - xh * m2);
   }
   reinterpret_cast<f32x4*>(dY)[i] = o;

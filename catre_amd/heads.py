@@ -87,6 +87,18 @@ class RotHead(nn.Module):
         return r[:, :rd], feat  # a padded column only carries conv_p.bias: sliced away
 
 
+def neck_weight3(weight, bias):
+    """neck Conv1d(256 -> rot_dim) parameters as [3,256] / [3], zero-padded (differentiable) for the 3-column kernels."""
+    import torch.nn.functional as F
+
+    rd = weight.shape[0]
+    w = weight.reshape(rd, -1)
+    if rd < 3:
+        w = F.pad(w, (0, 0, 0, 3 - rd))
+        bias = F.pad(bias, (0, 3 - rd)) if bias is not None else None
+    return w, bias
+
+
 def neck_rows(a, weight, bias):
     """neck Conv1d(256 -> rot_dim, k=1) on point rows, zero-padded to the 3 columns the point-sum kernels are built for
     (pure data movement on [rot_dim,256] / [rot_dim]; gradients of the padding rows are dropped by autograd)."""

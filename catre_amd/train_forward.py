@@ -84,11 +84,16 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     y, part = T.linear_cloudbias(pf_obj, W0[:, 1024:].contiguous(), bias0, B, N, M, with_gn_partials=True)
     a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
-    a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
-    from .heads import neck_rows
+    from .heads import neck_rows, neck_weight3
 
     rd = w("neck.0.weight").shape[0]
-    y3 = neck_rows(a, w("neck.0.weight"), w("neck.0.bias"))                  # [B*P,3] (columns >= rot_dim are zero)
+    if part is not None and P % 64 == 0:
+        # GroupNorm + GELU + neck in one op: the [B*P,256] activation in between is never stored
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        y3 = T.gn_points_gelu_neck(y, w("layers.4.weight"), w("layers.4.bias"), wn, bn, B, P, part)
+    else:
+        a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
+        y3 = neck_rows(a, w("neck.0.weight"), w("neck.0.bias"))              # [B*P,3] (columns >= rot_dim are zero)
     return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
 
 

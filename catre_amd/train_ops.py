@@ -581,6 +581,46 @@ def gn_points_gelu(y, gamma, beta, B, P, part=None):
     return _GNPointsGelu.apply(y, gamma, beta, B, P, part)
 
 
+class _GNPointsGeluNeck(torch.autograd.Function):
+    """neck(gelu(GroupNorm(32,256)(y))) -> [B*P, 3] in one op (RotHead's last stage, conv_out_per_rot_head.py:132-137):
+    the [B*P,256] activation between GroupNorm/GELU and the 256 -> rot_dim conv is neither stored forward nor
+    differentiated through backward - d a = dy3 Wn is rebuilt from the three floats of its row."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, wn, bn, B, P, part):
+        lib = hip.load()
+        y, wn = _c(y), _c(wn)
+        bnc = _c(bn) if bn is not None else None
+        y3 = torch.empty(y.shape[0], 3, dtype=torch.float32, device=y.device)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=y.device)
+        hip.check(lib.catre_op_gnp_gelu_neck_fwd(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                                 hip.ptr(bnc), hip.ptr(y3), hip.ptr(stat), B, P, _st(y)),
+                  "catre_op_gnp_gelu_neck_fwd")
+        ctx.save_for_backward(y, gamma, beta, wn, stat)
+        ctx.dims, ctx.has_bn = (B, P), bn is not None
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy3):
+        y, gamma, beta, wn, stat = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        dy3 = _c(dy3)
+        dy = torch.empty_like(y)
+        dpar = torch.empty(5, 256, dtype=torch.float32, device=y.device)
+        ws = _ws(lib.catre_op_gnp_gelu_neck_bwd_ws_bytes(B, P), y.device)
+        hip.check(lib.catre_op_gnp_gelu_neck_bwd(hip.ptr(dy3), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta),
+                                                 hip.ptr(wn), hip.ptr(dy), hip.ptr(dpar), 0, hip.ptr(ws), ws.numel(), B, P,
+                                                 _st(y)), "catre_op_gnp_gelu_neck_bwd")
+        dbn = _colsum(dy3) if ctx.has_bn else None
+        return dy, dpar[0], dpar[1], dpar[2:5], dbn, None, None, None
+
+
+def gn_points_gelu_neck(y, gamma, beta, wn, bn, B, P, part):
+    """y [B*P,256] with its tile partials ``part`` (linear_gn_partials), wn [3,256], bn [3] or None -> [B*P,3]."""
+    return _GNPointsGeluNeck.apply(y, gamma, beta, wn, bn, B, P, part)
+
+
 class _GNRowsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) on a [R,256] matrix (groups of 8 channels inside each row; ts head)."""
 

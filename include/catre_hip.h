@@ -342,6 +342,15 @@ int catre_op_gnp_gelu_fwd(const float* Y, const float* gamma, const float* beta,
 int catre_op_gnp_gelu_bwd(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
                           float* dY, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int B,
                           int P, void* stream);
+/* GroupNorm + GELU + neck Conv1d(256 -> rot_dim <= 3) of a RotHead in one op (conv_out_per_rot_head.py:132-137): the [R,256]
+ * activation between them is never stored.  Wn [3][256] (rows >= rot_dim zero), bn [3] or NULL, Y3 / dY3 [B*P][3],
+ * part64 as catre_op_gnp_gelu_fwd_pre (P % 64 == 0).  Backward: dY [B*P,256], dparams [5][256] = dgamma, dbeta, dWn. */
+int catre_op_gnp_gelu_neck_fwd(const float* Y, const float* part64, const float* gamma, const float* beta,
+                               const float* Wn, const float* bn, float* Y3, float* stat, int B, int P, void* stream);
+size_t catre_op_gnp_gelu_neck_bwd_ws_bytes(int B, int P);
+int catre_op_gnp_gelu_neck_bwd(const float* dY3, const float* Y, const float* stat, const float* gamma,
+                               const float* beta, const float* Wn, float* dY, float* dparams, int accumulate, void* ws,
+                               size_t ws_bytes, int B, int P, void* stream);
 int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
 int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);

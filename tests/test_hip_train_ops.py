@@ -257,6 +257,46 @@ def test_rowbias_gn_points_wsum():
         _cmp(got.grad, want.grad, nm, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("rd", [3, 2])
+def test_gn_gelu_neck_fused_op_matches_fp64_reference(rd):
+    """GroupNorm + GELU + neck conv as one op (no [R,256] activation in between): forward and every gradient against
+    fp64 torch, on the rot head's own composition linear -> GN -> GELU -> neck -> conv_p (conv_out_per_rot_head.py:126-140)."""
+    from catre_amd import train_ops as T
+    from catre_amd.heads import neck_weight3
+
+    B, N, M = 3, 128, 64
+    P = N + M
+    g = _gen(21 + rd)
+    a0, a0r = _leaf(torch.randn(B * P, 256, generator=g))
+    w1, w1r = _leaf(torch.randn(256, 256, generator=g) / 16)
+    b1, b1r = _leaf(torch.randn(256, generator=g) * 0.1 + 2.0)
+    ga, gar = _leaf(1 + 0.1 * torch.randn(256, generator=g))
+    be, ber = _leaf(0.1 * torch.randn(256, generator=g))
+    wn, wnr = _leaf(torch.randn(rd, 256, 1, generator=g) / 16)
+    bn, bnr = _leaf(torch.randn(rd, generator=g) * 0.1)
+    wp, wpr = _leaf(torch.rand(1, P, 1, generator=g) / P)
+    y, part = T.linear_gn_partials(a0, w1, b1, B, N, M)
+    assert part is not None
+    w3, b3 = neck_weight3(wn, bn)
+    y3 = T.gn_points_gelu_neck(y, ga, be, w3, b3, B, P, part)
+    assert y3.shape == (B * P, 3)
+    out = T.weighted_point_sum(y3, wp, None, B, P)[:, :rd]
+    yr = (a0r @ w1r.t() + b1r).reshape(B, P, 256).permute(0, 2, 1)
+    ar = F.gelu(F.group_norm(yr, 32, gar, ber, 1e-5))
+    y3r = F.conv1d(ar, wnr, bnr)                                  # [B,rd,P]
+    outr = F.conv1d(y3r.permute(0, 2, 1), wpr).squeeze(1)         # [B,rd]
+    _cmp(y3[:, :rd], y3r.permute(0, 2, 1).reshape(B * P, rd), "y3", atol=1e-5)
+    if rd < 3:
+        assert float(y3[:, rd:].abs().max()) == 0.0
+    _cmp(out, outr, "out", atol=1e-5)
+    d = torch.randn(B, rd, generator=g)
+    out.backward(d.to(DEV))
+    outr.backward(d.double())
+    for got, want, nm in ((a0, a0r, "da0"), (w1, w1r, "dw1"), (b1, b1r, "db1"), (ga, gar, "dgamma"), (be, ber, "dbeta"),
+                          (wn, wnr, "dneck"), (bn, bnr, "dneck_b"), (wp, wpr, "dwp")):
+        _cmp(got.grad, want.grad, nm, atol=2e-5, rtol=1e-4)
+
+
 def test_gn_rows_gelu():
     from catre_amd import train_ops as T
 
