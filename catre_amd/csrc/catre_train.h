@@ -370,54 +370,65 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
 // conflict-free) and read back with ds_read_b32 - consecutive lanes, consecutive columns.  (The first version
 // staged them transposed with scalar stores: 16-way bank conflicts, 24 % of the fp32 MFMA rate.)  The next step's
 // global loads are issued into registers before the current step's 64 MFMAs.
+// KB = k-blocks of 32 per wave: 2 -> 128 x 128 tile; 1 -> 128 x 64 for K <= 64 (the 64-channel point features: on the
+// wide tile half of every MFMA there is padding and the launch is bound by it; the narrow one also leaves LDS for a
+// third workgroup per CU).
+template <int KB>
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
                                                  int rows_per_split, float* __restrict__ colpart,
                                                  const float* __restrict__ ymask, int ldym, size_t pitch) {
+  constexpr int KT = 64 * KB;      // tile width along K
+  constexpr int XQ = KT / 4;       // float4 per staged X row
+  constexpr int XU = TN_ROWS * XQ / 512;
   __shared__ __attribute__((aligned(16))) float ys[TN_ROWS * 128];
-  __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float xs[TN_ROWS * KT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int j0 = blockIdx.x * 128, k0 = blockIdx.y * KT;
   const int row_lo = blockIdx.z * rows_per_split, row_hi = min(R, row_lo + rows_per_split);
-  const int jb = wave >> 1, kb0 = 2 * (wave & 1);
-  f32x16 acc[2] = {zero16(), zero16()};
+  const int jb = wave >> 1, kb0 = KB * (wave & 1);
+  f32x16 acc[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc[kb] = zero16();
   const int i = lane & 31, h = lane >> 5;
   // bias gradient for free: the k-tile-0 workgroups also column-sum the dY tile they stage anyway
   // (thread = column tid&127, 16-row slice tid>>7), which saves a separate pass over dY
   const bool do_col = colpart != nullptr && blockIdx.y == 0;
   float csum = 0.f;
-  // staging: float4 slot e = tid + 512*u  ->  row e>>5, float4 column e&31   (u = 0..3)
-  f32x4 vy[4], vx[4];
+  // staging: float4 slot e = tid + 512*u  ->  dY: row e>>5, float4 column e&31 (u = 0..3); X: row e / XQ, column e % XQ
+  f32x4 vy[4], vx[XU];
   auto fetch = [&](int rs) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 512 * u, row = e >> 5, c4 = e & 31, gr = rs + row;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      vy[u] = vx[u] = z;
-      if (gr < row_hi) {
-        const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
-        if (jc < J) {
-          vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
-          if (ymask) {  // ReLU backward folded into the operand load: dY .* (ymask > 0)
-            const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + (size_t)gr * ldym + jc);
+      vy[u] = z;
+      const int jc = j0 + c4 * 4;
+      if (gr < row_hi && jc < J) {
+        vy[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * ldy + jc);
+        if (ymask) {  // ReLU backward folded into the operand load: dY .* (ymask > 0)
+          const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + (size_t)gr * ldym + jc);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
-          }
+          for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
         }
-        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
       }
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int e = tid + 512 * u, row = e / XQ, c4 = e % XQ, gr = rs + row;
+      vx[u] = z;
+      const int kc = k0 + c4 * 4;
+      if (gr < row_hi && kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
     }
   };
   fetch(row_lo);
   for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
     __syncthreads();  // the previous step's reads are done
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + 512 * u;
-      *reinterpret_cast<f32x4*>(ys + e * 4) = vy[u];
-      *reinterpret_cast<f32x4*>(xs + e * 4) = vx[u];
-    }
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(ys + (tid + 512 * u) * 4) = vy[u];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) *reinterpret_cast<f32x4*>(xs + (tid + 512 * u) * 4) = vx[u];
     __syncthreads();
     if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);  // in flight during the MFMAs below
     if (do_col) {
@@ -428,25 +439,25 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
       csum += t;
     }
     const float* ya = ys + h * 128 + jb * 32 + i;
-    const float* xb = xs + h * 128 + kb0 * 32 + i;
+    const float* xb = xs + h * KT + kb0 * 32 + i;
     // MFMA step t contracts rows 2t (h = 0) and 2t + 1 (h = 1); operands two steps ahead of their use, pinned
-    float an[3], x0n[3], x1n[3];
+    float an[3], xn[KB][3];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       an[d] = ya[d * 256];
-      x0n[d] = xb[d * 256];
-      x1n[d] = xb[d * 256 + 32];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xn[kb][d] = xb[d * 2 * KT + kb * 32];
     }
 #pragma unroll
     for (int t = 0; t < TN_ROWS / 2; ++t) {
       if (t + 2 < TN_ROWS / 2) {
         an[(t + 2) % 3] = ya[(t + 2) * 256];
-        x0n[(t + 2) % 3] = xb[(t + 2) * 256];
-        x1n[(t + 2) % 3] = xb[(t + 2) * 256 + 32];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) xn[kb][(t + 2) % 3] = xb[(t + 2) * 2 * KT + kb * 32];
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc[0] = mfma32(an[t % 3], x0n[t % 3], acc[0]);  // D[j][k]
-      acc[1] = mfma32(an[t % 3], x1n[t % 3], acc[1]);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) acc[kb] = mfma32(an[t % 3], xn[kb][t % 3], acc[kb]);  // D[j][k]
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   // D[row = j][col = k]: lane holds col k = lane&31, rows (reg&3)+8(reg>>2)+4h
   float* out = part + (size_t)blockIdx.z * pitch;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     const int k = k0 + (kb0 + kb) * 32 + i;
     if (k >= K) continue;
 #pragma unroll

@@ -95,5 +95,12 @@ int main() {
   run<2, 4, 32, 2, 1, 8, 0>("8 waves MB2xNB4 K256 (128-row tile)", 1, L);
   run<2, 2, 64, 2, 1, 8, 0>("8 waves MB2xNB2 K512: twice the L2 weight bytes per MFMA", 1, L);
   run<4, 2, 64, 2, 1, 8, 0>("8 waves MB4xNB2 K512 again (drift check)", 1, L);
+  // the training row GEMM (k_gemm_rows<1,32>): one m-block per wave, K = 256, two workgroups per CU
+  run<1, 2, 32, 2, 1, 8, 0>("8 waves MB1xNB2 K256, 2 WG/CU, 2 weight chunks in flight", 2, 64 * 1024);
+  run<1, 2, 32, 4, 1, 8, 0>("  4 weight chunks in flight", 2, 64 * 1024);
+  run<1, 2, 32, 8, 2, 8, 0>("  8 weight + 2 LDS chunks in flight", 2, 64 * 1024);
+  run<1, 2, 32, 2, 1, 8, 0>("8 waves MB1xNB2 K256, 1 WG/CU", 1, 64 * 1024);
+  run<1, 2, 32, 8, 2, 8, 0>("  8 + 2 in flight", 1, 64 * 1024);
+  run<2, 2, 32, 2, 1, 4, 0>("4 waves MB2xNB2 K256, 2 WG/CU (rot layer 1)", 2, 64 * 1024);
   return 0;
 }
