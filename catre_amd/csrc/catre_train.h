@@ -1569,6 +1569,165 @@ __global__ void k_gnp_neck_bwd_apply(const float* __restrict__ dY3, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of a rot head's layer 0 block (per-cloud-bias linear 64 -> 256, GroupNorm, GELU; conv_out_per_rot_head.py:
+// 126-131) behind the GroupNorm sums, in ONE pass over (dA, Y): a workgroup walks the 64-row tiles of one cloud, rebuilds
+// dY = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) straight into LDS (the [R,256] gradient never reaches
+// HBM) and takes from that tile
+//   waves 0-3: dX tile [64 x 64] = dY W          (one 32 x 32 block each, K = 256 from packed W^T fragments)
+//   waves 4-7: dW [256 x 64] += dY^T X           (four 32 x 32 blocks each, contraction over the tile's rows)
+//   all waves: the cloud's bias gradient          (column sums of the values they staged)
+// instead of k_gnp_bwd_apply (2 loads + 1 store of [R,256]) + k_rowbias_bwd + dgrad + wgrad (one load of it each).
+// Rows object-major, N and M multiples of 64.  Clouds: blockIdx.x < B observed, else prior (the row order of bias2d).
+// ------------------------------------------------------------------------------------------------
+#define L0B_LDP 96  // pitch of the staged X tile: rows 2t / 2t+1 land in different bank halves
+__global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA, const float* __restrict__ Y,
+                                                    const float* __restrict__ stat, const float* __restrict__ sums,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ X, int ldx, const f32x4* __restrict__ WpT,
+                                                    float* __restrict__ dX, int lddx, float* __restrict__ wpart,
+                                                    float* __restrict__ dbias, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float dys[TP * 256];
+  __shared__ __attribute__((aligned(16))) float pfs[TP * L0B_LDP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = N + M;
+  const int obj = blockIdx.x % B, prior = blockIdx.x / B;
+  const int ntile = (prior ? M : N) / TP;
+  const size_t row0 = (size_t)obj * P + (prior ? N : 0);
+  // staging: wave -> rows wave + 8u of the tile, lane -> float4 column (channels 4 lane .. +3, GroupNorm group lane>>1)
+  const int grp = lane >> 1;
+  const float mean = stat[((size_t)obj * 32 + grp) * 2], rstd = stat[((size_t)obj * 32 + grp) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + grp) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + grp) * 2 + 1] * inv_m;
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
+  }
+  f32x4 vd[8], vy[8], vp[2];
+  auto fetch = [&](int t) {
+    const size_t r = row0 + (size_t)t * TP;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = ((r + wave + 8 * u) * 64 + lane);
+      vd[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dA) + o);
+      vy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 512 * u;
+      vp[u] = *reinterpret_cast<const f32x4*>(X + (r + (e >> 4)) * ldx + 4 * (e & 15));
+    }
+  };
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 wacc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) wacc[a][0] = wacc[a][1] = zero16();
+  // weight-gradient waves: j-blocks 2q, 2q+1 (q = wave - 4) x both k-blocks.  Element (row, col) of the swizzled dY image
+  // sits at row * 256 + (((col >> 2) ^ (row & 15)) << 2) + (col & 3); with row = 2t + h the XOR is (chunk ^ h) ^ (2t & 15):
+  // eight per-lane offsets cover the sweep, and the second j-block (chunk ^ 8) reuses them.
+  const int i = lane & 31, h = lane >> 5;
+  int offA[8];
+  {
+    const int col = ((wave & 3) * 2) * 32 + i;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) offA[v] = h * 256 + ((((col >> 2) ^ h) ^ (2 * v)) << 2) + (col & 3);
+  }
+  for (int t = 0; t < ntile; ++t) {
+    // (no prefetch across the MFMA phase: 72 staging registers next to 64 accumulators and the sweep's rings spill)
+    fetch(t);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (vy[u][q] - mean) * rstd;
+        const float dxh = vd[u][q] * gelu_grad(fmaf(vy[u][q], sc[q], sh[q])) * ga[q];
+        o[q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_bwd_apply
+        cs[q] += o[q];
+      }
+      *reinterpret_cast<f32x4*>(dys + swz_off(wave + 8 * u, lane, 256)) = o;
+      __builtin_amdgcn_sched_barrier(0);  // one row at a time: interleaving all eight costs ~100 VGPRs of temporaries
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 512 * u;
+      *reinterpret_cast<f32x4*>(pfs + (e >> 4) * L0B_LDP + 4 * (e & 15)) = vp[u];
+    }
+    __syncthreads();
+    if (wave < 4) {
+      const int mbk = wave & 1, nb = wave >> 1;
+      f32x16 acc[1][1];
+      acc[0][0] = zero16();
+      GemmPipe<1, 1, false, true, 32, 2, 1> gp;
+      // opaque per tile: otherwise the 32 fragment addresses of the sweep are loop-invariant, get hoisted out of the tile
+      // loop as 64-bit pairs and spill
+      unsigned lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      gp.prefetch(WpT + ((size_t)mbk * 32) * 64 + lane_o, 0);
+      gp.run(acc, dys + nb * 32 * 256, 256, lane);
+      float* o = dX + (row0 + (size_t)t * TP + nb * 32 + i) * lddx + mbk * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+      }
+    } else {
+      const float* pb = pfs + h * L0B_LDP + i;
+      // operands two steps ahead of their use, pinned (left alone hipcc hoists all 128 LDS reads above the MFMAs)
+      float a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        a0[d] = dys[2 * d * 256 + offA[d & 7]];
+        a1[d] = dys[2 * d * 256 + offA[(d & 7) ^ 4]];
+        b0[d] = pb[2 * d * L0B_LDP];
+        b1[d] = pb[2 * d * L0B_LDP + 32];
+      }
+#pragma unroll
+      for (int tt = 0; tt < TP / 2; ++tt) {
+        if (tt + 2 < TP / 2) {
+          const int n = tt + 2;
+          a0[n % 3] = dys[2 * n * 256 + offA[n & 7]];
+          a1[n % 3] = dys[2 * n * 256 + offA[(n & 7) ^ 4]];
+          b0[n % 3] = pb[2 * n * L0B_LDP];
+          b1[n % 3] = pb[2 * n * L0B_LDP + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wacc[0][0] = mfma32(a0[tt % 3], b0[tt % 3], wacc[0][0]);
+        wacc[0][1] = mfma32(a0[tt % 3], b1[tt % 3], wacc[0][1]);
+        wacc[1][0] = mfma32(a1[tt % 3], b0[tt % 3], wacc[1][0]);
+        wacc[1][1] = mfma32(a1[tt % 3], b1[tt % 3], wacc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave >= 4) {
+    float* out = wpart + (size_t)blockIdx.x * (256 * 64);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int j = ((wave & 3) * 2 + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          out[(size_t)j * 64 + kb * 32 + i] = wacc[a][kb][reg];
+        }
+  }
+  // bias gradient of the cloud: eight row slices (one per wave) of 256 column sums, merged in wave order
+  *reinterpret_cast<f32x4*>(dys + wave * 256 + 4 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __syncthreads();
+  if (tid < 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += dys[w * 256 + tid];
+    dbias[(size_t)blockIdx.x * 256 + tid] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm(32,256) + GELU on rows [R,256] (ts head): groups of 8 channels inside a row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gnr_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ gamma,

@@ -81,8 +81,12 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     W0 = w("layers.0.weight").reshape(256, 1088)
     bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))       # [2B,256]: global half + conv bias
     # [B*P,256]; the per-cloud bias and the GroupNorm tile partials are epilogue work of the GEMMs
-    y, part = T.linear_cloudbias(pf_obj, W0[:, 1024:].contiguous(), bias0, B, N, M, with_gn_partials=True)
-    a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
+    W0b = W0[:, 1024:].contiguous()
+    if T.rot_l0_block_ok(pf_obj, W0b, N, M):
+        a = T.rot_l0_block(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), B, N, M)
+    else:
+        y, part = T.linear_cloudbias(pf_obj, W0b, bias0, B, N, M, with_gn_partials=True)
+        a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     from .heads import neck_rows, neck_weight3
 

@@ -621,6 +621,61 @@ def gn_points_gelu_neck(y, gamma, beta, wn, bn, B, P, part):
     return _GNPointsGeluNeck.apply(y, gamma, beta, wn, bn, B, P, part)
 
 
+class _RotL0Block(torch.autograd.Function):
+    """A RotHead's first block in fp32 - 64 -> 256 linear with a per-cloud bias, GroupNorm(32,256), GELU
+    (conv_out_per_rot_head.py:126-131) - as one graph node.  Forward: the two kernels of linear_cloudbias +
+    gn_points_gelu.  Backward: the GroupNorm sums, then ONE pass over (da, y) that rebuilds the linear's output gradient
+    tile by tile in LDS and takes dx, dW and the per-cloud bias gradient from it (catre_op_rot_l0_bwd) - instead of
+    materialising that [R,256] gradient and reading it three more times."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias2d, gamma, beta, B, N, M):
+        lib = hip.load()
+        xc, w2, bc = _c(x), _c(w.reshape(256, -1)), _c(bias2d)
+        R, P = xc.shape[0], N + M
+        wp = torch.empty(256 * 64, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), 256, 64, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+        y = torch.empty(R, 256, dtype=torch.float32, device=x.device)
+        part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(bc), 1, hip.ptr(y), 256, 256, 64,
+                                            B, N, M, hip.ptr(part), 0, _st(x)), "catre_op_gemm_rows_gn")
+        a = torch.empty_like(y)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
+        hip.check(lib.catre_op_gnp_gelu_fwd_pre(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a),
+                                                hip.ptr(stat), B, P, _st(x)), "catre_op_gnp_gelu_fwd_pre")
+        ctx.save_for_backward(xc, w2, y, stat, gamma, beta)
+        ctx.dims, ctx.wshape = (B, N, M), w.shape
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w2, y, stat, gamma, beta = ctx.saved_tensors
+        B, N, M = ctx.dims
+        lib = hip.load()
+        da = _c(da)
+        dev = da.device
+        dx = torch.empty(x.shape[0], 64, dtype=torch.float32, device=dev)
+        dw = torch.empty(256, 64, dtype=torch.float32, device=dev)
+        db = torch.empty(2 * B if M > 0 else B, 256, dtype=torch.float32, device=dev)
+        dg, dbe = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
+        hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
+                                          x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
+                                          hip.ptr(dbe), hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
+        return dx, dw.view(ctx.wshape), db, dg, dbe, None, None, None
+
+
+def rot_l0_block_ok(x, w, N, M):
+    return (_amp() == 0 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 64 and x.shape[1] == 64
+            and N % 64 == 0 and M % 64 == 0 and N > 0)
+
+
+def rot_l0_block(x, w, bias2d, gamma, beta, B, N, M):
+    """gelu(GroupNorm(x w^T + bias2d[cloud])) for x [B*(N+M),64] object-major, w [256,64], bias2d [2B,256] (fp32 mode,
+    N and M multiples of 64: rot_l0_block_ok)."""
+    return _RotL0Block.apply(x, w, bias2d, gamma, beta, B, N, M)
+
+
 class _GNRowsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) on a [R,256] matrix (groups of 8 channels inside each row; ts head)."""
 

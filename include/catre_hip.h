@@ -351,6 +351,13 @@ size_t catre_op_gnp_gelu_neck_bwd_ws_bytes(int B, int P);
 int catre_op_gnp_gelu_neck_bwd(const float* dY3, const float* Y, const float* stat, const float* gamma,
                                const float* beta, const float* Wn, float* dY, float* dparams, int accumulate, void* ws,
                                size_t ws_bytes, int B, int P, void* stream);
+/* Backward of a RotHead's first block - Conv1d(1088 -> 256) on cat(point feature, global feature) = a 64 -> 256 linear with
+ * a per-cloud bias, GroupNorm(32,256), GELU (conv_out_per_rot_head.py:126-131) - from dA [R,256] in two passes over (dA, Y):
+ * the [R,256] gradient of the linear's output stays in LDS.  X [R,64], W [256][64], rows object-major, N, M % 64 == 0. */
+size_t catre_op_rot_l0_bwd_ws_bytes(int B, int N, int M);
+int catre_op_rot_l0_bwd(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
+                        const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
+                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B, int N, int M, void* stream);
 int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
 int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);

@@ -297,6 +297,43 @@ def test_gn_gelu_neck_fused_op_matches_fp64_reference(rd):
         _cmp(got.grad, want.grad, nm, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 64, 0), (5, 192, 320)])
+def test_rot_l0_block_fused_backward_matches_fp64_reference(B, N, M):
+    """Layer-0 block of a RotHead (per-cloud-bias linear -> GroupNorm -> GELU) with the one-pass backward: output and
+    every gradient against fp64 torch, and against the unfused op chain."""
+    from catre_amd import train_ops as T
+
+    P = N + M
+    g = _gen(100 + B)
+    x, xr = _leaf(torch.randn(B * P, 64, generator=g))
+    w, wr = _leaf(torch.randn(256, 64, generator=g) / 8)
+    bias, biasr = _leaf(torch.randn(2 * B if M else B, 256, generator=g) * 0.5 + 1.0)
+    ga, gar = _leaf(1 + 0.1 * torch.randn(256, generator=g))
+    be, ber = _leaf(0.1 * torch.randn(256, generator=g))
+    dout = torch.randn(B * P, 256, generator=g)
+    assert T.rot_l0_block_ok(x, w, N, M)
+    a = T.rot_l0_block(x, w, bias, ga, be, B, N, M)
+    yr = (xr @ wr.t()).reshape(B, P, 256)
+    bfull = biasr[:B].unsqueeze(1).expand(B, N, 256)
+    if M:
+        bfull = torch.cat([bfull, biasr[B:].unsqueeze(1).expand(B, M, 256)], 1)
+    ar = F.gelu(F.group_norm((yr + bfull).permute(0, 2, 1), 32, gar, ber, 1e-5)).permute(0, 2, 1).reshape(B * P, 256)
+    _cmp(a, ar, "a", atol=2e-5)
+    a.backward(dout.to(DEV))
+    ar.backward(dout.double())
+    fused = [t.grad.clone() for t in (x, w, bias, ga, be)]
+    for got, want, nm in zip(fused, (xr, wr, biasr, gar, ber), ("dx", "dw", "dbias", "dgamma", "dbeta")):
+        _cmp(got, want.grad, nm, atol=1e-4, rtol=1e-4)
+    for t in (x, w, bias, ga, be):
+        t.grad = None
+    y, part = T.linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=True)
+    a2 = T.gn_points_gelu(y, ga, be, B, P, part)
+    assert (a2 - a).abs().max() <= 2e-6  # (small R takes the untiled linear + its own statistics pass: last-bit differences)
+    a2.backward(dout.to(DEV))
+    for u, t, nm in zip(fused, (x, w, bias, ga, be), ("dx", "dw", "dbias", "dgamma", "dbeta")):
+        assert (u - t.grad).abs().max() <= 2e-5 * float(t.grad.abs().max()) + 1e-6, nm
+
+
 def test_gn_rows_gelu():
     from catre_amd import train_ops as T
 
