@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
 //   3. the waves walk the rows: dX[row][:] = sum over the row's channels of dg * W[channel][:], zeros for rows that
 //      were nobody's arg-max.
 #define MLX_MAXN 4096
-__global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restrict__ dg, const int* __restrict__ idx,
+__global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restrict__ dg, const int* __restrict__ idx,
                                                            const float* __restrict__ W, int ldw, float* __restrict__ dX,
                                                            int ldx, int J, int K, int B, int N, int M) {
   __shared__ int start[MLX_MAXN + 1];
@@ -953,19 +953,19 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restri
   cloud_rows(c, B, N, M, r0, n);
   const float* g = dg + (size_t)c * J;
   const int* ix = idx + (size_t)c * J;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += 512) {
     start[i] = 0;
     fill[i] = 0;
   }
   __syncthreads();
-  for (int j = tid; j < J; j += 256)
+  for (int j = tid; j < J; j += 512)
     if (g[j] != 0.f) atomicAdd(&start[ix[j] - r0], 1);
   __syncthreads();
-  {  // exclusive scan of start[0..n): thread t owns a contiguous run of bins
-    const int per = (n + 255) / 256, lo = tid * per, hi = min(n, lo + per);
+  {  // exclusive scan of start[0..n): thread t < 256 owns a contiguous run of bins
+    const int per = (n + 255) / 256, lo = min(n, tid * per), hi = tid < 256 ? min(n, lo + per) : lo;
     int s = 0;
     for (int i = lo; i < hi; ++i) s += start[i];
-    part[tid] = s;
+    if (tid < 256) part[tid] = s;
     __syncthreads();
     if (tid == 0) {
       int run = 0;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restri
       start[n] = run;
     }
     __syncthreads();
-    int run = part[tid];
+    int run = tid < 256 ? part[tid] : 0;
     for (int i = lo; i < hi; ++i) {
       const int v = start[i];
       start[i] = run;
@@ -1005,23 +1005,30 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_x_rows(const float* __restri
     }
   }
   __syncthreads();
-  const int nf4 = K / 4;  // K % 4 == 0 (checked by the launcher)
+  const int nf4 = K / 4;  // K % 4 == 0 (checked by the launcher); K <= 512: at most two float4 per lane
   // rows are dealt round-robin to (workgroup of the cloud, wave): with few clouds the launcher gives every cloud
-  // several workgroups (each repeats the cheap bucketing above) so that the row walk is not one long serial chain
-  for (int r = blockIdx.y * 4 + wave; r < n; r += 4 * gridDim.y) {
+  // several workgroups (each repeats the cheap bucketing above) so that the row walk is not one long serial chain.
+  // A row is a chain of dependent loads (bucket entry -> dg, W row): eight waves walk rows side by side and a lane's
+  // two column slices are requested together - the walk is bound by that latency, not by the bytes it writes.
+  for (int r = blockIdx.y * 8 + wave; r < n; r += 8 * gridDim.y) {
     const int b = start[r], e = start[r + 1];
     float* xr = dX + (size_t)(r0 + r) * ldx;
-    for (int q = lane; q < nf4; q += 64) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int t = b; t < e; ++t) {
-        const int j = lst[t];
-        const float gv = g[j];
-        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q * 4);
+    const int q0 = lane, q1 = lane + 64;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int t = b; t < e; ++t) {
+      const int j = lst[t];
+      const float gv = g[j];
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 w0 = q0 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q0 * 4) : z;
+      const f32x4 w1 = q1 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q1 * 4) : z;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = fmaf(gv, w[u], acc[u]);
+      for (int u = 0; u < 4; ++u) {
+        acc0[u] = fmaf(gv, w0[u], acc0[u]);
+        acc1[u] = fmaf(gv, w1[u], acc1[u]);
       }
-      *reinterpret_cast<f32x4*>(xr + q * 4) = acc;
     }
+    if (q0 < nf4) *reinterpret_cast<f32x4*>(xr + q0 * 4) = acc0;
+    if (q1 < nf4) *reinterpret_cast<f32x4*>(xr + q1 * 4) = acc1;
   }
 }
 
@@ -1947,7 +1954,16 @@ __global__ __launch_bounds__(256) void k_reduce_splits2(const float* __restrict_
   const int which = blockIdx.x, ch = threadIdx.x;
   float* out = which ? out_b : out_a;
   float s = accumulate ? out[ch] : 0.f;
-  for (int k = 0; k < S; ++k) s += part[((size_t)k * 2 + which) * 256 + ch];
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {  // eight rows requested together (a plain loop is one L2 round trip per row), added in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(k + u) * 2 + which) * 256 + ch];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < S; ++k) s += part[((size_t)k * 2 + which) * 256 + ch];
   out[ch] = s;
 }
 

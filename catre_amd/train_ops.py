@@ -79,9 +79,11 @@ def _pack_split(w, J, K, dev, transpose=0):
     return wp
 
 
-def _tiled_gemm_ok(R, J, K):
+def _tiled_gemm_ok(R, J, K, min_rows=2048):
     """Shapes the tiled row kernel (catre_op_gemm_rows) takes."""
-    return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= 256
+    # (64-row tiles: under ~2048 rows - the FC tails, whose rows are clouds - the tiled kernel would put a handful of
+    # workgroups on 256 CUs; the split-K catre_linear takes those)
+    return (J % 32 == 0) and (J <= 256 or J in (512, 1024)) and (K in (8, 16, 32, 64, 128) or K % 256 == 0) and R >= min_rows
 
 
 def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False, wT=None):
@@ -297,7 +299,7 @@ class _LinearMaxPool(torch.autograd.Function):
                                             C, J, K, _st(x)), "catre_op_maxlin_bwd_w")
         dx = None
         if ctx.needs_input_grad[0]:
-            if max(N, M) <= 4096 and J <= 1024 and K % 4 == 0 and xc.shape[1] == K:
+            if max(N, M) <= 4096 and J <= 1024 and K % 4 == 0 and K <= 512 and xc.shape[1] == K:
                 dx = torch.empty_like(xc)  # every row is written (zeros where no channel had its maximum)
                 hip.check(lib.catre_op_maxlin_bwd_x_rows(hip.ptr(dg), hip.ptr(idx), hip.ptr(w2), K, hip.ptr(dx),
                                                          dx.stride(0), J, K, B, N, M, _st(x)), "catre_op_maxlin_bwd_x_rows")
@@ -510,7 +512,7 @@ class _RotLinear(torch.autograd.Function):
 
 
 def _rot_linear_ok(R, J, K, N, M):
-    return N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(R, J, K) and K % 8 == 0
+    return N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(R, J, K, min_rows=64) and K % 8 == 0
 
 
 def linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=False):

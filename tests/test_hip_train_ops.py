@@ -24,7 +24,11 @@ def _gen(seed):
 
 @pytest.mark.parametrize("R,K,J,relu", [(300, 64, 128, True), (700, 128, 512, True), (1000, 512, 1024, False),
                                         (520, 3, 64, True), (515, 256, 3, False), (6, 1091, 256, False),
-                                        (10, 256, 9, False), (300, 256, 256, False), (257, 64, 64, True)])
+                                        (10, 256, 9, False), (300, 256, 256, False), (257, 64, 64, True),
+                                        # >= 2048 rows: the tiled MFMA row kernels (ragged last tile included); below, the
+                                        # split-K linear
+                                        (2100, 64, 128, True), (2300, 128, 512, True), (2112, 512, 1024, False),
+                                        (2049, 256, 256, False), (2500, 256, 64, True), (2050, 8, 64, True)])
 @pytest.mark.parametrize("mode", ["fp32", "split"])
 def test_linear_fwd_bwd(R, K, J, relu, mode):
     """mode 'split': the tiled shapes run hi + lo bf16 operands with three products on the bf16 pipe: 16-17 bits of
@@ -38,7 +42,9 @@ def test_linear_fwd_bwd(R, K, J, relu, mode):
     with T.amp_mode(mode):
         y = T.linear(x, w, b, relu=relu)
     yr = F.linear(xr, wr[:, :, 0], br)
-    yr = yr.relu() if relu else yr
+    # the reference takes the ReLU mask the device used: an output within the rounding error of zero (a few per 10^5
+    # at split precision) may sit on either side, and one flipped mask entry changes a whole row of dx
+    yr = yr * (y.detach() > 0).double().cpu() if relu else yr
     tol = dict(atol=1e-4, rtol=2e-5) if mode == "split" else {}
     _cmp(y, yr, "y", **tol)
     dy = torch.randn(R, J, generator=g)
@@ -138,9 +144,11 @@ def test_linear_with_per_cloud_bias(mode, B, N, M):
     bias, br = _leaf(torch.randn(nb, 256, generator=g))
     with T.amp_mode(mode):
         y = T.linear_cloudbias(x, w, bias, B, N, M)
-    rnd = (lambda t: t.to(torch.bfloat16).double()) if mode == "bf16" else (lambda t: t)
+    # (ragged clouds under 2048 rows take linear + rowbias_add on the split-K fp32 linear: no operand rounding there)
+    rounded = mode == "bf16" and (T._rot_linear_ok(B * P, 256, 64, N, M) or B * P >= 2048)
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if rounded else (lambda t: t)
     bfull = torch.cat([br[:B].unsqueeze(1).expand(B, N, 256)] + ([br[B:].unsqueeze(1).expand(B, M, 256)] if M else []), 1)
-    yr = (rnd(xr.float()).double() if mode == "bf16" else xr) @ (rnd(wr.float()).double() if mode == "bf16" else wr).t()
+    yr = (rnd(xr.float()).double() if rounded else xr) @ (rnd(wr.float()).double() if rounded else wr).t()
     yr = yr + bfull.reshape(B * P, 256)
     tol = dict(atol=1e-4, rtol=2e-5) if mode != "fp32" else {}
     _cmp(y, yr, "y", **tol)
@@ -192,9 +200,11 @@ def test_groupnorm_statistics_from_the_gemm_epilogue(mode):
 
     a1, g1 = run(True)
     a2, g2 = run(False)
-    assert (a1 - a2).abs().max() < 2e-5  # same statistics up to the order of the partial sums
+    # same statistics up to the order of the partial sums (split: the unfused chain's 576-row linears run on the fp32
+    # split-K kernel, the fused one on split-bf16 products)
+    assert (a1 - a2).abs().max() < (1e-4 if mode == "split" else 2e-5)
     for u, v in zip(g1, g2):
-        assert (u - v).abs().max() <= 2e-5 * float(v.abs().max()) + 1e-7
+        assert (u - v).abs().max() <= (1e-4 if mode == "split" else 2e-5) * float(v.abs().max()) + 1e-7
 
 
 def test_maxpool_points_and_cloud_matmul():
@@ -328,7 +338,7 @@ def test_rot_l0_block_fused_backward_matches_fp64_reference(B, N, M):
         t.grad = None
     y, part = T.linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=True)
     a2 = T.gn_points_gelu(y, ga, be, B, P, part)
-    assert (a2 - a).abs().max() <= 2e-6  # (small R takes the untiled linear + its own statistics pass: last-bit differences)
+    assert (a2 - a).abs().max() <= 1e-5  # (small R takes the untiled linear + its own statistics pass: last-bit differences)
     a2.backward(dout.to(DEV))
     for u, t, nm in zip(fused, (x, w, bias, ga, be), ("dx", "dw", "dbias", "dgamma", "dbeta")):
         assert (u - t.grad).abs().max() <= 2e-5 * float(t.grad.abs().max()) + 1e-6, nm
