@@ -1735,6 +1735,151 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of a rot head's SECOND block (256 -> 256 linear, GroupNorm, GELU, neck; conv_out_per_rot_head.py:129-137)
+// behind the GroupNorm sums, in one pass: a workgroup walks 64-row tiles of one object, rebuilds the linear's output
+// gradient dY from (dY3, Y) into LDS - the k_gnp_neck_bwd_apply arithmetic - stages the layer's input tile A next to it,
+// and takes dA = dY W (64 x 256, K = 256) and dW += dY^T A (256 x 256, contraction over the tile's rows) from the pair:
+// dY [R,256] is never written, nor read back by a dgrad and a wgrad launch.  256 threads = one wave per SIMD with the
+// whole register file: 256 weight-gradient accumulators (sixteen 32 x 32 blocks) + 64 for the data gradient per wave.
+// LDS images are row-major with pitches 260 / 288 floats (16-byte fragment reads of the dgrad and the 4-byte operand
+// reads of the wgrad both conflict-free).
+// ------------------------------------------------------------------------------------------------
+#define L1B_LDY 260
+#define L1B_LDA 288
+__global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY3, const float* __restrict__ Y,
+                                                    const float* __restrict__ stat, const float* __restrict__ sums,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ Wn, const float* __restrict__ A,
+                                                    const f32x4* __restrict__ WpT, float* __restrict__ dA,
+                                                    float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dys = lds;                  // [64][260]
+  float* as = lds + TP * L1B_LDY;    // [64][288]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int obj = blockIdx.x, T = P / TP;
+  const int t0 = blockIdx.y * tpw, t1 = min(T, t0 + tpw);
+  const int grp = lane >> 1;
+  const float mean = stat[((size_t)obj * 32 + grp) * 2], rstd = stat[((size_t)obj * 32 + grp) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + grp) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + grp) * 2 + 1] * inv_m;
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  const f32x4 w0 = reinterpret_cast<const f32x4*>(Wn)[lane], w1 = reinterpret_cast<const f32x4*>(Wn)[64 + lane],
+              w2 = reinterpret_cast<const f32x4*>(Wn)[128 + lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 wacc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) wacc[a][kb] = zero16();
+  const int i = lane & 31, h = lane >> 5;
+  for (int t = t0; t < t1; ++t) {
+    const size_t r0 = (size_t)obj * P + (size_t)t * TP;
+    // staging: wave -> rows wave + 4u, lane -> float4 column; eight rows per batch
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      f32x4 vy[8], va[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t o = (r0 + wave + 4 * (8 * hb + u)) * 64 + lane;
+        vy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + o);
+        va[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = wave + 4 * (8 * hb + u);
+        const float* d3 = dY3 + (r0 + row) * 3;
+        const float d0 = d3[0], d1 = d3[1], d2 = d3[2];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xh = (vy[u][q] - mean) * rstd;
+          const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
+          const float dxh = da * gelu_grad(fmaf(vy[u][q], sc[q], sh[q])) * ga[q];
+          o[q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
+          cs[q] += o[q];
+        }
+        *reinterpret_cast<f32x4*>(dys + row * L1B_LDY + 4 * lane) = o;
+        *reinterpret_cast<f32x4*>(as + row * L1B_LDA + 4 * lane) = va[u];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    {  // dA tile = dY W: m-blocks 2 wave, 2 wave + 1 of the 256 input channels, both 32-row halves
+      f32x16 acc[2][2];
+      acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16();
+      GemmPipe<2, 2, false, false, 32, 2, 1> gp;
+      unsigned lane_o = lane;  // opaque per tile: keeps the 64 fragment addresses of the sweep out of the tile loop's preheader
+      asm volatile("" : "+v"(lane_o));
+      gp.prefetch(WpT + ((size_t)(2 * wave) * 32) * 64 + lane_o, 32 * 64);
+      gp.run(acc, dys, L1B_LDY, lane);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          float* o = dA + (r0 + nb * 32 + i) * 256 + (2 * wave + mb) * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+          }
+        }
+    }
+    {  // dW += dY^T A: j-blocks 2 wave, 2 wave + 1 x all eight k-blocks; operands two steps ahead, pinned
+      const float* pa = dys + h * L1B_LDY + (2 * wave) * 32 + i;
+      const float* pb = as + h * L1B_LDA + i;
+      float a0[3], a1[3], b[3][8];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        a0[d] = pa[2 * d * L1B_LDY];
+        a1[d] = pa[2 * d * L1B_LDY + 32];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) b[d][kb] = pb[2 * d * L1B_LDA + kb * 32];
+      }
+#pragma unroll
+      for (int tt = 0; tt < TP / 2; ++tt) {
+        if (tt + 2 < TP / 2) {
+          const int n = tt + 2;
+          a0[n % 3] = pa[2 * n * L1B_LDY];
+          a1[n % 3] = pa[2 * n * L1B_LDY + 32];
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb) b[n % 3][kb] = pb[2 * n * L1B_LDA + kb * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          wacc[0][kb] = mfma32(a0[tt % 3], b[tt % 3][kb], wacc[0][kb]);
+          wacc[1][kb] = mfma32(a1[tt % 3], b[tt % 3][kb], wacc[1][kb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (256 * 256 + 256);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = (2 * wave + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[(size_t)j * 256 + kb * 32 + i] = wacc[a][kb][reg];
+      }
+  // bias gradient partial: four row slices (one per wave) of 256 column sums, merged in wave order
+  *reinterpret_cast<f32x4*>(dys + wave * 256 + 4 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __syncthreads();
+  out[256 * 256 + tid] = (dys[tid] + dys[256 + tid]) + (dys[512 + tid] + dys[768 + tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm(32,256) + GELU on rows [R,256] (ts head): groups of 8 channels inside a row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gnr_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ gamma,

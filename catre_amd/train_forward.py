@@ -87,10 +87,15 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     else:
         y, part = T.linear_cloudbias(pf_obj, W0b, bias0, B, N, M, with_gn_partials=True)
         a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, part)
-    y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     from .heads import neck_rows, neck_weight3
 
     rd = w("neck.0.weight").shape[0]
+    if T.rot_l1_block_ok(a, w("layers.3.weight"), N, M) and w("layers.3.bias") is not None:
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        y3 = T.rot_l1_block(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
+                            B, N, M)
+        return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
+    y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     if part is not None and P % 64 == 0:
         # GroupNorm + GELU + neck in one op: the [B*P,256] activation in between is never stored
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))

@@ -678,6 +678,62 @@ def rot_l0_block(x, w, bias2d, gamma, beta, B, N, M):
     return _RotL0Block.apply(x, w, bias2d, gamma, beta, B, N, M)
 
 
+class _RotL1Block(torch.autograd.Function):
+    """A RotHead's second block in fp32 - 256 -> 256 linear, GroupNorm(32,256), GELU, neck conv (conv_out_per_rot_head.py:
+    129-137) - as one graph node: y3 [B*P,3] from the block's input a [B*P,256].  Forward: the linear with GroupNorm tile
+    partials in its epilogue, then gn_points_gelu_neck's kernel.  Backward: the neck / GroupNorm sums, then ONE pass over
+    (y, a) that keeps the linear's output gradient in LDS and takes da and dW from it (catre_op_rot_l1_bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, gamma, beta, wn, bn, B, N, M):
+        lib = hip.load()
+        ac, w2, wn = _c(a), _c(w.reshape(256, -1)), _c(wn)
+        bc, bnc = _c(b), (_c(bn) if bn is not None else None)
+        R, P = ac.shape[0], N + M
+        wp = torch.empty(256 * 256, dtype=torch.float32, device=a.device)
+        hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), 256, 256, 0, hip.ptr(wp), _st(a)), "catre_op_pack")
+        y = torch.empty(R, 256, dtype=torch.float32, device=a.device)
+        part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=a.device)
+        hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(ac), ac.stride(0), hip.ptr(wp), hip.ptr(bc), 0, hip.ptr(y), 256, 256, 256,
+                                            B, N, M, hip.ptr(part), 0, _st(a)), "catre_op_gemm_rows_gn")
+        y3 = torch.empty(R, 3, dtype=torch.float32, device=a.device)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=a.device)
+        hip.check(lib.catre_op_gnp_gelu_neck_fwd(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                                 hip.ptr(bnc), hip.ptr(y3), hip.ptr(stat), B, P, _st(a)),
+                  "catre_op_gnp_gelu_neck_fwd")
+        ctx.save_for_backward(ac, w2, y, stat, gamma, beta, wn)
+        ctx.dims, ctx.wshape, ctx.has_bn = (B, P), w.shape, bn is not None
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy3):
+        a, w2, y, stat, gamma, beta, wn = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        dy3 = _c(dy3)
+        dev = dy3.device
+        da = torch.empty_like(a)
+        dwb = torch.empty(256 * 256 + 256, dtype=torch.float32, device=dev)
+        dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
+        ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
+        hip.check(lib.catre_op_rot_l1_bwd(hip.ptr(dy3), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                          hip.ptr(a), hip.ptr(w2), hip.ptr(da), hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws),
+                                          ws.numel(), B, P, _st(dy3)), "catre_op_rot_l1_bwd")
+        dbn = _colsum(dy3) if ctx.has_bn else None
+        return (da, dwb[: 256 * 256].view(ctx.wshape), dwb[256 * 256:], dpar[0], dpar[1], dpar[2:5], dbn, None, None, None)
+
+
+def rot_l1_block_ok(a, w, N, M):
+    return (_amp() == 0 and a.shape[1] == 256 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 256
+            and N % 64 == 0 and M % 64 == 0 and N > 0)
+
+
+def rot_l1_block(a, w, b, gamma, beta, wn, bn, B, N, M):
+    """neck(gelu(GroupNorm(a w^T + b))) -> [B*(N+M), 3] for a [B*(N+M),256] object-major, w [256,256], wn [3,256] (fp32 mode,
+    N and M multiples of 64: rot_l1_block_ok)."""
+    return _RotL1Block.apply(a, w, b, gamma, beta, wn, bn, B, N, M)
+
+
 class _GNRowsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) on a [R,256] matrix (groups of 8 channels inside each row; ts head)."""
 

@@ -358,6 +358,13 @@ size_t catre_op_rot_l0_bwd_ws_bytes(int B, int N, int M);
 int catre_op_rot_l0_bwd(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
                         const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B, int N, int M, void* stream);
+/* Backward of a RotHead's second block - Conv1d(256 -> 256), GroupNorm, GELU, neck (conv_out_per_rot_head.py:129-137) - from
+ * dY3 [R,3]: the sums pass, then one pass over (Y, A) that keeps the linear's output gradient in LDS.  A [R,256] the block's
+ * input, W [256][256]; dA [R,256], dWb [256*256 + 256] = dW then db, dparams [5][256] = dgamma, dbeta, dWn.  P % 64 == 0. */
+size_t catre_op_rot_l1_bwd_ws_bytes(int B, int P);
+int catre_op_rot_l1_bwd(const float* dY3, const float* Y, const float* stat, const float* gamma, const float* beta,
+                        const float* Wn, const float* A, const float* W, float* dA, float* dWb, float* dparams, void* ws,
+                        size_t ws_bytes, int B, int P, void* stream);
 int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
 int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);

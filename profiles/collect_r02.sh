@@ -12,7 +12,8 @@ python bench.py > $o/r02_bench_n1.json 2> $o/r02_bench_n1.err
 python profiles/small_batch.py 2>/dev/null | grep '^{' > $o/r02_other_configs.jsonl
 python profiles/train_step.py 16 64 256 2>/dev/null | grep '^{' > $o/r02_train_step.jsonl
 profiles/prof.sh $o/r02_kernel_stats.csv python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra
-profiles/prof.sh $o/r02_train_kernel_stats.csv python $PWD/bench.py --mode train --steps 3 --warmup 1
+PROF_TRACE="$PWD/$o/r02_train_trace.csv 1500" profiles/prof.sh $o/r02_train_kernel_stats.csv python $PWD/bench.py --mode train --steps 3 --warmup 1
+python profiles/gemm_probe.py 2>/dev/null | grep '^{' > $o/r02_gemm_probe.jsonl
 profiles/prof.sh $o/r02_b1_kernel_stats.csv python $PWD/profiles/b1_profile.py 1 50
 profiles/pmc.sh $o/pmc_r02 > /dev/null 2>&1
 python profiles/summarize_pmc.py $o/pmc_r02 $o/r02_pmc_summary.csv r02 > /dev/null

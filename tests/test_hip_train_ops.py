@@ -344,6 +344,49 @@ def test_rot_l0_block_fused_backward_matches_fp64_reference(B, N, M):
         assert (u - t.grad).abs().max() <= 2e-5 * float(t.grad.abs().max()) + 1e-6, nm
 
 
+@pytest.mark.parametrize("B,N,M,rd", [(3, 128, 64, 3), (2, 64, 0, 2), (5, 192, 320, 3), (300, 64, 64, 3)])
+def test_rot_l1_block_fused_backward_matches_fp64_reference(B, N, M, rd):
+    """Second block of a RotHead (linear -> GroupNorm -> GELU -> neck) with the one-pass backward: output and every
+    gradient against fp64 torch, and against the unfused op chain.  (B = 300: more workgroups than CUs, one tile chunk
+    per object; B = 3: several chunks per object.)"""
+    from catre_amd import train_ops as T
+    from catre_amd.heads import neck_weight3
+
+    P = N + M
+    g = _gen(200 + B)
+    a, ar = _leaf(torch.randn(B * P, 256, generator=g))
+    w, wr = _leaf(torch.randn(256, 256, generator=g) / 16)
+    b, br = _leaf(torch.randn(256, generator=g) * 0.1 + 1.0)
+    ga, gar = _leaf(1 + 0.1 * torch.randn(256, generator=g))
+    be, ber = _leaf(0.1 * torch.randn(256, generator=g))
+    wn, wnr = _leaf(torch.randn(rd, 256, 1, generator=g) / 16)
+    bn, bnr = _leaf(torch.randn(rd, generator=g) * 0.1)
+    dout = torch.randn(B * P, 3, generator=g)
+    dout[:, rd:] = 0
+    assert T.rot_l1_block_ok(a, w, N, M)
+    w3, b3 = neck_weight3(wn, bn)
+    y3 = T.rot_l1_block(a, w, b, ga, be, w3, b3, B, N, M)
+    yr = (ar @ wr.t() + br).reshape(B, P, 256).permute(0, 2, 1)
+    y3r = F.conv1d(F.gelu(F.group_norm(yr, 32, gar, ber, 1e-5)), wnr, bnr).permute(0, 2, 1).reshape(B * P, rd)
+    _cmp(y3[:, :rd], y3r, "y3", atol=2e-5)
+    y3.backward(dout.to(DEV))
+    y3r.backward(dout[:, :rd].double())
+    leaves, refs = (a, w, b, ga, be, wn, bn), (ar, wr, br, gar, ber, wnr, bnr)
+    names = ("da", "dw", "db", "dgamma", "dbeta", "dneck", "dneck_b")
+    fused = [t.grad.clone() for t in leaves]
+    for got, want, nm in zip(fused, refs, names):
+        _cmp(got, want.grad, nm, atol=2e-4 if B > 100 else 1e-4, rtol=1e-4)
+    for t in leaves:
+        t.grad = None
+    y, part = T.linear_gn_partials(a, w, b, B, N, M)
+    w3, b3 = neck_weight3(wn, bn)
+    y3u = T.gn_points_gelu_neck(y, ga, be, w3, b3, B, P, part)
+    assert (y3u - y3).abs().max() <= 1e-6
+    y3u.backward(dout.to(DEV))
+    for u, t, nm in zip(fused, leaves, names):
+        assert (u - t.grad).abs().max() <= 2e-5 * float(t.grad.abs().max()) + 1e-6, nm
+
+
 def test_gn_rows_gelu():
     from catre_amd import train_ops as T
 
