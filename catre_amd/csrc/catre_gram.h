@@ -30,16 +30,18 @@
 // leave the chip idle) four workgroups take one group each.  The consumer adds the four partials in a fixed order, so
 // an object's result does not depend on how many objects share its batch.
 #define PF_NG 4
-__global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ pointfeat,
-                                                    float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
-                                                    float* __restrict__ s1c /*[2B][PF_NG][64]*/,
-                                                    float* __restrict__ shc /*[2B][64]*/, int B, int N, int M) {
-  __shared__ __attribute__((aligned(16))) float pf[2][TP * LD64];
-  __shared__ float part[4][64];
-  __shared__ float shift[64];
+#define PF_MOM_SMEM (2 * TP * LD64 + 4 * 64 + 64)  // floats of LDS
+// body for cloud `cloud`, tile group by of gy (gy == 1: all four groups); 256 threads
+__device__ __forceinline__ void pf_moments_body(const float* __restrict__ pointfeat,
+                                                float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
+                                                float* __restrict__ s1c /*[2B][PF_NG][64]*/,
+                                                float* __restrict__ shc /*[2B][64]*/, int B, int N, int M, int cloud,
+                                                int by, int gy, float* lds /*PF_MOM_SMEM*/) {
+  float(*pf)[TP * LD64] = reinterpret_cast<float(*)[TP * LD64]>(lds);
+  float(*part)[64] = reinterpret_cast<float(*)[64]>(lds + 2 * TP * LD64);
+  float* shift = lds + 2 * TP * LD64 + 4 * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x;
   const int n = cloud < B ? N : M;
   const float* src = pointfeat + (cloud < B ? (size_t)cloud * N : (size_t)B * N + (size_t)(cloud - B) * M) * 64;
   const int nt = (n + TP - 1) / TP, tpg = (nt + PF_NG - 1) / PF_NG;  // tiles per group
@@ -66,13 +68,13 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
     if (tid < 64) {
       const float m = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / (float)v0;
       shift[tid] = m;
-      if (blockIdx.y == 0) shc[(size_t)cloud * 64 + tid] = m;
+      if (by == 0) shc[(size_t)cloud * 64 + tid] = m;
     }
     __syncthreads();
   }
   const f32x4 sh4 = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
   const int bi = wave >> 1, bj = wave & 1, i = lane & 31, h = lane >> 5;
-  const int g_lo = gridDim.y == 1 ? 0 : blockIdx.y, g_hi = gridDim.y == 1 ? PF_NG : blockIdx.y + 1;
+  const int g_lo = gy == 1 ? 0 : by, g_hi = gy == 1 ? PF_NG : by + 1;
 #pragma unroll 1
   for (int g = g_lo; g < g_hi; ++g) {
     const int t_lo = min(g * tpg, nt), t_hi = min(t_lo + tpg, nt);
@@ -115,6 +117,13 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
     if (tid < 64)
       s1c[((size_t)cloud * PF_NG + g) * 64 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
   }
+}
+
+__global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ pointfeat, float* __restrict__ Gc,
+                                                    float* __restrict__ s1c, float* __restrict__ shc, int B, int N,
+                                                    int M) {
+  __shared__ __attribute__((aligned(16))) float lds[PF_MOM_SMEM];
+  pf_moments_body(pointfeat, Gc, s1c, shc, B, N, M, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
 // aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256], as k_gn0_affine.  One workgroup per (object, head,

@@ -1,6 +1,7 @@
 // catre_kernels.hip - hand-written gfx950 kernels for CATRE's pose-refine hot path + their C ABI.
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see Makefile).
 // Reference citations (file:line) are relative to the CATRE tree; see include/catre_hip.h.
+#include <algorithm>
 #include <mutex>
 
 #include "catre_device.h"
@@ -575,26 +576,17 @@ __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm,
 // L2 (F.linear in pointnet.py:31-33,64-66 and the global-feature half of RotHead layer 0).
 // ------------------------------------------------------------------------------------------
 #define LIN_WAVES 8
-__global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restrict__ X, int ldx,
-                                                            const float* __restrict__ W, int ldw,
-                                                            const float* __restrict__ bias, float* __restrict__ Y,
-                                                            int ldy, int R, int J, int K, int relu, int iden_k,
-                                                            const float* __restrict__ W_z1 = nullptr,
-                                                            const float* __restrict__ bias_z1 = nullptr,
-                                                            float* __restrict__ Y_z1 = nullptr) {
-  // gridDim.z == 2: a second (W, bias, Y) on the same X in the same launch (the two rotation heads' global halves)
-  if (blockIdx.z == 1) {
-    W = W_z1;
-    bias = bias_z1;
-    Y = Y_z1;
-  }
+// The body of k_linear for output block (bx, by): X is a global matrix or an LDS staging buffer (k_linear_pm and
+// k_heads_a, catre_small.h) - the same fragment addressing, the same MFMA sequence, the same bits either way.
+__device__ __forceinline__ void linear_body(const float* X, int ldx, const float* __restrict__ W, int ldw,
+                                            const float* __restrict__ bias, float* __restrict__ Y, int ldy, int R, int J,
+                                            int K, int relu, int iden_k, int bx, int by, float (*part)[16][64]) {
   // 8 waves split K (interleaved 8-wide chunks), each with up to 8 chunk pairs in flight - the kernel is a chain of
   // L2 round trips, so the trip count (K/8/8/8 = 2 for K = 1024) is what sets its time; partial 32x32 blocks are
   // summed through LDS in wave order (deterministic).
-  __shared__ float part[LIN_WAVES][16][64];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = min((int)blockIdx.x * 32 + i, R - 1), j = min((int)blockIdx.y * 32 + i, J - 1);
+  const int r = min(bx * 32 + i, R - 1), j = min(by * 32 + i, J - 1);
   const f32x4* xa = reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + 4 * h);
   const f32x4* wb = reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + 4 * h);
   f32x16 acc = zero16();
@@ -612,6 +604,18 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);  // D[row r][col j]
   }
+  for (; kc + 3 * LIN_WAVES < nkc; kc += 4 * LIN_WAVES) {  // K = 256 (fc3 of the STNs): four chunks, one round trip
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = xa[(kc + LIN_WAVES * u) * 2];
+      b[u] = wb[(kc + LIN_WAVES * u) * 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);
+  }
   for (; kc < nkc; kc += LIN_WAVES) {
     const f32x4 a = xa[kc * 2], b = wb[kc * 2];
 #pragma unroll
@@ -620,14 +624,14 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) part[wave][reg][lane] = acc[reg];
   __syncthreads();
-  const int col = blockIdx.y * 32 + i;
+  const int col = by * 32 + i;
   if (col >= J) return;
   const float bv = bias ? bias[col] : 0.f;
   const float idv = (iden_k > 0 && col < iden_k * iden_k && (col % (iden_k + 1)) == 0) ? 1.f : 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {  // wave w finishes registers 2w, 2w+1 -> rows (reg&3) + 8(reg>>2) + 4h
     const int reg = wave * 2 + q;
-    const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    const int row = bx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     if (row < R) {
       float v = part[0][reg][lane];
 #pragma unroll
@@ -637,6 +641,24 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
       Y[(size_t)row * ldy + col] = v + idv;
     }
   }
+}
+
+
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restrict__ X, int ldx,
+                                                            const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ Y,
+                                                            int ldy, int R, int J, int K, int relu, int iden_k,
+                                                            const float* __restrict__ W_z1 = nullptr,
+                                                            const float* __restrict__ bias_z1 = nullptr,
+                                                            float* __restrict__ Y_z1 = nullptr) {
+  // gridDim.z == 2: a second (W, bias, Y) on the same X in the same launch (the two rotation heads' global halves)
+  if (blockIdx.z == 1) {
+    W = W_z1;
+    bias = bias_z1;
+    Y = Y_z1;
+  }
+  __shared__ float part[LIN_WAVES][16][64];
+  linear_body(X, ldx, W, ldw, bias, Y, ldy, R, J, K, relu, iden_k, blockIdx.x, blockIdx.y, part);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -667,13 +689,34 @@ __device__ __forceinline__ float group8_norm_gelu(float v, float gamma, float be
 // ts_feat and writes a partial sum per (object, slice, channel).  With one workgroup the layer is a serial chain of
 // ~1100 L2 round trips (33 us for a single object); eight slices cut it to ~140 and put 8x as many CUs to work.
 #define TS_KS 8
-__global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, const float* __restrict__ pose,
-                                               const float* __restrict__ scale, const float* __restrict__ W0T,
-                                               float* __restrict__ part /*[B][TS_KS][256]*/, int B, int in_dim, int with_kps,
-                                               int with_scale, int with_trans) {
-  extern __shared__ __attribute__((aligned(16))) float feat[];  // [TS_OB][slice length]
-  const int tid = threadIdx.x, ks = blockIdx.y;
-  const int b0i = blockIdx.x * TS_OB;
+// max over a cloud's tile partials (what k_reduce_pm writes to gfeat): out = max_t pm[row(cloud, t)][c]
+__device__ __forceinline__ float cloud_max1(const float* __restrict__ pm, int cloud, int c, int B, int N, int M) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
+  const int nt = cloud < B ? TN : TM;
+  const size_t row0 = cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM;
+  const float* src = pm + row0 * PMW + c;
+  float m = src[0];
+  int t = 1;
+  for (; t + 7 < nt; t += 8) {  // eight loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(t + u) * PMW];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+  }
+  for (; t < nt; ++t) m = fmaxf(m, src[(size_t)t * PMW]);
+  return m;
+}
+
+// Body for object group bx, K slice ks.  pm != nullptr (small batches, k_heads_a): gfeat does not exist yet - the gather
+// takes the maximum over the cloud's tile partials itself (max is exact: the same values k_reduce_pm would have written).
+__device__ __forceinline__ void ts_l0_body(const float* __restrict__ gfeat, const float* __restrict__ pm,
+                                           const float* __restrict__ pose, const float* __restrict__ scale,
+                                           const float* __restrict__ W0T, float* __restrict__ part /*[B][TS_KS][256]*/,
+                                           int B, int N, int M, int in_dim, int with_kps, int with_scale, int with_trans,
+                                           int bx, int ks, float* feat /*LDS [TS_OB][slice length]*/) {
+  const int tid = threadIdx.x;
+  const int b0i = bx * TS_OB;
   const int k0 = (in_dim * ks) / TS_KS, k1 = (in_dim * (ks + 1)) / TS_KS, len = k1 - k0;
   for (int o = 0; o < TS_OB; ++o) {
     const int b = min(b0i + o, B - 1);
@@ -681,11 +724,11 @@ __global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, 
       int kk = k;
       float v;
       if (kk < PMW) {
-        v = gfeat[(size_t)b * PMW + kk];
+        v = pm ? cloud_max1(pm, b, kk, B, N, M) : gfeat[(size_t)b * PMW + kk];
       } else {
         kk -= PMW;
         if (with_kps && kk < PMW) {
-          v = gfeat[(size_t)(B + b) * PMW + kk];
+          v = pm ? cloud_max1(pm, B + b, kk, B, N, M) : gfeat[(size_t)(B + b) * PMW + kk];
         } else {
           if (with_kps) kk -= PMW;
           if (with_scale && kk < 3) {
@@ -727,20 +770,35 @@ __global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, 
     if (b0i + o < B) part[((size_t)(b0i + o) * TS_KS + ks) * 256 + tid] = acc[o];
 }
 
-__global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ l0part /*[B][TS_KS][256]*/,
-                                                 const float* __restrict__ b0, const float* __restrict__ g0,
-                                                 const float* __restrict__ be0, const float* __restrict__ W1T,
-                                                 const float* __restrict__ b1, const float* __restrict__ g1,
-                                                 const float* __restrict__ be1, const float* __restrict__ Wt,
-                                                 const float* __restrict__ bt, const float* __restrict__ Ws,
-                                                 const float* __restrict__ bs, float* __restrict__ dt,
-                                                 float* __restrict__ ds, int B) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__global__ __launch_bounds__(256) void k_ts_l0(const float* __restrict__ gfeat, const float* __restrict__ pose,
+                                               const float* __restrict__ scale, const float* __restrict__ W0T,
+                                               float* __restrict__ part /*[B][TS_KS][256]*/, int B, int in_dim, int with_kps,
+                                               int with_scale, int with_trans) {
+  extern __shared__ __attribute__((aligned(16))) float feat[];  // [TS_OB][slice length]
+  ts_l0_body(gfeat, nullptr, pose, scale, W0T, part, B, 0, 0, in_dim, with_kps, with_scale, with_trans, blockIdx.x,
+             blockIdx.y, feat);
+}
+
+struct TsHeadArgs {
+  const float *l0part /*[B][TS_KS][256]*/, *b0, *g0, *be0, *W1T, *b1, *g1, *be1, *Wt, *bt, *Ws, *bs;
+  float *dt, *ds;
+  int B;
+};
+
+// body for object group bx (1024 threads); sm: TS_OB * (256 + 4 * 256) floats of LDS
+__device__ __forceinline__ void ts_head_body(const TsHeadArgs& A, int bx, float* sm) {
+  const float* __restrict__ l0part = A.l0part;
+  const float *__restrict__ b0 = A.b0, *__restrict__ g0 = A.g0, *__restrict__ be0 = A.be0, *__restrict__ W1T = A.W1T,
+                           *__restrict__ b1 = A.b1, *__restrict__ g1 = A.g1, *__restrict__ be1 = A.be1,
+                           *__restrict__ Wt = A.Wt, *__restrict__ bt = A.bt, *__restrict__ Ws = A.Ws,
+                           *__restrict__ bs = A.bs;
+  float *__restrict__ dt = A.dt, *__restrict__ ds = A.ds;
+  const int B = A.B;
   float* hbuf = sm;                          // [TS_OB][256]
   float* kpart = hbuf + TS_OB * 256;         // [4][TS_OB][256] K-slice partial sums
   // 1024 threads: 4 K-slices x 256 output channels; slice partials are merged in slice order
   const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
-  const int b0i = blockIdx.x * TS_OB;
+  const int b0i = bx * TS_OB;
   float acc[TS_OB];
   if (ks == 0) {
     const float ga = g0[tid], be = be0[tid], bb = b0[tid];
@@ -800,6 +858,11 @@ __global__ __launch_bounds__(1024) void k_ts_head(const float* __restrict__ l0pa
         ds[b * 3 + c - 3] = s;
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void k_ts_head(TsHeadArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  ts_head_body(A, blockIdx.x, sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -885,22 +948,22 @@ __device__ __forceinline__ void normalize3(float* v) {  // F.normalize(p=2, eps=
   v[2] /= nrm;
 }
 
-__global__ void k_pose_update(const float* __restrict__ rot6d, const float* __restrict__ dtr,
-                              const float* __restrict__ dsr, const float* __restrict__ pose0,
-                              const float* __restrict__ scale0, const float* __restrict__ mean_scales,
-                              const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
-                              float* __restrict__ scale_out, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// one object b; rotp: this object's rotation parameters (catre_rot_dim values, or 9 when rot_input_is_matrix) - global
+// memory or LDS (k_finish_update, catre_small.h)
+__device__ __forceinline__ void pose_update_obj(const float* rotp, const float* __restrict__ dtr,
+                                                const float* __restrict__ dsr, const float* __restrict__ pose0,
+                                                const float* __restrict__ scale0, const float* __restrict__ mean_scales,
+                                                const float* __restrict__ Ks, const catre_opts& o,
+                                                float* __restrict__ pose_out, float* __restrict__ scale_out, int b) {
   float dR[9];
   if (o.rot_input_is_matrix) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dR[i] = rot6d[b * 9 + i];
+    for (int i = 0; i < 9; ++i) dR[i] = rotp[i];
   } else {  // get_rot_mat, models/model_utils.py:28-40
     const int rd = catre_rot_dim(o.rot_type);
     float r[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = i < rd ? rot6d[b * rd + i] : 0.f;
+    for (int i = 0; i < 6; ++i) r[i] = i < rd ? rotp[i] : 0.f;
     rot_param_to_mat(r, o.rot_type, dR);
   }
 
@@ -963,6 +1026,17 @@ __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __re
   for (int i = 0; i < 3; ++i) scale_out[b * 3 + i] = o.refine_scale ? s[i] : scale0[b * 3 + i];
 }
 
+__global__ void k_pose_update(const float* __restrict__ rot6d, const float* __restrict__ dtr,
+                              const float* __restrict__ dsr, const float* __restrict__ pose0,
+                              const float* __restrict__ scale0, const float* __restrict__ mean_scales,
+                              const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
+                              float* __restrict__ scale_out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  pose_update_obj(rot6d + (size_t)b * (o.rot_input_is_matrix ? 9 : catre_rot_dim(o.rot_type)), dtr, dsr, pose0, scale0,
+                  mean_scales, Ks, o, pose_out, scale_out, b);
+}
+
 // ------------------------------------------------------------------------------------------
 // stand-alone channel-wise max-pool [B,C,N] -> [B,C]: one wave per row, float4 streaming loads
 // ------------------------------------------------------------------------------------------
@@ -994,6 +1068,7 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 #include "catre_bf16.h"
 #include "catre_split.h"
 #include "catre_gram.h"
+#include "catre_small.h"
 #include "catre_train.h"
 #include "catre_aug.h"
 #include "catre_pcl.h"
@@ -1133,18 +1208,28 @@ inline int row_split(int tiles) { return tiles * 4 <= 256 ? 4 : tiles * 2 <= 256
 inline const f32x4* pk4(const float* packed, size_t off) { return reinterpret_cast<const f32x4*>(packed + off); }
 inline const u32x4* pkb(const float* packed, size_t off) { return reinterpret_cast<const u32x4*>(packed + off); }
 
+inline TsHeadArgs ts_head_args(const float* l0part, const float* const* prm, const float* packed, const PackLayout& L,
+                               float* dt, float* ds, int B) {
+  return TsHeadArgs{l0part, prm[CATRE_P_TS_L0_B], prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B], packed + L.ts_w1t,
+                    prm[CATRE_P_TS_L1_B], prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B], prm[CATRE_P_TS_FCT_W],
+                    prm[CATRE_P_TS_FCT_B], prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B], dt, ds, B};
+}
+
 int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
-                float* out, int k, int R, hipStream_t st) {
+                float* out, int k, int R, hipStream_t st, const float* pm = nullptr, int B = 0, int N = 0, int M = 0) {
   // relu(fc1) -> relu(fc2) -> fc3 + I_k   (pointnet.py:31-40 / 64-77)
-  hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(64 * LIN_WAVES), 0, st, pooled, 1024, prm[base], 1024,
-                     prm[base + 1], h1, 512, R, 512, 1024, 1, 0);
+  if (pm)  // small batches (catre_small.h): fc1 pools the tile partials itself, no k_reduce_pm launch in front
+    hipLaunchKernelGGL(k_linear_pm, dim3(1, 512 / 32), dim3(64 * LIN_WAVES), 0, st, pm, B, N, M, prm[base], 1024,
+                       prm[base + 1], h1, 512, R, 512, 1, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 512 / 32), dim3(64 * LIN_WAVES), 0, st, pooled, 1024, prm[base], 1024,
+                       prm[base + 1], h1, 512, R, 512, 1024, 1, 0);
   hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, 256 / 32), dim3(64 * LIN_WAVES), 0, st, h1, 512, prm[base + 2], 512,
                      prm[base + 3], h2, 256, R, 256, 512, 1, 0);
   hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (k * k + 31) / 32), dim3(64 * LIN_WAVES), 0, st, h2, 256, prm[base + 4], 256,
                      prm[base + 5], out, k * k, R, k * k, 256, 0, k);
   return check_launch();
 }
-
 
 // ---- opt-in per-kernel timing with HIP events recorded on the launch stream -----------------
 // bench.py uses this to measure the dominant kernel's average launch duration inside its timed
@@ -1184,6 +1269,78 @@ struct ProfScope {
   ProfScope(int, hipStream_t) {}
 };
 #endif
+
+
+// The three encoder kernels of one iteration (fp32 or split compute), tile partial maxima -> ws + W.pm
+void launch_stn3d(const catre_points* pts, const float* const* prm, const float* packed, float* ws, const WsLayout& W,
+                  int B, int N, int M, bool split, hipStream_t st) {
+  const PackLayout L = pack_layout(1);  // conv offsets do not depend on ts_in
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  ProfScope ps(CATRE_K_STN3D, st);
+  if (split) {
+#define LAUNCH_(RS)                                                                                            \
+  hipLaunchKernelGGL(k_stn3d_split<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
+                     prm[CATRE_P_STN_CONV1_B], pkb(packed, L.sp_stn_c2), prm[CATRE_P_STN_CONV2_B],              \
+                     pkb(packed, L.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  } else {
+#define LAUNCH_(RS)                                                                                      \
+  hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
+                     prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B],           \
+                     pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  }
+}
+
+void launch_stnkd(const catre_points* pts, const float* trans3, const float* const* prm, const float* packed, float* ws,
+                  const WsLayout& W, int B, int N, int M, bool split, hipStream_t st) {
+  const PackLayout L = pack_layout(1);
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  ProfScope ps(CATRE_K_STNKD, st);
+  if (split) {
+#define LAUNCH_(RS)                                                                                                \
+  hipLaunchKernelGGL(k_stnkd_split<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],     \
+                     prm[CATRE_P_CONV1_B], pkb(packed, L.sp_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],                    \
+                     pkb(packed, L.sp_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.sp_fstn_c3),               \
+                     prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  } else {
+#define LAUNCH_(RS)                                                                                                     \
+  hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],                \
+                     prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),    \
+                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  }
+}
+
+void launch_trunk(const catre_points* pts, const float* trans3, const float* trans64, const float* const* prm,
+                  const float* packed, float* pointfeat, float* ws, const WsLayout& W, int B, int N, int M, bool split,
+                  hipStream_t st) {
+  const PackLayout L = pack_layout(1);
+  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  ProfScope ps(CATRE_K_TRUNK, st);
+  if (split) {
+#define LAUNCH_(RS)                                                                                           \
+  hipLaunchKernelGGL(k_trunk_split<RS>, dim3(tiles * RS), dim3(512), 0, st, *pts, trans3, trans64,             \
+                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B],      \
+                     pkb(packed, L.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, L.sp_c4), prm[CATRE_P_CONV4_B],   \
+                     ws + W.pm, pointfeat, B, N, M, g_trunk_trace)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  } else {
+#define LAUNCH_(RS)                                                                                             \
+  hipLaunchKernelGGL(k_trunk<RS>, dim3(tiles * RS), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W], \
+                     prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),            \
+                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M, \
+                     g_trunk_trace)
+    RS_DISPATCH(row_split(tiles), LAUNCH_)
+#undef LAUNCH_
+  }
+}
 
 }  // namespace
 
@@ -1314,18 +1471,8 @@ int catre_stn3d_pool(const catre_points* pts, const float* const* prm, const flo
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
-  const PackLayout L = pack_layout(1);  // conv offsets do not depend on ts_in
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
-  {
-    ProfScope ps(CATRE_K_STN3D, st);
-#define LAUNCH_STN3D(RS)                                                                                  \
-  hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],       \
-                     prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B],             \
-                     pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
-    RS_DISPATCH(row_split(tiles), LAUNCH_STN3D)
-#undef LAUNCH_STN3D
-  }
+  launch_stn3d(pts, prm, packed, ws, W, B, N, M, false, st);
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
@@ -1344,18 +1491,8 @@ int catre_stnkd_pool(const catre_points* pts, const float* trans3, const float* 
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
-  const PackLayout L = pack_layout(1);
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
-  {
-    ProfScope ps(CATRE_K_STNKD, st);
-#define LAUNCH_STNKD(RS)                                                                                       \
-  hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],        \
-                     prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2), \
-                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
-    RS_DISPATCH(row_split(tiles), LAUNCH_STNKD)
-#undef LAUNCH_STNKD
-  }
+  launch_stnkd(pts, trans3, prm, packed, ws, W, B, N, M, false, st);
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, pooled, 1024, 1024, B, N, M);
   return check_launch();
 }
@@ -1367,19 +1504,8 @@ int catre_trunk(const catre_points* pts, const float* trans3, const float* trans
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
-  const PackLayout L = pack_layout(1);
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
-  {
-    ProfScope ps(CATRE_K_TRUNK, st);
-#define LAUNCH_TRUNK(RS)                                                                                        \
-  hipLaunchKernelGGL(k_trunk<RS>, dim3(tiles * RS), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W], \
-                     prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),            \
-                     prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M, \
-                     g_trunk_trace)
-    RS_DISPATCH(row_split(tiles), LAUNCH_TRUNK)
-#undef LAUNCH_TRUNK
-  }
+  launch_trunk(pts, trans3, trans64, prm, packed, pointfeat, ws, W, B, N, M, false, st);
   hipLaunchKernelGGL(k_reduce_pm, dim3(n_clouds(B, M), (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, gfeat, PMW, PMW, B, N, M);
   return check_launch();
 }
@@ -1401,10 +1527,8 @@ int catre_ts_head(const float* gfeat, const float* init_pose, const float* init_
     hipLaunchKernelGGL(k_ts_l0, dim3(groups, TS_KS), dim3(256), smem0, st, gfeat, init_pose, init_scale, packed + L.ts_w0t,
                        l0part, B, o->ts_in_dim, o->with_kps_feature, o->with_init_scale, o->with_init_trans);
     const size_t smem = (size_t)TS_OB * (256 + 4 * 256) * sizeof(float);
-    hipLaunchKernelGGL(k_ts_head, dim3(groups), dim3(1024), smem, st, (const float*)l0part, prm[CATRE_P_TS_L0_B],
-                       prm[CATRE_P_TS_GN0_W], prm[CATRE_P_TS_GN0_B], packed + L.ts_w1t, prm[CATRE_P_TS_L1_B],
-                       prm[CATRE_P_TS_GN1_W], prm[CATRE_P_TS_GN1_B], prm[CATRE_P_TS_FCT_W], prm[CATRE_P_TS_FCT_B],
-                       prm[CATRE_P_TS_FCS_W], prm[CATRE_P_TS_FCS_B], trans_deltas, scale_deltas, B);
+    hipLaunchKernelGGL(k_ts_head, dim3(groups), dim3(1024), smem, st,
+                       ts_head_args(l0part, prm, packed, L, trans_deltas, scale_deltas, B));
   }
   return check_launch();
 }
@@ -1606,74 +1730,128 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
                           st);
   if (o->compute_dtype != CATRE_DTYPE_F32 && o->compute_dtype != CATRE_DTYPE_SPLIT) return CATRE_ERR_UNSUPPORTED;
   const bool split = o->compute_dtype == CATRE_DTYPE_SPLIT;
-  const PackLayout PL = pack_layout(1);
-  const int tiles_all = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, R = 2 * B;
+  const int rd = catre_rot_dim(o->rot_type) / 2;
+  // Small batches take the latency path (catre_small.h): the same arithmetic on fewer launches.
+  const size_t smem_d = sizeof(float) * (size_t)std::max(T * 64 + 64 + 16, TS_OB * (256 + 4 * 256));
+  const bool small = R <= SMALL_ROWS && smem_d <= 64 * 1024;
+  const float* pm = small ? ws + W.pm : nullptr;
+  auto reduce_pm = [&](float* out, int ldo, int C) {
+    hipLaunchKernelGGL(k_reduce_pm, dim3(R, (C + 255) / 256), dim3(256), 0, st, ws + W.pm, out, ldo, C, B, N, M);
+  };
   // STN3d (pointnet.py:98) on both clouds
-  if (split) {
-    {
-      ProfScope ps(CATRE_K_STN3D, st);
-#define LAUNCH_(RS)                                                                                                \
-  hipLaunchKernelGGL(k_stn3d_split<RS>, dim3(tiles_all * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
-                     prm[CATRE_P_STN_CONV1_B], pkb(packed, PL.sp_stn_c2), prm[CATRE_P_STN_CONV2_B],                 \
-                     pkb(packed, PL.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
-      RS_DISPATCH(row_split(tiles_all), LAUNCH_)
-#undef LAUNCH_
-    }
-    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
-    if ((rc = check_launch())) return rc;
-  } else if ((rc = catre_stn3d_pool(pts, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M, stream))) {
-    return rc;
-  }
-  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
+  launch_stn3d(pts, prm, packed, ws, W, B, N, M, split, st);
+  if (!small) reduce_pm(ws + W.pool, 1024, 1024);
+  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, R, st, pm, B, N, M)))
     return rc;
   const float* t64 = nullptr;
   if (o->feature_transform) {  // STNkd (pointnet.py:105-106)
-    if (split) {
-      {
-        ProfScope ps(CATRE_K_STNKD, st);
-#define LAUNCH_(RS)                                                                                                  \
-  hipLaunchKernelGGL(k_stnkd_split<RS>, dim3(tiles_all * RS), dim3(256), 0, st, *pts, ws + W.trans3,                  \
-                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pkb(packed, PL.sp_fstn_c1), prm[CATRE_P_FSTN_CONV1_B], \
-                     pkb(packed, PL.sp_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, PL.sp_fstn_c3),               \
-                     prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
-        RS_DISPATCH(row_split(tiles_all), LAUNCH_)
-#undef LAUNCH_
-      }
-      hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
-      if ((rc = check_launch())) return rc;
-    } else if ((rc = catre_stnkd_pool(pts, ws + W.trans3, prm, packed, ws + W.pool, workspace, ws_bytes, B, N, M,
-                                      stream))) {
-      return rc;
-    }
-    if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
+    launch_stnkd(pts, ws + W.trans3, prm, packed, ws, W, B, N, M, split, st);
+    if (!small) reduce_pm(ws + W.pool, 1024, 1024);
+    if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, R, st, pm, B, N,
+                          M)))
       return rc;
     t64 = ws + W.trans64;
   }
-  if (split) {
-    {
-      ProfScope ps(CATRE_K_TRUNK, st);
-#define LAUNCH_(RS)                                                                                             \
-  hipLaunchKernelGGL(k_trunk_split<RS>, dim3(tiles_all * RS), dim3(512), 0, st, *pts, ws + W.trans3, t64,        \
-                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, PL.c2), prm[CATRE_P_CONV2_B],       \
-                     pkb(packed, PL.sp_c3), prm[CATRE_P_CONV3_B], pkb(packed, PL.sp_c4), prm[CATRE_P_CONV4_B],   \
-                     ws + W.pm, ws + W.pointfeat, B, N, M, g_trunk_trace)
-      RS_DISPATCH(row_split(tiles_all), LAUNCH_)
-#undef LAUNCH_
-    }
-    hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
+  launch_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.pointfeat, ws, W, B, N, M, split, st);
+  if (!small) {
+    reduce_pm(ws + W.gfeat, PMW, PMW);
     if ((rc = check_launch())) return rc;
-  } else if ((rc = catre_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.gfeat, ws + W.pointfeat, workspace, ws_bytes,
-                               B, N, M, stream))) {
-    return rc;
+    if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, workspace, ws_bytes,
+                            B, stream)))
+      return rc;
+    if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split, rd)))
+      return rc;
+    return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                             scale_out, B, stream);
   }
-  if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, workspace, ws_bytes, B,
-                          stream)))
-    return rc;
-  if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split,
-                          catre_rot_dim(o->rot_type) / 2)))
-    return rc;
-  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
-                           scale_out, B, stream);
+  // ---- latency path after the trunk: 5 launches (catre_small.h) ----
+  {
+    const int expect = PMW * (o->with_kps_feature ? 2 : 1) + (o->with_init_scale ? 3 : 0) + (o->with_init_trans ? 3 : 0);
+    if (o->ts_in_dim != expect) return CATRE_ERR_BAD_ARG;
+    if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
+    if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
+  }
+  const PackLayout L = pack_layout(o->ts_in_dim);
+  float* bias0 = ws + W.bias0;
+  float* Gc = ws + W.y1;  // the moment buffers borrow y1 (see rot_head_impl)
+  float* s1c = Gc + (size_t)2 * B * PF_NG * 4096;
+  float* shc = s1c + (size_t)2 * B * PF_NG * 64;
+  const int groups = (B + TS_OB - 1) / TS_OB;
+  {
+    HeadsAArgs A;
+    A.pointfeat = ws + W.pointfeat;
+    A.Gc = Gc;
+    A.s1c = s1c;
+    A.shc = shc;
+    A.pose = init_pose;
+    A.scale = init_scale;
+    A.W0T = packed + L.ts_w0t;
+    A.tspart = ws + W.tspart;
+    A.in_dim = o->ts_in_dim;
+    A.with_kps = o->with_kps_feature;
+    A.with_scale = o->with_init_scale;
+    A.with_trans = o->with_init_trans;
+    A.w0x = prm[CATRE_P_ROTX_L0_W];
+    A.b0x = prm[CATRE_P_ROTX_L0_W + 1];
+    A.w0y = prm[CATRE_P_ROTY_L0_W];
+    A.b0y = prm[CATRE_P_ROTY_L0_W + 1];
+    A.bias0 = bias0;
+    A.pm = ws + W.pm;
+    A.B = B;
+    A.N = N;
+    A.M = M;
+    A.n_mom = R * PF_NG;
+    A.n_ts = groups * TS_KS;
+    ProfScope ps(CATRE_K_ROT_L0_STATS, st);
+    hipLaunchKernelGGL(k_heads_a, dim3(A.n_mom + A.n_ts + 2 * 8), dim3(64 * LIN_WAVES), 0, st, A);
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
+                       prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
+                       prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
+  }
+  {
+    ProfScope ps(CATRE_K_ROT_L1, st);
+    if (split)
+      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, ws + W.pointfeat, pkb(packed, L.sp_rot_l0[0]),
+                         pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
+                         prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
+                         g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
+    else {
+#define LAUNCH_ROT_L1(RS)                                                                                               \
+  hipLaunchKernelGGL(k_rot_l1<RS>, dim3(B * T * RS), dim3(256), 0, st, ws + W.pointfeat, pk4(packed, L.rot_l0[0]),        \
+                     pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),         \
+                     prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,                     \
+                     g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr)
+      RS_DISPATCH(row_split(B * T), LAUNCH_ROT_L1)
+#undef LAUNCH_ROT_L1
+    }
+  }
+  {
+    HeadsDArgs D;
+    D.y1 = ws + W.y1;
+    D.gn1 = ws + W.gn1;
+    D.gam1x = prm[CATRE_P_ROTX_GN1_W];
+    D.bet1x = prm[CATRE_P_ROTX_GN1_B];
+    D.gam1y = prm[CATRE_P_ROTY_GN1_W];
+    D.bet1y = prm[CATRE_P_ROTY_GN1_B];
+    D.neckx = prm[CATRE_P_ROTX_NECK_W];
+    D.necky = prm[CATRE_P_ROTY_NECK_W];
+    D.wpx = prm[CATRE_P_ROTX_CONVP_W];
+    D.wpy = prm[CATRE_P_ROTY_CONVP_W];
+    D.rpart = ws + W.rpart;
+    D.B = B;
+    D.N = N;
+    D.M = M;
+    D.rd = rd;
+    D.n_rot = B * T * 2;
+    D.ts = ts_head_args(ws + W.tspart, prm, packed, L, ws + W.dt, ws + W.ds, B);
+    ProfScope ps(CATRE_K_ROT_OUT, st);
+    hipLaunchKernelGGL(k_heads_d, dim3(D.n_rot + groups), dim3(1024), smem_d, st, D);
+  }
+  hipLaunchKernelGGL(k_finish_update, dim3((B + 7) / 8), dim3(64), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
+                     prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B], T, rd,
+                     ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
+  return check_launch();
 }
 
 int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,

@@ -240,24 +240,24 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 }
 
 // GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
-__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1stat,
-                                                 const float* __restrict__ gam1x, const float* __restrict__ bet1x,
-                                                 const float* __restrict__ gam1y, const float* __restrict__ bet1y,
-                                                 const float* __restrict__ neckx, const float* __restrict__ necky,
-                                                 const float* __restrict__ wpx, const float* __restrict__ wpy,
-                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M,
-                                                 int rd /* neck rows: RotHead.rot_dim <= 3 */) {
-  __shared__ float red[4][4];
+// Body for tile bx, head hd.  stat_oh: the 32 (mean, rstd) pairs of this (object, head) - k_gn_finalize's output or an
+// LDS copy (k_heads_d, catre_small.h).
+__device__ __forceinline__ void rot_out_body(const float* __restrict__ y1, const float* stat_oh,
+                                             const float* __restrict__ gam1x, const float* __restrict__ bet1x,
+                                             const float* __restrict__ gam1y, const float* __restrict__ bet1y,
+                                             const float* __restrict__ neckx, const float* __restrict__ necky,
+                                             const float* __restrict__ wpx, const float* __restrict__ wpy,
+                                             float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M,
+                                             int rd /* neck rows: RotHead.rot_dim <= 3 */, const RotTile& rt, int hd,
+                                             float (*red)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
-  const int hd = blockIdx.y;
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
   const int c0 = lane * 4;  // this lane's 4 channels
   const float* gam = hd ? gam1y : gam1x;
   const float* bet = hd ? bet1y : bet1x;
   const float* neck = hd ? necky : neckx;
   const float* wp = hd ? wpy : wpx;
-  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
+  const float* st = stat_oh + (c0 >> 3) * 2;
   const float mean = st[0], rstd = st[1];
   f32x4 sc, sh;
   float nk[3][4];
@@ -296,4 +296,18 @@ __global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, c
   if (tid < 3) {
     rpart[(((size_t)rt.obj * 2 + hd) * T + rt.t) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
   }
+}
+
+__global__ __launch_bounds__(256) void k_rot_out(const float* __restrict__ y1, const float* __restrict__ gn1stat,
+                                                 const float* __restrict__ gam1x, const float* __restrict__ bet1x,
+                                                 const float* __restrict__ gam1y, const float* __restrict__ bet1y,
+                                                 const float* __restrict__ neckx, const float* __restrict__ necky,
+                                                 const float* __restrict__ wpx, const float* __restrict__ wpy,
+                                                 float* __restrict__ rpart /*[B][2][T][4]*/, int B, int N, int M,
+                                                 int rd /* neck rows: RotHead.rot_dim <= 3 */) {
+  __shared__ float red[4][4];
+  const int hd = blockIdx.y;
+  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
+  rot_out_body(y1, gn1stat + ((size_t)rt.obj * 2 + hd) * 64, gam1x, bet1x, gam1y, bet1y, neckx, necky, wpx, wpy, rpart, B,
+               N, M, rd, rt, hd, red);
 }

@@ -1,0 +1,192 @@
+// catre_small.h - the latency path of small batches (included by catre_kernels.hip after catre_gram.h).
+//
+// The reference's evaluator refines one image at a time: a handful of objects per call (catre_evaluator.py:292-311).
+// There a refine iteration is a chain of ~22 dependent launches of 4-18 us each - what it costs is the NUMBER of
+// launches on the critical path, not their work.  For 2B <= SMALL_ROWS clouds catre_refine_iter therefore runs
+// 14 launches instead of 22, every one the SAME arithmetic in the same order as the large-batch kernels (the bodies
+// are shared device functions), so an object's result still does not depend on the batch it came in, bit for bit:
+//
+//   * no k_reduce_pm launches: a consumer of a cloud's pooled feature takes the maximum over the cloud's tile partials
+//     itself while it gathers its input (max is exact) - fc1 of both STN tails (k_linear_pm), the ts head's layer 0 and
+//     the rot heads' global halves (k_heads_a);
+//   * k_heads_a: what only needs the trunk's outputs runs side by side in ONE launch, on disjoint workgroups -
+//     pointfeat moments | ts-head layer 0 | both rot heads' global halves;
+//   * k_heads_d: GN1 finalize + k_rot_out (every workgroup merges its (object, head)'s tile partials from LDS first: at
+//     B <= 8 that is cheaper than a launch; at B = 256 it was not, see catre_rot.h) | the rest of the ts head, whose
+//     result is not needed before the pose update;
+//   * k_finish_update: the rot heads' tile sums (k_rot_finish) and the pose update in one launch.
+#pragma once
+
+#define SMALL_ROWS 16            // clouds (2B) up to which the latency path is taken
+#define XS_LD (1024 + 4)         // LDS pitch of a staged pooled-feature row
+#define LINPM_SMEM (LIN_WAVES * 16 * 64 + SMALL_ROWS * XS_LD)  // floats: k_linear partial blocks + staged X rows
+
+// xs[r][0..1023] = max over the tiles of cloud r of pm[tile][c]  (r < R <= SMALL_ROWS), all threads of the workgroup
+__device__ __forceinline__ void stage_cloud_max(const float* __restrict__ pm, float* xs, int R, int B, int N, int M,
+                                                int nthreads) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
+  for (int idx = threadIdx.x; idx < R * 256; idx += nthreads) {
+    const int r = idx >> 8, c4 = idx & 255;
+    const int nt = r < B ? TN : TM;
+    const size_t row0 = r < B ? (size_t)r * TN : (size_t)B * TN + (size_t)(r - B) * TM;
+    const f32x4* src = reinterpret_cast<const f32x4*>(pm + row0 * PMW) + c4;
+    f32x4 m = src[0];
+    int t = 1;
+    for (; t + 7 < nt; t += 8) {  // eight tile rows in flight
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(t + u) * (PMW / 4)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[u][q]);
+    }
+    for (; t < nt; ++t) {
+      const f32x4 v = src[(size_t)t * (PMW / 4)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
+    }
+    *reinterpret_cast<f32x4*>(xs + r * XS_LD + c4 * 4) = m;
+  }
+}
+
+// y = act(max_tiles(pm) W^T + b): k_linear on the pooled feature of R <= SMALL_ROWS clouds without the k_reduce_pm launch
+// in front of it.  grid (1, J / 32, 1 or 2); gridDim.z == 2 as in k_linear.
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_linear_pm(const float* __restrict__ pm, int B, int N, int M,
+                                                               const float* __restrict__ W, int ldw,
+                                                               const float* __restrict__ bias, float* __restrict__ Y,
+                                                               int ldy, int R, int J, int relu,
+                                                               const float* __restrict__ W_z1,
+                                                               const float* __restrict__ bias_z1,
+                                                               float* __restrict__ Y_z1) {
+  __shared__ __attribute__((aligned(16))) float smem[LINPM_SMEM];
+  if (blockIdx.z == 1) {
+    W = W_z1;
+    bias = bias_z1;
+    Y = Y_z1;
+  }
+  float* xs = smem + LIN_WAVES * 16 * 64;
+  stage_cloud_max(pm, xs, R, B, N, M, 64 * LIN_WAVES);
+  __syncthreads();
+  linear_body(xs, XS_LD, W, ldw, bias, Y, ldy, R, J, 1024, relu, 0, 0, blockIdx.y,
+              reinterpret_cast<float(*)[16][64]>(smem));
+}
+
+// ---- after the trunk, launch 1 of 5 ----------------------------------------------------------------------------------
+struct HeadsAArgs {
+  // pointfeat moments (k_pf_moments)
+  const float* pointfeat;
+  float *Gc, *s1c, *shc;
+  // ts-head layer 0 (k_ts_l0)
+  const float *pose, *scale, *W0T;
+  float* tspart;
+  int in_dim, with_kps, with_scale, with_trans;
+  // rot heads' global halves (k_linear, gridDim.z == 2)
+  const float *w0x, *b0x, *w0y, *b0y;
+  float* bias0;
+  const float* pm;
+  int B, N, M;
+  int n_mom, n_ts;  // workgroups of the first two roles
+};
+
+#define HEADS_A_SMEM (LINPM_SMEM > PF_MOM_SMEM ? LINPM_SMEM : PF_MOM_SMEM)
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_heads_a(HeadsAArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[HEADS_A_SMEM];
+  int j = blockIdx.x;
+  if (j < A.n_mom) {
+    if (threadIdx.x >= 256) return;  // whole waves leave: the role's barriers count the surviving ones
+    pf_moments_body(A.pointfeat, A.Gc, A.s1c, A.shc, A.B, A.N, A.M, j / PF_NG, j % PF_NG, PF_NG, smem);
+    return;
+  }
+  j -= A.n_mom;
+  if (j < A.n_ts) {
+    if (threadIdx.x >= 256) return;
+    ts_l0_body(nullptr, A.pm, A.pose, A.scale, A.W0T, A.tspart, A.B, A.N, A.M, A.in_dim, A.with_kps, A.with_scale,
+               A.with_trans, j / TS_KS, j % TS_KS, smem);
+    return;
+  }
+  j -= A.n_ts;  // (head z, column block by) of bias0[z][cloud][:] = W0_z[:, :1024] g_cloud + b0_z
+  const int z = j >> 3, by = j & 7, R = 2 * A.B;
+  float* xs = smem + LIN_WAVES * 16 * 64;
+  stage_cloud_max(A.pm, xs, R, A.B, A.N, A.M, 64 * LIN_WAVES);
+  __syncthreads();
+  linear_body(xs, XS_LD, z ? A.w0y : A.w0x, PMW, z ? A.b0y : A.b0x, A.bias0 + (size_t)z * R * 256, 256, R, 256, 1024, 0, 0, 0,
+              by, reinterpret_cast<float(*)[16][64]>(smem));
+}
+
+// ---- after k_rot_l1: GN1 finalize + k_rot_out | rest of the ts head ---------------------------------------------------
+struct HeadsDArgs {
+  const float *y1, *gn1;
+  const float *gam1x, *bet1x, *gam1y, *bet1y, *neckx, *necky, *wpx, *wpy;
+  float* rpart;
+  int B, N, M, rd;
+  int n_rot;  // workgroups of the rot role: B * T * 2
+  TsHeadArgs ts;
+};
+
+__global__ __launch_bounds__(1024) void k_heads_d(HeadsDArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // max(T * 64 + 64 + 16, TS_OB * 1280) floats
+  const int j = blockIdx.x;
+  if (j >= A.n_rot) {
+    ts_head_body(A.ts, j - A.n_rot, sm);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  const int TN = (A.N + TP - 1) / TP, T = TN + (A.M + TP - 1) / TP;
+  const int hd = j & 1;
+  const RotTile rt = rot_tile(j >> 1, A.B, A.N, A.M);
+  float* sp = sm;              // [T][64] the (object, head)'s tile partials
+  float* stat = sm + T * 64;   // [32][2]
+  float(*red)[4] = reinterpret_cast<float(*)[4]>(stat + 64);
+  const float* src = A.gn1 + ((size_t)rt.obj * 2 + hd) * T * 64;
+  for (int i = threadIdx.x; i < T * 64; i += 256) sp[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x < 32) {  // k_gn_finalize's merge, same order
+    float mean, rstd;
+    merge_gn(sp, threadIdx.x, T, TN, A.N, A.M, mean, rstd);
+    stat[threadIdx.x * 2] = mean;
+    stat[threadIdx.x * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  rot_out_body(A.y1, stat, A.gam1x, A.bet1x, A.gam1y, A.bet1y, A.neckx, A.necky, A.wpx, A.wpy, A.rpart, A.B, A.N, A.M, A.rd,
+               rt, hd, red);
+}
+
+// ---- k_rot_finish + k_pose_update: 8 objects per 64-thread workgroup --------------------------------------------------
+__global__ __launch_bounds__(64) void k_finish_update(const float* __restrict__ rpart, const float* __restrict__ neckbx,
+                                                      const float* __restrict__ neckby, const float* __restrict__ sumwp,
+                                                      const float* __restrict__ cpbx, const float* __restrict__ cpby,
+                                                      int T, int rd, const float* __restrict__ dtr,
+                                                      const float* __restrict__ dsr, const float* __restrict__ pose0,
+                                                      const float* __restrict__ scale0,
+                                                      const float* __restrict__ mean_scales, const float* __restrict__ Ks,
+                                                      catre_opts o, float* __restrict__ pose_out,
+                                                      float* __restrict__ scale_out, int B) {
+  __shared__ float rot[8][8];
+  const int tid = threadIdx.x, nv = 2 * rd;
+  if (tid < 8 * nv) {
+    const int ob = tid / nv, i = tid % nv, b = blockIdx.x * 8 + ob;
+    if (b < B) {  // k_rot_finish: the tile sums in tile order, then neck bias and conv_p bias
+      const int hd = i / rd, c = i % rd;
+      const float* rp = rpart + ((size_t)b * 2 + hd) * T * 4 + c;
+      float s = 0.f;
+      int t = 0;
+      for (; t + 8 <= T; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rp[(t + u) * 4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; t < T; ++t) s += rp[t * 4];
+      const float nb = (hd ? neckby : neckbx)[c];
+      const float* cpb = hd ? cpby : cpbx;
+      s = fmaf(nb, sumwp[hd], s);
+      if (cpb) s += cpb[0];
+      rot[ob][i] = s;
+    }
+  }
+  __syncthreads();
+  const int b = blockIdx.x * 8 + tid;
+  if (tid < 8 && b < B) pose_update_obj(rot[tid], dtr, dsr, pose0, scale0, mean_scales, Ks, o, pose_out, scale_out, b);
+}

@@ -261,21 +261,26 @@ def test_full_size_properties():
 @pytest.mark.parametrize("dtype", ["fp32", "split"])
 def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtype):
     """Small grids run 2 or 4 workgroups per 64-point tile of the encoder kernels (each sweeps a share of the output
-    channels, csrc row_split): B=1 -> 4, B=3 -> 2, B=5 -> 1 at N=M=1024.  An object's result must not depend on it -
-    bit for bit."""
+    channels, csrc row_split): B=1 -> 4, B=3 -> 2, B>=5 -> 1 at N=M=1024; and batches of up to 8 objects take the latency
+    path of csrc/catre_small.h (14 launches per iteration instead of 22: pooled features taken from the tile partials by
+    their consumers, independent stages side by side in one launch).  An object's result must not depend on any of it -
+    bit for bit: objects of a B=12 batch (the plain launch chain) equal the same objects refined in batches of 1, 3, 8."""
     from catre_amd import synth
     from catre_amd.config import default_cfg
 
     cfg = default_cfg()
     model, _ = build_model(cfg, 0)
     model.cfg.MODEL.CATRE.COMPUTE_DTYPE = dtype
-    batch = to_dev(synth.make_inputs(5, 1024, 1024, seed=23))
+    batch = to_dev(synth.make_inputs(12, 1024, 1024, seed=23))
     ref = model.refine(batch, n_iter=2)
-    for nb in (1, 3):
+    for nb in (1, 3, 8):
         sub = {k: v[:nb].contiguous() for k, v in batch.items()}
         out = model.refine(sub, n_iter=2)
         for key in ("pose_1", "pose_2", "scale_2"):
             assert torch.equal(out[key], ref[key][:nb]), (dtype, nb, key)
+    sub = {k: v[9:12].contiguous() for k, v in batch.items()}
+    out = model.refine(sub, n_iter=2)
+    assert torch.equal(out["pose_2"], ref["pose_2"][9:12]) and torch.equal(out["scale_2"], ref["scale_2"][9:12])
 
 
 def test_batches_past_2_to_the_31_elements_index_correctly():
