@@ -141,6 +141,28 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
   __shared__ float qpart[2][4][64];
   const int obj = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
   const int cq = tid & 63, rq = tid >> 6, ch = blockIdx.z * 64 + cq;
+  // Everything that does not depend on LDS is requested first (the kernel is a chain of L2 round trips at small batches:
+  // with these loads behind the barriers below, B = 1 spent 5 of them back to back)
+  const float* wrow = (hd ? w0y : w0x) + (size_t)ch * ldw + coloff;
+  float w[64];
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + k4 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[k4 * 4 + q] = v[q];
+  }
+  // the 16 entries of w that multiply this thread's rows, loaded together (indexing w[] with the runtime row would put
+  // the array in scratch; loading them one by one inside the loop serialises 32 L2 round trips)
+  float wr[16];
+#pragma unroll
+  for (int u4 = 0; u4 < 4; ++u4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + rq * 16 + u4 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[u4 * 4 + q] = v[q];
+  }
+  const float b0v[2] = {bias0[((size_t)hd * 2 * B + obj) * 256 + ch], bias0[((size_t)hd * 2 * B + B + obj) * 256 + ch]};
+  const float gam = (hd ? gamy : gamx)[ch], bet = (hd ? bety : betx)[ch];
+  __builtin_amdgcn_sched_barrier(0);
   if (tid < 128) {
     const int cl = tid >> 6, k = tid & 63;
     const size_t cloud = cl ? (size_t)B + obj : obj;
@@ -169,23 +191,6 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
       for (int q = 0; q < 4; ++q) g[q] = fmaf(-sr, s1[cl][c0 + q], g[q]);
       *reinterpret_cast<f32x4*>(&S[cl][e4 * 4]) = g;
     }
-  }
-  const float* wrow = (hd ? w0y : w0x) + (size_t)ch * ldw + coloff;
-  float w[64];
-#pragma unroll
-  for (int k4 = 0; k4 < 16; ++k4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + k4 * 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[k4 * 4 + q] = v[q];
-  }
-  // the 16 entries of w that multiply this thread's rows, loaded together (indexing w[] with the runtime row would put
-  // the array in scratch; loading them one by one inside the loop serialises 32 L2 round trips)
-  float wr[16];
-#pragma unroll
-  for (int u4 = 0; u4 < 4; ++u4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + rq * 16 + u4 * 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wr[u4 * 4 + q] = v[q];
   }
   __syncthreads();
 #pragma unroll
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
     float dotm = 0.f;
 #pragma unroll
     for (int k = 0; k < 64; ++k) dotm = fmaf(w[k], mu[cl][k], dotm);
-    a[cl] = dotm + bias0[((size_t)hd * 2 * B + (cl ? B + obj : obj)) * 256 + ch];
+    a[cl] = dotm + b0v[cl];
     v2[cl] = fmaxf((qpart[cl][0][cq] + qpart[cl][1][cq]) + (qpart[cl][2][cq] + qpart[cl][3][cq]), 0.f);
   }
   // group = 8 consecutive channels = 8 consecutive lanes
@@ -233,11 +238,11 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
   m2 += __shfl_xor(m2, 2);
   m2 += __shfl_xor(m2, 4);
   const float rstd = 1.0f / sqrtf(m2 / ntot + 1e-5f);
-  const float sc = rstd * (hd ? gamy : gamx)[ch];
-  const float sh0 = (hd ? bety : betx)[ch] - gmean * sc;
+  const float sc = rstd * gam;
+  const float sh0 = bet - gmean * sc;
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl) {
-    const float b0 = bias0[((size_t)hd * 2 * B + (cl ? B + obj : obj)) * 256 + ch];
+    const float b0 = b0v[cl];
     float* o = aff + ((((size_t)obj * 2 + hd) * 2 + cl) * 2) * 256;
     o[ch] = sc;
     o[256 + ch] = fmaf(b0, sc, sh0);

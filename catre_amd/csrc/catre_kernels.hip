@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   if (SAVE) save_tile_rows<64, 256, false>(a1, LD64, sv.s1 + row0 * 64, tid);
   // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks (RS = 1); RS workgroups
   // per tile: 8/RS m-blocks per wave from mb0 in one pass (see k_trunk)
-  constexpr int MB3 = RS == 4 ? 2 : 4;
+  constexpr int MB3 = RS == 8 ? 1 : RS == 4 ? 2 : 4;
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
-  GemmPipe<MB3, 2, true, false, 16, 2, 1> g3a, g3b;
+  GemmPipe<MB3, 2, true, false, 16, RS == 8 ? 3 : 2, 1> g3a, g3b;
   float bl[2][MB3];
   g3a.prefetch(wp3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
   load_bias_lane<MB3>(bl[0], b3, mb0 * 32, lane);
@@ -330,9 +330,9 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
   if (SAVE) save_tile_rows<64, 256, false>(f1, LD64, sv.s1 + row0 * 64, tid);
-  constexpr int MB3 = RS == 4 ? 2 : 4;
+  constexpr int MB3 = RS == 8 ? 1 : RS == 4 ? 2 : 4;
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
-  GemmPipe<MB3, 2, true, false, 16, 2, 1> g3a, g3b;
+  GemmPipe<MB3, 2, true, false, 16, RS == 8 ? 3 : 2, 1> g3a, g3b;
   float bl[2][MB3];
   g3a.prefetch(wpf3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
   load_bias_lane<MB3>(bl[0], bf3, mb0 * 32, lane);
@@ -505,9 +505,11 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
   if (SAVE) save_tile_rows<128, 512, true>(a2, 128, sv.s3 + trow0 * 128, tid);
   // conv4 512->1024: wave owns MB4 m-blocks from mb0 (RS = 1: out channels [wave*128, +128)); first weight chunks +
   // bias requested now
-  constexpr int MB4 = 4 / RS;
-  const int mb0 = part * (32 / RS) + wave * MB4;
-  GemmPipe<MB4, 2, true, true, 64, RS == 1 ? 2 : 3, 1> g4;
+  // RS = 8 (a single object): four m-blocks per workgroup, wave -> (m-block wave / 2, point block wave % 2); the two point
+  // blocks' maxima of a channel meet in LDS before the store (max is exact: same result)
+  constexpr int MB4 = RS == 8 ? 1 : 4 / RS, NB4 = RS == 8 ? 1 : 2;
+  const int mb0 = RS == 8 ? part * 4 + (wave >> 1) : part * (32 / RS) + wave * MB4;
+  GemmPipe<MB4, NB4, true, true, 64, RS == 1 ? 2 : 3, 1> g4;
   g4.prefetch(wp4 + ((size_t)mb0 * 64) * 64 + lane, 64 * 64);
   float bl4[MB4];
   load_bias_lane<MB4>(bl4, b4, mb0 * 32, lane);
@@ -533,16 +535,28 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
     if (part == 0 && tid < 64) pm[(size_t)tile * PMW + 1024 + tid] = pf_max;
   }
   if (SAVE) save_tile_rows<512, 512, true>(a3, 512, sv.s4 + trow0 * 512, tid);
-  f32x16 acc4[MB4][2];
+  f32x16 acc4[MB4][NB4];
 #pragma unroll
-  for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
-  g4.run(acc4, a3, 512, lane);
+  for (int mb = 0; mb < MB4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB4; ++nb) acc4[mb][nb] = zero16();
+  g4.run(acc4, a3 + (RS == 8 ? (wave & 1) * 32 * 512 : 0), 512, lane);
   TRUNK_STAMP(6);
-  if (SAVE)
+  if constexpr (RS == 8) {
+    float m = acc4[0][0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc4[0][0][r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float* xch = a2 + (wave >> 1) * 32;  // a2 is dead since the barrier after conv3
+    if ((wave & 1) && lane < 32) xch[lane] = m;
+    __syncthreads();
+    if (!(wave & 1) && lane < 32) pm[(size_t)tile * PMW + mb0 * 32 + lane] = fmaxf(m, xch[lane]) + bl4[0];
+  } else if constexpr (SAVE) {
     argmax_tile_store<MB4, 2>(acc4, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl4,
                               (int)trow0, lane);
-  else
+  } else {
     max_tile_store_pre<MB4, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
+  }
   TRUNK_STAMP(7);
 #undef TRUNK_STAMP
 }
@@ -578,9 +592,13 @@ __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm,
 #define LIN_WAVES 8
 // The body of k_linear for output block (bx, by): X is a global matrix or an LDS staging buffer (k_linear_pm and
 // k_heads_a, catre_small.h) - the same fragment addressing, the same MFMA sequence, the same bits either way.
+// `stage()` runs after the first trip's weight fragments have been requested and before X is read: the LDS-staged callers
+// fill X there (+ barrier), so that their weight round trip overlaps the staging instead of following it.
+template <class StageF>
 __device__ __forceinline__ void linear_body(const float* X, int ldx, const float* __restrict__ W, int ldw,
                                             const float* __restrict__ bias, float* __restrict__ Y, int ldy, int R, int J,
-                                            int K, int relu, int iden_k, int bx, int by, float (*part)[16][64]) {
+                                            int K, int relu, int iden_k, int bx, int by, float (*part)[16][64],
+                                            StageF stage) {
   // 8 waves split K (interleaved 8-wide chunks), each with up to 8 chunk pairs in flight - the kernel is a chain of
   // L2 round trips, so the trip count (K/8/8/8 = 2 for K = 1024) is what sets its time; partial 32x32 blocks are
   // summed through LDS in wave order (deterministic).
@@ -592,12 +610,20 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
   f32x16 acc = zero16();
   const int nkc = K / 8;
   int kc = wave;
+  f32x4 b[8];
+  const bool first = kc + 7 * LIN_WAVES < nkc;
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = wb[(kc + LIN_WAVES * u) * 2];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  stage();
   for (; kc + 7 * LIN_WAVES < nkc; kc += 8 * LIN_WAVES) {  // 8 chunks of this wave per trip
-    f32x4 a[8], b[8];
+    f32x4 a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       a[u] = xa[(kc + LIN_WAVES * u) * 2];
-      b[u] = wb[(kc + LIN_WAVES * u) * 2];
+      if (kc != wave) b[u] = wb[(kc + LIN_WAVES * u) * 2];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -658,7 +684,7 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
     Y = Y_z1;
   }
   __shared__ float part[LIN_WAVES][16][64];
-  linear_body(X, ldx, W, ldw, bias, Y, ldy, R, J, K, relu, iden_k, blockIdx.x, blockIdx.y, part);
+  linear_body(X, ldx, W, ldw, bias, Y, ldy, R, J, K, relu, iden_k, blockIdx.x, blockIdx.y, part, [] {});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,10 +716,12 @@ __device__ __forceinline__ float group8_norm_gelu(float v, float gamma, float be
 // ~1100 L2 round trips (33 us for a single object); eight slices cut it to ~140 and put 8x as many CUs to work.
 #define TS_KS 8
 // max over a cloud's tile partials (what k_reduce_pm writes to gfeat): out = max_t pm[row(cloud, t)][c]
-__device__ __forceinline__ float cloud_max1(const float* __restrict__ pm, int cloud, int c, int B, int N, int M) {
+// (rpt partial rows per tile: 2 after the half-tile trunk of catre_small.h, else 1)
+__device__ __forceinline__ float cloud_max1(const float* __restrict__ pm, int cloud, int c, int B, int N, int M,
+                                            int rpt) {
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
-  const int nt = cloud < B ? TN : TM;
-  const size_t row0 = cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM;
+  const int nt = (cloud < B ? TN : TM) * rpt;
+  const size_t row0 = (cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM) * rpt;
   const float* src = pm + row0 * PMW + c;
   float m = src[0];
   int t = 1;
@@ -714,7 +742,7 @@ __device__ __forceinline__ void ts_l0_body(const float* __restrict__ gfeat, cons
                                            const float* __restrict__ pose, const float* __restrict__ scale,
                                            const float* __restrict__ W0T, float* __restrict__ part /*[B][TS_KS][256]*/,
                                            int B, int N, int M, int in_dim, int with_kps, int with_scale, int with_trans,
-                                           int bx, int ks, float* feat /*LDS [TS_OB][slice length]*/) {
+                                           int bx, int ks, float* feat /*LDS [TS_OB][slice length]*/, int rpt = 1) {
   const int tid = threadIdx.x;
   const int b0i = bx * TS_OB;
   const int k0 = (in_dim * ks) / TS_KS, k1 = (in_dim * (ks + 1)) / TS_KS, len = k1 - k0;
@@ -724,11 +752,11 @@ __device__ __forceinline__ void ts_l0_body(const float* __restrict__ gfeat, cons
       int kk = k;
       float v;
       if (kk < PMW) {
-        v = pm ? cloud_max1(pm, b, kk, B, N, M) : gfeat[(size_t)b * PMW + kk];
+        v = pm ? cloud_max1(pm, b, kk, B, N, M, rpt) : gfeat[(size_t)b * PMW + kk];
       } else {
         kk -= PMW;
         if (with_kps && kk < PMW) {
-          v = pm ? cloud_max1(pm, B + b, kk, B, N, M) : gfeat[(size_t)(B + b) * PMW + kk];
+          v = pm ? cloud_max1(pm, B + b, kk, B, N, M, rpt) : gfeat[(size_t)(B + b) * PMW + kk];
         } else {
           if (with_kps) kk -= PMW;
           if (with_scale && kk < 3) {
@@ -1158,7 +1186,7 @@ WsLayout ws_layout(int B, int N, int M) {
   L.tspart = take(b * 8 * 256);  // first: catre_ts_head finds it without knowing N, M (TS_KS = 8 layer-0 partials)
   L.xbuf = take(b * N * 3);
   L.kbuf = take(b * M * 3);
-  L.pm = take(b * T * PMW);
+  L.pm = take((2 * b <= 16 ? 2 : 1) * b * T * PMW);  // small batches: a partial row per HALF tile (k_trunk_h, catre_small.h)
   L.pool = take(2 * b * 1024);
   L.h1 = take(2 * b * 512);
   L.h2 = take(2 * b * 256);
@@ -1199,6 +1227,17 @@ inline int n_clouds(int B, int M) { return M > 0 ? 2 * B : B; }
     default: L(1);         \
   }
 inline int row_split(int tiles) { return tiles * 4 <= 256 ? 4 : tiles * 2 <= 256 ? 2 : 1; }
+// the fp32 encoder kernels also come with eight workgroups per tile (a single object: 32 tiles on 256 CUs)
+#define RS_DISPATCH8(rs, L) \
+  switch (rs) {             \
+    case 8: L(8); break;    \
+    case 4: L(4); break;    \
+    case 2: L(2); break;    \
+    default: L(1);          \
+  }
+inline int row_split8(int tiles) { return tiles * 8 <= 256 ? 8 : row_split(tiles); }
+// workgroups per HALF tile of k_trunk_h (0: too many tiles for it)
+inline int trunk_h_split(int tiles) { return tiles * 8 <= 256 ? 4 : tiles * 4 <= 256 ? 2 : tiles * 2 <= 256 ? 1 : 0; }
 
 #define REQUIRE(cond) \
   do {                \
@@ -1289,7 +1328,7 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
   hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
                      prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B],           \
                      pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
-    RS_DISPATCH(row_split(tiles), LAUNCH_)
+    RS_DISPATCH8(row_split8(tiles), LAUNCH_)
 #undef LAUNCH_
   }
 }
@@ -1312,7 +1351,7 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
   hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],                \
                      prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),    \
                      prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
-    RS_DISPATCH(row_split(tiles), LAUNCH_)
+    RS_DISPATCH8(row_split8(tiles), LAUNCH_)
 #undef LAUNCH_
   }
 }
@@ -1337,7 +1376,7 @@ void launch_trunk(const catre_points* pts, const float* trans3, const float* tra
                      prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),            \
                      prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M, \
                      g_trunk_trace)
-    RS_DISPATCH(row_split(tiles), LAUNCH_)
+    RS_DISPATCH8(row_split8(tiles), LAUNCH_)
 #undef LAUNCH_
   }
 }
@@ -1753,7 +1792,21 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       return rc;
     t64 = ws + W.trans64;
   }
-  launch_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.pointfeat, ws, W, B, N, M, split, st);
+  // a handful of objects, fp32: the trunk on HALF tiles (32 points per workgroup: half the per-tile prologue)
+  const int rsh = small && !split ? trunk_h_split(B * T) : 0;
+  if (rsh) {
+    const PackLayout L = pack_layout(1);
+    ProfScope ps(CATRE_K_TRUNK, st);
+#define LAUNCH_(RSH)                                                                                                  \
+  hipLaunchKernelGGL(k_trunk_h<RSH>, dim3(B * T * 2 * RSH), dim3(512), 0, st, *pts, (const float*)(ws + W.trans3), t64,  \
+                     prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B],               \
+                     pk4(packed, L.c3), prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm,       \
+                     ws + W.pointfeat, B, N, M)
+    RS_DISPATCH(rsh, LAUNCH_)
+#undef LAUNCH_
+  } else {
+    launch_trunk(pts, ws + W.trans3, t64, prm, packed, ws + W.pointfeat, ws, W, B, N, M, split, st);
+  }
   if (!small) {
     reduce_pm(ws + W.gfeat, PMW, PMW);
     if ((rc = check_launch())) return rc;
@@ -1801,6 +1854,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     A.B = B;
     A.N = N;
     A.M = M;
+    A.rpt = rsh ? 2 : 1;
     A.n_mom = R * PF_NG;
     A.n_ts = groups * TS_KS;
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);

@@ -23,21 +23,30 @@
 
 // xs[r][0..1023] = max over the tiles of cloud r of pm[tile][c]  (r < R <= SMALL_ROWS), all threads of the workgroup
 __device__ __forceinline__ void stage_cloud_max(const float* __restrict__ pm, float* xs, int R, int B, int N, int M,
-                                                int nthreads) {
+                                                int nthreads, int rpt = 1 /*partial rows per tile*/) {
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
   for (int idx = threadIdx.x; idx < R * 256; idx += nthreads) {
     const int r = idx >> 8, c4 = idx & 255;
-    const int nt = r < B ? TN : TM;
-    const size_t row0 = r < B ? (size_t)r * TN : (size_t)B * TN + (size_t)(r - B) * TM;
+    const int nt = (r < B ? TN : TM) * rpt;
+    const size_t row0 = (r < B ? (size_t)r * TN : (size_t)B * TN + (size_t)(r - B) * TM) * rpt;
     const f32x4* src = reinterpret_cast<const f32x4*>(pm + row0 * PMW) + c4;
     f32x4 m = src[0];
     int t = 1;
-    for (; t + 7 < nt; t += 8) {  // eight tile rows in flight
-      f32x4 v[8];
+    for (; t + 14 < nt; t += 15) {  // 15 partial rows in flight together
+      f32x4 v[15];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(t + u) * (PMW / 4)];
+      for (int u = 0; u < 15; ++u) v[u] = src[(size_t)(t + u) * (PMW / 4)];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 15; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[u][q]);
+    }
+    for (; t + 3 < nt; t += 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(t + u) * (PMW / 4)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[u][q]);
     }
@@ -66,10 +75,11 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear_pm(const float* __res
     Y = Y_z1;
   }
   float* xs = smem + LIN_WAVES * 16 * 64;
-  stage_cloud_max(pm, xs, R, B, N, M, 64 * LIN_WAVES);
-  __syncthreads();
   linear_body(xs, XS_LD, W, ldw, bias, Y, ldy, R, J, 1024, relu, 0, 0, blockIdx.y,
-              reinterpret_cast<float(*)[16][64]>(smem));
+              reinterpret_cast<float(*)[16][64]>(smem), [&] {
+                stage_cloud_max(pm, xs, R, B, N, M, 64 * LIN_WAVES);
+                __syncthreads();
+              });
 }
 
 // ---- after the trunk, launch 1 of 5 ----------------------------------------------------------------------------------
@@ -86,6 +96,7 @@ struct HeadsAArgs {
   float* bias0;
   const float* pm;
   int B, N, M;
+  int rpt;          // partial rows per tile in pm (2 after k_trunk_h)
   int n_mom, n_ts;  // workgroups of the first two roles
 };
 
@@ -102,16 +113,17 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_heads_a(HeadsAArgs A) {
   if (j < A.n_ts) {
     if (threadIdx.x >= 256) return;
     ts_l0_body(nullptr, A.pm, A.pose, A.scale, A.W0T, A.tspart, A.B, A.N, A.M, A.in_dim, A.with_kps, A.with_scale,
-               A.with_trans, j / TS_KS, j % TS_KS, smem);
+               A.with_trans, j / TS_KS, j % TS_KS, smem, A.rpt);
     return;
   }
   j -= A.n_ts;  // (head z, column block by) of bias0[z][cloud][:] = W0_z[:, :1024] g_cloud + b0_z
   const int z = j >> 3, by = j & 7, R = 2 * A.B;
   float* xs = smem + LIN_WAVES * 16 * 64;
-  stage_cloud_max(A.pm, xs, R, A.B, A.N, A.M, 64 * LIN_WAVES);
-  __syncthreads();
   linear_body(xs, XS_LD, z ? A.w0y : A.w0x, PMW, z ? A.b0y : A.b0x, A.bias0 + (size_t)z * R * 256, 256, R, 256, 1024, 0, 0, 0,
-              by, reinterpret_cast<float(*)[16][64]>(smem));
+              by, reinterpret_cast<float(*)[16][64]>(smem), [&] {
+                stage_cloud_max(A.pm, xs, R, A.B, A.N, A.M, 64 * LIN_WAVES, A.rpt);
+                __syncthreads();
+              });
 }
 
 // ---- after k_rot_l1: GN1 finalize + k_rot_out | rest of the ts head ---------------------------------------------------
@@ -189,4 +201,133 @@ __global__ __launch_bounds__(64) void k_finish_update(const float* __restrict__ 
   __syncthreads();
   const int b = blockIdx.x * 8 + tid;
   if (tid < 8 && b < B) pose_update_obj(rot[tid], dtr, dsr, pose0, scale0, mean_scales, Ks, o, pose_out, scale_out, b);
+}
+
+// ---- the trunk on HALF tiles ----------------------------------------------------------------------------------------
+// k_trunk with 32 points per workgroup: (tile, half, part) -> the conv1-conv3 prologue, which every workgroup of a tile
+// repeats, is half as long (conv3 alone is 14 us per 64-point tile), and RSH workgroups per half tile share conv4's
+// output channels.  Used while tiles * 2 * RSH <= 256 (B <= 4 at N = M = 1024).  Every output element sees the same
+// operands in the same K order as in k_trunk, the pooled maxima are maxima of the same values: same bits.  The partial
+// maxima go to pm[(tile * 2 + half)][PMW]: consumers walk two rows per tile (rpt = 2).
+#define HP 32
+template <int RSH>
+__global__ __launch_bounds__(512) void k_trunk_h(catre_points P, const float* __restrict__ trans3,
+                                                 const float* __restrict__ trans64, const float* __restrict__ Wc1,
+                                                 const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
+                                                 const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                                 const float* __restrict__ b3, const f32x4* __restrict__ wp4,
+                                                 const float* __restrict__ b4, float* __restrict__ pm,
+                                                 float* __restrict__ pointfeat, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float smem[HP * 512 + HP * 128];
+  float* h1 = smem;                          // [32][68]
+  float* t64 = smem + HP * LD64;             // [64][64]
+  float* pf = smem + HP * LD64 + 4096;       // [32][68]
+  float* scratch = smem + 2 * HP * LD64 + 4096;  // [8][64]
+  float* a3 = smem;                          // [32][512] swizzled
+  float* a2 = smem + HP * 512;               // [32][128] swizzled
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x / (2 * RSH), rem = blockIdx.x % (2 * RSH), hh = rem / RSH, part = rem % RSH;
+  const TileInfo ti = tile_info(tile, B, N, M);
+  const int valid_h = min(HP, max(ti.valid - hh * HP, 0));  // real points of this half (its other rows are duplicates)
+  const bool ft = trans64 != nullptr;
+  const int n = lane & 31, h = lane >> 5;
+
+  const int mblk2 = wave & 3;  // conv2 64->128: 4 m-blocks on waves 0-3
+  GemmPipe<1, 1, false, false, 8, 4> g2;
+  g2.prefetch(wp2 + (mblk2 * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, mblk2 * 32, lane);
+  {
+    float x, y, z;
+    load_point(P, ti, hh * HP + n, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_row<4>(x, y, z, Wc1, bc1, wave * 8 + h * 4, h1 + n * LD64);
+    if (ft) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(trans64 + (size_t)ti.cloud * 4096);
+      f32x4* dst = reinterpret_cast<f32x4*>(t64);
+      dst[tid] = src[tid];
+      dst[tid + 512] = src[tid + 512];
+    }
+  }
+  __syncthreads();
+  if (ft) {
+    if (wave < 2) {  // pointfeat[j][n] = sum_i T64[i][j] h1[i][n]: two m-blocks, one point block
+      const int mblk = wave;
+      f32x16 acc = zero16();
+      const float* xr = h1 + n * LD64 + 4 * h;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float a = t64[(kc * 8 + 4 * h + s) * 64 + mblk * 32 + n];
+          acc = mfma32(a, bx[s], acc);
+        }
+      }
+      f32x16 accs[1][1] = {{acc}};
+      store_tile_lds<1, 1, false>(accs, pf, LD64, mblk * 32, nullptr, lane);
+    }
+    __syncthreads();
+  } else {
+    pf = h1;
+  }
+  // conv3 128->512: 16 m-blocks, two per wave
+  GemmPipe<2, 1, false, true, 16, 3, 1> g3;
+  g3.prefetch(wp3 + (wave * 2 * 16) * 64 + lane, 16 * 64);
+  f32x4 bv3[2][4];
+  load_bias_quads<2>(bv3, b3, wave * 64, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  const int pf_row = tid >> 4, pf_c4 = tid & 15;
+  f32x4 pf_out = {0.f, 0.f, 0.f, 0.f};
+  float pf_max = 0.f;
+  {
+    if (pf_row < valid_h) pf_out = reinterpret_cast<const f32x4*>(pf + pf_row * LD64)[pf_c4];
+    {  // max_n pointfeat over this half: wave w reduces points [4w, 4w+4) for channel `lane`
+      const float* col = pf + (wave * 4) * LD64 + lane;
+      float m = col[0];
+#pragma unroll
+      for (int p = 1; p < 4; ++p) m = fmaxf(m, col[p * LD64]);
+      scratch[wave * 64 + lane] = m;
+      __syncthreads();
+      if (tid < 64) {
+        m = scratch[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, scratch[w * 64 + tid]);
+        pf_max = m;
+      }
+    }
+    if (wave < 4) {
+      f32x16 acc[1][1] = {{zero16()}};
+      g2.run(acc, pf, LD64, lane);
+      store_tile_lds_pre<1, 1, true, true>(acc, a2, 128, mblk2 * 32, bv2, lane);
+    }
+  }
+  __syncthreads();
+  constexpr int MB4 = 4 / RSH;
+  const int mb0 = part * (32 / RSH) + wave * MB4;
+  GemmPipe<MB4, 1, true, true, 64, 3, 1> g4;
+  g4.prefetch(wp4 + ((size_t)mb0 * 64) * 64 + lane, 64 * 64);
+  float bl4[MB4];
+  load_bias_lane<MB4>(bl4, b4, mb0 * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc3[2][1];
+    acc3[0][0] = acc3[1][0] = zero16();
+    g3.run(acc3, a2, 128, lane);
+    store_tile_lds_pre<2, 1, true, true>(acc3, a3, 512, wave * 64, bv3, lane);
+  }
+  __syncthreads();
+  float* pmrow = pm + ((size_t)tile * 2 + hh) * PMW;
+  {
+    float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0 + hh * HP) * 64
+                                            : ((size_t)B * N + (size_t)ti.obj * M + ti.p0 + hh * HP) * 64);
+    if (part == 0 && pf_row < valid_h) reinterpret_cast<f32x4*>(dstbase + pf_row * 64)[pf_c4] = pf_out;
+    if (part == 0 && tid < 64) pmrow[1024 + tid] = pf_max;
+  }
+  f32x16 acc4[MB4][1];
+#pragma unroll
+  for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = zero16();
+  g4.run(acc4, a3, 512, lane);
+  max_tile_store_pre<MB4, 1>(acc4, pmrow, mb0 * 32, bl4, false, lane);
 }

@@ -264,7 +264,7 @@ def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtyp
     channels, csrc row_split): B=1 -> 4, B=3 -> 2, B>=5 -> 1 at N=M=1024; and batches of up to 8 objects take the latency
     path of csrc/catre_small.h (14 launches per iteration instead of 22: pooled features taken from the tile partials by
     their consumers, independent stages side by side in one launch).  An object's result must not depend on any of it -
-    bit for bit: objects of a B=12 batch (the plain launch chain) equal the same objects refined in batches of 1, 3, 8."""
+    bit for bit: objects of a B=12 batch (the plain launch chain) equal the same objects refined in batches of 1, 2, 3, 8."""
     from catre_amd import synth
     from catre_amd.config import default_cfg
 
@@ -273,7 +273,7 @@ def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtyp
     model.cfg.MODEL.CATRE.COMPUTE_DTYPE = dtype
     batch = to_dev(synth.make_inputs(12, 1024, 1024, seed=23))
     ref = model.refine(batch, n_iter=2)
-    for nb in (1, 3, 8):
+    for nb in (1, 2, 3, 8):
         sub = {k: v[:nb].contiguous() for k, v in batch.items()}
         out = model.refine(sub, n_iter=2)
         for key in ("pose_1", "pose_2", "scale_2"):
