@@ -126,8 +126,15 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
   pf_moments_body(pointfeat, Gc, s1c, shc, B, N, M, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
-// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256], as k_gn0_affine.  One workgroup per (object, head,
-// 64 channels); thread = (channel, quarter of the rows of S) so that small batches still fill some of the chip.
+// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256], as k_gn0_affine.  Workgroup = object x `gridDim.y`
+// shares of the 8 (head, 64-channel block) combinations: 8 shares on small grids (one combination each: a single object
+// still gets eight CUs), one share on large ones (the object's two 64 x 64 scatter matrices are then fetched and centred
+// once instead of eight times - at B = 256 that traffic, 268 MB through L2, was the kernel's time).
+// Per combination the quadratic forms run on the matrix pipe: T = W_blk S (64 x 64 x 64 per cloud, wave = (32-channel
+// half, cloud): 64 MFMAs), then q_c = sum_j T[c][j] W[c][j] with a butterfly over the 32 column lanes.  (Round 2 first
+// did them as 16 LDS-broadcast rows x 64 FMAs per thread: 2 k ds_read_b128 per workgroup, LDS-bound, 16 us at B = 1.)
+#define GN0_SLD 96  // pitch of S in LDS: the two k rows an MFMA B-fragment reads (h = 0 / 1) land 32 banks apart
+#define GN0_WLD 66  // pitch of the staged weight block: lane (i, h) reads bank 2 i + h
 __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
                                                           const float* __restrict__ s1c, const float* __restrict__ shc,
                                                           const float* __restrict__ w0x, const float* __restrict__ w0y,
@@ -135,34 +142,14 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
                                                           const float* __restrict__ gamx, const float* __restrict__ betx,
                                                           const float* __restrict__ gamy, const float* __restrict__ bety,
                                                           float* __restrict__ aff, int B, int N, int M) {
-  __shared__ __attribute__((aligned(16))) float S[2][64 * 64];
+  __shared__ __attribute__((aligned(16))) float S[2][64 * GN0_SLD];
+  __shared__ __attribute__((aligned(16))) float Wl[64 * GN0_WLD];
   __shared__ float mu[2][64];
   __shared__ float s1[2][64];
-  __shared__ float qpart[2][4][64];
-  const int obj = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
-  const int cq = tid & 63, rq = tid >> 6, ch = blockIdx.z * 64 + cq;
-  // Everything that does not depend on LDS is requested first (the kernel is a chain of L2 round trips at small batches:
-  // with these loads behind the barriers below, B = 1 spent 5 of them back to back)
-  const float* wrow = (hd ? w0y : w0x) + (size_t)ch * ldw + coloff;
-  float w[64];
-#pragma unroll
-  for (int k4 = 0; k4 < 16; ++k4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + k4 * 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[k4 * 4 + q] = v[q];
-  }
-  // the 16 entries of w that multiply this thread's rows, loaded together (indexing w[] with the runtime row would put
-  // the array in scratch; loading them one by one inside the loop serialises 32 L2 round trips)
-  float wr[16];
-#pragma unroll
-  for (int u4 = 0; u4 < 4; ++u4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + rq * 16 + u4 * 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wr[u4 * 4 + q] = v[q];
-  }
-  const float b0v[2] = {bias0[((size_t)hd * 2 * B + obj) * 256 + ch], bias0[((size_t)hd * 2 * B + B + obj) * 256 + ch]};
-  const float gam = (hd ? gamy : gamx)[ch], bet = (hd ? bety : betx)[ch];
-  __builtin_amdgcn_sched_barrier(0);
+  __shared__ float qv[2][64];
+  const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = 8 / gridDim.y, combo0 = blockIdx.y * per;
   if (tid < 128) {
     const int cl = tid >> 6, k = tid & 63;
     const size_t cloud = cl ? (size_t)B + obj : obj;
@@ -189,62 +176,99 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
       const float sr = s1[cl][r] * inv_n;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = fmaf(-sr, s1[cl][c0 + q], g[q]);
-      *reinterpret_cast<f32x4*>(&S[cl][e4 * 4]) = g;
+      *reinterpret_cast<f32x4*>(&S[cl][r * GN0_SLD + c0]) = g;
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int cl = 0; cl < 2; ++cl) {  // this thread's 16 rows of w^T S w
-    float quad = 0.f;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int r = rq * 16 + u;
-      const f32x4* Sr = reinterpret_cast<const f32x4*>(S[cl] + r * 64);
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;  // four independent chains (fixed association)
-#pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4) {
-        const f32x4 s4 = Sr[k4];
-        t0 = fmaf(s4[0], w[k4 * 4], t0);
-        t1 = fmaf(s4[1], w[k4 * 4 + 1], t1);
-        t2 = fmaf(s4[2], w[k4 * 4 + 2], t2);
-        t3 = fmaf(s4[3], w[k4 * 4 + 3], t3);
-      }
-      const float t = (t0 + t1) + (t2 + t3);
-      quad = fmaf(wr[u], t, quad);
-    }
-    qpart[cl][rq][cq] = quad;
-  }
-  __syncthreads();
-  if (rq != 0) return;  // wave 0 (64 channels) finishes
+  const int i = lane & 31, h = lane >> 5, cb = wave & 1, wcl = wave >> 1;
   const float nobs = (float)N, npri = (float)M, ntot = 8.f * (float)(N + M);
-  float a[2], v2[2];
+#pragma unroll 1
+  for (int combo = combo0; combo < combo0 + per; ++combo) {
+    const int hd = combo >> 2, bz = combo & 3;
+    const float* wblk = (hd ? w0y : w0x) + (size_t)(bz * 64) * ldw + coloff;
+    f32x4 wv[4];
 #pragma unroll
-  for (int cl = 0; cl < 2; ++cl) {
-    float dotm = 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = tid + 256 * u;
+      wv[u] = *reinterpret_cast<const f32x4*>(wblk + (size_t)(e4 >> 4) * ldw + (e4 & 15) * 4);
+    }
+    // the finishing wave's per-channel scalars, requested with the weights
+    const int ch = bz * 64 + lane;
+    float b0v[2] = {0.f, 0.f}, gam = 0.f, bet = 0.f;
+    if (wave == 0) {
+      b0v[0] = bias0[((size_t)hd * 2 * B + obj) * 256 + ch];
+      b0v[1] = bias0[((size_t)hd * 2 * B + B + obj) * 256 + ch];
+      gam = (hd ? gamy : gamx)[ch];
+      bet = (hd ? bety : betx)[ch];
+    }
+    __syncthreads();  // S is complete (first pass) / the previous combination is done with Wl and qv
 #pragma unroll
-    for (int k = 0; k < 64; ++k) dotm = fmaf(w[k], mu[cl][k], dotm);
-    a[cl] = dotm + b0v[cl];
-    v2[cl] = fmaxf((qpart[cl][0][cq] + qpart[cl][1][cq]) + (qpart[cl][2][cq] + qpart[cl][3][cq]), 0.f);
-  }
-  // group = 8 consecutive channels = 8 consecutive lanes
-  float gs = nobs * a[0] + npri * a[1];
-  gs += __shfl_xor(gs, 1);
-  gs += __shfl_xor(gs, 2);
-  gs += __shfl_xor(gs, 4);
-  const float gmean = gs / ntot;
-  const float d0 = a[0] - gmean, d1 = a[1] - gmean;
-  float m2 = (v2[0] + nobs * d0 * d0) + (v2[1] + npri * d1 * d1);
-  m2 += __shfl_xor(m2, 1);
-  m2 += __shfl_xor(m2, 2);
-  m2 += __shfl_xor(m2, 4);
-  const float rstd = 1.0f / sqrtf(m2 / ntot + 1e-5f);
-  const float sc = rstd * gam;
-  const float sh0 = bet - gmean * sc;
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = tid + 256 * u;
+      float* d = Wl + (e4 >> 4) * GN0_WLD + (e4 & 15) * 4;
+      d[0] = wv[u][0];
+      d[1] = wv[u][1];
+      d[2] = wv[u][2];
+      d[3] = wv[u][3];
+    }
+    __syncthreads();
+    {  // wave (cb, wcl): T = W[cb*32.., :] S_wcl as two 32 x 32 blocks, K = 64
+      f32x16 acc0 = zero16(), acc1 = zero16();
+      const float* ap = Wl + (cb * 32 + i) * GN0_WLD + h;
+      const float* bp = S[wcl] + h * GN0_SLD + i;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        const float a = ap[2 * kk];
+        acc0 = mfma32(a, bp[2 * kk * GN0_SLD], acc0);
+        acc1 = mfma32(a, bp[2 * kk * GN0_SLD + 32], acc1);
+      }
+      // q_c = sum_j T[c][j] W[c][j]: this lane's column j = i (and 32 + i) of its 16 rows, then a butterfly over i
+      float pr[16];
 #pragma unroll
-  for (int cl = 0; cl < 2; ++cl) {
-    const float b0 = b0v[cl];
-    float* o = aff + ((((size_t)obj * 2 + hd) * 2 + cl) * 2) * 256;
-    o[ch] = sc;
-    o[256 + ch] = fmaf(b0, sc, sh0);
+      for (int reg = 0; reg < 16; ++reg) {
+        const float* wr = Wl + (cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * GN0_WLD + i;
+        pr[reg] = fmaf(acc1[reg], wr[32], acc0[reg] * wr[0]);
+      }
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) pr[reg] += __shfl_xor(pr[reg], m);
+      if (i == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) qv[wcl][cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = pr[reg];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {  // 64 channels finish
+      float a[2], v2[2];
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        float dotm = 0.f;
+        const float* wrow = Wl + lane * GN0_WLD;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) dotm = fmaf(wrow[k], mu[cl][k], dotm);
+        a[cl] = dotm + b0v[cl];
+        v2[cl] = fmaxf(qv[cl][lane], 0.f);
+      }
+      // group = 8 consecutive channels = 8 consecutive lanes
+      float gs = nobs * a[0] + npri * a[1];
+      gs += __shfl_xor(gs, 1);
+      gs += __shfl_xor(gs, 2);
+      gs += __shfl_xor(gs, 4);
+      const float gmean = gs / ntot;
+      const float d0 = a[0] - gmean, d1 = a[1] - gmean;
+      float m2 = (v2[0] + nobs * d0 * d0) + (v2[1] + npri * d1 * d1);
+      m2 += __shfl_xor(m2, 1);
+      m2 += __shfl_xor(m2, 2);
+      m2 += __shfl_xor(m2, 4);
+      const float rstd = 1.0f / sqrtf(m2 / ntot + 1e-5f);
+      const float sc = rstd * gam;
+      const float sh0 = bet - gmean * sc;
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        float* o = aff + ((((size_t)obj * 2 + hd) * 2 + cl) * 2) * 256;
+        o[ch] = sc;
+        o[256 + ch] = fmaf(b0v[cl], sc, sh0);
+      }
+    }
   }
 }

@@ -1236,6 +1236,8 @@ inline int row_split(int tiles) { return tiles * 4 <= 256 ? 4 : tiles * 2 <= 256
     default: L(1);          \
   }
 inline int row_split8(int tiles) { return tiles * 8 <= 256 ? 8 : row_split(tiles); }
+// workgroups per object of k_gn0_from_moments (catre_gram.h): its 8 (head, channel block) combinations on 8 / 4 / 2 / 1
+inline int gn0_shares(int B) { return B * 8 <= 512 ? 8 : B * 4 <= 512 ? 4 : B * 2 <= 512 ? 2 : 1; }
 // workgroups per HALF tile of k_trunk_h (0: too many tiles for it)
 inline int trunk_h_split(int tiles) { return tiles * 8 <= 256 ? 4 : tiles * 4 <= 256 ? 2 : tiles * 2 <= 256 ? 1 : 0; }
 
@@ -1592,7 +1594,7 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
     // a handful of clouds: the four tile groups of a cloud on four workgroups (same partial sums, same result)
     hipLaunchKernelGGL(k_pf_moments, dim3(2 * B, 2 * B * PF_NG <= 256 ? PF_NG : 1), dim3(256), 0, st, pointfeat, Gc, s1c,
                        shc, B, N, M);
-    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, gn0_shares(B)), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
                        prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   }
@@ -1859,7 +1861,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     A.n_ts = groups * TS_KS;
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
     hipLaunchKernelGGL(k_heads_a, dim3(A.n_mom + A.n_ts + 2 * 8), dim3(64 * LIN_WAVES), 0, st, A);
-    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, 2, 4), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, gn0_shares(B)), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
                        prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   }
