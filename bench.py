@@ -393,6 +393,27 @@ def main():
                        "ms_per_step": round(dts / args.steps * 1e3, 3),
                        "max_abs_diff_vs_fp32_after_K": dev_max}
 
+    # The evaluator's operating point next to the headline (outside the timed region, rank 0 of a 1-GPU run only): one
+    # image = a handful of objects per call (catre_evaluator.py:292-311).  Object 0 of the batch alone, K refine
+    # iterations, and the check that it gets the very bits it got inside the batch of 256 (latency path).
+    small_extra = None
+    if rank == 0 and world == 1 and args.dtype == "fp32" and args.shape == "headline":
+        small_extra = {"what": "K=4 refine of 1 / 4 objects (the reference evaluator's shape: one image per call), fp32 "
+                               "kernels, whole K loop as one C call; outside the timed region", "unit": "ms per K=4 refine"}
+        for nb in (1, 4):
+            sub = {k: v[:nb].contiguous() for k, v in batch.items()}
+            for _ in range(10):
+                osm = model.refine(sub, n_iter=K_ITER)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(200):
+                osm = model.refine(sub, n_iter=K_ITER)
+            torch.cuda.synchronize(dev)
+            small_extra[f"B{nb}_ms"] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
+            small_extra[f"B{nb}_bitwise_equal_to_batch_of_256"] = bool(
+                torch.equal(osm[f"pose_{K_ITER}"], out[f"pose_{K_ITER}"][:nb])
+                and torch.equal(osm[f"scale_{K_ITER}"], out[f"scale_{K_ITER}"][:nb]))
+
     # BASELINE.json config 3 next to the headline (outside the timed region, rank 0 of a 1-GPU run only): the training
     # step of engine.py:293-355 at the same batch, fp32, a few steps - so the driver's record carries a train number too
     train_extra = None
@@ -469,6 +490,8 @@ def main():
         line["maxpool_standalone"] = maxpool
         if split_extra is not None:
             line["split_mode"] = split_extra
+        if small_extra is not None:
+            line["single_image"] = small_extra
         if train_extra is not None:
             line["train_fp32"] = train_extra
         if world == 1 and not args.no_cpu_baseline:

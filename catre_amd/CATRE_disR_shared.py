@@ -83,7 +83,7 @@ class CATRE_disR_shared(nn.Module):
         if self._rt is None:
             num_points = self.rot_head.num_points
             n = int(self.cfg.INPUT.get("NUM_PCL", num_points // 2))
-            self._rt = HipRuntime(lambda: dict(self.named_parameters()), n, num_points - n, self._opts.ts_in_dim)
+            self._rt = HipRuntime(lambda: dict(self.named_parameters()), n, num_points - n, self._opts.ts_in_dim, root=self)
         return self._rt
 
     def forward(

@@ -50,9 +50,15 @@ def opts_from_cfg(cfg, feature_transform=True):
 class HipRuntime:
     """One per model instance (and device)."""
 
-    def __init__(self, named_params, N, M, ts_in_dim):
-        """``named_params``: callable returning ``{state_dict key: tensor}`` of the LIVE parameters."""
+    def __init__(self, named_params, N, M, ts_in_dim, root=None):
+        """``named_params``: callable returning ``{state_dict key: tensor}`` of the LIVE parameters.  ``root`` (optional):
+        the module whose ``named_parameters()`` keys are the state_dict keys as they are - lets ``_live_params`` read the
+        parameters through cached ``module._parameters`` slots instead of walking the module tree on every call (the walk
+        was 60 % of a forward's host time at B=1, profiles/eval_loop_cprofile.py)."""
         self._named_params = named_params
+        self._root = root
+        self._slots = None
+        self._links = None
         self.N, self.M, self.ts_in_dim = int(N), int(M), int(ts_in_dim)
         self._fingerprint = None
         self._param_arr = None
@@ -63,8 +69,23 @@ class HipRuntime:
 
     # ------------------------------------------------------------------ weights
     def _live_params(self):
-        named = self._named_params()
-        return [named.get(k) for k in hip.PARAM_KEYS]
+        if self._root is None:
+            named = self._named_params()
+            return [named.get(k) for k in hip.PARAM_KEYS]
+        # The live Parameter objects, read through the owning modules' `_parameters` dicts: a re-assigned parameter
+        # (`m.weight = nn.Parameter(...)`) is seen because the lookup goes through the dict, a replaced sub-module
+        # because every parent -> child link of the tree is re-checked (identity) first.
+        links = self._links
+        if links is None or not all(d.get(n) is c for d, n, c in links):
+            root = self._root
+            self._links = [(parent._modules, n, c) for parent in root.modules() for n, c in parent._modules.items()
+                           if c is not None]
+            slot = {}
+            for prefix, mod in root.named_modules():
+                for pn in mod._parameters:
+                    slot[f"{prefix}.{pn}" if prefix else pn] = (mod._parameters, pn)
+            self._slots = [slot.get(k) for k in hip.PARAM_KEYS]
+        return [s[0].get(s[1]) if s is not None else None for s in self._slots]
 
     def params(self, device, sel=hip.PACK_ALL):
         """(param pointer array, packed weights) - re-packed on the current stream if stale.  ``sel``: the packs the

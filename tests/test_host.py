@@ -326,3 +326,27 @@ def test_loss_type_names_of_the_reference_are_accepted():
         cfg2.MODEL.CATRE.LOSS_CFG[field] = "huber"
         with pytest.raises(ValueError, match=msg):
             _loss_cfg_struct(cfg2)
+
+
+def test_runtime_reads_live_parameters_through_cached_slots():
+    """HipRuntime resolves the 74 parameters through cached `module._parameters` slots (no module-tree walk per forward).
+    A re-assigned Parameter and a replaced sub-module must still be seen - the packed weights are keyed on what this
+    returns."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    cfg = default_cfg(device="cpu")
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    rt = model._runtime()
+    want = dict(model.named_parameters())
+    got = rt._live_params()
+    assert len(got) == len(hip.PARAM_KEYS)
+    assert all(t is want.get(k) for k, t in zip(hip.PARAM_KEYS, got))
+    i = hip.PARAM_KEYS.index("pcl_net.conv4.weight")
+    model.pcl_net.conv4.weight = torch.nn.Parameter(torch.zeros_like(model.pcl_net.conv4.weight))
+    assert rt._live_params()[i] is model.pcl_net.conv4.weight
+    fresh = copy.deepcopy(model.ts_head)
+    model.ts_head = fresh
+    j = hip.PARAM_KEYS.index("ts_head.fc_t.weight")
+    assert rt._live_params()[j] is fresh.fc_t.weight
+    want = dict(model.named_parameters())
+    assert all(t is want.get(k) for k, t in zip(hip.PARAM_KEYS, rt._live_params()))
