@@ -1779,39 +1779,68 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) wacc[a][kb] = zero16();
   const int i = lane & 31, h = lane >> 5;
+  // staging: wave -> rows wave + 4 j (j = 0..15), lane -> float4 column, in four batches of four rows.  Two batches of
+  // (Y, A) rows are in flight while a batch is being transformed: a batch is requested when the batch two before it has
+  // been consumed, and the first batch of the NEXT tile before this tile's MFMA phases - with one wave per SIMD nothing
+  // else can run under a global round trip, so every load that is waited for right after its issue is ~2 us of idle CU.
+  f32x4 vy[2][4], va[2][4];
+  auto request_y = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      vy[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (rr + wave + 4 * (4 * bb + u)) * 64 + lane);
+  };
+  auto request_a = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      va[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + (rr + wave + 4 * (4 * bb + u)) * 64 + lane);
+  };
+  auto request = [&](int tt, int bb) {
+    request_y(tt, bb);
+    request_a(tt, bb);
+  };
+  if (t0 < t1) request_y(t0, 0);
   for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)obj * P + (size_t)t * TP;
-    // staging: wave -> rows wave + 4u, lane -> float4 column; eight rows per batch
+    request_a(t, 0);
+    request(t, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      f32x4 vy[8], va[8];
+    for (int bb = 0; bb < 4; ++bb) {
+      float d3v[4][3];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const size_t o = (r0 + wave + 4 * (8 * hb + u)) * 64 + lane;
-        vy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + o);
-        va[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + o);
+      for (int u = 0; u < 4; ++u) {
+        const float* d3 = dY3 + (r0 + wave + 4 * (4 * bb + u)) * 3;
+        d3v[u][0] = d3[0];
+        d3v[u][1] = d3[1];
+        d3v[u][2] = d3[2];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = wave + 4 * (8 * hb + u);
-        const float* d3 = dY3 + (r0 + row) * 3;
-        const float d0 = d3[0], d1 = d3[1], d2 = d3[2];
+      for (int u = 0; u < 4; ++u) {
+        const int row = wave + 4 * (4 * bb + u);
+        const float d0 = d3v[u][0], d1 = d3v[u][1], d2 = d3v[u][2];
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float xh = (vy[u][q] - mean) * rstd;
+          const float yv = vy[bb & 1][u][q];
+          const float xh = (yv - mean) * rstd;
           const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
-          const float dxh = da * gelu_grad(fmaf(vy[u][q], sc[q], sh[q])) * ga[q];
+          const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
           o[q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
           cs[q] += o[q];
         }
         *reinterpret_cast<f32x4*>(dys + row * L1B_LDY + 4 * lane) = o;
-        *reinterpret_cast<f32x4*>(as + row * L1B_LDA + 4 * lane) = va[u];
-        __builtin_amdgcn_sched_barrier(0);
+        *reinterpret_cast<f32x4*>(as + row * L1B_LDA + 4 * lane) = va[bb & 1][u];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (bb < 2) request(t, bb + 2);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    if (t + 1 < t1) request_y(t + 1, 0);  // (16 registers across the MFMA phases: the A rows too, or two batches, would spill)
+    __builtin_amdgcn_sched_barrier(0);
     {  // dA tile = dY W: m-blocks 2 wave, 2 wave + 1 of the 256 input channels, both 32-row halves
       f32x16 acc[2][2];
       acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16();
