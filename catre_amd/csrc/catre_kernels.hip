@@ -1186,7 +1186,7 @@ WsLayout ws_layout(int B, int N, int M) {
   L.tspart = take(b * 8 * 256);  // first: catre_ts_head finds it without knowing N, M (TS_KS = 8 layer-0 partials)
   L.xbuf = take(b * N * 3);
   L.kbuf = take(b * M * 3);
-  L.pm = take((2 * b <= 16 ? 2 : 1) * b * T * PMW);  // small batches: a partial row per HALF tile (k_trunk_h, catre_small.h)
+  L.pm = take((2 * b <= SMALL_ROWS ? 2 : 1) * b * T * PMW);  // small batches: a partial row per HALF tile (k_trunk_h, catre_small.h)
   L.pool = take(2 * b * 1024);
   L.h1 = take(2 * b * 512);
   L.h2 = take(2 * b * 256);

@@ -15,6 +15,8 @@ profiles/prof.sh $o/r02_kernel_stats.csv python $PWD/bench.py --steps 5 --warmup
 PROF_TRACE="$PWD/$o/r02_train_trace.csv 1500" profiles/prof.sh $o/r02_train_kernel_stats.csv python $PWD/bench.py --mode train --steps 3 --warmup 1
 python profiles/gemm_probe.py 2>/dev/null | grep '^{' > $o/r02_gemm_probe.jsonl
 profiles/prof.sh $o/r02_b1_kernel_stats.csv python $PWD/profiles/b1_profile.py 1 50
+python profiles/small_sweep.py 1 2 3 4 6 8 16 32 2>/dev/null | grep '^{' > $o/r02_small_sweep.jsonl
+python profiles/eval_loop_probe.py 1 2 4 6 2>/dev/null | grep '^{' > $o/r02_eval_loop.jsonl
 profiles/pmc.sh $o/pmc_r02 > /dev/null 2>&1
 python profiles/summarize_pmc.py $o/pmc_r02 $o/r02_pmc_summary.csv r02 > /dev/null
 rm -rf $o/pmc_r02
