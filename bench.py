@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the bounded fp32 training measurement of the default line")
+    ap.add_argument("--no-small-extra", action="store_true", help="skip the single-image (B=1 / B=4) measurement of the default line")
     ap.add_argument("--mode", choices=("refine", "train"), default="refine",
                     help="refine: the headline inference metric (default); train: configs 3/4 (fwd+loss+bwd+step)")
     ap.add_argument("--dtype", choices=("fp32", "split", "bf16"), default="fp32",
@@ -397,7 +398,7 @@ def main():
     # image = a handful of objects per call (catre_evaluator.py:292-311).  Object 0 of the batch alone, K refine
     # iterations, and the check that it gets the very bits it got inside the batch of 256 (latency path).
     small_extra = None
-    if rank == 0 and world == 1 and args.dtype == "fp32" and args.shape == "headline":
+    if rank == 0 and world == 1 and args.dtype == "fp32" and args.shape == "headline" and not args.no_small_extra:
         small_extra = {"what": "K=4 refine of 1 / 4 objects (the reference evaluator's shape: one image per call), fp32 "
                                "kernels, whole K loop as one C call; outside the timed region", "unit": "ms per K=4 refine"}
         for nb in (1, 4):

@@ -123,9 +123,17 @@ class HipRuntime:
         need = lib.catre_workspace_bytes(B, N, M)
         if need == 0:
             raise ValueError(f"bad sizes B={B} N={N} M={M}")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+        # one scratch buffer per (device, stream): calls issued on different streams (several images refined
+        # concurrently, profiles/multi_stream_probe.py) must not share intermediates; calls on one stream are ordered
+        if self._ws is None:
+            self._ws = {}
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is None and len(self._ws) >= 16:
+                self._ws.clear()  # stale streams: the caching allocator keeps the blocks alive until their work is done
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     # ------------------------------------------------------------------ drivers
     def refine_iter(self, x, tfd_kps, init_pose, init_scale, K_zoom, mean_scales, opts):
