@@ -122,3 +122,86 @@ class GraphedTrainStep:
         self.graph.replay()
         hip.bump_param_epoch()
         return self.out, self.losses
+
+
+_REFINE_INPUTS = ("pcl", "obj_kps", "obj_pose_est", "obj_scale_est", "K", "obj_mean_scales")
+
+
+class GraphedRefine:
+    """``model.refine`` for a fixed (B, N, M, K) as ONE HIP-graph replay.
+
+    The evaluator's operating point (one image = a handful of objects per call, ``catre_evaluator.py:292-311``) is a chain
+    of 14 short launches per iteration: at B=1 the K=4 loop is 0.60 ms of GPU time and 0.24 ms of host time, all of it
+    ``hipLaunchKernel`` (56 launches).  One stream hides that behind the GPU; several images refined concurrently on
+    separate streams do not - four streams saturate at 3.5 k refines/s because the HOST is busy launching
+    (``profiles/multi_stream_probe.py``).  Replaying a captured graph costs the host one packed copy of the inputs (a
+    single ``torch.cat`` into the static buffer) and one graph launch:
+
+        g = GraphedRefine(model, example_batch)          # warm-up + capture on a side stream
+        out = g(batch)                                   # pose_0..pose_K / scale_0..scale_K, same keys as model.refine
+
+    The outputs are static tensors that the next call overwrites (``clone()`` what must survive).  Shapes and ``n_iter``
+    are fixed at capture; the weights are re-checked on every call (an in-place update is re-packed before the replay, a
+    re-allocated parameter triggers a new capture).  Replays are bit-identical to ``model.refine``.  One instance per
+    stream for concurrent use (each owns its inputs, outputs and scratch).
+    """
+
+    def __init__(self, model, example, n_iter=None, warmup=2):
+        self.model = model
+        self.n_iter = int(model.cfg.MODEL.CATRE.N_ITER_TEST if n_iter is None else n_iter)
+        self.keys = [k for k in _REFINE_INPUTS if example.get(k) is not None]
+        for k in ("pcl", "obj_kps", "obj_pose_est", "obj_scale_est"):
+            if k not in self.keys:
+                raise KeyError(f"example batch lacks {k!r}")
+        dev = example["pcl"].device
+        self.dev = dev
+        self.shapes = {k: tuple(example[k].shape) for k in self.keys}
+        sizes = [int(example[k].numel()) for k in self.keys]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.static, off = {}, 0
+        for k, n in zip(self.keys, sizes):
+            self.static[k] = self.flat[off:off + n].view(self.shapes[k])
+            off += n
+        self._stage(example)
+        self._capture(warmup)
+
+    def _stage(self, batch):
+        parts = []
+        for k in self.keys:
+            v = batch[k]
+            if tuple(v.shape) != self.shapes[k]:
+                raise ValueError(f"{k}: captured with shape {self.shapes[k]}, got {tuple(v.shape)}")
+            parts.append(hip.require_dev_f32(v, k, contiguous=False).reshape(-1))
+        torch.cat(parts, out=self.flat)  # one launch for all inputs
+
+    def _param_ptrs(self):
+        return tuple(t.data_ptr() if t is not None else 0 for t in self.model._runtime()._live_params())
+
+    def _capture(self, warmup):
+        dev, rt = self.dev, self.model._runtime()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):  # allocates this stream's workspace, packs the weights
+                self.model.refine(self.static, n_iter=self.n_iter)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side, capture_error_mode="relaxed"):
+            self.out = self.model.refine(self.static, n_iter=self.n_iter)
+        # the scratch buffer the captured kernels point at: owned here, whatever the runtime's per-stream cache does
+        self._ws = rt._ws.get((dev.index, side.cuda_stream))
+        self._packed = rt._packed
+        self._ptrs = self._param_ptrs()
+        self._side = side
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        rt = self.model._runtime()
+        with torch.cuda.device(self.dev):
+            rt.params(self.dev)  # stale packed weights are re-packed in place, stream-ordered before the replay
+            if rt._packed is not self._packed or self._param_ptrs() != self._ptrs:
+                self._capture(1)  # parameters moved: the captured pointers are stale
+            self._stage(batch)
+            self.graph.replay()
+        return self.out

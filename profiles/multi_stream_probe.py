@@ -33,3 +33,20 @@ for S in counts:
     same = all(torch.equal(o[f"pose_{K}"], w) for o, w in zip(outs, want))
     print(json.dumps({"B": B, "streams": S, "refines_per_s": round(S * reps / dt, 1),
                       "ms_per_refine_amortised": round(dt / (S * reps) * 1e3, 4), "results_equal_single_stream": same}))
+    # the same with one captured graph per stream (catre_amd.graphed.GraphedRefine): the host launches one graph per refine
+    from catre_amd.graphed import GraphedRefine
+    graphs = [GraphedRefine(model, batches[i], n_iter=K) for i in range(S)]
+    def gsweep(reps):
+        outs = [None] * S
+        for _ in range(reps):
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    outs[i] = graphs[i](batches[i])
+        return outs
+    gsweep(5); torch.cuda.synchronize()
+    t0 = time.perf_counter(); outs = gsweep(reps); t1 = time.perf_counter(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    same = all(torch.equal(o[f"pose_{K}"], w) for o, w in zip(outs, want))
+    print(json.dumps({"B": B, "streams": S, "graphed": True, "refines_per_s": round(S * reps / dt, 1),
+                      "ms_per_refine_amortised": round(dt / (S * reps) * 1e3, 4),
+                      "host_ms_per_refine": round((t1 - t0) / (S * reps) * 1e3, 4), "results_equal_single_stream": same}))
+    del graphs

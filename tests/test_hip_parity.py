@@ -463,3 +463,39 @@ def test_concurrent_streams_do_not_share_scratch():
     torch.cuda.synchronize()
     for o, w in zip(outs, want):
         assert torch.equal(o["pose_3"], w["pose_3"]) and torch.equal(o["scale_3"], w["scale_3"])
+
+
+def test_graphed_refine_replays_the_eager_loop():
+    """catre_amd.graphed.GraphedRefine: the K loop of a small batch as one HIP-graph replay - the same bits as
+    model.refine, for new inputs of the captured shape, after an in-place weight update (re-packed before the replay)
+    and with two instances replaying on two streams."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+    from catre_amd.graphed import GraphedRefine
+
+    cfg = default_cfg()
+    model, _ = build_model(cfg, 0)
+    b0, b1 = (to_dev(synth.make_inputs(2, 1024, 1024, seed=s)) for s in (81, 82))
+    g = GraphedRefine(model, b0, n_iter=3)
+    for b in (b0, b1, b0):
+        want = model.refine(b, n_iter=3)
+        got = g(b)
+        for k in ("pose_0", "pose_1", "pose_3", "scale_3"):
+            assert torch.equal(got[k], want[k]), k
+    with pytest.raises(ValueError):
+        g(to_dev(synth.make_inputs(3, 1024, 1024, seed=83)))
+    with torch.no_grad():  # in-place update: same storage, new values
+        model.ts_head.fc_t.weight.mul_(1.5)
+    want = model.refine(b1, n_iter=3)
+    assert torch.equal(g(b1)["pose_3"], want["pose_3"])
+    g2 = GraphedRefine(model, b0, n_iter=3)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    w0, w1 = model.refine(b0, n_iter=3)["pose_3"].clone(), want["pose_3"].clone()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            o1 = g(b1)
+        with torch.cuda.stream(s2):
+            o2 = g2(b0)
+    torch.cuda.synchronize()
+    assert torch.equal(o1["pose_3"], w1) and torch.equal(o2["pose_3"], w0)
