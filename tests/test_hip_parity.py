@@ -499,3 +499,21 @@ def test_graphed_refine_replays_the_eager_loop():
             o2 = g2(b0)
     torch.cuda.synchronize()
     assert torch.equal(o1["pose_3"], w1) and torch.equal(o2["pose_3"], w0)
+
+
+def test_small_batch_of_long_clouds_takes_the_plain_chain_with_the_same_bits():
+    """The latency path keeps an (object, head)'s GroupNorm tile partials in LDS (64 KiB of dynamic LDS at most): with
+    N = M = 8192 (256 tiles per object) a small batch falls back to the plain launch chain - and, as everywhere, an
+    object's result does not depend on the batch it came in."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+
+    N = M = 8192
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=2)
+    model, _ = build_model(cfg, 0)
+    batch = to_dev(synth.make_inputs(9, N, M, seed=91))
+    ref = model.refine(batch, n_iter=2)
+    assert torch.isfinite(ref["pose_2"]).all()
+    sub = {k: v[:2].contiguous() for k, v in batch.items()}
+    out = model.refine(sub, n_iter=2)
+    assert torch.equal(out["pose_2"], ref["pose_2"][:2]) and torch.equal(out["scale_2"], ref["scale_2"][:2])
