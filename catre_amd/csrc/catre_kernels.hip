@@ -132,6 +132,29 @@ __global__ void k_pack_frag(const float* __restrict__ src, int ld, int coloff, i
   dst[idx] = src[(size_t)row * ld + coloff + col];
 }
 
+// several fp32 fragment packs in one launch (a training step re-packs the eight encoder matrices after every optimizer
+// step: eight 5 us launches on the critical path of each iteration)
+#define PACK_MAX_JOBS 12
+struct PackJobs {
+  const float* src[PACK_MAX_JOBS];
+  float* dst[PACK_MAX_JOBS];
+  int ld[PACK_MAX_JOBS], coloff[PACK_MAX_JOBS], K[PACK_MAX_JOBS];
+  int end[PACK_MAX_JOBS];  // exclusive prefix end of the job's elements (rows * K) in the launch's index space
+  int n;
+};
+__global__ void k_pack_frag_multi(PackJobs J) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= J.end[J.n - 1]) return;
+  int j = 0;
+  while (gi >= J.end[j]) ++j;
+  const int idx = gi - (j ? J.end[j - 1] : 0);
+  const int s = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+  const int nkc = J.K[j] / 8;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 8 + 4 * (lane >> 5) + s;
+  J.dst[j][idx] = J.src[j][(size_t)row * J.ld[j] + J.coloff[j] + col];
+}
+
 __global__ void k_pack_transpose(const float* __restrict__ src, int J, int K, float* __restrict__ dst) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // dst[k*J + j] = src[j*K + k]
   if (idx >= J * K) return;
@@ -1424,10 +1447,22 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
   // a NULL source is skipped, so a sub-module (e.g. PointNetfeat alone) can pack just its own layers
   const bool enc32 = sel & CATRE_PACK_F32_ENCODER, head32 = sel & CATRE_PACK_F32_HEADS, bf = sel & CATRE_PACK_BF16,
              sp = sel & CATRE_PACK_SPLIT;
-  auto frag = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
+  PackJobs jobs;
+  jobs.n = 0;
+  auto flush = [&]() {
+    if (jobs.n) hipLaunchKernelGGL(k_pack_frag_multi, dim3((jobs.end[jobs.n - 1] + 255) / 256), dim3(256), 0, st, jobs);
+    jobs.n = 0;
+  };
+  auto frag = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {  // queued: one launch for all
     if (!src) return;
-    const int n = rows * K;
-    hipLaunchKernelGGL(k_pack_frag, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K, packed + off);
+    if (jobs.n == PACK_MAX_JOBS) flush();
+    const int j = jobs.n++;
+    jobs.src[j] = src;
+    jobs.dst[j] = packed + off;
+    jobs.ld[j] = ld;
+    jobs.coloff[j] = coloff;
+    jobs.K[j] = K;
+    jobs.end[j] = (j ? jobs.end[j - 1] : 0) + rows * K;
   };
   auto frag_bf = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
     if (!src) return;
@@ -1486,6 +1521,7 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
     if (prm[base + 10])
       hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, prm[base + 10], N + M, packed + L.sumwp + h);
   }
+  flush();
   if (head32 && prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
     int n = ts_in * 256;
     hipLaunchKernelGGL(k_pack_transpose, dim3((n + 255) / 256), dim3(256), 0, st, prm[CATRE_P_TS_L0_W], 256, ts_in,

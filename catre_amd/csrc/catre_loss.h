@@ -194,6 +194,22 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
 // losses[6 .. 6+14) = the reference's vis/ scalars in its own order: error_R [deg], error_t [cm], |t_pred - t_gt| of
 // object 0 [cm] x3, t_pred x3, trans_deltas x3 (0 when no deltas are passed), t_gt x3 - all of object 0 like the
 // reference (`pred_trans[0, 0]` ...)
+// sum_b col[b * LOSS_NP] in object order (the order is part of the result), sixteen loads requested together: left as a
+// plain loop the adds wait for one L2 round trip per object (50 us for B = 256 on a single wave)
+__device__ __forceinline__ float loss_column_sum(const float* __restrict__ col, int B) {
+  float s = 0.f;
+  int b = 0;
+  for (; b + 16 <= B; b += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(b + u) * LOSS_NP];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; b < B; ++b) s += col[(size_t)b * LOSS_NP];
+  return s;
+}
+
 __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
                               float* __restrict__ losses, int* __restrict__ counts, int B, int M,
                               const float* __restrict__ pose, const float* __restrict__ gt_trans,
@@ -203,8 +219,7 @@ __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restr
     const int k = i - 6;
     float v;
     if (k < 2) {
-      float s = 0.f;
-      for (int b = 0; b < B; ++b) s += part[(size_t)b * LOSS_NP + 6 + k];
+      const float s = loss_column_sum(part + 6 + k, B);
       v = s / (float)B * (k == 1 ? 100.f : 1.f);
     } else {
       const int c = (k - 2) % 3, what = (k - 2) / 3;
@@ -216,14 +231,23 @@ __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restr
   }
   if (i >= 6) return;
   int n_sym = 0;
-  for (int b = 0; b < B; ++b) n_sym += is_sym[b] != 0;
+  {
+    int b = 0;
+    for (; b + 16 <= B; b += 16) {
+      int f[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) f[u] = is_sym[b + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) n_sym += f[u] != 0;
+    }
+    for (; b < B; ++b) n_sym += is_sym[b] != 0;
+  }
   const int n_nonsym = B - n_sym;
   if (i == 0) {
     counts[0] = n_sym;
     counts[1] = n_nonsym;
   }
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[(size_t)b * LOSS_NP + i];
+  const float s = loss_column_sum(part + i, B);
   float v = 0.f;
   switch (i) {
     case 0: v = 3.f * (s / ((float)B * M * 3.f)) * cfg.pm_lw; break;
