@@ -334,9 +334,10 @@ def test_errors():
 
 
 @pytest.mark.parametrize("B,N,M", [(1, 1, 1), (5, 63, 65), (3, 64, 64), (2, 129, 1), (7, 130, 257), (4, 2, 300),
-                                   (1, 4096, 32)])
+                                   (1, 4096, 32), (2, 32, 33), (1, 31, 97), (4, 96, 160), (8, 33, 31), (9, 33, 95)])
 def test_ragged_shapes_match_oracle(B, N, M):
-    """Edge shapes: single points, tile boundaries +-1, tails in both clouds, B not a multiple of anything."""
+    """Edge shapes: single points, tile and half-tile boundaries +-1 (the trunk of B <= 4 works on 32-point halves), tails
+    in both clouds, B not a multiple of anything, either side of the 8-object switch to the plain launch chain."""
     from catre_amd import synth
     from catre_amd.config import default_cfg
     from oracle import catre_oracle as O
