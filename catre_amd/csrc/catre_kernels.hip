@@ -588,14 +588,14 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
 // tile partial maxima -> per-cloud max:  out[cloud][c] = max_t pm[row(cloud,t)][c]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm, float* __restrict__ out, int ldo, int C,
-                                                   int B, int N, int M) {
+                                                   int B, int N, int M, int rpt = 1 /*partial rows per tile*/) {
   // grid (clouds, C / 256): one thread per (cloud, channel), so that a single object still spreads over several CUs
   const int cloud = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP;
-  const int nt = cloud < B ? TN : TM;
-  const size_t row0 = cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM;
+  const int nt = (cloud < B ? TN : TM) * rpt;
+  const size_t row0 = (cloud < B ? (size_t)cloud * TN : (size_t)B * TN + (size_t)(cloud - B) * TM) * rpt;
   const float* src = pm + row0 * PMW + c;
   float m = src[0];
   int t = 1;
@@ -1812,19 +1812,22 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   // Small batches take the latency path (catre_small.h): the same arithmetic on fewer launches.
   const size_t smem_d = sizeof(float) * (size_t)std::max(T * 64 + 64 + 16, TS_OB * (256 + 4 * 256));
   const bool small = R <= SMALL_ROWS && smem_d <= 64 * 1024;
-  const float* pm = small ? ws + W.pm : nullptr;
-  auto reduce_pm = [&](float* out, int ldo, int C) {
-    hipLaunchKernelGGL(k_reduce_pm, dim3(R, (C + 255) / 256), dim3(256), 0, st, ws + W.pm, out, ldo, C, B, N, M);
+  // ... and while a consumer of a pooled feature can take the maximum over the tile partials itself: every one of fc1's
+  // 16 workgroups stages all R rows x 16 tiles, which beats a k_reduce_pm launch up to R = 4 clouds (B = 4: 15 vs 5 + 5.5 us)
+  const bool fold = small && R <= SMALL_FOLD_ROWS;
+  const float* pm = fold ? ws + W.pm : nullptr;
+  auto reduce_pm = [&](float* out, int ldo, int C, int rpt = 1) {
+    hipLaunchKernelGGL(k_reduce_pm, dim3(R, (C + 255) / 256), dim3(256), 0, st, ws + W.pm, out, ldo, C, B, N, M, rpt);
   };
   // STN3d (pointnet.py:98) on both clouds
   launch_stn3d(pts, prm, packed, ws, W, B, N, M, split, st);
-  if (!small) reduce_pm(ws + W.pool, 1024, 1024);
+  if (!fold) reduce_pm(ws + W.pool, 1024, 1024);
   if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, R, st, pm, B, N, M)))
     return rc;
   const float* t64 = nullptr;
   if (o->feature_transform) {  // STNkd (pointnet.py:105-106)
     launch_stnkd(pts, ws + W.trans3, prm, packed, ws, W, B, N, M, split, st);
-    if (!small) reduce_pm(ws + W.pool, 1024, 1024);
+    if (!fold) reduce_pm(ws + W.pool, 1024, 1024);
     if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, R, st, pm, B, N,
                           M)))
       return rc;
@@ -1856,7 +1859,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
                              scale_out, B, stream);
   }
-  // ---- latency path after the trunk: 5 launches (catre_small.h) ----
+  // ---- latency path after the trunk: 5 launches (catre_small.h), 6 when the pooled feature is reduced by its own ----
+  if (!fold) reduce_pm(ws + W.gfeat, PMW, PMW, rsh ? 2 : 1);
   {
     const int expect = PMW * (o->with_kps_feature ? 2 : 1) + (o->with_init_scale ? 3 : 0) + (o->with_init_trans ? 3 : 0);
     if (o->ts_in_dim != expect) return CATRE_ERR_BAD_ARG;
@@ -1888,7 +1892,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
     A.w0y = prm[CATRE_P_ROTY_L0_W];
     A.b0y = prm[CATRE_P_ROTY_L0_W + 1];
     A.bias0 = bias0;
-    A.pm = ws + W.pm;
+    A.pm = fold ? ws + W.pm : nullptr;
+    A.gfeat = ws + W.gfeat;
     A.B = B;
     A.N = N;
     A.M = M;

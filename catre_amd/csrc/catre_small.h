@@ -3,12 +3,14 @@
 // The reference's evaluator refines one image at a time: a handful of objects per call (catre_evaluator.py:292-311).
 // There a refine iteration is a chain of ~22 dependent launches of 4-18 us each - what it costs is the NUMBER of
 // launches on the critical path, not their work.  For 2B <= SMALL_ROWS clouds catre_refine_iter therefore runs
-// 14 launches instead of 22, every one the SAME arithmetic in the same order as the large-batch kernels (the bodies
+// 14 launches (B <= 2; 17 up to B = 8) instead of 22, every one the SAME arithmetic in the same order as the large-batch kernels (the bodies
 // are shared device functions), so an object's result still does not depend on the batch it came in, bit for bit:
 //
-//   * no k_reduce_pm launches: a consumer of a cloud's pooled feature takes the maximum over the cloud's tile partials
-//     itself while it gathers its input (max is exact) - fc1 of both STN tails (k_linear_pm), the ts head's layer 0 and
-//     the rot heads' global halves (k_heads_a);
+//   * up to SMALL_FOLD_ROWS clouds (B <= 2) no k_reduce_pm launches: a consumer of a cloud's pooled feature takes the
+//     maximum over the cloud's tile partials itself while it gathers its input (max is exact) - fc1 of both STN tails
+//     (k_linear_pm), the ts head's layer 0 and the rot heads' global halves (k_heads_a).  Beyond that the staging - every
+//     one of fc1's 16 workgroups reads all R rows x 16 tiles - costs more than the launch it saves (B = 8: 20 us against
+//     5 + 6), and the three reductions stay launches of their own;
 //   * k_heads_a: what only needs the trunk's outputs runs side by side in ONE launch, on disjoint workgroups -
 //     pointfeat moments | ts-head layer 0 | both rot heads' global halves;
 //   * k_heads_d: GN1 finalize + k_rot_out (every workgroup merges its (object, head)'s tile partials from LDS first: at
@@ -18,6 +20,7 @@
 #pragma once
 
 #define SMALL_ROWS 16            // clouds (2B) up to which the latency path is taken
+#define SMALL_FOLD_ROWS 4        // clouds up to which the consumers of a pooled feature reduce the tile partials themselves
 #define XS_LD (1024 + 4)         // LDS pitch of a staged pooled-feature row
 #define LINPM_SMEM (LIN_WAVES * 16 * 64 + SMALL_ROWS * XS_LD)  // floats: k_linear partial blocks + staged X rows
 
@@ -94,7 +97,8 @@ struct HeadsAArgs {
   // rot heads' global halves (k_linear, gridDim.z == 2)
   const float *w0x, *b0x, *w0y, *b0y;
   float* bias0;
-  const float* pm;
+  const float* pm;     // tile partials: the consumers pool them themselves (R <= SMALL_FOLD_ROWS) ...
+  const float* gfeat;  // ... or nullptr: the pooled features [2B][PMW] that a k_reduce_pm launch wrote
   int B, N, M;
   int rpt;          // partial rows per tile in pm (2 after k_trunk_h)
   int n_mom, n_ts;  // workgroups of the first two roles
@@ -112,18 +116,22 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_heads_a(HeadsAArgs A) {
   j -= A.n_mom;
   if (j < A.n_ts) {
     if (threadIdx.x >= 256) return;
-    ts_l0_body(nullptr, A.pm, A.pose, A.scale, A.W0T, A.tspart, A.B, A.N, A.M, A.in_dim, A.with_kps, A.with_scale,
+    ts_l0_body(A.gfeat, A.pm, A.pose, A.scale, A.W0T, A.tspart, A.B, A.N, A.M, A.in_dim, A.with_kps, A.with_scale,
                A.with_trans, j / TS_KS, j % TS_KS, smem, A.rpt);
     return;
   }
   j -= A.n_ts;  // (head z, column block by) of bias0[z][cloud][:] = W0_z[:, :1024] g_cloud + b0_z
   const int z = j >> 3, by = j & 7, R = 2 * A.B;
   float* xs = smem + LIN_WAVES * 16 * 64;
-  linear_body(xs, XS_LD, z ? A.w0y : A.w0x, PMW, z ? A.b0y : A.b0x, A.bias0 + (size_t)z * R * 256, 256, R, 256, 1024, 0, 0, 0,
-              by, reinterpret_cast<float(*)[16][64]>(smem), [&] {
-                stage_cloud_max(A.pm, xs, R, A.B, A.N, A.M, 64 * LIN_WAVES, A.rpt);
-                __syncthreads();
-              });
+  if (A.pm)
+    linear_body(xs, XS_LD, z ? A.w0y : A.w0x, PMW, z ? A.b0y : A.b0x, A.bias0 + (size_t)z * R * 256, 256, R, 256, 1024, 0, 0,
+                0, by, reinterpret_cast<float(*)[16][64]>(smem), [&] {
+                  stage_cloud_max(A.pm, xs, R, A.B, A.N, A.M, 64 * LIN_WAVES, A.rpt);
+                  __syncthreads();
+                });
+  else
+    linear_body(A.gfeat, PMW, z ? A.w0y : A.w0x, PMW, z ? A.b0y : A.b0x, A.bias0 + (size_t)z * R * 256, 256, R, 256, 1024, 0,
+                0, 0, by, reinterpret_cast<float(*)[16][64]>(smem), [] {});
 }
 
 // ---- after k_rot_l1: GN1 finalize + k_rot_out | rest of the ts head ---------------------------------------------------

@@ -213,7 +213,7 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
 /* ---- fused drivers ------------------------------------------------------------------------ */
 
 /* One CATRE_disR_shared.forward (test path, CATRE_disR_shared.py:57-124) on given x / tfd_kps.
- * Batches of up to 8 objects (the evaluator's one-image calls, catre_evaluator.py:292-311) take a latency path of 14
+ * Batches of up to 8 objects (the evaluator's one-image calls, catre_evaluator.py:292-311) take a latency path of 14-17
  * launches instead of 22 (csrc/catre_small.h); the result of an object does not depend on which path its batch took,
  * bit for bit. */
 int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
