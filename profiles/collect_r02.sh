@@ -14,8 +14,8 @@ if want bench; then
   { python bench.py --dtype split --no-cpu-baseline; python bench.py --dtype bf16 --no-cpu-baseline;
     python bench.py --shape config5 --no-cpu-baseline --steps 5; python bench.py --shape config5 --dtype bf16 --no-cpu-baseline --steps 5;
     python bench.py --shape config5 --dtype split --no-cpu-baseline --steps 5; } 2>/dev/null | grep '^{' > $o/r02_modes_bench.jsonl
-  { python bench.py --mode train --steps 4 --warmup 2; python bench.py --mode train --dtype bf16 --steps 4 --warmup 2;
-    python bench.py --mode train --dtype split --steps 4 --warmup 2; } 2>/dev/null | grep '^{' > $o/r02_train_bench.jsonl
+  { python bench.py --mode train --steps 4 --warmup 4; python bench.py --mode train --dtype bf16 --steps 4 --warmup 4;
+    python bench.py --mode train --dtype split --steps 4 --warmup 4; } 2>/dev/null | grep '^{' > $o/r02_train_bench.jsonl
 fi
 if want small; then
   python profiles/small_batch.py 2>/dev/null | grep '^{' > $o/r02_other_configs.jsonl
