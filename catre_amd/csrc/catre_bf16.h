@@ -698,15 +698,18 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
     const float v[4] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
     const float w = wp[rt.gp0 + p];
     float z[4];
+    gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));  // unpacked on purpose: see rot_out_body
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));  // scalar neck sums on purpose: see rot_out_body
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float t = nk[c][0] * z[0];
       t = fmaf(nk[c][1], z[1], t);
       t = fmaf(nk[c][2], z[2], t);
       t = fmaf(nk[c][3], z[3], t);
+      asm volatile("" : "+v"(t));
       a3[c] = fmaf(w, t, a3[c]);
+      asm volatile("" : "+v"(a3[c]));
     }
   }
 #pragma unroll

@@ -275,21 +275,24 @@ __device__ __forceinline__ void rot_out_body(const float* __restrict__ y1, const
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)p * 256));
     const float w = wp[rt.gp0 + p];
     float z[4];
+    gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
+    // The neck sums stay SCALAR instructions (the empty asm statements keep the SLP vectoriser from pairing components 0
+    // and 1 into v_pk_fma_f32 with op_sel operands).  Paired, THIS kernel returned a wrong first component - the low half of
+    // the packed accumulator - in ~3 % of its runs whenever kernels issuing bf16 MFMAs were co-resident on the CUs (refines
+    // in split / bf16 mode on a second stream; never on one stream, never next to fp32 kernels: profiles/soak_victim.py,
+    // soak_streams.py).  The packed ISA is hazard-clean as far as LLVM's gfx950 tables go and the cause was not established;
+    // with scalar sums 0 of 2400 runs differ (the packed GELU above is not involved: it stays).
 #pragma unroll
-    // Unpacked on purpose (same values as gelu_affine4, which every other kernel keeps).  With the packed form
-    // (v_pk_fma_f32 / v_pk_mul_f32 through the GELU and the neck sums) THIS kernel returned a wrong first component -
-    // the low half of its packed accumulator - in ~3 % of its runs whenever kernels issuing bf16 MFMAs were co-resident on
-    // the CUs (refines in split / bf16 mode on a second stream; never on one stream, never next to fp32 kernels:
-    // profiles/soak_victim.py, soak_streams.py).  The ISA of the packed loop is hazard-clean as far as LLVM's tables go and
-    // the cause was not established; the unpacked stream is not affected (0 of 2400 runs) and costs 0.02 ms at B = 256.
-    for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[q], sc[q], sh[q]));
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float t = nk[c][0] * z[0];
       t = fmaf(nk[c][1], z[1], t);
       t = fmaf(nk[c][2], z[2], t);
       t = fmaf(nk[c][3], z[3], t);
+      asm volatile("" : "+v"(t));
       a3[c] = fmaf(w, t, a3[c]);
+      asm volatile("" : "+v"(a3[c]));
     }
   }
 #pragma unroll

@@ -1462,14 +1462,17 @@ __global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd(const float* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float z[4];
+      gelu_affine4(v[u][0], v[u][1], v[u][2], v[u][3], sc, sh, z);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) z[q] = gelu_erf(fmaf(v[u][q], sc[q], sh[q]));  // unpacked on purpose: see rot_out_body
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));  // scalar neck sums on purpose: see rot_out_body
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float a = nk[k][0] * z[0];
         a = fmaf(nk[k][1], z[1], a);
         a = fmaf(nk[k][2], z[2], a);
-        t[u][k] = fmaf(nk[k][3], z[3], a);
+        a = fmaf(nk[k][3], z[3], a);
+        asm volatile("" : "+v"(a));
+        t[u][k] = a;
       }
     }
 #pragma unroll
