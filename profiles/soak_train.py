@@ -20,7 +20,7 @@ def mk(test):
     m.load_state_dict({k: v.cuda() for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()})
     return m, cfg
 vict, vcfg = mk(False); vict.train()
-aggr, _ = mk(True); aggr.eval(); aggr.cfg.MODEL.CATRE.COMPUTE_DTYPE = am
+aggr, _ = mk(True); aggr.eval(); aggr.cfg.MODEL.CATRE.COMPUTE_DTYPE = am if am != "none" else "fp32"
 b = {k: v.cuda() for k, v in synth.make_inputs(B, N, M, seed=4).items()}
 ab = {k: v.cuda() for k, v in synth.make_inputs(16, N, M, seed=9).items()}
 batch_updater_test(vcfg, b)
@@ -37,12 +37,18 @@ sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 with torch.cuda.stream(sa): want = step()
 with torch.no_grad(), torch.cuda.stream(sb): aggr.refine(ab, n_iter=2)
 torch.cuda.synchronize()
-bad = {}
+bad, events = {}, []
 for r in range(rounds):
-    with torch.no_grad(), torch.cuda.stream(sb):
-        for _ in range(3): aggr.refine(ab, n_iter=2)
+    if am != "none":
+        with torch.no_grad(), torch.cuda.stream(sb):
+            for _ in range(3): aggr.refine(ab, n_iter=2)
     with torch.cuda.stream(sa): got = step()
     torch.cuda.synchronize()
-    for k in want:
-        if not torch.equal(got[k], want[k]): bad[k] = bad.get(k, 0) + 1
-print(json.dumps({"victim": f"training iteration ({vmode})", "aggressor": am, "rounds": rounds, "tensors_that_differed": bad}))
+    hit = [k for k in want if not torch.equal(got[k], want[k])]
+    for k in hit: bad[k] = bad.get(k, 0) + 1
+    if hit and len(events) < 4:
+        events.append({"round": r, "n": len(hit), "same": sorted(k for k in want if k not in hit)[:12],
+                       "max_rel": max(float(((got[k] - want[k]).abs().max() / (want[k].abs().max() + 1e-30))) for k in hit)})
+print(json.dumps({"victim": f"training iteration ({vmode})", "aggressor": am, "rounds": rounds,
+                  "n_tensors_that_differed": len(bad), "rounds_hit": max(bad.values()) if bad else 0,
+                  "some": sorted(bad)[:6], "events": events}))
