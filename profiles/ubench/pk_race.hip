@@ -13,6 +13,38 @@
 #include <cstring>
 #include <vector>
 #include "catre_device.h"
+// gelu_affine4 of catre_device.h with wait states pinned right behind the two v_rcp_f32 (VAR 11-13)
+#ifndef RCP_NOP
+#define RCP_NOP "s_nop 0"
+#endif
+__device__ __forceinline__ f32x2 erf_rational2n(f32x2 x) {
+  x[0] = __builtin_amdgcn_fmed3f(x[0], -4.f, 4.f);
+  x[1] = __builtin_amdgcn_fmed3f(x[1], -4.f, 4.f);
+  const f32x2 x2 = x * x;
+  f32x2 p = pk_fma(x2, splat2(-2.72614225801306e-10f), splat2(2.77068142495902e-08f));
+  p = pk_fma(x2, p, splat2(-2.10102402082508e-06f));
+  p = pk_fma(x2, p, splat2(-5.69250639462346e-05f));
+  p = pk_fma(x2, p, splat2(-7.34990630326855e-04f));
+  p = pk_fma(x2, p, splat2(-2.95459980854025e-03f));
+  p = pk_fma(x2, p, splat2(-1.60960333262415e-02f));
+  f32x2 q = pk_fma(x2, splat2(-1.45660718464996e-05f), splat2(-2.13374055278905e-04f));
+  q = pk_fma(x2, q, splat2(-1.68282697438203e-03f));
+  q = pk_fma(x2, q, splat2(-7.37332916720468e-03f));
+  q = pk_fma(x2, q, splat2(-1.42647390514189e-02f));
+  float r0 = __builtin_amdgcn_rcpf(q[0]), r1 = __builtin_amdgcn_rcpf(q[1]);
+  asm volatile(RCP_NOP : "+v"(r0), "+v"(r1));
+  const f32x2 r = {r0, r1};
+  return x * p * r;
+}
+__device__ __forceinline__ void gelu_affine4n(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
+                                              float (&z)[4]) {
+  const f32x2 a = {v0, v1}, b = {v2, v3}, sca = {sc[0], sc[1]}, scb = {sc[2], sc[3]}, sha = {sh[0], sh[1]}, shb = {sh[2], sh[3]};
+  const f32x2 ua = pk_fma(a, sca, sha), ub = pk_fma(b, scb, shb);
+  const f32x2 ha = ua * splat2(0.5f), hb = ub * splat2(0.5f);
+  const f32x2 za = pk_fma(ha, erf_rational2n(ua * splat2(0.70710678118654752440f)), ha);
+  const f32x2 zb = pk_fma(hb, erf_rational2n(ub * splat2(0.70710678118654752440f)), hb);
+  z[0] = za[0]; z[1] = za[1]; z[2] = zb[0]; z[3] = zb[1];
+}
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -62,7 +94,14 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ y1, const flo
     const float w = wp[blockIdx.x * 64 + p];
 #endif
     float z[4];
+#if VAR == 10  // no GELU (no v_rcp, no packed polynomial): only the affine in front of the neck sums
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = fmaf(v[q], sc[q], sh[q]);
+#elif VAR >= 11
+    gelu_affine4n(v[0], v[1], v[2], v[3], sc, sh, z);  // wait states behind the v_rcp_f32: -DRCP_NOP='"s_nop 3"'
+#else
     gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
+#endif
 #if VAR == 9  // the form the library ships: packed GELU, scalar neck sums
 #pragma unroll
     for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));
