@@ -91,12 +91,25 @@ class GraphedTrainStep:
         # capture: gradients are allocated inside the graph's private pool, so their addresses are fixed
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+        # captured on the warm-up stream, so the kernels point at THAT stream's scratch buffers (train_ops._ws and the
+        # runtime's workspace are per (device, stream)), which the warm-up has already grown to their final size
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="relaxed"):
             self.out, self.losses = iteration()
             # host half runs now (addresses of the captured gradients go into the record table) ...
             self.opt.prepare_step(wait=False)
             # ... and only the kernels are captured; the table upload is issued eagerly before every replay
             self.opt.launch_step(upload=False)
+        # the buffers whose addresses are baked into the graph are owned here, whatever the per-stream caches do later
+        # (an eager step that outgrows a cache entry replaces it; the captured block must not be recycled under the graph)
+        from . import train_ops
+
+        rt = self.model._runtime() if hasattr(self.model, "_runtime") else None
+        self._keep = (train_ops.scratch_of(dev, side), side,
+                      None if rt is None or rt._ws is None else rt._ws.get((dev.index, side.cuda_stream)),
+                      None if rt is None else rt._packed)
+        # the packs recorded above did not execute: the next eager forward must re-pack (HipRuntime.params also refuses
+        # to call a pack fresh while capturing)
+        hip.bump_param_epoch()
         # the capture did not execute anything: undo the step counter it advanced
         for st in self.opt.state.values():
             if "step" in st:

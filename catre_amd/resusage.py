@@ -53,6 +53,48 @@ def table(rows):
     return "\n".join(lines) + "\n"
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def disassemble(lib_path):
+    """gfx950 code object of ``lib_path`` -> {kernel symbol: [instruction mnemonics]} (llvm-objdump of the offload bundle,
+    extracted into a temporary directory).  Used by the ISA lint of tests/test_resources.py."""
+    import shutil
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="catre_isa.")
+    try:
+        so = os.path.join(d, "lib.so")
+        shutil.copy(lib_path, so)
+        subprocess.run([OBJDUMP, "--offloading", so], check=True, capture_output=True, cwd=d)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        assert len(co) == 1, os.listdir(d)
+        text = subprocess.run([OBJDUMP, "-d", os.path.join(d, co[0])], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    out, cur = {}, None
+    for ln in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+([a-z_0-9]+)", ln)
+        if m and cur is not None:
+            cur.append(m.group(1))
+    return out
+
+
+def packed_fp32_kernels(lib_path):
+    """-> {kernel: count} of kernels whose ISA holds a packed-fp32 VALU op (v_pk_{mul,add,fma}_f32 / v_pk_mov_b32 excluded:
+    the move has no arithmetic).  The library is built with the feature off (csrc/Makefile NOPK); see DESIGN.md 6.5."""
+    bad = {}
+    for k, ins in disassemble(lib_path).items():
+        n = sum(1 for i in ins if re.fullmatch(r"v_pk_(mul|add|fma)_f32", i))
+        if n:
+            bad[k] = n
+    return bad
+
+
 if __name__ == "__main__":
     rows = parse()
     text = table(rows)

@@ -113,7 +113,9 @@ class HipRuntime:
                                            self._packed.numel(), int(sel), hip.stream_ptr(device)),
                 "catre_pack_weights_sel",
             )
-            self._fingerprint = fp
+            # a pack issued while the stream is being captured is only RECORDED (GraphedTrainStep): the buffer still holds
+            # whatever the last executed pack wrote, so the cache must not call it fresh
+            self._fingerprint = None if torch.cuda.is_current_stream_capturing() else fp
             self._packed_sel = int(sel)
         return self._param_arr, self._packed
 
@@ -211,6 +213,10 @@ class HipRuntime:
 
     def train_stn3d(self, pts, buf, B, N, M, device):
         lib = hip.load()
+        # first encoder kernel of a training forward: always re-pack the fp32 encoder image (one 6 us launch).  The
+        # (data_ptr, _version, epoch) fingerprint cannot see writes through `p.data` (EMA, third-party optimizers), and a
+        # stale forward image next to a live-weight backward would give inconsistent gradients without any error.
+        self._fingerprint = None
         prm, packed = self.params(device, hip.PACK_F32_ENCODER)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_stn3d_fwd(ctypes.byref(pts), prm, hip.ptr(packed), hip.ptr(buf["a1"]), hip.ptr(buf["a2"]),

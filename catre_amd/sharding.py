@@ -28,18 +28,28 @@ PER_OBJECT_KEYS = frozenset((
     "obj_cls", "obj_bbox", "obj_pose", "obj_scale", "obj_pose_est", "obj_scale_est", "obj_mean_points", "obj_mean_scales",
     "obj_fps_points", "obj_kps", "im_id", "inst_id", "K", "sym_info", "pcl", "x", "tfd_kps",
     "gt_rot", "gt_trans", "gt_scale", "obj_pose_gt", "obj_scale_gt", "nocs_scale",
+    "last_frame_poses", "obj_visib_mask", "obj_trunc_mask",       # batching.py:29-41 (concatenated over instances)
 ))
+# per-IMAGE entries (batching.py:12-27): never sliced, and never warned about when an image count happens to equal B
+PER_IMAGE_KEYS = frozenset(("img", "depth_obs", "roi_img", "roi_depth", "file_name", "scene_im_id", "cam", "im_H", "im_W"))
 
 
-def shard_batch(batch, rank, world, extra_keys=()):
+def shard_batch(batch, rank, world, extra_keys=(), per_image_keys=()):
     """Slice the per-object tensors / lists of a reference-style batch dict (``PER_OBJECT_KEYS`` + ``extra_keys``);
-    everything else is passed through untouched."""
+    per-image entries (``PER_IMAGE_KEYS`` + ``per_image_keys``), scalars and anything whose length is not the object
+    count pass through untouched; an unlisted entry with exactly B rows raises (ambiguous)."""
     B = batch["pcl"].shape[0]
     lo, hi = shard_bounds(B, rank, world)
     keys = PER_OBJECT_KEYS | frozenset(extra_keys)
     out = {}
     for k, v in batch.items():
         if k not in keys:
+            # an unknown entry whose first dimension is the object count is most likely a per-object entry the caller
+            # added: passing it through whole would pair B_local objects with B_global rows - refuse instead of guessing
+            n = v.shape[0] if isinstance(v, torch.Tensor) and v.dim() > 0 else (len(v) if isinstance(v, (list, tuple)) else -1)
+            if n == B and world > 1 and k not in PER_IMAGE_KEYS and k not in per_image_keys:
+                raise ValueError(f"batch[{k!r}] has {B} rows like a per-object entry but is not in PER_OBJECT_KEYS: pass "
+                                 f"extra_keys=({k!r},) to slice it or per_image_keys=({k!r},) to keep it whole")
             out[k] = v
             continue
         n = v.shape[0] if isinstance(v, torch.Tensor) else len(v)

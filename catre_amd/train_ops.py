@@ -16,12 +16,24 @@ _scratch = {}
 
 
 def _ws(nbytes, device):
-    """Grow-only scratch (stream-ordered reuse: every op that uses it runs on the current stream)."""
-    buf = _scratch.get(device)
+    """Grow-only scratch, one buffer per (device, stream) like ``HipRuntime.workspace``: every op that uses it runs on the
+    current stream, so reuse on one stream is ordered, and training iterations on different streams (or a captured
+    ``GraphedTrainStep`` next to eager steps) never share split-K partials.  A buffer that is outgrown is dropped here
+    only - whoever captured its address (``GraphedTrainStep``) keeps its own reference (``scratch_of``)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is None and len(_scratch) >= 32:
+            _scratch.clear()  # stale streams: the caching allocator keeps a block alive until its queued work is done
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _scratch[device] = buf
+        _scratch[key] = buf
     return buf
+
+
+def scratch_of(device, stream):
+    """The scratch buffer training ops issued on ``stream`` currently use (None if none yet)."""
+    return _scratch.get((device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream))
 
 
 def _st(t):
@@ -413,7 +425,7 @@ class _ObjectMajor(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d):
         B, N, M, C = ctx.dims
-        d = d.view(B, N + M, C)
+        d = _c(d).view(B, N + M, C)
         return torch.cat([d[:, :N].reshape(B * N, C), d[:, N:].reshape(B * M, C)], 0), None, None, None
 
 

@@ -505,3 +505,135 @@ def test_pose_update_backward_with_expanded_gradients():
     p1, s1 = pose_update(rot, dt, ds, pose0, scale0, ms_wide[:, ::2], K_wide[:, :, ::2], o2)
     p2, s2 = pose_update(rot, dt, ds, pose0, scale0, ms_wide[:, ::2].contiguous(), K, o2)
     assert torch.equal(p1, p2) and torch.equal(s1, s2)
+
+
+# ------------------------------------------------------------------------------------------------- scratch ownership
+def _train_setup(B, N, M, seed, n_models=1):
+    from catre_amd import synth
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from oracle.catre_oracle import y_axis_symmetries
+
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    sd = {k: v.to(DEV) for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()}
+    b = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=seed).items()}
+    batch_updater_test(cfg, b)
+    sym = [y_axis_symmetries(12) if j % 3 == 0 else None for j in range(B)]
+    kw = dict(x=b["x"].contiguous(), tfd_kps=b["tfd_kps"].contiguous(), init_pose=b["obj_pose_est"],
+              init_scale=b["obj_scale_est"], K_zoom=b["K"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"],
+              gt_scale=b["gt_scale"], obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"])
+    pairs = []
+    for _ in range(n_models):
+        model, opt = build_model_optimizer(cfg, is_test=False)
+        model.load_state_dict(sd)
+        pairs.append((model, opt))
+    return cfg, sd, kw, sym, pairs
+
+
+def _iteration(model, kw, sym):
+    kw = dict(kw)
+    out, ld = model(kw.pop("x"), kw.pop("tfd_kps"), sym_info=sym, do_loss=True, cur_iter=1, **kw)
+    sum(ld.values()).backward()
+    return {k: v.detach().clone() for k, v in ld.items()}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_two_models_training_on_two_streams_reproduce_their_solo_gradients(mode):
+    """SURVEY 8(b) Threading: workspace per stream, re-entrant.  Two models run training iterations CONCURRENTLY on two
+    streams (different batch sizes, so their split-K partials and reduction scratch differ in size and content); every
+    gradient must equal, bit for bit, what the same model produced alone.  With one scratch buffer per device (round 2)
+    the two streams raced on it."""
+    from catre_amd import train_ops
+
+    N, M = 256, 128
+    setups = [_train_setup(B, N, M, seed, 1) for B, seed in ((12, 71), (7, 72))]
+    solo = []
+    with train_ops.amp_mode(mode):
+        for cfg, sd, kw, sym, ((model, opt),) in setups:
+            _iteration(model, kw, sym)
+            torch.cuda.synchronize()
+            solo.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+            opt.zero_grad(set_to_none=True)
+        streams = [torch.cuda.Stream(device=DEV) for _ in setups]
+        bad = []
+        for rnd in range(12):
+            torch.cuda.synchronize()
+            for (cfg, sd, kw, sym, ((model, opt),)), st in zip(setups, streams):
+                with torch.cuda.stream(st):
+                    for _ in range(2):   # back to back: keeps both streams busy at the same time
+                        opt.zero_grad(set_to_none=True)
+                        _iteration(model, kw, sym)
+            torch.cuda.synchronize()
+            for i, (cfg, sd, kw, sym, ((model, opt),)) in enumerate(setups):
+                for k, p in model.named_parameters():
+                    if p.grad is not None and not torch.equal(p.grad, solo[i][k]):
+                        bad.append((rnd, i, k))
+        assert not bad, f"{len(bad)} gradients differ from the solo run, first: {bad[:4]}"
+        keys = {k for k in train_ops._scratch}
+        assert len({s.cuda_stream for s in streams} & {k[1] for k in keys}) == 2   # one scratch per stream
+
+
+def test_graphed_train_step_survives_a_scratch_grow_and_leaves_eager_weights_fresh():
+    """(i) ADVICE r2 medium: the packs recorded during capture did not execute - an EAGER training forward issued after
+    the capture and before the first replay must still run on the live weights.  (ii) VERDICT r2 weak #2: the graph owns
+    the scratch it captured; an eager step at 4x the batch (which outgrows every per-stream cache entry) must not
+    recycle it - replays stay bit-identical to the eager loop."""
+    from catre_amd.graphed import GraphedTrainStep
+
+    B, N, M = 4, 128, 64
+    cfg, sd, kw, sym, ((m_e, o_e), (m_g, o_g)) = _train_setup(B, N, M, 81, n_models=2)
+    _, _, kw_big, sym_big, ((m_big, o_big),) = _train_setup(4 * B, N, M, 82)
+    want_first = _iteration(m_e, kw, sym)
+    o_e.zero_grad(set_to_none=True)
+
+    step = GraphedTrainStep(m_g, o_g, kw, sym, max_sym=12)
+    # (i) eager forward on the graphed model right after capture: the warm-up's weights must not be what it sees
+    got_first = _iteration(m_g, kw, sym)
+    o_g.zero_grad(set_to_none=True)
+    for k, v in want_first.items():
+        assert torch.equal(v, got_first[k]), f"eager forward after capture ran on stale packed weights: {k}"
+
+    eager = []
+    for i in range(3):
+        ld = _iteration(m_e, kw, sym)
+        o_e.step()
+        o_e.zero_grad(set_to_none=True)
+        eager.append((ld, {k: p.detach().clone() for k, p in m_e.named_parameters()}))
+    for i in range(3):
+        if i == 1:  # (ii) a bigger eager step in between, on the SAME stream the replays are issued from and on the
+            # capture's own stream key: every cache entry is outgrown and replaced
+            from catre_amd import train_ops
+
+            for st in (torch.cuda.current_stream(), step._keep[1]):
+                with torch.cuda.stream(st):
+                    _iteration(m_big, kw_big, sym_big)
+                    o_big.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            assert train_ops.scratch_of(torch.device(DEV), step._keep[1]) is not step._keep[0]
+            # churn the allocator so that a recycled block would actually be overwritten
+            junk = [torch.randn(1 << 20, device=DEV) for _ in range(32)]
+            del junk
+        out, ld = step(sym_info=sym, **kw)
+        torch.cuda.synchronize()
+        for k, v in eager[i][0].items():
+            assert torch.equal(ld[k], v), f"replay {i}: {k}"
+        for k, p in m_g.named_parameters():
+            assert torch.equal(p, eager[i][1][k]), f"replay {i}: parameter {k}"
+
+
+def test_training_forward_sees_out_of_band_weight_writes():
+    """`p.data.copy_()` (EMA, third-party optimizers) bumps neither _version nor the parameter epoch; the
+    fused encoder forward must still read the live weights (the training forward re-packs unconditionally)."""
+    cfg, sd, kw, sym, ((m_a, o_a), (m_b, o_b)) = _train_setup(3, 128, 64, 91, n_models=2)
+    _iteration(m_a, kw, sym)
+    o_a.zero_grad(set_to_none=True)
+    new = {k: v * 1.01 for k, v in sd.items()}
+    for k, p in m_a.named_parameters():
+        p.data.copy_(new[k])
+    m_b.load_state_dict(new)
+    la, lb = _iteration(m_a, kw, sym), _iteration(m_b, kw, sym)
+    for k in la:
+        assert torch.equal(la[k], lb[k]), k
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None) and (pa.grad is None or torch.equal(pa.grad, pb.grad)), k

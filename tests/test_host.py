@@ -262,6 +262,15 @@ def test_shard_batch_slices_only_per_object_entries():
     assert shard_batch(batch, 0, 2, extra_keys=("img",))["img"].shape[0] == 2
     with pytest.raises(ValueError, match="per-object entry"):
         shard_batch(dict(batch, obj_cls=torch.arange(3)), 0, 2)
+    # batching.py:40: concatenated over instances -> per object
+    assert shard_batch(dict(batch, last_frame_poses=torch.zeros(B, 3, 4)), 1, 2)["last_frame_poses"].shape[0] == 2
+    # an unlisted entry with exactly B rows is ambiguous: refuse, unless the caller says which it is
+    extra = dict(batch, my_feat=torch.zeros(B, 5))
+    with pytest.raises(ValueError, match="not in PER_OBJECT_KEYS"):
+        shard_batch(extra, 0, 2)
+    assert shard_batch(extra, 0, 2, extra_keys=("my_feat",))["my_feat"].shape[0] == 2
+    assert shard_batch(extra, 0, 2, per_image_keys=("my_feat",))["my_feat"].shape[0] == B
+    assert shard_batch(extra, 0, 1)["my_feat"].shape[0] == B         # world 1: nothing to pair wrongly
 
 
 def test_optimizer_factory_follows_the_reference_builder():
