@@ -79,6 +79,34 @@ def rank_stats(dist, dev, dt):
     return float(allv[:, 0].max()), [round(float(v) * 1e3, 3) for v in allv[:, 0]], int(allv[:, 1].sum())
 
 
+def comm_info(dist, dev, world, rank, local_rank):
+    """What a reader of an N > 1 line needs to trust it: the collective library and its version, and one
+    `NCCL_DEBUG`-style line per rank (rank -> device, PCI bus id, which peers it reaches over P2P / xGMI), gathered
+    through the job's own backend."""
+    info = {"backend": "none (single rank)" if dist is None else dist.get_backend()}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001 - a CPU-only torch build has no nccl module
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    info["hip"] = torch.version.hip
+    props = torch.cuda.get_device_properties(dev)
+    ndev = torch.cuda.device_count()
+    peers = [j for j in range(ndev) if j != dev.index and torch.cuda.can_device_access_peer(dev.index, j)]
+    mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "gcn_arch": getattr(props, "gcnArchName", "?"),
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "visible_devices": ndev, "p2p_peers": peers}
+    if dist is None:
+        info["ranks"] = [mine]
+    else:
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        info["ranks"] = allv
+    for k in ("NCCL_DEBUG", "NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        if k in os.environ:
+            info.setdefault("env", {})[k] = os.environ[k]
+    return info
+
+
 def bench_dryrun(args, world, rank):
     import torch.distributed as dist
 
@@ -240,10 +268,11 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     split = args.dtype == "split"
     dt = run_train(cfg_fn, dev, dist, rank, args.dtype, args.steps, args.warmup)
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
+    comm = comm_info(dist, dev, world, rank, dev.index)
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
         print(json.dumps({
-            "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms,
+            "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms, "comm": comm,
             "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if world > 1 else 0,
             "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else " [split-bf16 GEMMs]" if split else ""),
             "value": round(value, 1),
@@ -428,6 +457,7 @@ def main():
                        "ms_per_step": round(tdt / tsteps * 1e3, 3), "ms_per_iteration": round(tdt / tsteps / K_ITER * 1e3, 3)}
 
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
+    comm = comm_info(dist, dev, world, rank, local_rank)
 
     if rank == 0:
         obj_iters = world * B_PER_GPU * K_ITER * args.steps
@@ -455,6 +485,7 @@ def main():
             "n_gpus": world,
             "ranks_seen": ranks_seen,  # ranks that reported through the job's backend (RCCL for N > 1)
             "per_rank_ms": per_rank_ms,
+            "comm": comm,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),

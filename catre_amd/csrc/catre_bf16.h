@@ -100,9 +100,22 @@ struct GemmPipeB {
   __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const u32x4* x, int lane) {
     const int n = lane & 31, h = lane >> 5, key = bf_key<CP>(n);
     const u32x4* xrow = x + n * CP;
+    // rows of >= 256 B: the XOR key (< 16) only touches the low four bits of the chunk index 2*kc + h, so eight per-lane
+    // pointers (kc & 7) + compile-time offsets (kc >> 3, nb) address every fragment - no address arithmetic in the sweep
+    // (left to itself the compiler keeps one swizzled index per kc in registers: 32 of them for K = 512)
+    const u32x4* xl[8];
+    if constexpr (CP >= 16) {
+#pragma unroll
+      for (int lo = 0; lo < 8; ++lo) xl[lo] = xrow + ((2 * lo + h) ^ key);
+    }
     auto issue_b = [&](int kc) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b[kc % RB][nb] = xrow[nb * 32 * CP + ((2 * kc + h) ^ key)];
+      for (int nb = 0; nb < NB; ++nb) {
+        if constexpr (CP >= 16)
+          b[kc % RB][nb] = xl[kc & 7][nb * 32 * CP + 16 * (kc >> 3)];
+        else
+          b[kc % RB][nb] = xrow[nb * 32 * CP + ((2 * kc + h) ^ key)];
+      }
     };
 #pragma unroll
     for (int d = 0; d < PFB; ++d) issue_b(d);
@@ -455,6 +468,233 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
   }
   TRUNKB_STAMP(7);
 #undef TRUNKB_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// a3+a5 for LARGE grids: the same trunk on PAIRS of tiles (128 points per workgroup, 512 threads, all 160 KiB of LDS).
+// Why: at the bf16 matrix rate k_trunk_bf is bound by the L2 -> CU weight stream, not by the MFMAs - every 64-point
+// tile pulls the whole 1.28 MB of bf16 weights (conv4: 512 B per MFMA with a 4 x 2 wave tile = 64 B/clk/CU at full
+// matrix rate, above what the L2 sustains per CU), so its matrix pipes sit at 60 %.  Here a wave tile is 2 m-blocks x
+// 4 point blocks: one weight fragment feeds four MFMAs (256 B per MFMA from L2, 512 B from LDS = half the LDS rate).
+// Same contraction order per output as k_trunk_bf (kc ascending into one fp32 accumulator) and exact maxima, so the
+// two kernels return the same bits; the pair's maxima are written to BOTH tiles' rows of the partial-max buffer
+// (k_reduce_pm takes a maximum over them).  A pair never straddles clouds; a cloud with an odd tile count ends in a
+// pair whose second half holds duplicates of the last point.
+//   a3 [128][512 ch] 128 KiB | a2 [128][128 ch] 32 KiB; h1 / T64 image / pointfeat image / scratch alias a3.
+// ------------------------------------------------------------------------------------------
+template <int MB, int NB>
+__device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB], float* __restrict__ out,
+                                                    float* __restrict__ out2, int ch0, const float* __restrict__ bias,
+                                                    int lane) {
+  // the bias is requested here and consumed after the 16 * NB maxima + shuffle of each m-block (its latency hides
+  // behind them; held across the sweep it would cost registers the 2 x 4 wave tile does not have)
+  float bl[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) bl[mb] = bias[ch0 + mb * 32 + (lane & 31)];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float m = acc[mb][0][0];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mb][nb][r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane < 32) {
+      const float v = m + bl[mb];
+      out[ch0 + mb * 32 + lane] = v;
+      if (out2) out2[ch0 + mb * 32 + lane] = v;
+    }
+  }
+}
+
+#define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)
+__global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* __restrict__ trans3,
+                                                   const float* __restrict__ trans64, const float* __restrict__ Wc1,
+                                                   const float* __restrict__ bc1, const u32x4* __restrict__ wp2,
+                                                   const float* __restrict__ b2, const u32x4* __restrict__ wp3,
+                                                   const float* __restrict__ b3, const u32x4* __restrict__ wp4,
+                                                   const float* __restrict__ b4, float* __restrict__ pm,
+                                                   u32x4* __restrict__ pointfeat, int B, int N, int M,
+                                                   unsigned long long* __restrict__ trace) {
+  __shared__ u32x4 smem[TRUNKB2_SMEM];
+#define TRUNKB2_STAMP(i)                                                                                   \
+  do {                                                                                                     \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                \
+      trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter();      \
+  } while (0)
+  constexpr int TP2 = 2 * TP;
+  u32x4* a3 = smem;
+  u32x4* a2 = smem + TP2 * 64;
+  u32x4* h1 = smem;                                               // [128][8]
+  u32x4* tA = smem + TP2 * 8;                                     // [64 j][8]: T64 transposed, rows = out channel j
+  u32x4* pf = smem + TP2 * 8 + TP * 8;                            // [128][8]
+  float* scratch = reinterpret_cast<float*>(smem + 2 * TP2 * 8 + TP * 8);  // [8][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  // pair bookkeeping: a TileInfo of up to 128 valid points + the index of its first 64-point tile
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, PN = (TN + 1) / 2, PM_ = (TM + 1) / 2;
+  TileInfo ti;
+  int tile0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < B * PN) {
+      ti.obj = bid / PN;
+      ti.cloud = ti.obj;
+      ti.is_obs = 1;
+      const int pi = bid % PN;
+      ti.p0 = pi * TP2;
+      ti.valid = min(TP2, N - ti.p0);
+      tile0 = ti.obj * TN + 2 * pi;
+    } else {
+      const int r = bid - B * PN;
+      ti.obj = r / PM_;
+      ti.cloud = B + ti.obj;
+      ti.is_obs = 0;
+      const int pi = r % PM_;
+      ti.p0 = pi * TP2;
+      ti.valid = min(TP2, M - ti.p0);
+      tile0 = B * TN + ti.obj * TM + 2 * pi;
+    }
+  }
+  const bool has2 = ti.valid > TP;
+  const bool ft = trans64 != nullptr;
+  TRUNKB2_STAMP(0);
+
+  const int ph = wave >> 2, w4 = wave & 3;  // point half / quarter-of-the-channels roles of the prologue
+  GemmPipeB<1, 2, false, 8, 3> g2;          // conv2 64->128: wave -> m-block w4, the two point blocks of half ph
+  g2.prefetch(wp2 + (w4 * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, w4 * 32, lane);
+  {
+    const int p = ph * TP + lane;
+    float x, y, z;
+    load_point(P, ti, p, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_chunks(x, y, z, Wc1, bc1, w4, (ft ? h1 : pf) + p * 8, bf_key<8>(p));
+    if (ft) {  // A-operand image of the feature transform: row j holds T64[i][j] over i (pointnet.py:107-109);
+               // wave (G = w4, s = ph) fills chunk 2G+s: i = 16G + {4s..4s+3, 8+4s..8+4s+3}
+      const float* src = trans64 + (size_t)ti.cloud * 4096 + (w4 * 16 + 4 * ph) * 64 + lane;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = src[r * 64];
+        v[4 + r] = src[(8 + r) * 64];
+      }
+      tA[lane * 8 + ((2 * w4 + ph) ^ bf_key<8>(lane))] = pack_bf8(v);
+    }
+  }
+  __syncthreads();
+  TRUNKB2_STAMP(1);
+  if (ft) {
+    {  // pointfeat[j][p] = sum_i T64[i][j] h1[i][p]: 2 m-blocks x 4 point blocks, one per wave
+      const int mblk = wave >> 2, nb = wave & 3, key = bf_key<8>(n);
+      f32x16 acc[1][1] = {{zero16()}};
+      const u32x4* ar = tA + (mblk * 32 + n) * 8;
+      const u32x4* br = h1 + (nb * 32 + n) * 8;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) acc[0][0] = mfma_bf(ar[(2 * kc + h) ^ key], br[(2 * kc + h) ^ key], acc[0][0]);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 zb[1][4] = {{z4, z4, z4, z4}};
+      store_tile_bf<1, 1, false, 8>(acc, pf + nb * 32 * 8, mblk, zb, lane);
+    }
+    __syncthreads();
+  }
+  TRUNKB2_STAMP(2);
+  // conv3 128->512: wave owns m-blocks [2*wave, +2) over all four point blocks; first weights + bias requested now
+  GemmPipeB<2, 4, false, 16, 2, 1> g3;
+  g3.prefetch(wp3 + ((wave * 2) * 8) * 64 + lane, 8 * 64);
+  f32x4 bv3[2][4];
+  load_bias_quads<2>(bv3, b3, wave * 64, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  // pointfeat tile -> registers (stored to HBM after the last barrier) and its per-channel max over the pair
+  const int pf_cc = tid & 7, pf_row = tid >> 3;  // 8 chunks x 64 rows, rows r and r+64
+  const u32x4 pfc0 = pf[bf_off<8>(pf_row, pf_cc)], pfc1 = pf[bf_off<8>(pf_row + TP, pf_cc)];
+  {
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[2 * i] = fmaxf(bf_lo(pfc0[i]), bf_lo(pfc1[i]));
+      m[2 * i + 1] = fmaxf(bf_hi(pfc0[i]), bf_hi(pfc1[i]));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 8));
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 16));
+      m[e] = fmaxf(m[e], __shfl_xor(m[e], 32));
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) scratch[wave * 64 + bf_chunk_channel(lane, e)] = m[e];
+    }
+  }
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, pf + ph * TP * 8, lane);
+    store_tile_bf<1, 2, true, 16>(acc, a2 + ph * TP * 16, w4, bv2, lane);
+  }
+  __syncthreads();
+  float pf_max = 0.f;
+  if (tid < 64) {
+    pf_max = scratch[tid];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) pf_max = fmaxf(pf_max, scratch[w * 64 + tid]);
+  }
+  __syncthreads();  // scratch / pf / h1 live inside a3, which conv3 overwrites next
+  TRUNKB2_STAMP(3);
+  {  // HBM stores of the pair's pointfeat rows and their maxima: issued here, a whole conv3 sweep before the next barrier
+     // (which waits for their acknowledge), so that their 8 + 1 registers are free during the sweeps
+    const size_t prow0 = ti.is_obs ? (size_t)ti.obj * N + ti.p0 : (size_t)B * N + (size_t)ti.obj * M + ti.p0;
+    if (pf_row < ti.valid) pointfeat[(prow0 + pf_row) * 8 + pf_cc] = pfc0;
+    if (pf_row + TP < ti.valid) pointfeat[(prow0 + pf_row + TP) * 8 + pf_cc] = pfc1;
+    if (tid < 64) {
+      float* o1 = pm + (size_t)tile0 * PMW + 1024 + tid;
+      o1[0] = pf_max;
+      if (has2) o1[PMW] = pf_max;
+    }
+  }
+  // conv4 512->1024 + max: wave owns m-blocks [4*wave, +4) in two passes of 2 x 4 point blocks
+  GemmPipeB<2, 4, true, 64, 3, 1> g4a, g4b;
+  {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    g3.run(acc, a2, lane);
+    store_tile_bf<2, 4, true, 64>(acc, a3, wave * 2, bv3, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  g4a.prefetch(wp4 + ((wave * 4) * 32) * 64 + lane, 32 * 64);  // in flight across the barrier
+  __builtin_amdgcn_sched_barrier(0);
+  TRUNKB2_STAMP(4);
+  __syncthreads();
+  TRUNKB2_STAMP(5);
+  float* out = pm + (size_t)tile0 * PMW;
+  float* out2 = has2 ? out + PMW : nullptr;
+  {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    g4a.run(acc, a3, lane);
+    g4b.prefetch(wp4 + ((wave * 4 + 2) * 32) * 64 + lane, 32 * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4) * 32, b4, lane);
+    TRUNKB2_STAMP(6);
+  }
+  {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    g4b.run(acc, a3, lane);
+    max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4 + 2) * 32, b4, lane);
+  }
+  TRUNKB2_STAMP(7);
+#undef TRUNKB2_STAMP
 }
 
 // ------------------------------------------------------------------------------------------

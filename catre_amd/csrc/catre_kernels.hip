@@ -2,6 +2,7 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see Makefile).
 // Reference citations (file:line) are relative to the CATRE tree; see include/catre_hip.h.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "catre_device.h"
@@ -1306,6 +1307,16 @@ struct ProfState {
 ProfState g_prof;
 unsigned long long* g_trunk_trace = nullptr;  // catre_debug_trunk_trace
 
+// Smallest grid (in PAIRS of tiles) that takes the 128-point bf16 trunk; read once (CATRE_BF_PAIR_MIN overrides it for A/B
+// measurements: 0 = always, a huge value = never).  512 pairs = two workgroups for each of the 256 CUs.
+static int bf_pair_min() {
+  static const int v = [] {
+    const char* e = getenv("CATRE_BF_PAIR_MIN");
+    return e ? atoi(e) : 512;
+  }();
+  return v;
+}
+
 // The measurement hooks are the library's only process-global mutable state.  They are fenced: compiled out entirely
 // with -DCATRE_NO_PROFILING (catre_profile_* then return CATRE_ERR_UNSUPPORTED), off unless catre_profile_enable was
 // called, and the record table is guarded by a mutex so that concurrent callers of the data path cannot corrupt it.
@@ -1744,10 +1755,19 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   u32x4* pointfeat = reinterpret_cast<u32x4*>(ws + W.pointfeat);
   {
     ProfScope ps(CATRE_K_TRUNK, st);
-    hipLaunchKernelGGL(k_trunk_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
-                       prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
-                       prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
-                       g_trunk_trace);
+    // grids that fill the chip twice over take PAIRS of tiles per workgroup (half the L2 weight stream per MFMA; same
+    // bits); below that the 64-point kernel with two workgroups per CU spreads better
+    const int pairs = B * ((TN + 1) / 2 + (TM + 1) / 2);
+    if (pairs >= bf_pair_min())
+      hipLaunchKernelGGL(k_trunk_bf2, dim3(pairs), dim3(512), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
+                         prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
+                         prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
+                         g_trunk_trace);
+    else
+      hipLaunchKernelGGL(k_trunk_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
+                         prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
+                         prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
+                         g_trunk_trace);
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (PMW + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.gfeat, PMW, PMW, B, N, M);
   if ((rc = catre_ts_head(ws + W.gfeat, init_pose, init_scale, prm, packed, o, ws + W.dt, ws + W.ds, ws,

@@ -107,6 +107,10 @@ class GraphedTrainStep:
         self._keep = (train_ops.scratch_of(dev, side), side,
                       None if rt is None or rt._ws is None else rt._ws.get((dev.index, side.cuda_stream)),
                       None if rt is None else rt._packed)
+        # the gradient tensors the captured backward writes and the captured optimizer step reads: re-attached before every
+        # replay (an eager `zero_grad(set_to_none=True)` in between detaches them, and the host half of the step would
+        # then find no gradient to describe)
+        self._grads = [(p, p.grad) for p in params if p.grad is not None]
         # the packs recorded above did not execute: the next eager forward must re-pack (HipRuntime.params also refuses
         # to call a pack fresh while capturing)
         hip.bump_param_epoch()
@@ -130,6 +134,9 @@ class GraphedTrainStep:
             self.sym.cands.copy_(new.cands, non_blocking=True)
             self.sym.valid.copy_(new.valid, non_blocking=True)
             self.sym.is_sym.copy_(new.is_sym, non_blocking=True)
+        for p, g in self._grads:
+            if p.grad is not g:
+                p.grad = g
         self.opt.prepare_step()   # host: step counters, RAdam scalars -> pinned table
         self.opt.upload_table()   # stream-ordered before the replay
         self.graph.replay()

@@ -164,3 +164,29 @@ def test_bf16_ragged_and_full_size_properties():
     half = {k: (v[: B // 2] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in b.items()}
     o3 = m5.refine(half, n_iter=K)
     assert torch.equal(o3[f"pose_{K}"], o1[f"pose_{K}"][: B // 2]), "objects must be independent of their batch"
+
+
+@pytest.mark.parametrize("B,N,M", [(40, 1024, 1024), (130, 300, 100), (48, 1000, 500)])
+def test_bf16_pair_trunk_returns_the_bits_of_the_tile_trunk(B, N, M):
+    """Grids of >= 512 tile PAIRS run the bf16 trunk on 128 points per workgroup (`k_trunk_bf2`: half the L2 weight stream per
+    MFMA), smaller ones on 64 (`k_trunk_bf`).  Same contraction order per output and exact maxima: an object refined inside the
+    big batch must get the very bits it gets in a batch of 3 - incl. clouds with an odd tile count (the last pair holds one
+    tile) and ragged last tiles."""
+    from catre_amd import synth
+    from tests.test_hip_parity import build_model, to_dev
+
+    TN, TM = -(-N // 64), -(-M // 64)
+    assert B * ((TN + 1) // 2 + (TM + 1) // 2) >= 512 > 3 * ((TN + 1) // 2 + (TM + 1) // 2)
+    g = load_golden("refine_b3_ragged")
+    cfg = g["cfg"].__deepcopy__({})
+    cfg.INPUT.NUM_PCL, cfg.INPUT.NUM_KPS = N, M
+    cfg.MODEL.CATRE.ROT_HEAD.INIT_CFG.num_points = N + M
+    model, _ = build_model(cfg, 2)
+    model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "bf16"
+    b = to_dev(synth.make_inputs(B, N, M, seed=60 + B))
+    big = model.refine(b, n_iter=2)
+    for idx in ([0, 1, 2], [B - 3, B // 2, B - 1]):
+        sub = {k: v[idx].contiguous() for k, v in b.items()}
+        small = model.refine(sub, n_iter=2)
+        for key in ("pose_1", "scale_1", "pose_2", "scale_2"):
+            assert torch.equal(small[key], big[key][idx]), (key, idx)
