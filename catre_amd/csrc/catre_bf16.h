@@ -76,7 +76,11 @@ __global__ void k_pack_frag_bf(const float* __restrict__ src, int ld, int coloff
 // K-sweep of a wave tile of MB x NB 32x32 blocks, K = 8*CP (CP chunks per LDS row, NKC = CP/2 MFMA steps).
 // Same software pipeline as GemmPipe: weight fragments stream L2 -> registers PFD steps ahead, activation
 // fragments LDS -> registers PFB steps ahead, both pinned with sched_barrier.
-template <int MB, int NB, bool SWAP, int CP, int PFD, int PFB = 1>
+// XA (K >= 128 only): the image base is aligned to its row pitch, so the swizzled fragment address is ONE v_xor of a
+// per-lane base with a compile-time constant - (chunk ^ key) << 4 == (chunk << 4) ^ (key << 4), and neither overlaps the
+// row bits - instead of eight (sixteen past 64 KiB) per-lane pointers held across the sweep.
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+template <int MB, int NB, bool SWAP, int CP, int PFD, int PFB = 1, bool XA = false>
 struct GemmPipeB {
   static constexpr int NKC = CP / 2;
   static_assert(PFD >= 1 && PFD <= NKC && PFB >= 1 && PFB <= PFD, "prefetch depth");
@@ -84,8 +88,10 @@ struct GemmPipeB {
   u32x4 a[RA][MB], b[RB][NB];
   const u32x4* wp;
   int wp_mb;
+  int ablate = 0;  // instrumented build only (catre_debug_knob 1): skip operand loads to price them; always 0 in the product
 
   __device__ __forceinline__ void issue_a(int kc) {
+    if (CATRE_TRACE_ON && (ablate & 1) && kc >= PFD) return;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) a[kc % RA][mb] = wp[mb * wp_mb + kc * 64];
   }
@@ -98,29 +104,54 @@ struct GemmPipeB {
   }
   // x: image row of point 0 of this wave tile (a multiple of 32 rows into the image)
   __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const u32x4* x, int lane) {
+    run(acc, x, lane, [](int) {});
+  }
+  // hook(kc) runs before the loads of K-step kc are issued (k_trunk_bf2 re-balances the two waves of a SIMD there)
+  template <class Hook>
+  __device__ __forceinline__ void run(f32x16 (&acc)[MB][NB], const u32x4* x, int lane, Hook hook) {
     const int n = lane & 31, h = lane >> 5, key = bf_key<CP>(n);
     const u32x4* xrow = x + n * CP;
     // rows of >= 256 B: the XOR key (< 16) only touches the low four bits of the chunk index 2*kc + h, so eight per-lane
     // pointers (kc & 7) + compile-time offsets (kc >> 3, nb) address every fragment - no address arithmetic in the sweep
     // (left to itself the compiler keeps one swizzled index per kc in registers: 32 of them for K = 512)
     const u32x4* xl[8];
-    if constexpr (CP >= 16) {
+    if constexpr (CP >= 16 && !XA) {
 #pragma unroll
       for (int lo = 0; lo < 8; ++lo) xl[lo] = xrow + ((2 * lo + h) ^ key);
     }
+    unsigned xa0 = 0;  // XA: LDS byte address of (row n, chunk h ^ key)
+    if constexpr (XA) {
+      static_assert(CP >= 16, "XA needs rows of >= 256 B");
+      xa0 = (unsigned)(size_t)(lds_cu32x4*)xrow ^ (unsigned)((h ^ key) << 4);
+    }
     auto issue_b = [&](int kc) {
+      if (CATRE_TRACE_ON && (ablate & 2) && kc >= PFB) return;
+      if constexpr (XA) {
+        // two point blocks (2 x 32 rows) per 16-bit ds offset window
+        unsigned a;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a) : "i"(kc << 5), "v"(xa0));
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        if constexpr (CP >= 16)
-          b[kc % RB][nb] = xl[kc & 7][nb * 32 * CP + 16 * (kc >> 3)];
-        else
-          b[kc % RB][nb] = xrow[nb * 32 * CP + ((2 * kc + h) ^ key)];
+        for (int nb = 0; nb < NB; ++nb) {
+          constexpr int WIN = 65536 / (32 * CP * 16);  // point blocks per 64 KiB
+          static_assert(WIN >= 1, "row block larger than the ds offset window");
+          const unsigned aw = a + (unsigned)((nb / WIN) * WIN * 32 * CP * 16);
+          b[kc % RB][nb] = *(lds_cu32x4*)(size_t)(aw + (unsigned)((nb % WIN) * 32 * CP * 16));
+        }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if constexpr (CP >= 16)
+            b[kc % RB][nb] = xl[kc & 7][nb * 32 * CP + 16 * (kc >> 3)];
+          else
+            b[kc % RB][nb] = xrow[nb * 32 * CP + ((2 * kc + h) ^ key)];
+        }
       }
     };
 #pragma unroll
     for (int d = 0; d < PFB; ++d) issue_b(d);
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
+      hook(kc);
       if (kc + PFD < NKC) issue_a(kc + PFD);
       if (kc + PFB < NKC) issue_b(kc + PFB);
       __builtin_amdgcn_sched_barrier(0);
@@ -489,8 +520,10 @@ __device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB],
   // the bias is requested here and consumed after the 16 * NB maxima + shuffle of each m-block (its latency hides
   // behind them; held across the sweep it would cost registers the 2 x 4 wave tile does not have)
   float bl[MB];
+  int l31;  // lane & 31, recomputed here (opaque to CSE: kept live across the sweep it costs the register that spills)
+  asm volatile("v_and_b32 %0, 31, %1" : "=v"(l31) : "v"(lane));
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) bl[mb] = bias[ch0 + mb * 32 + (lane & 31)];
+  for (int mb = 0; mb < MB; ++mb) bl[mb] = bias[ch0 + mb * 32 + l31];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     float m = acc[mb][0][0];
@@ -501,13 +534,16 @@ __device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB],
     m = fmaxf(m, __shfl_xor(m, 32));
     if (lane < 32) {
       const float v = m + bl[mb];
-      out[ch0 + mb * 32 + lane] = v;
-      if (out2) out2[ch0 + mb * 32 + lane] = v;
+      out[ch0 + mb * 32 + l31] = v;
+      if (out2) out2[ch0 + mb * 32 + l31] = v;
     }
   }
 }
 
 #define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)
+#ifndef CATRE_BF2_PFD
+#define CATRE_BF2_PFD 4  // conv4 weight K-steps in flight per wave
+#endif
 __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* __restrict__ trans3,
                                                    const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                    const float* __restrict__ bc1, const u32x4* __restrict__ wp2,
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
                                                    const float* __restrict__ b4, float* __restrict__ pm,
                                                    u32x4* __restrict__ pointfeat, int B, int N, int M,
                                                    unsigned long long* __restrict__ trace) {
-  __shared__ u32x4 smem[TRUNKB2_SMEM];
+  __shared__ __attribute__((aligned(1024))) u32x4 smem[TRUNKB2_SMEM];
 #define TRUNKB2_STAMP(i)                                                                                   \
   do {                                                                                                     \
     if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                \
@@ -654,7 +690,10 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
     }
   }
   // conv4 512->1024 + max: wave owns m-blocks [4*wave, +4) in two passes of 2 x 4 point blocks
-  GemmPipeB<2, 4, true, 64, 3, 1> g4a, g4b;
+  GemmPipeB<2, 4, true, 64, CATRE_BF2_PFD, 1, true> g4a, g4b;
+#ifdef CATRE_DEBUG_TRACE
+  g4a.ablate = g4b.ablate = __builtin_amdgcn_readfirstlane(g_ablate);
+#endif
   {
     f32x16 acc[2][4];
 #pragma unroll

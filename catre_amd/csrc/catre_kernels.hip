@@ -198,6 +198,7 @@ __global__ void k_pose_apply(const float* __restrict__ pcl, const float* __restr
 // dispatch round can be started `g_dephase_cycles` apart, to test whether pairs that begin in lock step keep stalling
 // in their load / thin-layer prologues at the same time.  Product build: no code.
 #ifdef CATRE_DEBUG_TRACE
+__device__ int g_ablate = 0;  // knob 1 (instrumented build): bit 0 = no weight loads, bit 1 = no LDS fragment loads in the bf16 pair trunk's conv4
 __device__ int g_dephase_cycles = 0;
 __device__ __forceinline__ void debug_dephase(int first_round_blocks) {
   const int cyc = g_dephase_cycles;
@@ -2021,6 +2022,7 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
 int catre_debug_knob(int id, int value) {
 #ifdef CATRE_DEBUG_TRACE
   if (id == 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_dephase_cycles), &value, sizeof(int)) == hipSuccess ? CATRE_OK : CATRE_ERR_LAUNCH;
+  if (id == 1) return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &value, sizeof(int)) == hipSuccess ? CATRE_OK : CATRE_ERR_LAUNCH;
   return CATRE_ERR_BAD_ARG;
 #else
   (void)id;

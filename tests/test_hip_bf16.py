@@ -166,6 +166,7 @@ def test_bf16_ragged_and_full_size_properties():
     assert torch.equal(o3[f"pose_{K}"], o1[f"pose_{K}"][: B // 2]), "objects must be independent of their batch"
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,N,M", [(40, 1024, 1024), (130, 300, 100), (48, 1000, 500)])
 def test_bf16_pair_trunk_returns_the_bits_of_the_tile_trunk(B, N, M):
     """Grids of >= 512 tile PAIRS run the bf16 trunk on 128 points per workgroup (`k_trunk_bf2`: half the L2 weight stream per
