@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""The roofline table of DESIGN.md, generated from the committed rocprofv3 summaries so that the document cannot drift
+from `profiles/`:
+
+    python profiles/make_tables.py [r03]            # prints the markdown block
+    python profiles/make_tables.py r03 --write      # rewrites the block between the GENERATED markers in DESIGN.md
+
+Inputs (all under profiles/, tag = round): <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py`, fp32),
+<tag>_pmc_summary.csv (separate --pmc passes), <tag>_bf16_kernel_stats.csv / <tag>_split_kernel_stats.csv /
+<tag>_bf16_pmc_summary.csv, <tag>_train_kernel_stats.csv / <tag>_train_pmc_summary.csv.  `tests/test_host.py` checks that
+the block in DESIGN.md equals what this script prints.
+
+Algorithmic FLOPs per launch are SURVEY.md 8(d)'s per-point figures x the 512 clouds x 1024 points one launch processes at
+B=256, N=M=1024 (stated next to each kernel below); peaks are /opt/skills/guides/MI355X_MICROARCH.md's dense figures."""
+import csv
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PTS = 256 * 2048  # points per launch at B=256, N=M=1024
+FP32_PEAK, BF16_PEAK = 157.3, 2500.0
+SPLIT_PEAK = BF16_PEAK / 3
+
+# kernel -> (algorithmic FLOP per point, what it is, peak TFLOP/s or None for HBM / latency kernels)
+TRUNK = 2 * (64 * 64 + 64 * 128 + 128 * 512 + 512 * 1024) + 2 * 3 * 64 + 18
+STN3D = 2 * (64 * 128 + 128 * 1024) + 2 * 3 * 64
+STNKD = 2 * (64 * 64 + 64 * 128 + 128 * 1024) + 2 * 3 * 64 + 18
+ROT_L1 = 2 * 2 * (64 * 256 + 256 * 256)          # both heads: layer 0 recomputed + layer 1
+ALGO = {
+    "k_trunk<1, false>": (TRUNK, "a3+a5 trunk, conv4 + max", FP32_PEAK),
+    "k_stn3d<1, false>": (STN3D, "a2 STN3d conv stack + max", FP32_PEAK),
+    "k_stnkd<1, false>": (STNKD, "a4 STNkd conv stack + max", FP32_PEAK),
+    "k_rot_l1<1>": (ROT_L1, "a9 rot heads: layer 0 (recomputed) + GN0 + GELU + layer 1", FP32_PEAK),
+    "k_trunk_split<1>": (TRUNK, "trunk, conv3/conv4 as split-bf16 (3 products)", SPLIT_PEAK),
+    "k_rot_l1_split": (ROT_L1, "rot heads, split-bf16", SPLIT_PEAK),
+    "k_stn3d_split<1>": (STN3D, "STN3d, split-bf16", SPLIT_PEAK),
+    "k_stnkd_split<1>": (STNKD, "STNkd, split-bf16", SPLIT_PEAK),
+    "k_trunk_bf2": (TRUNK, "trunk, bf16 operands, 128-point pairs", BF16_PEAK),
+    "k_trunk_bf": (TRUNK, "trunk, bf16 operands, 64-point tiles", BF16_PEAK),
+    "k_rot_l1_bf": (ROT_L1, "rot heads, bf16 operands", BF16_PEAK),
+    "k_stn3d_bf": (STN3D, "STN3d, bf16 operands", BF16_PEAK),
+    "k_stnkd_bf": (STNKD, "STNkd, bf16 operands", BF16_PEAK),
+    # training (config 3): dense GEMM FLOPs of the op, per row of the [rows, C] activation
+    "k_trunk<1, true>": (TRUNK, "training forward: trunk + activation saves", FP32_PEAK),
+    "k_stn3d<1, true>": (STN3D, "training forward: STN3d + saves", FP32_PEAK),
+    "k_stnkd<1, true>": (STNKD, "training forward: STNkd + saves", FP32_PEAK),
+    "k_rot_l1_bwd": (2 * 2 * 256 * 256, "rot head layer-1 backward (dgrad + wgrad), one head, rows = B*(N+M)", FP32_PEAK),
+    "k_rot_l0_bwd": (2 * 2 * 64 * 256, "rot head layer-0 backward (dgrad + wgrad), one head", FP32_PEAK),
+    # the row GEMMs serve several layers: FLOPs = what the launches issued on average (PMC: MFMA ops x 512), None here
+    "k_gemm_rows<1, 32, false>": (None, "row GEMM, K = 256 / 512 (rot layer-1 forward 256 -> 256, conv3 dgrad 512 -> 128)", FP32_PEAK),
+    "k_gemm_rows<1, 8, false>": (None, "row GEMM, K = 64 (rot layer-0 forward, conv2-class dgrads)", FP32_PEAK),
+    "k_gemm_rows<1, 16, false>": (None, "row GEMM, K = 128 (conv2-class dgrads)", FP32_PEAK),
+    "k_gemm_tn<2>": (None, "weight gradients, 128 x 128 tiles", FP32_PEAK),
+    "k_gemm_tn<1>": (None, "weight gradients, 128 x 64 tiles (K <= 64)", FP32_PEAK),
+}
+
+
+def short(name):
+    n = name.replace("void ", "").strip()
+    return n.split("(")[0].strip()
+
+
+def stats(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+    return out
+
+
+def pmc(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            g = lambda k: float(r[k]) if r.get(k) not in (None, "") else None
+            gui, busy = g("mean_GRBM_GUI_ACTIVE"), g("mean_SQ_VALU_MFMA_BUSY_CYCLES")
+            simd_cycles = gui / 8 * 1024 if gui else None     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
+            fetch, write = g("mean_FETCH_SIZE"), g("mean_WRITE_SIZE")
+            mops = g("mean_SQ_INSTS_VALU_MFMA_MOPS_F32")
+            out[r["Kernel"].strip()] = dict(
+                gflop=mops * 512 / 1e9 if mops else None,
+                busy=busy / simd_cycles if busy and simd_cycles else None,
+                rd_mb=fetch * 1024 * 2 / 1e6 if fetch is not None else None,   # gfx950 FETCH_SIZE x2 correction (guide)
+                wr_mb=write * 1024 / 1e6 if write is not None else None)
+    return out
+
+
+def block(tag, title, stats_file, pmc_file, keys, note):
+    st, pm = stats(os.path.join(HERE, stats_file)), pmc(os.path.join(HERE, pmc_file)) if pmc_file else {}
+    if not st:
+        return [f"*{title}: `profiles/{stats_file}` not collected.*", ""]
+    lines = [f"**{title}** (`profiles/{stats_file}`" + (f", `profiles/{pmc_file}`" if pmc_file and pm else "") + f"){note}", "",
+             "| kernel | what | GFLOP / launch | rocprof avg µs | TFLOP/s | % of peak | MFMA busy (PMC) | HBM read / write MB (PMC) |",
+             "|---|---|---|---|---|---|---|---|"]
+    for k in keys:
+        if k not in st:
+            continue
+        calls, us = st[k]
+        per_pt, what, peak = ALGO[k]
+        p = pm.get(k, {})
+        gflop = per_pt * PTS / 1e9 if per_pt else p.get("gflop")
+        if gflop is None:
+            continue
+        tf = gflop / us * 1e3   # GFLOP / µs = PFLOP/s
+        busy = f"{100 * p['busy']:.1f} %" if p.get("busy") else "-"
+        hbm = f"{p['rd_mb']:.0f} / {p['wr_mb']:.0f}" if p.get("rd_mb") is not None and p.get("wr_mb") is not None else "-"
+        lines.append(f"| `{k}` | {what} | {gflop:.1f} | {us:.1f} | {tf:.1f} | {100 * tf / peak:.1f} % of {peak:.0f} | {busy} | {hbm} |")
+    rest = sorted(((us * calls, k, calls, us) for k, (calls, us) in st.items() if k not in keys), reverse=True)[:8]
+    if rest:
+        lines += ["", "Largest other kernels of the same run (no matrix roofline: HBM- or latency-bound): " +
+                  "; ".join(f"`{re.sub(r'<.*', '', k)[:40]}` {calls} x {us:.1f} µs" for _, k, calls, us in rest) + "."]
+    lines.append("")
+    return lines
+
+
+def render(tag="r03"):
+    out = [f"<!-- BEGIN GENERATED by profiles/make_tables.py {tag} -->"]
+    out += block(tag, "fp32 headline path, B=256, N=M=1024, one refine iteration per row",
+                 f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv",
+                 ["k_trunk<1, false>", "k_stn3d<1, false>", "k_stnkd<1, false>", "k_rot_l1<1>"], "")
+    out += block(tag, "split mode (opt-in)", f"{tag}_split_kernel_stats.csv", f"{tag}_pmc_summary.csv",
+                 ["k_trunk_split<1>", "k_stn3d_split<1>", "k_stnkd_split<1>", "k_rot_l1_split"],
+                 "; peak = a third of the bf16 dense peak (three products per fp32-grade product)")
+    out += block(tag, "bf16 operands (BASELINE config 5 arithmetic)", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv",
+                 ["k_trunk_bf2", "k_trunk_bf", "k_stn3d_bf", "k_stnkd_bf", "k_rot_l1_bf"], "")
+    out += block(tag, "training iteration (BASELINE config 3), fp32", f"{tag}_train_kernel_stats.csv", f"{tag}_train_pmc_summary.csv",
+                 ["k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
+                  "k_gemm_rows<1, 32, false>", "k_gemm_rows<1, 8, false>", "k_gemm_rows<1, 16, false>", "k_gemm_tn<2>",
+                  "k_gemm_tn<1>"],
+                 "; GFLOP = the op's dense GEMM work on B*(N+M) rows")
+    out.append("<!-- END GENERATED -->")
+    return "\n".join(out)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = args[0] if args else "r03"
+    text = render(tag)
+    if "--write" in sys.argv:
+        path = os.path.join(ROOT, "DESIGN.md")
+        doc = open(path).read()
+        new = re.sub(r"<!-- BEGIN GENERATED.*?<!-- END GENERATED -->", lambda m: text, doc, flags=re.S)
+        if new == doc and text not in doc:
+            raise SystemExit("DESIGN.md has no GENERATED block")
+        open(path, "w").write(new)
+        print("DESIGN.md updated")
+    else:
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
