@@ -425,7 +425,7 @@ def main():
 
     # The evaluator's operating point next to the headline (outside the timed region, rank 0 of a 1-GPU run only): one
     # image = a handful of objects per call (catre_evaluator.py:292-311).  Object 0 of the batch alone, K refine
-    # iterations, and the check that it gets the very bits it got inside the batch of 256 (latency path, DESIGN.md 5).
+    # iterations, and the check that it gets the very bits it got inside the batch of 256 (latency path, DESIGN.md 5a).
     small_extra = None
     if rank == 0 and world == 1 and args.dtype == "fp32" and args.shape == "headline" and not args.no_small_extra:
         small_extra = {"what": "K=4 refine of 1 / 4 objects (the reference evaluator's shape: one image per call), fp32 "

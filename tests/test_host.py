@@ -359,3 +359,19 @@ def test_runtime_reads_live_parameters_through_cached_slots():
     assert rt._live_params()[j] is fresh.fc_t.weight
     want = dict(model.named_parameters())
     assert all(t is want.get(k) for k, t in zip(hip.PARAM_KEYS, rt._live_params()))
+
+
+def test_design_roofline_table_is_generated_from_the_committed_profiles():
+    """DESIGN.md section 3's per-kernel table is emitted by profiles/make_tables.py from the CSVs under profiles/ - the
+    document cannot quote a number the committed rocprofv3 summaries do not hold."""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("make_tables", os.path.join(ROOT, "profiles", "make_tables.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!-- BEGIN GENERATED by profiles/make_tables.py (\w+) -->.*?<!-- END GENERATED -->", doc, flags=re.S)
+    assert m, "DESIGN.md lost its GENERATED block"
+    assert m.group(0) == mt.render(m.group(1)), "DESIGN.md table is stale: python profiles/make_tables.py <tag> --write"
+    assert "k_trunk<1, false>" in m.group(0) and "k_rot_l1_bwd" in m.group(0) and "k_trunk_bf2" in m.group(0)
