@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           float z[4];
-          gelu_affine4(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
+          gelu_affine4_lp(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
                        scr[i % 3], shr[i % 3], z);
           if ((g & 1) == 0) {
 #pragma unroll
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
     const float v[4] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
     const float w = wp[rt.gp0 + p];
     float z[4];
-    gelu_affine4(v[0], v[1], v[2], v[3], sc, sh, z);
+    gelu_affine4_lp(v[0], v[1], v[2], v[3], sc, sh, z);
 #pragma unroll
     for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));  // scalar neck sums on purpose: see rot_out_body
 #pragma unroll

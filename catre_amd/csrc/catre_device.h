@@ -123,6 +123,30 @@ __device__ __forceinline__ void gelu_affine4(float v0, float v1, float v2, float
   z[3] = zb[1];
 }
 
+// Reduced-precision modes only (bf16 operands: csrc/catre_bf16.h): erf as x P3(x^2) / Q3(x^2) on |x| <= 3.6 - 6 FMAs + v_rcp
+// instead of 10, GELU max abs error 1.7e-5 (fitted and evaluated on the goldens by tests/emulate_gelu.py: 3.3e-5 on
+// (R, t, s), an order of magnitude inside what rounding the operands to bf16 costs; NOT used by the fp32 / split kernels,
+// whose 2e-5 bar it would eat).  The bf16 rotation-head kernels are VALU-bound on this function.
+__device__ __forceinline__ float gelu_erf_lp(float v) {
+  const float z = __builtin_amdgcn_fmed3f(v * 0.70710678118654752440f, -3.6f, 3.6f);
+  const float t = z * z;
+  float p = fmaf(t, 0.0006665938417427242f, 0.04241189360618591f);
+  p = fmaf(t, p, 0.1693669706583023f);
+  p = fmaf(t, p, 1.1281505823135376f);
+  float q = fmaf(t, 0.008663873188197613f, 0.09953298419713974f);
+  q = fmaf(t, q, 0.4826095402240753f);
+  q = fmaf(t, q, 1.0f);
+  const float hv = 0.5f * v;
+  return fmaf(hv, z * p * __builtin_amdgcn_rcpf(q), hv);
+}
+__device__ __forceinline__ void gelu_affine4_lp(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
+                                                float (&z)[4]) {
+  z[0] = gelu_erf_lp(fmaf(v0, sc[0], sh[0]));
+  z[1] = gelu_erf_lp(fmaf(v1, sc[1], sh[1]));
+  z[2] = gelu_erf_lp(fmaf(v2, sc[2], sh[2]));
+  z[3] = gelu_erf_lp(fmaf(v3, sc[3], sh[3]));
+}
+
 // One K-sweep of a wave tile: MB x NB blocks of 32x32, K = 8*NKC.
 //   wp   : fragment-packed weights, already offset to [first m-block][first k-chunk][lane]
 //   wp_mb: float4 stride between consecutive m-blocks  (= (Ktotal/8)*64)
