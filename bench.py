@@ -52,6 +52,11 @@ def flops_per_object_iteration(N, M):
 # rank-0 JSON plumbing only (tests/test_bench_launcher.py runs `python bench.py --gpus 2` this way).  The line it
 # prints is marked "dryrun" and carries no throughput.
 DRYRUN = os.environ.get("CATRE_BENCH_DRYRUN", "0") == "1"
+# CATRE_BENCH_SHARE_GPU=1: every rank of an N > 1 job drives GPU 0 and the job's collectives go through gloo (RCCL refuses
+# two ranks on one device).  For boxes with ONE GPU: the launcher, the rendezvous, DDP's gradient exchange and the timing /
+# JSON plumbing run with real device work (tests/test_multi_gpu.py).  The line is marked "shared_gpu": true - its `value`
+# is NOT a scaling number.
+SHARE_GPU = os.environ.get("CATRE_BENCH_SHARE_GPU", "0") == "1"
 GRAD_ALLREDUCE_BYTES = 4297175 * 4  # trainable-and-used fp32 parameters: one all-reduce per backward
 
 
@@ -72,7 +77,7 @@ def rank_stats(dist, dev, dt):
     """(max dt over ranks, per-rank ms list, number of ranks that took part) - one all_gather on the job's backend."""
     if dist is None:
         return dt, [round(dt * 1e3, 3)], 1
-    mine = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
+    mine = torch.tensor([dt, 1.0], device="cpu" if SHARE_GPU else dev, dtype=torch.float64)
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allv, mine)
     allv = torch.stack(allv).cpu()
@@ -272,7 +277,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
         print(json.dumps({
-            "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms, "comm": comm,
+            "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms, "comm": comm, "shared_gpu": SHARE_GPU,
             "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if world > 1 else 0,
             "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else " [split-bf16 GEMMs]" if split else ""),
             "value": round(value, 1),
@@ -328,13 +333,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     if DRYRUN:
         return bench_dryrun(args, world, rank)
+    if SHARE_GPU:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm; used for barrier / max only
+        if SHARE_GPU:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm; used for barrier / max only
 
     from catre_amd import hip, synth
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
@@ -486,6 +496,7 @@ def main():
             "ranks_seen": ranks_seen,  # ranks that reported through the job's backend (RCCL for N > 1)
             "per_rank_ms": per_rank_ms,
             "comm": comm,
+            "shared_gpu": SHARE_GPU,  # true only under CATRE_BENCH_SHARE_GPU=1 (all ranks on GPU 0: plumbing test, not a scaling run)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),

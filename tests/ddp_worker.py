@@ -19,9 +19,17 @@ if ROOT not in sys.path:
 def main():
     out_path = sys.argv[1]
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    # CATRE_SHARE_GPU=1: every rank drives GPU 0 and the collectives go through gloo (RCCL refuses two ranks on one
+    # device) - the 1-GPU box's stand-in for a 2-GPU node: real processes, real DDP hooks on HIP-computed gradients
+    share = os.environ.get("CATRE_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group(backend="nccl", device_id=dev)
+    if share:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     from catre_amd import synth
     from catre_amd.batching import batch_updater_test
@@ -50,12 +58,15 @@ def main():
     solo = iteration(model)
     names = sorted(solo)
     flat = torch.cat([solo[k].reshape(-1) for k in names])
-    gathered = [torch.zeros_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    src = flat.cpu() if share else flat
+    gathered = [torch.zeros_like(src) for _ in range(world)]
+    dist.all_gather(gathered, src)
+    gathered = [g.to(dev) for g in gathered]
     mean = torch.stack(gathered).double().mean(0)
     differ = float((gathered[0] - gathered[-1]).abs().max())   # ranks saw different data
 
     ddp = DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False, find_unused_parameters=True)
+    assert sum(1 for _ in ddp.parameters()) == 74
     got = iteration(ddp)
     assert sorted(got) == names, "DDP changed which parameters receive gradients"
     gflat = torch.cat([got[k].reshape(-1) for k in names]).double()
@@ -68,7 +79,7 @@ def main():
             worst = (k, err)
         off += n
     opt.step()   # the wrapped module steps
-    verdict = torch.tensor([worst[1]], device=dev, dtype=torch.float64)
+    verdict = torch.tensor([worst[1]], device="cpu" if share else dev, dtype=torch.float64)
     dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
     if rank == 0:
         with open(out_path, "w") as f:
