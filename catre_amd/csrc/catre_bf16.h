@@ -214,14 +214,34 @@ __device__ __forceinline__ void conv3_relu_chunks(float x, float y, float z, con
 // channel of element e of chunk c (k-slot order)
 __device__ __forceinline__ int bf_chunk_channel(int c, int e) { return 16 * (c >> 1) + 8 * (e >> 2) + 4 * (c & 1) + (e & 3); }
 
+// Training forward (SAVE instances): a bf16 LDS image [ROWS][C] (chunks in k-slot order, swizzled) -> fp32 rows dst[row][C] in
+// channel order, rows >= valid skipped.  What the layer-wise backward reads; the values are the bf16-rounded activations - the
+// reduced-precision dgrad / wgrad kernels round their operands to bf16 when they stage them anyway.
+template <int C, int NT, int ROWS>
+__device__ __forceinline__ void save_tile_rows_bf(const u32x4* __restrict__ img, float* __restrict__ dst, int valid, int tid) {
+  constexpr int CP = C / 8;
+#pragma unroll
+  for (int u = 0; u < ROWS * CP / NT; ++u) {
+    const int i = tid + NT * u, row = i / CP, c = i % CP;
+    if (row >= valid) continue;
+    const u32x4 v = img[bf_off<CP>(row, c)];
+    const f32x4 lo = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+    const f32x4 hi = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
+    float* d = dst + (size_t)row * C + 16 * (c >> 1) + 4 * (c & 1);
+    *reinterpret_cast<f32x4*>(d) = lo;
+    *reinterpret_cast<f32x4*>(d + 8) = hi;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // a2: STN3d conv stack (pointnet.py:24-28), bf16 operands.  256 threads, 24 KiB LDS.
 // ------------------------------------------------------------------------------------------
+template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float* __restrict__ W1,
                                                      const float* __restrict__ b1, const u32x4* __restrict__ wp2,
                                                      const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                      const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
-                                                     int M) {
+                                                     int M, TrainSave sv = TrainSave{}) {
   __shared__ u32x4 smem[TP * 8 + TP * 16];
   u32x4* a1 = smem;           // [64][64 ch]
   u32x4* a2 = smem + TP * 8;  // [64][128 ch]
@@ -239,6 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float
     conv3_relu_chunks(x, y, z, W1, b1, wave, a1 + lane * 8, bf_key<8>(lane));
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_bf<64, 256, TP>(a1, sv.s1 + row0 * 64, ti.valid, tid);
   // conv3 128->1024 + max: wave owns m-blocks [8*wave, +8) in two passes of 4
   GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
   float bl[2][4];
@@ -252,33 +274,44 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float
     store_tile_bf<1, 2, true, 16>(acc, a2, wave, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows_bf<128, 256, TP>(a2, sv.s2 + row0 * 128, ti.valid, tid);
   float* out = pm + (size_t)blockIdx.x * PMW;
+  float* pmax = SAVE ? sv.pmax + (size_t)blockIdx.x * 1024 : nullptr;
+  int* pidx = SAVE ? sv.pidx + (size_t)blockIdx.x * 1024 : nullptr;
   {
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, a2, lane);
     g3b.prefetch(wp3 + ((wave * 8 + 4) * 8) * 64 + lane, 8 * 64);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+    if (SAVE)
+      argmax_tile_store<4, 2>(acc, pmax, pidx, (wave * 8) * 32, bl[0], (int)row0, lane);
+    else
+      max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
   }
   {
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, a2, lane);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+    if (SAVE)
+      argmax_tile_store<4, 2>(acc, pmax, pidx, (wave * 8 + 4) * 32, bl[1], (int)row0, lane);
+    else
+      max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // a3+a4: x T3 -> relu(conv1) -> STNkd conv stack 64->64->128->1024 (+ReLU) + per-tile max, bf16 operands.
 // ------------------------------------------------------------------------------------------
+template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float* __restrict__ trans3,
                                                      const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                      const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                      const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                      const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
-                                                     float* __restrict__ pm, int B, int N, int M) {
+                                                     float* __restrict__ pm, int B, int N, int M,
+                                                     TrainSave sv = TrainSave{}) {
   __shared__ u32x4 smem[2 * TP * 8 + TP * 16];
   u32x4* h1 = smem;
   u32x4* f1 = smem + TP * 8;
@@ -310,6 +343,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float
     store_tile_bf<1, 1, true, 8>(acc, f1 + nb1 * 32 * 8, mblk1, bv1, lane);
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_bf<64, 256, TP>(f1, sv.s1 + row0 * 64, ti.valid, tid);
   GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
   float bl[2][4];
   g3a.prefetch(wpf3 + ((wave * 8) * 8) * 64 + lane, 8 * 64);
@@ -322,21 +357,30 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float
     store_tile_bf<1, 2, true, 16>(acc, f2, wave, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows_bf<128, 256, TP>(f2, sv.s2 + row0 * 128, ti.valid, tid);
   float* out = pm + (size_t)blockIdx.x * PMW;
+  float* pmax = SAVE ? sv.pmax + (size_t)blockIdx.x * 1024 : nullptr;
+  int* pidx = SAVE ? sv.pidx + (size_t)blockIdx.x * 1024 : nullptr;
   {
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, f2, lane);
     g3b.prefetch(wpf3 + ((wave * 8 + 4) * 8) * 64 + lane, 8 * 64);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
+    if (SAVE)
+      argmax_tile_store<4, 2>(acc, pmax, pidx, (wave * 8) * 32, bl[0], (int)row0, lane);
+    else
+      max_tile_store_pre<4, 2>(acc, out, (wave * 8) * 32, bl[0], true, lane);
   }
   {
     f32x16 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3b.run(acc, f2, lane);
-    max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
+    if (SAVE)
+      argmax_tile_store<4, 2>(acc, pmax, pidx, (wave * 8 + 4) * 32, bl[1], (int)row0, lane);
+    else
+      max_tile_store_pre<4, 2>(acc, out, (wave * 8 + 4) * 32, bl[1], true, lane);
   }
 }
 
@@ -540,10 +584,54 @@ __device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB],
   }
 }
 
+// arg-max form of the epilogue above (training): first maximum in point order wins, like torch.max; written to the rows of
+// both tiles of the pair
+template <int MB, int NB>
+__device__ __forceinline__ void argmax_pair_store(const f32x16 (&acc)[MB][NB], float* __restrict__ pmax, int* __restrict__ pidx,
+                                                  bool has2, int ch0, const float* __restrict__ bias, int row0, int lane) {
+  int n, h;  // lane & 31, lane >> 5: recomputed here, opaque to CSE (held across the sweep they are what spills)
+  asm volatile("v_and_b32 %0, 31, %1" : "=v"(n) : "v"(lane));
+  asm volatile("v_lshrrev_b32 %0, 5, %1" : "=v"(h) : "v"(lane));
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const float bl = bias[ch0 + mb * 32 + n];
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // increasing point order inside a half-wave: strict > keeps the first
+        const float v = acc[mb][nb][r] + bl;
+        if (v > m) {
+          m = v;
+          am = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        }
+      }
+    const float mo = __shfl_xor(m, 32);
+    const int ao = __shfl_xor(am, 32);
+    if (mo > m || (mo == m && ao < am)) {
+      m = mo;
+      am = ao;
+    }
+    if (h == 0) {
+      pmax[ch0 + mb * 32 + n] = m;
+      pidx[ch0 + mb * 32 + n] = row0 + am;
+      if (has2) {
+        pmax[1024 + ch0 + mb * 32 + n] = m;
+        pidx[1024 + ch0 + mb * 32 + n] = row0 + am;
+      }
+    }
+  }
+}
+
 #define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)
 #ifndef CATRE_BF2_PFD
 #define CATRE_BF2_PFD 4  // conv4 weight K-steps in flight per wave
 #endif
+// SAVE (training forward under autocast, catre_train_trunk_fwd): additionally writes the fp32 rows the layer-wise backward
+// reads - x1 = x T3 (sv.s1, [rows,8]), h1 (sv.s2), conv2 / conv3 outputs (sv.s3, sv.s4), pointfeat (sv.s5, [rows,64]; the
+// bf16 `pointfeat` buffer is then not written) - and the per-tile (max, arg-max row) pairs instead of the maxima.
+template <bool SAVE = false>
 __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* __restrict__ trans3,
                                                    const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                    const float* __restrict__ bc1, const u32x4* __restrict__ wp2,
@@ -551,7 +639,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
                                                    const float* __restrict__ b3, const u32x4* __restrict__ wp4,
                                                    const float* __restrict__ b4, float* __restrict__ pm,
                                                    u32x4* __restrict__ pointfeat, int B, int N, int M,
-                                                   unsigned long long* __restrict__ trace) {
+                                                   unsigned long long* __restrict__ trace, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(1024))) u32x4 smem[TRUNKB2_SMEM];
 #define TRUNKB2_STAMP(i)                                                                                   \
   do {                                                                                                     \
@@ -607,6 +695,12 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
     float x, y, z;
     load_point(P, ti, p, x, y, z);
     apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    if (SAVE && w4 == 0 && p < ti.valid) {  // x1 rows, zero-padded to 8 columns (train_ops.cloud_matmul out_cols=8)
+      const size_t r = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0 + p;
+      const f32x4 lo = {x, y, z, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(sv.s1 + r * 8) = lo;
+      *reinterpret_cast<f32x4*>(sv.s1 + r * 8 + 4) = hi;
+    }
     conv3_relu_chunks(x, y, z, Wc1, bc1, w4, (ft ? h1 : pf) + p * 8, bf_key<8>(p));
     if (ft) {  // A-operand image of the feature transform: row j holds T64[i][j] over i (pointnet.py:107-109);
                // wave (G = w4, s = ph) fills chunk 2G+s: i = 16G + {4s..4s+3, 8+4s..8+4s+3}
@@ -637,6 +731,11 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
     __syncthreads();
   }
   TRUNKB2_STAMP(2);
+  const size_t srow0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) {  // h1 and pointfeat images are both complete here (the feature transform reads one and writes the other)
+    if (ft) save_tile_rows_bf<64, 512, 2 * TP>(h1, sv.s2 + srow0 * 64, ti.valid, tid);
+    save_tile_rows_bf<64, 512, 2 * TP>(pf, sv.s5 + srow0 * 64, ti.valid, tid);
+  }
   // conv3 128->512: wave owns m-blocks [2*wave, +2) over all four point blocks; first weights + bias requested now
   GemmPipeB<2, 4, false, 16, 2, 1> g3;
   g3.prefetch(wp3 + ((wave * 2) * 8) * 64 + lane, 8 * 64);
@@ -678,11 +777,14 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
   }
   __syncthreads();  // scratch / pf / h1 live inside a3, which conv3 overwrites next
   TRUNKB2_STAMP(3);
+  if (SAVE) save_tile_rows_bf<128, 512, 2 * TP>(a2, sv.s3 + srow0 * 128, ti.valid, tid);
   {  // HBM stores of the pair's pointfeat rows and their maxima: issued here, a whole conv3 sweep before the next barrier
      // (which waits for their acknowledge), so that their 8 + 1 registers are free during the sweeps
     const size_t prow0 = ti.is_obs ? (size_t)ti.obj * N + ti.p0 : (size_t)B * N + (size_t)ti.obj * M + ti.p0;
-    if (pf_row < ti.valid) pointfeat[(prow0 + pf_row) * 8 + pf_cc] = pfc0;
-    if (pf_row + TP < ti.valid) pointfeat[(prow0 + pf_row + TP) * 8 + pf_cc] = pfc1;
+    if (!SAVE) {
+      if (pf_row < ti.valid) pointfeat[(prow0 + pf_row) * 8 + pf_cc] = pfc0;
+      if (pf_row + TP < ti.valid) pointfeat[(prow0 + pf_row + TP) * 8 + pf_cc] = pfc1;
+    }
     if (tid < 64) {
       float* o1 = pm + (size_t)tile0 * PMW + 1024 + tid;
       o1[0] = pf_max;
@@ -690,7 +792,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
     }
   }
   // conv4 512->1024 + max: wave owns m-blocks [4*wave, +4) in two passes of 2 x 4 point blocks
-  GemmPipeB<2, 4, true, 64, CATRE_BF2_PFD, 1, true> g4a, g4b;
+  GemmPipeB<2, 4, true, 64, SAVE ? 3 : CATRE_BF2_PFD, 1, true> g4a, g4b;  // SAVE: the arg-max epilogue needs the registers of one ring slot
 #ifdef CATRE_DEBUG_TRACE
   g4a.ablate = g4b.ablate = __builtin_amdgcn_readfirstlane(g_ablate);
 #endif
@@ -709,8 +811,13 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
   TRUNKB2_STAMP(4);
   __syncthreads();
   TRUNKB2_STAMP(5);
+  if (SAVE) save_tile_rows_bf<512, 512, 2 * TP>(a3, sv.s4 + srow0 * 512, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
   float* out2 = has2 ? out + PMW : nullptr;
+  // SAVE: (max, arg-max row) of the PAIR into both tiles' rows of the per-tile tables - k_maxpool_tiles keeps the first
+  // maximum in tile order, and both rows name the same point
+  float* pmax = SAVE ? sv.pmax + (size_t)tile0 * 1024 : nullptr;
+  int* pidx = SAVE ? sv.pidx + (size_t)tile0 * 1024 : nullptr;
   {
     f32x16 acc[2][4];
 #pragma unroll
@@ -718,9 +825,15 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
     g4a.run(acc, a3, lane);
-    g4b.prefetch(wp4 + ((wave * 4 + 2) * 32) * 64 + lane, 32 * 64);
+    if (!SAVE) g4b.prefetch(wp4 + ((wave * 4 + 2) * 32) * 64 + lane, 32 * 64);
     __builtin_amdgcn_sched_barrier(0);
-    max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4) * 32, b4, lane);
+    if (SAVE) {  // the arg-max epilogue needs the registers the next pass's first weights would hold
+      argmax_pair_store<2, 4>(acc, pmax, pidx, has2, (wave * 4) * 32, b4, (int)srow0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      g4b.prefetch(wp4 + ((wave * 4 + 2) * 32) * 64 + lane, 32 * 64);
+    } else {
+      max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4) * 32, b4, lane);
+    }
     TRUNKB2_STAMP(6);
   }
   {
@@ -730,7 +843,10 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
     g4b.run(acc, a3, lane);
-    max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4 + 2) * 32, b4, lane);
+    if (SAVE)
+      argmax_pair_store<2, 4>(acc, pmax, pidx, has2, (wave * 4 + 2) * 32, b4, (int)srow0, lane);
+    else
+      max_tile_store_pre2<2, 4>(acc, out, out2, (wave * 4 + 2) * 32, b4, lane);
   }
   TRUNKB2_STAMP(7);
 #undef TRUNKB2_STAMP

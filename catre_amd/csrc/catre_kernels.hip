@@ -1732,7 +1732,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   int rc;
   {
     ProfScope ps(CATRE_K_STN3D, st);
-    hipLaunchKernelGGL(k_stn3d_bf, dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+    hipLaunchKernelGGL((k_stn3d_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
                        prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
                        pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
   }
@@ -1743,7 +1743,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   if (o->feature_transform) {
     {
       ProfScope ps(CATRE_K_STNKD, st);
-      hipLaunchKernelGGL(k_stnkd_bf, dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+      hipLaunchKernelGGL((k_stnkd_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
                          prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
                          pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
                          prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
@@ -1760,7 +1760,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     // bits); below that the 64-point kernel with two workgroups per CU spreads better
     const int pairs = B * ((TN + 1) / 2 + (TM + 1) / 2);
     if (pairs >= bf_pair_min())
-      hipLaunchKernelGGL(k_trunk_bf2, dim3(pairs), dim3(512), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
+      hipLaunchKernelGGL((k_trunk_bf2<false>), dim3(pairs), dim3(512), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
                          prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
                          prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
                          g_trunk_trace);

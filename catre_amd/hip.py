@@ -93,9 +93,9 @@ _SIGS = {
     "catre_packed_floats": (_SZ, [_I, _I, _I]),
     "catre_pack_weights": (_I, [_P, _I, _I, _I, _P, _SZ, _P]),
     "catre_pack_weights_sel": (_I, [_P, _I, _I, _I, _P, _SZ, _I, _P]),
-    "catre_train_stn3d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
-    "catre_train_stnkd_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
-    "catre_train_trunk_fwd": (_I, [_P] * 12 + [_P, _SZ, _I, _I, _I, _P]),
+    "catre_train_stn3d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_train_stnkd_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_train_trunk_fwd": (_I, [_P] * 12 + [_P, _SZ, _I, _I, _I, _I, _P]),
     "catre_pose_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "catre_stn3d_pool": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_linear": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -211,34 +211,38 @@ class HipRuntime:
             f1=e(R, 64), f2=e(R, 128), g_fstn=e(C, 1024), i_fstn=e(C, 1024, dt=torch.int32),
             x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128), c3=e(R, 512), g=e(C, 1024), i=e(C, 1024, dt=torch.int32))
 
-    def train_stn3d(self, pts, buf, B, N, M, device):
+    def _train_packs(self, device, mode):
+        """(params, packed) for the fused training forward in `mode` (0 = fp32 kernels, 1 = bf16-operand kernels)."""
+        return self.params(device, hip.PACK_F32_ENCODER if mode == 0 else hip.PACK_BF16)
+
+    def train_stn3d(self, pts, buf, B, N, M, device, mode=0):
         lib = hip.load()
-        # first encoder kernel of a training forward: always re-pack the fp32 encoder image (one 6 us launch).  The
+        # first encoder kernel of a training forward: always re-pack the encoder image it reads (one ~6 us launch).  The
         # (data_ptr, _version, epoch) fingerprint cannot see writes through `p.data` (EMA, third-party optimizers), and a
         # stale forward image next to a live-weight backward would give inconsistent gradients without any error.
         self._fingerprint = None
-        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        prm, packed = self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_stn3d_fwd(ctypes.byref(pts), prm, hip.ptr(packed), hip.ptr(buf["a1"]), hip.ptr(buf["a2"]),
                                             hip.ptr(buf["g_stn"]), hip.ptr(buf["i_stn"]), hip.ptr(ws), ws.numel(), B, N, M,
-                                            hip.stream_ptr(device)), "catre_train_stn3d_fwd")
+                                            int(mode), hip.stream_ptr(device)), "catre_train_stn3d_fwd")
 
-    def train_stnkd(self, pts, trans3, buf, B, N, M, device):
+    def train_stnkd(self, pts, trans3, buf, B, N, M, device, mode=0):
         lib = hip.load()
-        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        prm, packed = self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_stnkd_fwd(ctypes.byref(pts), hip.ptr(trans3), prm, hip.ptr(packed), hip.ptr(buf["f1"]),
                                             hip.ptr(buf["f2"]), hip.ptr(buf["g_fstn"]), hip.ptr(buf["i_fstn"]), hip.ptr(ws),
-                                            ws.numel(), B, N, M, hip.stream_ptr(device)), "catre_train_stnkd_fwd")
+                                            ws.numel(), B, N, M, int(mode), hip.stream_ptr(device)), "catre_train_stnkd_fwd")
 
-    def train_trunk(self, pts, trans3, trans64, buf, B, N, M, device):
+    def train_trunk(self, pts, trans3, trans64, buf, B, N, M, device, mode=0):
         lib = hip.load()
-        prm, packed = self.params(device, hip.PACK_F32_ENCODER)
+        prm, packed = self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_trunk_fwd(ctypes.byref(pts), hip.ptr(trans3), hip.ptr(trans64), prm, hip.ptr(packed),
                                             hip.ptr(buf["x1"]), hip.ptr(buf["h1"]), hip.ptr(buf["pf"]), hip.ptr(buf["c2"]),
                                             hip.ptr(buf["c3"]), hip.ptr(buf["g"]), hip.ptr(buf["i"]), hip.ptr(ws),
-                                            ws.numel(), B, N, M, hip.stream_ptr(device)), "catre_train_trunk_fwd")
+                                            ws.numel(), B, N, M, int(mode), hip.stream_ptr(device)), "catre_train_trunk_fwd")
 
     # ------------------------------------------------------------------ single stages (tests, sub-modules)
     def stage_linear(self, x, W, bias, relu=False, add_identity_k=0):

@@ -32,24 +32,26 @@ def _stn(rows, p, prefix, k, B, N, M, pre=None):
     return t.view(-1, k, k)
 
 
-def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net"):
+def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
     """The same graph as :func:`pointnet_rows` (feature_transform=True), but the three conv stacks run as the FUSED encoder
     kernels with extra stores (``catre_train_{stn3d,stnkd,trunk}_fwd``): one launch per block instead of a row GEMM per
     layer.  Every layer op becomes a graph node around an output that exists already (``pre=``); the backward is the
-    layer-wise one, unchanged.  fp32 only; N, M multiples of 64."""
+    layer-wise one, unchanged.  N, M multiples of 64.  mode 0: the fp32 kernels; mode 1 (autocast): the bf16-operand kernels -
+    the rows they save are the bf16-rounded activations, which is what the reduced-precision dgrad / wgrad kernels of the
+    backward make of their operands anyway."""
     w = lambda n: p[f"{prefix}.{n}"]
     dev = pts.device
     buf = rt.train_encoder_buffers(B, N, M, dev)
-    rt.train_stn3d(desc, buf, B, N, M, dev)
+    rt.train_stn3d(desc, buf, B, N, M, dev, mode)
     trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M, pre=(buf["a1"], buf["a2"], buf["g_stn"], buf["i_stn"]))
     trans3 = trans.detach().reshape(-1, 9).contiguous()
     # x1 / h1 are written by the trunk kernel further down (same stream, before anything reads them)
     x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8, pre=buf["x1"])
     h1 = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True, pre=buf["h1"])
-    rt.train_stnkd(desc, trans3, buf, B, N, M, dev)
+    rt.train_stnkd(desc, trans3, buf, B, N, M, dev, mode)
     trans_feat = _stn(h1, p, f"{prefix}.fstn", 64, B, N, M, pre=(buf["f1"], buf["f2"], buf["g_fstn"], buf["i_fstn"]))
     trans64 = trans_feat.detach().reshape(-1, 4096).contiguous()
-    rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev)
+    rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode)
     pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
     h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
     h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
@@ -113,9 +115,9 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
     hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)
     pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
-    if rt is not None and T._amp() == 0 and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
+    if rt is not None and T._amp() in (0, 1) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
-        g, pf = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M)
+        g, pf = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp())
     else:
         g, pf = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform))
     pfmax = T.maxpool_points(pf, B, N, M)                                     # max_n pointfeat (flat_pcl_feat tail)

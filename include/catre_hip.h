@@ -386,15 +386,20 @@ int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const fl
  *   stnkd: f1 = relu(fstn.conv1) [R,64], f2 = relu(fstn.conv2) [R,128]           (pointnet.py:57-61)
  *   trunk: x1 = x T3 [R,8] (zero-padded), h1 = relu(conv1) [R,64], pf = h1 T64 [R,64], a2 = relu(conv2) [R,128],
  *          a3 = relu(conv3) [R,512]                                               (pointnet.py:98-116)
- * N and M multiples of 64; fp32 packs (CATRE_PACK_F32_ENCODER) in `packed`; `workspace` as catre_workspace_bytes. */
+ * N and M multiples of 64; `workspace` as catre_workspace_bytes.  compute_dtype = CATRE_DTYPE_F32 (fp32 packs,
+ * CATRE_PACK_F32_ENCODER, in `packed`) or CATRE_DTYPE_BF16 (what torch.autocast selects, engine.py:304: the bf16-operand
+ * kernels, CATRE_PACK_BF16 packs; the saved rows then hold the bf16-rounded activations as fp32 - the reduced-precision
+ * dgrad / wgrad ops round their operands the same way when they stage them; trans64 required). */
 int catre_train_stn3d_fwd(const catre_points* pts, const float* const* params, const float* packed, float* a1, float* a2,
-                          float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+                          float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, int compute_dtype,
+                          void* stream);
 int catre_train_stnkd_fwd(const catre_points* pts, const float* trans3, const float* const* params, const float* packed,
                           float* f1, float* f2, float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N,
-                          int M, void* stream);
+                          int M, int compute_dtype, void* stream);
 int catre_train_trunk_fwd(const catre_points* pts, const float* trans3, const float* trans64, const float* const* params,
                           const float* packed, float* x1, float* h1, float* pf, float* a2, float* a3, float* g,
-                          int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, void* stream);
+                          int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, int compute_dtype,
+                          void* stream);
 
 /* f4: one fused multi-tensor Ranger step = RAdam + Lookahead + gradient centralization
  * (lib/torch_utils/solver/ranger.py:102-202) with the train loop's grad nan_to_num folded in

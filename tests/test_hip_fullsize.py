@@ -57,7 +57,7 @@ def _subset_grads(model, cfg, b, idx, G):
     return out, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("compute", [None, "split"])
+@pytest.mark.parametrize("compute", [None, "split", "bf16"])
 def test_config3_training_step_at_full_size(compute):
     """B=256, N=M=1024, do_loss=True (313 symmetry candidates for half the objects): finite, bitwise deterministic, and an
     optimizer step on it changes the weights."""

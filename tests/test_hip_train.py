@@ -174,6 +174,80 @@ def test_amp_training_iteration_tracks_fp32():
     assert checked >= 20
 
 
+def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path():
+    """Under autocast the encoder forward of the training path runs on SAVE instances of the bf16-operand inference kernels
+    (`catre_train_*_fwd`, compute_dtype = bf16: k_stn3d_bf / k_stnkd_bf / k_trunk_bf2 with fp32 row saves + arg-max) instead of
+    one bf16 row GEMM per layer.  Same operand rounding (weights at pack time, activations when they are staged), so against the
+    layer-wise autocast forward: refined pose within 2e-3, every saved activation within one bf16 ulp of the layer-wise one
+    (the saved rows hold the ROUNDED activations; the feature transform is a bf16 MFMA here and an fp32 kernel there),
+    gradients with cosine >= 0.97; pooled arg-max rows agree except where two candidates tie within rounding."""
+    from catre_amd import synth, train_ops
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from catre_amd.train_forward import forward_train
+
+    B, N, M = 6, 192, 128   # N/64 = 3: the observed clouds end in a pair that holds ONE tile
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.to(DEV) for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()})
+    model.train()
+    b = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=23).items()}
+    batch_updater_test(cfg, b)
+    p = dict(model.named_parameters())
+    gen = torch.Generator().manual_seed(5)
+    Gp, Gs = torch.randn(B, 3, 4, generator=gen).to(DEV), torch.randn(B, 3, generator=gen).to(DEV)
+
+    def run(rt):
+        model.zero_grad(set_to_none=True)
+        with train_ops.amp_mode("bf16"):
+            pose, scale, _ = forward_train(p, model._opts, b["x"], b["tfd_kps"], b["obj_pose_est"], b["obj_scale_est"], b["K"],
+                                           b["obj_mean_scales"], rt=rt)
+            ((pose * Gp).sum() + (scale * Gs).sum()).backward()
+        return pose.detach().clone(), {k: v.grad.clone() for k, v in p.items() if v.grad is not None}
+
+    rt = model._runtime()
+    pose_l, g_l = run(None)
+    pose_f, g_f = run(rt)
+    assert not torch.equal(pose_l, pose_f), "the fused bf16 forward was not taken"
+    assert (pose_l - pose_f).abs().max() < 2e-3
+    assert set(g_l) == set(g_f) and len(g_f) == 68
+    for k, g in g_l.items():
+        if g.numel() < 1024 or float(g.norm()) < 1e-8:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), g_f[k].reshape(-1), dim=0))
+        # two bf16 pipelines flip single arg-max decisions in front of the pools: the fp32-vs-autocast test above holds 0.98
+        assert cos >= 0.97 and 0.9 <= float(g_f[k].norm() / g.norm()) <= 1.1, (k, cos)
+    # the saved rows themselves: fused (bf16-rounded) vs the fp32 kernels' saves rounded the same way
+    desc = __import__("catre_amd.hip", fromlist=["points_desc"]).points_desc(b["x"], b["tfd_kps"])
+    bufs = {}
+    for mode in (0, 1):
+        buf = rt.train_encoder_buffers(B, N, M, torch.device(DEV))
+        for v in buf.values():
+            v.fill_(0) if v.dtype == torch.int32 else v.fill_(float("nan"))
+        rt.train_stn3d(desc, buf, B, N, M, torch.device(DEV), mode)
+        trans3 = torch.eye(3, device=DEV).reshape(1, 9).repeat(2 * B, 1).contiguous()
+        rt.train_stnkd(desc, trans3, buf, B, N, M, torch.device(DEV), mode)
+        trans64 = torch.eye(64, device=DEV).reshape(1, 4096).repeat(2 * B, 1).contiguous()
+        rt.train_trunk(desc, trans3, trans64, buf, B, N, M, torch.device(DEV), mode)
+        torch.cuda.synchronize()
+        bufs[mode] = buf
+    for k in ("a1", "x1", "h1", "pf"):   # inputs of the first bf16 GEMMs: exactly the fp32 values rounded to bf16
+        want = bufs[0][k].to(torch.bfloat16).float()
+        assert torch.isfinite(bufs[1][k]).all(), k
+        assert torch.equal(bufs[1][k], want) or (bufs[1][k] - want).abs().max() <= 1e-2 * want.abs().max(), k
+    for k in ("a2", "f1", "f2", "c2", "c3"):
+        assert torch.isfinite(bufs[1][k]).all(), k
+        err = (bufs[1][k] - bufs[0][k]).abs().max() / bufs[0][k].abs().max()
+        assert err <= 2e-2, (k, float(err))
+    for k in ("g_stn", "g_fstn", "g"):
+        err = (bufs[1][k] - bufs[0][k]).abs().max() / bufs[0][k].abs().max()
+        assert err <= 2e-2, (k, float(err))
+    for k in ("i_stn", "i_fstn", "i"):
+        assert (bufs[1][k] >= 0).all() and (bufs[1][k] < B * (N + M)).all(), k
+        assert float((bufs[1][k] == bufs[0][k]).float().mean()) >= 0.9, k
+
+
 def test_split_training_iteration_matches_fp32():
     """COMPUTE_DTYPE='split' in training: the tiled forward / dgrad / wgrad GEMMs run hi + lo bf16 operands with three
     products (fp32-grade results on the bf16 pipe).  Losses within 1e-5 relative of the fp32 iteration, every gradient
