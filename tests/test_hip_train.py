@@ -439,10 +439,12 @@ def test_fused_loss_matches_oracle_values_and_gradients(variant):
         assert err <= 2e-5, (name, err)
 
 
-def test_graphed_train_step_replays_the_eager_iteration():
+@pytest.mark.parametrize("amp", [False, True])
+def test_graphed_train_step_replays_the_eager_iteration(amp):
     """GraphedTrainStep (forward + loss + backward + fused Ranger step in one HIP graph) against the eager loop on
     the same batches: same losses, same parameters after every step (the same kernels run in the same order), the
-    caller's model / optimizer state untouched by the capture's warm-up, and a changing symmetric / non-symmetric mix."""
+    caller's model / optimizer state untouched by the capture's warm-up, and a changing symmetric / non-symmetric mix.
+    amp: the same under torch.autocast (fused bf16-operand encoder forward, bf16-operand dgrad / wgrad GEMMs)."""
     from catre_amd import synth
     from catre_amd.batching import batch_updater_test
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
@@ -472,7 +474,8 @@ def test_graphed_train_step_replays_the_eager_iteration():
     eager = []
     for b, s in zip(batches, syms):
         kw = kwargs(b)
-        out, ld = model_e(kw.pop("x"), kw.pop("tfd_kps"), sym_info=s, do_loss=True, cur_iter=1, **kw)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out, ld = model_e(kw.pop("x"), kw.pop("tfd_kps"), sym_info=s, do_loss=True, cur_iter=1, **kw)
         sum(ld.values()).backward()
         opt_e.step()
         opt_e.zero_grad(set_to_none=True)
@@ -481,7 +484,7 @@ def test_graphed_train_step_replays_the_eager_iteration():
 
     model_g, opt_g = build_model_optimizer(cfg, is_test=False)
     model_g.load_state_dict(sd)
-    step = GraphedTrainStep(model_g, opt_g, kwargs(batches[0]), syms[0], max_sym=12)
+    step = GraphedTrainStep(model_g, opt_g, kwargs(batches[0]), syms[0], max_sym=12, amp=amp)
     for k, p in model_g.named_parameters():
         assert torch.equal(p, sd[k]), f"capture warm-up changed {k}"
     assert all(st["step"] == 0 for st in opt_g.state.values())
