@@ -187,6 +187,12 @@ _param_epoch = [0]
 
 
 def bump_param_epoch():
+    """Tell every runtime that parameters may have been rewritten out of band.
+
+    The packed weight images are rebuilt when a parameter's ``(data_ptr, _version)`` changes - what ``load_state_dict``,
+    ``p.copy_()`` and the optimizers do.  Writes through ``p.data`` (EMA updates, some third-party optimizers) bump neither;
+    INFERENCE callers that do that call this once afterwards.  The training forward does not depend on it: it re-packs the
+    encoder image it reads on every call."""
     _param_epoch[0] += 1
 
 
