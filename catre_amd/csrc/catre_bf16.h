@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_bf(catre_points P, const float
 // pair whose second half holds duplicates of the last point.
 //   a3 [128][512 ch] 128 KiB | a2 [128][128 ch] 32 KiB; h1 / T64 image / pointfeat image / scratch alias a3.
 // ------------------------------------------------------------------------------------------
-template <int MB, int NB>
+template <int MB, int NB, bool RELU = false>
 __device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB], float* __restrict__ out,
                                                     float* __restrict__ out2, int ch0, const float* __restrict__ bias,
                                                     int lane) {
@@ -577,7 +577,8 @@ __device__ __forceinline__ void max_tile_store_pre2(const f32x16 (&acc)[MB][NB],
       for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mb][nb][r]);
     m = fmaxf(m, __shfl_xor(m, 32));
     if (lane < 32) {
-      const float v = m + bl[mb];
+      const float t = m + bl[mb];
+      const float v = RELU ? fmaxf(t, 0.f) : t;
       out[ch0 + mb * 32 + l31] = v;
       if (out2) out2[ch0 + mb * 32 + l31] = v;
     }
@@ -624,6 +625,141 @@ __device__ __forceinline__ void argmax_pair_store(const f32x16 (&acc)[MB][NB], f
   }
 }
 
+// pair bookkeeping: a TileInfo of up to 128 valid points + the index of its first 64-point tile
+__device__ __forceinline__ void pair_info(int bid, int B, int N, int M, TileInfo& ti, int& tile0) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, PN = (TN + 1) / 2, PM_ = (TM + 1) / 2;
+  if (bid < B * PN) {
+    ti.obj = bid / PN;
+    ti.cloud = ti.obj;
+    ti.is_obs = 1;
+    const int pi = bid % PN;
+    ti.p0 = pi * 2 * TP;
+    ti.valid = min(2 * TP, N - ti.p0);
+    tile0 = ti.obj * TN + 2 * pi;
+  } else {
+    const int r = bid - B * PN;
+    ti.obj = r / PM_;
+    ti.cloud = B + ti.obj;
+    ti.is_obs = 0;
+    const int pi = r % PM_;
+    ti.p0 = pi * 2 * TP;
+    ti.valid = min(2 * TP, M - ti.p0);
+    tile0 = B * TN + ti.obj * TM + 2 * pi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// STN conv stacks on PAIRS of tiles (large grids, like k_trunk_bf2): 128 points and 256 threads per workgroup, two
+// workgroups per CU.  At the bf16 rate the 64-point kernels spend half their time in the point loads / conv1 / conv2
+// prologue and in the start-up of four K = 128 sweeps; a pair amortises both over twice the MFMAs (2 x 4 wave tiles: a
+// weight fragment feeds four MFMAs).  Same contraction order per output, exact maxima: the bits of k_stn3d_bf / k_stnkd_bf.
+// conv3 128 -> 1024 + ReLU + max: the wave owns m-blocks [8 wave, +8) in four passes of two.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stn_conv3_pair_bf(const u32x4* __restrict__ wp3, const float* __restrict__ b3, const u32x4* a2,
+                                                  float* __restrict__ out, float* __restrict__ out2, int wave, int lane) {
+  GemmPipeB<2, 4, true, 16, 3, 1, true> g[2];
+  g[0].prefetch(wp3 + ((size_t)(wave * 8) * 8) * 64 + lane, 8 * 64);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    g[ps & 1].run(acc, a2, lane);
+    if (ps < 3) g[(ps + 1) & 1].prefetch(wp3 + ((size_t)(wave * 8 + (ps + 1) * 2) * 8) * 64 + lane, 8 * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    max_tile_store_pre2<2, 4, true>(acc, out, out2, (wave * 8 + ps * 2) * 32, b3, lane);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const u32x4* __restrict__ wp2,
+                                                      const float* __restrict__ b2, const u32x4* __restrict__ wp3,
+                                                      const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
+                                                      int M) {
+  __shared__ __attribute__((aligned(1024))) u32x4 smem[2 * TP * 16 + 2 * TP * 8];
+  u32x4* a2 = smem;                // [128][128 ch] (first: its rows are the XOR-addressed ones)
+  u32x4* a1 = smem + 2 * TP * 16;  // [128][64 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TileInfo ti;
+  int tile0;
+  pair_info(blockIdx.x, B, N, M, ti, tile0);
+
+  GemmPipeB<1, 4, false, 8, 3> g2;  // conv2 64->128: wave -> m-block `wave`, all four point blocks
+  g2.prefetch(wp2 + (wave * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  {  // conv1 3->64 on the VALU: thread = (point, two 16-channel groups)
+    const int p = (wave & 1) * TP + lane, g0 = (wave >> 1) * 2;
+    float x, y, z;
+    load_point(P, ti, p, x, y, z);
+    conv3_relu_chunks(x, y, z, W1, b1, g0, a1 + p * 8, bf_key<8>(p));
+    conv3_relu_chunks(x, y, z, W1, b1, g0 + 1, a1 + p * 8, bf_key<8>(p));
+  }
+  __syncthreads();
+  {
+    f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
+    g2.run(acc, a1, lane);
+    store_tile_bf<1, 4, true, 16>(acc, a2, wave, bv2, lane);
+  }
+  __syncthreads();
+  float* out = pm + (size_t)tile0 * PMW;
+  stn_conv3_pair_bf(wp3, b3, a2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+}
+
+__global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const float* __restrict__ trans3,
+                                                      const float* __restrict__ Wc1, const float* __restrict__ bc1,
+                                                      const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
+                                                      const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
+                                                      const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
+                                                      float* __restrict__ pm, int B, int N, int M) {
+  __shared__ __attribute__((aligned(1024))) u32x4 smem[2 * TP * 16 + 2 * 2 * TP * 8];
+  u32x4* f2 = smem;                              // [128][128 ch]
+  u32x4* h1 = smem + 2 * TP * 16;                // [128][64 ch]
+  u32x4* f1 = smem + 2 * TP * 16 + 2 * TP * 8;   // [128][64 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TileInfo ti;
+  int tile0;
+  pair_info(blockIdx.x, B, N, M, ti, tile0);
+
+  const int mblk1 = wave >> 1, half1 = wave & 1;
+  GemmPipeB<1, 2, false, 8, 4> g1;  // fstn.conv1 64->64: 2 m-blocks x 4 point blocks, (m-block, point half) per wave
+  g1.prefetch(wpf1 + (mblk1 * 4) * 64 + lane, 0);
+  f32x4 bv1[1][4];
+  load_bias_quads<1>(bv1, bf1, mblk1 * 32, lane);
+  {
+    const int p = (wave & 1) * TP + lane, g0 = (wave >> 1) * 2;
+    float x, y, z;
+    load_point(P, ti, p, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_chunks(x, y, z, Wc1, bc1, g0, h1 + p * 8, bf_key<8>(p));
+    conv3_relu_chunks(x, y, z, Wc1, bc1, g0 + 1, h1 + p * 8, bf_key<8>(p));
+  }
+  __syncthreads();
+  GemmPipeB<1, 4, false, 8, 3> g2;
+  g2.prefetch(wpf2 + (wave * 4) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, bf2, wave * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g1.run(acc, h1 + half1 * TP * 8, lane);
+    store_tile_bf<1, 2, true, 8>(acc, f1 + half1 * TP * 8, mblk1, bv1, lane);
+  }
+  __syncthreads();
+  {
+    f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
+    g2.run(acc, f1, lane);
+    store_tile_bf<1, 4, true, 16>(acc, f2, wave, bv2, lane);
+  }
+  __syncthreads();
+  float* out = pm + (size_t)tile0 * PMW;
+  stn_conv3_pair_bf(wpf3, bf3, f2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+}
+
 #define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)
 #ifndef CATRE_BF2_PFD
 #define CATRE_BF2_PFD 4  // conv4 weight K-steps in flight per wave
@@ -656,31 +792,9 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, h = lane >> 5;
-  // pair bookkeeping: a TileInfo of up to 128 valid points + the index of its first 64-point tile
-  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, PN = (TN + 1) / 2, PM_ = (TM + 1) / 2;
   TileInfo ti;
   int tile0;
-  {
-    const int bid = blockIdx.x;
-    if (bid < B * PN) {
-      ti.obj = bid / PN;
-      ti.cloud = ti.obj;
-      ti.is_obs = 1;
-      const int pi = bid % PN;
-      ti.p0 = pi * TP2;
-      ti.valid = min(TP2, N - ti.p0);
-      tile0 = ti.obj * TN + 2 * pi;
-    } else {
-      const int r = bid - B * PN;
-      ti.obj = r / PM_;
-      ti.cloud = B + ti.obj;
-      ti.is_obs = 0;
-      const int pi = r % PM_;
-      ti.p0 = pi * TP2;
-      ti.valid = min(TP2, M - ti.p0);
-      tile0 = B * TN + ti.obj * TM + 2 * pi;
-    }
-  }
+  pair_info(blockIdx.x, B, N, M, ti, tile0);
   const bool has2 = ti.valid > TP;
   const bool ft = trans64 != nullptr;
   TRUNKB2_STAMP(0);

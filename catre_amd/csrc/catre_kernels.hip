@@ -1730,11 +1730,20 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM, tiles = B * T;
   const int rd = catre_rot_dim(o->rot_type) / 2;
   int rc;
+  // grids that fill the chip twice over take PAIRS of tiles per workgroup in all three encoder kernels (same bits, fewer
+  // prologues and weight fetches per MFMA); below that the 64-point kernels spread better
+  const int pairs = B * ((TN + 1) / 2 + (TM + 1) / 2);
+  const bool paired = pairs >= bf_pair_min();
   {
     ProfScope ps(CATRE_K_STN3D, st);
-    hipLaunchKernelGGL((k_stn3d_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
-                       prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
-                       pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+    if (paired)
+      hipLaunchKernelGGL(k_stn3d_bf2, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+                         prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
+                         pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+    else
+      hipLaunchKernelGGL((k_stn3d_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+                         prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
+                         pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
   }
   hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
   if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, 2 * B, st)))
@@ -1743,10 +1752,16 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   if (o->feature_transform) {
     {
       ProfScope ps(CATRE_K_STNKD, st);
-      hipLaunchKernelGGL((k_stnkd_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
-                         prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
-                         pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
-                         prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+      if (paired)
+        hipLaunchKernelGGL(k_stnkd_bf2, dim3(pairs), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+                           prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
+                           pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
+                           prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+      else
+        hipLaunchKernelGGL((k_stnkd_bf<false>), dim3(tiles), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+                           prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
+                           pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
+                           prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
     }
     hipLaunchKernelGGL(k_reduce_pm, dim3(2 * B, (1024 + 255) / 256), dim3(256), 0, st, ws + W.pm, ws + W.pool, 1024, 1024, B, N, M);
     if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, 2 * B, st)))
@@ -1756,10 +1771,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   u32x4* pointfeat = reinterpret_cast<u32x4*>(ws + W.pointfeat);
   {
     ProfScope ps(CATRE_K_TRUNK, st);
-    // grids that fill the chip twice over take PAIRS of tiles per workgroup (half the L2 weight stream per MFMA; same
-    // bits); below that the 64-point kernel with two workgroups per CU spreads better
-    const int pairs = B * ((TN + 1) / 2 + (TM + 1) / 2);
-    if (pairs >= bf_pair_min())
+    if (paired)
       hipLaunchKernelGGL((k_trunk_bf2<false>), dim3(pairs), dim3(512), 0, st, *pts, ws + W.trans3, t64, prm[CATRE_P_CONV1_W],
                          prm[CATRE_P_CONV1_B], pkb(packed, L.bf_c2), prm[CATRE_P_CONV2_B], pkb(packed, L.bf_c3),
                          prm[CATRE_P_CONV3_B], pkb(packed, L.bf_c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
