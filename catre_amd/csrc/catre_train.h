@@ -150,13 +150,18 @@ template <int MB, int NKC, bool MAXP = false>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
-                                                   int relu, const float* __restrict__ xmask, int ldxm, CloudBias cb) {
+                                                   int relu, const float* __restrict__ xmask, int ldxm, CloudBias cb,
+                                                   const int* __restrict__ Rdev = nullptr) {
   constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
   constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
   __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TP;
+  if (Rdev) {  // row count known only on the device (row-compacted operands, catre_op_rows_compact): tiles past it leave
+    R = min(R, *Rdev);
+    if (r0 >= R) return;
+  }
   const int nblk = J / 32, nkc_total = K / 8, nchunks = K / KC;
   f32x16 acc[MB][2];
 #pragma unroll
@@ -377,7 +382,12 @@ template <int KB>
 __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
                                                  int rows_per_split, float* __restrict__ colpart,
-                                                 const float* __restrict__ ymask, int ldym, size_t pitch) {
+                                                 const float* __restrict__ ymask, int ldym, size_t pitch,
+                                                 const int* __restrict__ Rdev = nullptr) {
+  if (Rdev) {  // device-side row count: the splits share the rows that exist (empty splits write zero partials)
+    R = min(R, *Rdev);
+    rows_per_split = (int)((R + gridDim.z * TN_ROWS - 1) / (gridDim.z * TN_ROWS)) * TN_ROWS;
+  }
   constexpr int KT = 64 * KB;      // tile width along K
   constexpr int XQ = KT / 4;       // float4 per staged X row
   constexpr int XU = TN_ROWS * XQ / 512;
@@ -491,7 +501,12 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                         int ldx, float* __restrict__ part, int J, int K, int R,
                                                         int rows_per_split, float* __restrict__ colpart,
-                                                        const float* __restrict__ ymask, int ldym, size_t pitch) {
+                                                        const float* __restrict__ ymask, int ldym, size_t pitch,
+                                                        const int* __restrict__ Rdev = nullptr) {
+  if (Rdev) {
+    R = min(R, *Rdev);
+    rows_per_split = (int)((R + gridDim.x * 32 - 1) / (gridDim.x * 32)) * 32;
+  }
   extern __shared__ float red[];  // [row lane][column quad][4 * KS products + 4 column sums]
   constexpr int E = 4 * KS + 4;
   const int JQ = J >> 2, RL = 256 / JQ;
@@ -941,9 +956,13 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
 //   3. the waves walk the rows: dX[row][:] = sum over the row's channels of dg * W[channel][:], zeros for rows that
 //      were nobody's arg-max.
 #define MLX_MAXN 4096
+// rowpos != nullptr (row-sparse chains, below): only the rows that are somebody's arg-max are written, row r of the cloud at
+// compact row rowpos[r0 + r]; ymask (the layer's own ReLU output, dense rows) zeroes what that ReLU killed.
 __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restrict__ dg, const int* __restrict__ idx,
                                                            const float* __restrict__ W, int ldw, float* __restrict__ dX,
-                                                           int ldx, int J, int K, int B, int N, int M) {
+                                                           int ldx, int J, int K, int B, int N, int M,
+                                                           const int* __restrict__ rowpos = nullptr,
+                                                           const float* __restrict__ ymask = nullptr, int ldym = 0) {
   __shared__ int start[MLX_MAXN + 1];
   __shared__ int fill[MLX_MAXN];
   __shared__ int lst[1024];
@@ -1012,7 +1031,8 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
   // two column slices are requested together - the walk is bound by that latency, not by the bytes it writes.
   for (int r = blockIdx.y * 8 + wave; r < n; r += 8 * gridDim.y) {
     const int b = start[r], e = start[r + 1];
-    float* xr = dX + (size_t)(r0 + r) * ldx;
+    if (rowpos && b == e) continue;  // compact destination: rows without a channel do not exist
+    float* xr = dX + (size_t)(rowpos ? rowpos[r0 + r] : r0 + r) * ldx;
     const int q0 = lane, q1 = lane + 64;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     for (int t = b; t < e; ++t) {
@@ -1027,8 +1047,144 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
         acc1[u] = fmaf(gv, w1[u], acc1[u]);
       }
     }
+    if (ymask) {
+      const float* mr = ymask + (size_t)(r0 + r) * ldym;
+      if (q0 < nf4) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mr + q0 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc0[u] = m[u] > 0.f ? acc0[u] : 0.f;
+      }
+      if (q1 < nf4) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mr + q1 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc1[u] = m[u] > 0.f ? acc1[u] : 0.f;
+      }
+    }
     if (q0 < nf4) *reinterpret_cast<f32x4*>(xr + q0 * 4) = acc0;
     if (q1 < nf4) *reinterpret_cast<f32x4*>(xr + q1 * 4) = acc1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sparse backward of linear + max-pool chains.  Only the arg-max row of a (cloud, channel) carries gradient, so the
+// gradient of the layer in front of a pool - and of every layer further up the conv stack, until it meets a dense side
+// input - is zero on every row that is nobody's arg-max: ~70 % of the rows at N = M = 1024 (profiles/argmax_row_fraction.py).
+// These kernels build the ascending list of live rows and a dense -> compact map on the device (no host sync: the
+// count stays in `count[0]`, the row GEMMs read it - Rdev above), so that dgrad / wgrad run on the compacted rows only.
+//   k_rows_count   : per cloud, how many distinct rows are the arg-max of a channel with dg != 0
+//   k_rows_scan    : exclusive scan over the clouds' counts -> base[c]; count[0] = total
+//   k_rows_fill    : rows[base[c] + rank] = r (ascending), rowpos[r] = base[c] + rank or -1
+// One workgroup per cloud, flags in LDS (clouds of <= MLX_MAXN points).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rows_flag_scan(const float* __restrict__ g, const int* __restrict__ ix, int J, int r0, int n,
+                                              int* flag /*[MLX_MAXN]*/, int* part /*[256]*/, int tid) {
+  for (int i = tid; i < n; i += 512) flag[i] = 0;
+  __syncthreads();
+  for (int j = tid; j < J; j += 512)
+    if (g[j] != 0.f) flag[ix[j] - r0] = 1;
+  __syncthreads();
+  // exclusive scan of flag[0..n) in place (flag[i] becomes the rank, bit 30 keeps "live"): thread t < 256 owns a run
+  const int per = (n + 255) / 256, lo = min(n, tid * per), hi = tid < 256 ? min(n, lo + per) : lo;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += flag[i];
+  if (tid < 256) part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    flag[MLX_MAXN] = run;  // total of the cloud
+  }
+  __syncthreads();
+  int run = tid < 256 ? part[tid] : 0;
+  for (int i = lo; i < hi; ++i) {
+    const int v = flag[i];
+    flag[i] = v ? run : -1;
+    run += v;
+  }
+  __syncthreads();
+  return flag[MLX_MAXN];
+}
+
+__global__ __launch_bounds__(512) void k_rows_count(const float* __restrict__ dg, const int* __restrict__ idx, int J, int B,
+                                                    int N, int M, int* __restrict__ cnt) {
+  __shared__ int flag[MLX_MAXN + 1];
+  __shared__ int part[256];
+  const int c = blockIdx.x;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  const int total = rows_flag_scan(dg + (size_t)c * J, idx + (size_t)c * J, J, r0, n, flag, part, threadIdx.x);
+  if (threadIdx.x == 0) cnt[c] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_rows_scan(const int* __restrict__ cnt, int C, int* __restrict__ base /*[C]*/,
+                                                    int* __restrict__ count /*[1]*/) {
+  __shared__ int sums[1024];
+  const int tid = threadIdx.x, per = (C + 1023) / 1024, lo = min(C, tid * per), hi = min(C, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  sums[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const int v = sums[t];
+      sums[t] = run;
+      run += v;
+    }
+    count[0] = run;
+  }
+  __syncthreads();
+  int run = sums[tid];
+  for (int i = lo; i < hi; ++i) {
+    base[i] = run;
+    run += cnt[i];
+  }
+}
+
+__global__ __launch_bounds__(512) void k_rows_fill(const float* __restrict__ dg, const int* __restrict__ idx, int J, int B,
+                                                   int N, int M, const int* __restrict__ base, int* __restrict__ rows,
+                                                   int* __restrict__ rowpos) {
+  __shared__ int flag[MLX_MAXN + 1];
+  __shared__ int part[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  int r0, n;
+  cloud_rows(c, B, N, M, r0, n);
+  rows_flag_scan(dg + (size_t)c * J, idx + (size_t)c * J, J, r0, n, flag, part, tid);
+  const int b = base[c];
+  for (int i = tid; i < n; i += 512) {
+    const int rk = flag[i];
+    rowpos[r0 + i] = rk < 0 ? -1 : b + rk;
+    if (rk >= 0) rows[b + rk] = r0 + i;
+  }
+}
+
+// dst[i][:cols] = src[rows[i]][:cols] for i < count[0]  (cols % 4 == 0); one wave per row, grid-stride
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int lds_, const int* __restrict__ rows,
+                                                     const int* __restrict__ count, float* __restrict__ dst, int ldd,
+                                                     int cols) {
+  const int n = count[0], lane = threadIdx.x & 63, q = cols >> 2;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+    const float* s = src + (size_t)rows[i] * lds_;
+    float* d = dst + (size_t)i * ldd;
+    for (int c4 = lane; c4 < q; c4 += 64)
+      *reinterpret_cast<f32x4*>(d + 4 * c4) = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s) + c4);
+  }
+}
+
+// dense[r][:cols] = rowpos[r] >= 0 ? srcc[rowpos[r]][:cols] : 0 for every r < R: every row written once, no memset
+__global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ srcc, int lds_, const int* __restrict__ rowpos,
+                                                      float* __restrict__ dst, int ldd, int cols, int R) {
+  const int lane = threadIdx.x & 63, q = cols >> 2;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+    const int p = rowpos[r];
+    float* d = dst + (size_t)r * ldd;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int c4 = lane; c4 < q; c4 += 64)
+      *reinterpret_cast<f32x4*>(d + 4 * c4) = p >= 0 ? reinterpret_cast<const f32x4*>(srcc + (size_t)p * lds_)[c4] : z;
   }
 }
 

@@ -23,9 +23,14 @@ def _stn(rows, p, prefix, k, B, N, M, pre=None):
     out, pooled maxima, arg-max rows) already computed by the fused forward kernel - the nodes then only build the graph."""
     w = lambda n: p[f"{prefix}.{n}"]
     p1, p2, pg = (pre[0], pre[1], (pre[2], pre[3])) if pre is not None else (None, None, None)
-    h = T.linear(rows, w("conv1.weight"), w("conv1.bias"), relu=True, pre=p1)
-    h = T.linear(h, w("conv2.weight"), w("conv2.bias"), relu=True, pre=p2)
-    g = T.linear_maxpool(h, w("conv3.weight"), w("conv3.bias"), True, B, N, M, pre=pg)  # relu(conv3) then max
+    if pre is not None and T.pooled_chain_ok(rows, w("conv1.weight"), w("conv2.weight"), w("conv3.weight"), N, M):
+        # the conv stack + pool as one node with a row-sparse backward (train_ops._PooledChain)
+        g = T.pooled_chain(rows, w("conv1.weight"), w("conv1.bias"), w("conv2.weight"), w("conv2.bias"),
+                           w("conv3.weight"), w("conv3.bias"), True, B, N, M, pre)
+    else:
+        h = T.linear(rows, w("conv1.weight"), w("conv1.bias"), relu=True, pre=p1)
+        h = T.linear(h, w("conv2.weight"), w("conv2.bias"), relu=True, pre=p2)
+        g = T.linear_maxpool(h, w("conv3.weight"), w("conv3.bias"), True, B, N, M, pre=pg)  # relu(conv3) then max
     h = T.linear(g, w("fc1.weight"), w("fc1.bias"), relu=True)
     h = T.linear(h, w("fc2.weight"), w("fc2.bias"), relu=True)
     t = T.linear(h, w("fc3.weight"), w("fc3.bias"), identity_k=k)
@@ -53,9 +58,13 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
     trans64 = trans_feat.detach().reshape(-1, 4096).contiguous()
     rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode)
     pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
-    h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
-    h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
-    g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
+    if T.pooled_chain_ok(pf, w("conv2.weight"), w("conv3.weight"), w("conv4.weight"), N, M):
+        g = T.pooled_chain(pf, w("conv2.weight"), w("conv2.bias"), w("conv3.weight"), w("conv3.bias"), w("conv4.weight"),
+                           w("conv4.bias"), False, B, N, M, (buf["c2"], buf["c3"], buf["g"], buf["i"]))
+    else:
+        h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
+        h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
+        g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
     return g, pf
 
 

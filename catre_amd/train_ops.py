@@ -322,6 +322,150 @@ class _LinearMaxPool(torch.autograd.Function):
         return dx, dw.reshape(w.shape), db, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------- row-sparse pooled chains
+def _rows_compact(dg, idx, B, N, M):
+    """Ascending list of the rows that are the arg-max of a channel with dg != 0, the dense -> compact map and the count -
+    all on the device (no host sync): -> rows [R] int32, rowpos [R] int32, count [1] int32."""
+    lib = hip.load()
+    R, C = B * (N + M), dg.shape[0]
+    dev = dg.device
+    rows = torch.empty(R, dtype=torch.int32, device=dev)
+    rowpos = torch.empty(R, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(2 * C, dtype=torch.int32, device=dev)
+    hip.check(lib.catre_op_rows_compact(hip.ptr(dg), hip.ptr(idx), dg.shape[1], B, N, M, hip.ptr(rows), hip.ptr(rowpos),
+                                        hip.ptr(count), hip.ptr(scratch), _st(dg)), "catre_op_rows_compact")
+    return rows, rowpos, count
+
+
+def _gather_rows(src, rows, count):
+    lib = hip.load()
+    cap, cols = rows.shape[0], src.shape[1]
+    dst = torch.empty(cap, cols, dtype=torch.float32, device=src.device)
+    hip.check(lib.catre_op_gather_rows(hip.ptr(src), src.stride(0), hip.ptr(rows), hip.ptr(count), hip.ptr(dst), cols, cols,
+                                       cap, _st(src)), "catre_op_gather_rows")
+    return dst
+
+
+def _scatter_rows(srcc, rowpos, cols):
+    lib = hip.load()
+    R = rowpos.shape[0]
+    dst = torch.empty(R, cols, dtype=torch.float32, device=srcc.device)
+    hip.check(lib.catre_op_scatter_rows(hip.ptr(srcc), srcc.stride(0), hip.ptr(rowpos), hip.ptr(dst), cols, cols, R,
+                                        _st(srcc)), "catre_op_scatter_rows")
+    return dst
+
+
+def _dgrad_n(dy, w2, xmask, count):
+    """dx[:n] = (dy[:n] .* (xmask[:n] > 0)) W  for the n = count[0] compact rows; w2: the layer's [J,K] weight."""
+    lib = hip.load()
+    cap, J = dy.shape
+    K = w2.shape[1]
+    assert _tiled_gemm_ok(cap, K, J, min_rows=0), (cap, K, J)
+    dev = dy.device
+    wp = torch.empty(J * K, dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
+    dx = torch.empty(cap, K, dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0,
+                                       hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), _st(dy)),
+              "catre_op_gemm_rows_n")
+    return dx
+
+
+def _wgrad_n(dy, x, ymask, count):
+    """(dW [J,K], db [J]) = ((dy .* (ymask > 0))[:n]^T x[:n], column sums) over the n = count[0] compact rows."""
+    lib = hip.load()
+    cap, J = dy.shape
+    K = x.shape[1]
+    assert J % 4 == 0 and K % 4 == 0
+    buf = torch.empty(J * K + J, dtype=torch.float32, device=dy.device)
+    dw, db = buf[: J * K].view(J, K), buf[J * K:]
+    ws = _ws(lib.catre_op_gemm_tn_bias_ws_bytes(J, K, cap), dy.device)
+    hip.check(lib.catre_op_gemm_tn_bias_n(hip.ptr(dy), dy.stride(0), hip.ptr(ymask), ymask.stride(0) if ymask is not None else 0,
+                                          hip.ptr(x), x.stride(0), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws),
+                                          ws.numel(), hip.ptr(count), _st(dy)), "catre_op_gemm_tn_bias_n")
+    return dw, db
+
+
+class _PooledChain(torch.autograd.Function):
+    """x -> y1 = relu(x W1^T + b1) -> y2 = relu(y1 W2^T + b2) -> g = max over the points of each cloud of (y2 W3^T + b3)
+    (-> ReLU): one conv stack of the encoder in front of its max-pool (pointnet.py:24-28, 57-61, 112-116) as ONE graph node
+    around outputs the fused forward kernels have already written (y1, y2, g, idx).
+
+    The backward is ROW-SPARSE.  Only the arg-max row of a (cloud, channel) carries gradient into y2, so dy2 - and with it
+    dy1 and dx - is zero on every row that is nobody's arg-max: ~70 % of them at N = M = 1024.  The live rows are compacted
+    on the device (ascending; the count never reaches the host) and the two dgrad and two wgrad GEMMs run on those rows
+    only; dx is scattered back to dense rows (zeros elsewhere), the weight gradients are sums over the same rows in the
+    same order as before minus exact zeros.  fp32 kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, y1, y2, g, idx):
+        gout = _Relu.forward_only(g) if relu_pool else g
+        ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, gout if relu_pool else None)
+        ctx.dims, ctx.relu_pool = (B, N, M), relu_pool
+        ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
+        return gout
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, w1, w2, w3, y1, y2, idx, gout = ctx.saved_tensors
+        B, N, M = ctx.dims
+        lib = hip.load()
+        dg = _c(dg)
+        if ctx.relu_pool:
+            t = torch.empty_like(dg)
+            hip.check(lib.catre_op_relu_bwd(hip.ptr(dg), hip.ptr(gout), hip.ptr(t), dg.numel(), _st(dg)), "catre_op_relu_bwd")
+            dg = t
+        C, J3 = dg.shape
+        w1m, w2m, w3m = (_c(w.reshape(w.shape[0], -1)) for w in (w1, w2, w3))
+        K3, K2 = w3m.shape[1], w2m.shape[1]
+        y1, y2 = _c(y1), _c(y2)
+        # pooled layer: its own weight / bias gradient gathers the arg-max rows of y2 (unchanged)
+        dw3 = torch.empty(J3, K3, dtype=torch.float32, device=dg.device)
+        db3 = torch.empty(J3, dtype=torch.float32, device=dg.device)
+        hip.check(lib.catre_op_maxlin_bwd_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(y2), y2.stride(0), hip.ptr(dw3), hip.ptr(db3),
+                                            C, J3, K3, _st(dg)), "catre_op_maxlin_bwd_w")
+        rows, rowpos, count = _rows_compact(dg, idx, B, N, M)
+        cap = rows.shape[0]
+        # dy2 on the live rows, with y2's own ReLU applied on the way out
+        dy2 = torch.empty(cap, K3, dtype=torch.float32, device=dg.device)
+        hip.check(lib.catre_op_maxlin_bwd_x_compact(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2),
+                                                    y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
+                  "catre_op_maxlin_bwd_x_compact")
+        y1c = _gather_rows(y1, rows, count)
+        dw2, db2 = _wgrad_n(dy2, y1c, None, count)
+        dy1 = _dgrad_n(dy2, w2m, None, count)                       # [cap, K2], y1's ReLU still to apply: folded below
+        xk = x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4))
+        xc = _gather_rows(_c(xk), rows, count)
+        dw1, db1 = _wgrad_n(dy1, xc, y1c, count)
+        dw1 = dw1[:, : w1m.shape[1]]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxc = _dgrad_n(dy1, w1m, y1c, count)                    # [cap, K1]
+            dx = _scatter_rows(dxc, rowpos, dxc.shape[1])
+            if dx.shape[1] != x.shape[1]:
+                dx = _c(dx[:, : x.shape[1]])
+        hb = ctx.has_b
+        return (dx, _c(dw1).reshape(w1.shape), _c(db1) if hb[0] else None, _c(dw2).reshape(w2.shape),
+                _c(db2) if hb[1] else None, dw3.reshape(w3.shape), db3 if hb[2] else None,
+                None, None, None, None, None, None, None, None)
+
+
+def pooled_chain_ok(x, w1, w2, w3, N, M):
+    """Shapes the row-sparse chain takes (fp32 mode, the encoder's three conv stacks at N, M multiples of 64)."""
+    if _amp() != 0 or N % 64 or M % 64 or max(N, M) > 4096:
+        return False
+    j1, j2, j3 = w1.shape[0], w2.shape[0], w3.shape[0]
+    k1 = w1.reshape(j1, -1).shape[1]
+    return (j1 in (64, 128) and j2 in (128, 512) and j3 <= 1024 and j3 % 32 == 0 and (k1 <= 8 or k1 in (64, 128)))
+
+
+def pooled_chain(x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, pre):
+    """pre = (y1, y2, g, idx) written by the fused forward kernel."""
+    y1, y2, g, idx = pre
+    return _PooledChain.apply(x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, y1, y2, g, idx)
+
+
 class _Relu:
     @staticmethod
     def forward_only(g):

@@ -379,6 +379,31 @@ int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const fl
                              const float* mean_scales, const float* Ks, const catre_opts* opts, float* d_rot6d,
                              float* d_dt, float* d_ds, int B, void* stream);
 
+/* Row-sparse backward of linear + max-pool chains (the backward of core/catre/models/pointnets/pointnet.py:24-28, 57-61,
+ * 112-116 as torch.autograd runs it, minus the zeros): only the arg-max row of a (cloud, channel) carries gradient, so the
+ * gradient in front of a pool - and of every layer further up the conv stack until a dense side input joins - is zero on
+ * every row that is nobody's arg-max (~70 % of the rows at N = M = 1024).  catre_op_rows_compact builds the ascending list of
+ * live rows, the dense -> compact map and the live-row COUNT on the device (no host sync); catre_op_maxlin_bwd_x_compact
+ * writes the pool's data gradient for the live rows only; catre_op_gemm_rows_n / catre_op_gemm_tn_bias_n are the row GEMMs
+ * of catre_op_gemm_rows_m / catre_op_gemm_tn_bias_m on the first nrows_dev[0] rows; catre_op_gather_rows /
+ * catre_op_scatter_rows move rows between the dense and the compact order.  rows, rowpos: [R] int32; count: [1] int32;
+ * scratch: [2 * clouds] int32; clouds of at most 4096 points.  fp32 kernels. */
+int catre_op_rows_compact(const float* dg, const int32_t* idx, int J, int B, int N, int M, int32_t* rows, int32_t* rowpos,
+                          int32_t* count, int32_t* scratch, void* stream);
+int catre_op_maxlin_bwd_x_compact(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
+                                  const float* ymask, int ldym, float* dXc, int ldx, int J, int K, int B, int N, int M,
+                                  void* stream);
+int catre_op_gather_rows(const float* src, int lds, const int32_t* rows, const int32_t* count, float* dst, int ldd, int cols,
+                         int cap, void* stream);
+int catre_op_scatter_rows(const float* srcc, int lds, const int32_t* rowpos, float* dst, int ldd, int cols, int R,
+                          void* stream);
+int catre_op_gemm_rows_n(const float* X, int ldx, const float* xmask, int ldxm, const float* Wp, const float* bias,
+                         const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu,
+                         const int32_t* nrows_dev, void* stream);
+int catre_op_gemm_tn_bias_n(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
+                            float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes,
+                            const int32_t* nrows_dev, void* stream);
+
 /* Training forward of the three encoder blocks on the FUSED kernels (the inference kernels with extra stores): the
  * pooled feature g [2B,1024] (bias added, no activation) with its arg-max rows idx [2B,1024], plus the activations the
  * layer-wise backward ops above read, as cloud-major point rows (B*N observed rows, then B*M prior rows):

@@ -442,3 +442,77 @@ def test_pose_update_bwd(space, zstyle, ka, stype, allo):
     _cmp(r6.grad, r6r.grad, "d_rot6d", atol=1e-4, rtol=1e-4)
     _cmp(dt.grad, dtr.grad, "d_dt", atol=1e-4, rtol=1e-4)
     _cmp(ds.grad, dsr.grad, "d_ds", atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,M,K0,J1,J2,J3,relu_pool", [
+    (3, 128, 64, 64, 128, 512, 1024, False),    # the trunk tail: pointfeat -> conv2 -> conv3 -> conv4 + max
+    (4, 192, 128, 64, 64, 128, 1024, True),     # fstn: h1 -> conv1 -> conv2 -> conv3 + max + ReLU
+    (3, 64, 256, 3, 64, 128, 1024, True),       # stn: points (3 columns, no input gradient) -> ...
+    (40, 64, 64, 64, 128, 512, 1024, False),    # 5120 rows: several row tiles / wgrad splits past the live-row count
+])
+def test_pooled_chain_row_sparse_backward_matches_fp64_reference(B, N, M, K0, J1, J2, J3, relu_pool):
+    """`pooled_chain` (one node for conv -> conv -> conv + max-pool with the ROW-SPARSE backward: live rows compacted on the
+    device, dgrad / wgrad on those rows only) vs fp64 torch autograd of the same three layers, and vs the layer-wise HIP ops
+    it replaces.  The forward outputs come from the layer-wise ops (what the fused kernels save)."""
+    from catre_amd import train_ops as T
+
+    g = _gen(B * 7 + N + J2)
+    R = B * (N + M)
+    x, xr = _leaf(torch.randn(R, K0, generator=g))
+    if K0 == 3:
+        x = x.detach()   # the STN's input points carry no gradient
+    ws = []
+    for (j, k) in ((J1, K0), (J2, J1), (J3, J2)):
+        ws.append(_leaf(torch.randn(j, k, 1, generator=g) / k ** 0.5))
+        ws.append(_leaf(0.1 * torch.randn(j, generator=g)))
+    (w1, w1r), (b1, b1r), (w2, w2r), (b2, b2r), (w3, w3r), (b3, b3r) = ws
+    Gd = torch.randn(2 * B, J3, generator=g)
+
+    def cloud_max(y):
+        parts = [y[: B * N].view(B, N, -1).max(1)[0], y[B * N:].view(B, M, -1).max(1)[0]]
+        return torch.cat(parts, 0)
+
+    # fp64 reference
+    y1r = F.relu(F.linear(xr, w1r[:, :, 0], b1r))
+    y2r = F.relu(F.linear(y1r, w2r[:, :, 0], b2r))
+    gr = cloud_max(F.linear(y2r, w3r[:, :, 0], b3r))
+    if relu_pool:
+        gr = F.relu(gr)
+    (gr * Gd.double()).sum().backward()
+
+    # layer-wise HIP ops: forward values for `pre`, and their own gradients for comparison
+    y1 = T.linear(x, w1, b1, relu=True)
+    y2 = T.linear(y1, w2, b2, relu=True)
+    gl = T.linear_maxpool(y2, w3, b3, relu_pool, B, N, M)
+    (gl * Gd.to(DEV)).sum().backward()
+    lw = {k: v.grad.clone() for k, v in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("w3", w3), ("b3", b3))}
+    lx = x.grad.clone() if x.requires_grad else None
+    for t in (w1, b1, w2, b2, w3, b3) + ((x,) if x.requires_grad else ()):
+        t.grad = None
+    # recover (g without the pooled ReLU, idx) the way the fused kernels hand them over
+    with torch.no_grad():
+        ypre = F.linear(y2.detach().double(), w3.detach().double()[:, :, 0], b3.detach().double())
+        gp = cloud_max(ypre).float()
+        idx_o = ypre[: B * N].view(B, N, -1).argmax(1).int() + (torch.arange(B, device=DEV).int() * N)[:, None]
+        idx_p = ypre[B * N:].view(B, M, -1).argmax(1).int() + (B * N + torch.arange(B, device=DEV).int() * M)[:, None]
+        idx = torch.cat([idx_o, idx_p], 0).contiguous()
+    assert T.pooled_chain_ok(x, w1, w2, w3, N, M)
+    gc = T.pooled_chain(x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, (y1.detach(), y2.detach(), gp, idx))
+    _cmp(gc, gr, "pooled output", atol=1e-4, rtol=1e-4)
+    (gc * Gd.to(DEV)).sum().backward()
+    for name, t, tr in (("w1", w1, w1r), ("b1", b1, b1r), ("w2", w2, w2r), ("b2", b2, b2r), ("w3", w3, w3r), ("b3", b3, b3r)):
+        scale = float(tr.grad.abs().max()) + 1e-12
+        err = float((t.grad.cpu().double() - tr.grad).abs().max()) / scale
+        assert err <= 2e-4, (name, err)
+        errl = float((t.grad - lw[name]).abs().max()) / scale
+        assert errl <= 2e-4, (name, "vs layer-wise", errl)
+    if x.requires_grad:
+        scale = float(xr.grad.abs().max()) + 1e-12
+        assert float((x.grad.cpu().double() - xr.grad).abs().max()) / scale <= 2e-4
+        # rows that are nobody's arg-max get EXACT zeros, the others the layer-wise values up to re-association
+        live = torch.zeros(R, dtype=torch.bool, device=DEV)
+        live[idx.long().reshape(-1)] = True
+        assert float(x.grad[~live].abs().max()) == 0.0
+        assert float((x.grad - lx).abs().max()) / scale <= 2e-4
+    else:
+        assert x.grad is None
