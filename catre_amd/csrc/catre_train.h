@@ -1004,26 +1004,31 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
     }
   }
   __syncthreads();
-  if (wave == 0) {
-    for (int j0 = 0; j0 < J; j0 += 64) {
-      const int j = j0 + lane;
+  {
+    // buckets in ascending (row, channel) order = a sort of the keys row << 10 | channel (dead channels: a sentinel that
+    // sorts last).  Bitonic network over 1024 keys in LDS, one compare-exchange per thread and step (55 steps) - the
+    // per-row summation order, and with it every bit of the result, is fixed.  (The first version let ONE wave drop
+    // the channels into their buckets with a ballot loop per distinct row: ~800 serial LDS round trips, 70 us of a
+    // 200 us kernel, and the reason several workgroups per cloud did not pay.)
+    for (int j = tid; j < 1024; j += 512) {
       const bool live = j < J && g[min(j, J - 1)] != 0.f;
-      const int row = live ? ix[j] - r0 : -1;
-      unsigned long long todo = __ballot(live);
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lrow = __shfl(row, leader);
-        const unsigned long long same = __ballot(live && row == lrow) & todo;
-        if (live && row == lrow) {
-          const int rank = __popcll(same & ((1ull << lane) - 1ull));
-          lst[start[lrow] + fill[lrow] + rank] = j;
-        }
-        if (lane == leader) fill[lrow] += __popcll(same);
-        todo &= ~same;
-      }
+      lst[j] = live ? ((ix[j] - r0) << 10) | j : 0x7fffffff;
     }
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        const int i = ((tid / jj) * 2 * jj) + (tid % jj), p = i + jj;
+        const int a = lst[i], b = lst[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          lst[i] = b;
+          lst[p] = a;
+        }
+        __syncthreads();
+      }
+    for (int j = tid; j < 1024; j += 512) lst[j] &= 1023;  // bucket entries: the channel (sentinels are never read)
+    __syncthreads();
   }
-  __syncthreads();
   const int nf4 = K / 4;  // K % 4 == 0 (checked by the launcher); K <= 512: at most two float4 per lane
   // rows are dealt round-robin to (workgroup of the cloud, wave): with few clouds the launcher gives every cloud
   // several workgroups (each repeats the cheap bucketing above) so that the row walk is not one long serial chain.
