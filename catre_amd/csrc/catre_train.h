@@ -261,12 +261,17 @@ template <int MB, int CP, bool MAXP>
 __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
-                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb) {
+                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb,
+                                                      const int* __restrict__ Rdev = nullptr) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   __shared__ u32x4 xs[TP * CP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TP;
+  if (Rdev) {
+    R = min(R, *Rdev);
+    if (r0 >= R) return;
+  }
   const int nblk = J / 32;
   for (int i = tid; i < TP * CP; i += 512) {
     const int row = i / CP, ch = i % CP;
@@ -319,13 +324,18 @@ template <int MB, int CP, bool MAXP>
 __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
-                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb) {
+                                                      const float* __restrict__ xmask, int ldxm, CloudBias cb,
+                                                      const int* __restrict__ Rdev = nullptr) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   constexpr int PMB = MB >= 2 ? 2 : 1;
   __shared__ u32x4 xs[2][TP * CP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TP;
+  if (Rdev) {
+    R = min(R, *Rdev);
+    if (r0 >= R) return;
+  }
   const int nblk = J / 32;
   for (int i = tid; i < TP * CP; i += 512) {
     const int row = i / CP, ch = i % CP;
@@ -592,7 +602,12 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                        int ldx, float* __restrict__ part, int J, int K, int R,
                                                        int rows_per_split, float* __restrict__ colpart,
-                                                       const float* __restrict__ ymask, int ldym, size_t pitch) {
+                                                       const float* __restrict__ ymask, int ldym, size_t pitch,
+                                                       const int* __restrict__ Rdev = nullptr) {
+  if (Rdev) {
+    R = min(R, *Rdev);
+    rows_per_split = (int)((R + gridDim.z * 64 - 1) / (gridDim.z * 64)) * 64;
+  }
   constexpr int NI = SPLIT ? 2 : 1;
   __shared__ u32x4 ys[NI][128 * 8];  // [column][8 chunks of 8 rows] bf16, 16 KiB per image
   __shared__ u32x4 xs[NI][128 * 8];

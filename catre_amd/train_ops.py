@@ -356,23 +356,28 @@ def _scatter_rows(srcc, rowpos, cols):
     return dst
 
 
-def _dgrad_n(dy, w2, xmask, count):
-    """dx[:n] = (dy[:n] .* (xmask[:n] > 0)) W  for the n = count[0] compact rows; w2: the layer's [J,K] weight."""
+def _dgrad_n(dy, w2, xmask, count, amp=0):
+    """dx[:n] = (dy[:n] .* (xmask[:n] > 0)) W  for the n = count[0] compact rows; w2: the layer's [J,K] weight; amp: the
+    matrix pipe (0 fp32, 1 bf16 operands, 2 split) - the reduced-precision kernels want J in {64, 128, 256, 512}."""
     lib = hip.load()
     cap, J = dy.shape
     K = w2.shape[1]
     assert _tiled_gemm_ok(cap, K, J, min_rows=0), (cap, K, J)
     dev = dy.device
-    wp = torch.empty(J * K, dtype=torch.float32, device=dev)
-    hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
+    if amp in (1, 2) and J in (64, 128, 256, 512):
+        wp = (_pack_bf16 if amp == 1 else _pack_split)(w2, K, J, dev, 1)
+    else:
+        amp = 0
+        wp = torch.empty(J * K, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
     dx = torch.empty(cap, K, dtype=torch.float32, device=dev)
     hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0,
-                                       hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), _st(dy)),
-              "catre_op_gemm_rows_n")
+                                       hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), int(amp),
+                                       _st(dy)), "catre_op_gemm_rows_n")
     return dx
 
 
-def _wgrad_n(dy, x, ymask, count):
+def _wgrad_n(dy, x, ymask, count, amp=0):
     """(dW [J,K], db [J]) = ((dy .* (ymask > 0))[:n]^T x[:n], column sums) over the n = count[0] compact rows."""
     lib = hip.load()
     cap, J = dy.shape
@@ -383,7 +388,7 @@ def _wgrad_n(dy, x, ymask, count):
     ws = _ws(lib.catre_op_gemm_tn_bias_ws_bytes(J, K, cap), dy.device)
     hip.check(lib.catre_op_gemm_tn_bias_n(hip.ptr(dy), dy.stride(0), hip.ptr(ymask), ymask.stride(0) if ymask is not None else 0,
                                           hip.ptr(x), x.stride(0), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws),
-                                          ws.numel(), hip.ptr(count), _st(dy)), "catre_op_gemm_tn_bias_n")
+                                          ws.numel(), hip.ptr(count), int(amp), _st(dy)), "catre_op_gemm_tn_bias_n")
     return dw, db
 
 
@@ -396,13 +401,14 @@ class _PooledChain(torch.autograd.Function):
     dy1 and dx - is zero on every row that is nobody's arg-max: ~70 % of them at N = M = 1024.  The live rows are compacted
     on the device (ascending; the count never reaches the host) and the two dgrad and two wgrad GEMMs run on those rows
     only; dx is scattered back to dense rows (zeros elsewhere), the weight gradients are sums over the same rows in the
-    same order as before minus exact zeros.  fp32 kernels."""
+    same order as before minus exact zeros.  The GEMMs run on the matrix pipe of the mode the forward ran in (fp32, bf16
+    operands under autocast, split); the pooled layer's own sparse gathers are fp32 in every mode, as before."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, y1, y2, g, idx):
         gout = _Relu.forward_only(g) if relu_pool else g
         ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, gout if relu_pool else None)
-        ctx.dims, ctx.relu_pool = (B, N, M), relu_pool
+        ctx.dims, ctx.relu_pool, ctx.amp = (B, N, M), relu_pool, _amp()
         ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
         return gout
 
@@ -433,15 +439,16 @@ class _PooledChain(torch.autograd.Function):
                                                     y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
                   "catre_op_maxlin_bwd_x_compact")
         y1c = _gather_rows(y1, rows, count)
-        dw2, db2 = _wgrad_n(dy2, y1c, None, count)
-        dy1 = _dgrad_n(dy2, w2m, None, count)                       # [cap, K2], y1's ReLU still to apply: folded below
+        amp = ctx.amp
+        dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
+        dy1 = _dgrad_n(dy2, w2m, None, count, amp)                  # [cap, K2], y1's ReLU still to apply: folded below
         xk = x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4))
         xc = _gather_rows(_c(xk), rows, count)
-        dw1, db1 = _wgrad_n(dy1, xc, y1c, count)
+        dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
         dw1 = dw1[:, : w1m.shape[1]]
         dx = None
         if ctx.needs_input_grad[0]:
-            dxc = _dgrad_n(dy1, w1m, y1c, count)                    # [cap, K1]
+            dxc = _dgrad_n(dy1, w1m, y1c, count, amp)               # [cap, K1]
             dx = _scatter_rows(dxc, rowpos, dxc.shape[1])
             if dx.shape[1] != x.shape[1]:
                 dx = _c(dx[:, : x.shape[1]])
@@ -452,8 +459,8 @@ class _PooledChain(torch.autograd.Function):
 
 
 def pooled_chain_ok(x, w1, w2, w3, N, M):
-    """Shapes the row-sparse chain takes (fp32 mode, the encoder's three conv stacks at N, M multiples of 64)."""
-    if _amp() != 0 or N % 64 or M % 64 or max(N, M) > 4096:
+    """Shapes the row-sparse chain takes (the encoder's three conv stacks at N, M multiples of 64; every compute mode)."""
+    if N % 64 or M % 64 or max(N, M) > 4096:
         return False
     j1, j2, j3 = w1.shape[0], w2.shape[0], w3.shape[0]
     k1 = w1.reshape(j1, -1).shape[1]

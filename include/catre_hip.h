@@ -387,7 +387,8 @@ int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const fl
  * writes the pool's data gradient for the live rows only; catre_op_gemm_rows_n / catre_op_gemm_tn_bias_n are the row GEMMs
  * of catre_op_gemm_rows_m / catre_op_gemm_tn_bias_m on the first nrows_dev[0] rows; catre_op_gather_rows /
  * catre_op_scatter_rows move rows between the dense and the compact order.  rows, rowpos: [R] int32; count: [1] int32;
- * scratch: [2 * clouds] int32; clouds of at most 4096 points.  fp32 kernels. */
+ * scratch: [2 * clouds] int32; clouds of at most 4096 points.  compute_dtype selects the matrix pipe of the two GEMMs
+ * (CATRE_DTYPE_F32 / _BF16 / _SPLIT; Wp = the weight pack of that dtype: catre_op_pack / _pack_bf16 / _pack_split). */
 int catre_op_rows_compact(const float* dg, const int32_t* idx, int J, int B, int N, int M, int32_t* rows, int32_t* rowpos,
                           int32_t* count, int32_t* scratch, void* stream);
 int catre_op_maxlin_bwd_x_compact(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
@@ -397,12 +398,12 @@ int catre_op_gather_rows(const float* src, int lds, const int32_t* rows, const i
                          int cap, void* stream);
 int catre_op_scatter_rows(const float* srcc, int lds, const int32_t* rowpos, float* dst, int ldd, int cols, int R,
                           void* stream);
-int catre_op_gemm_rows_n(const float* X, int ldx, const float* xmask, int ldxm, const float* Wp, const float* bias,
+int catre_op_gemm_rows_n(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
                          const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu,
-                         const int32_t* nrows_dev, void* stream);
+                         const int32_t* nrows_dev, int compute_dtype, void* stream);
 int catre_op_gemm_tn_bias_n(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
                             float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes,
-                            const int32_t* nrows_dev, void* stream);
+                            const int32_t* nrows_dev, int compute_dtype, void* stream);
 
 /* Training forward of the three encoder blocks on the FUSED kernels (the inference kernels with extra stores): the
  * pooled feature g [2B,1024] (bias added, no activation) with its arg-max rows idx [2B,1024], plus the activations the

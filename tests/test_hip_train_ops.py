@@ -450,11 +450,15 @@ def test_pose_update_bwd(space, zstyle, ka, stype, allo):
     (3, 64, 256, 3, 64, 128, 1024, True),       # stn: points (3 columns, no input gradient) -> ...
     (40, 64, 64, 64, 128, 512, 1024, False),    # 5120 rows: several row tiles / wgrad splits past the live-row count
 ])
-def test_pooled_chain_row_sparse_backward_matches_fp64_reference(B, N, M, K0, J1, J2, J3, relu_pool):
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "split"])
+def test_pooled_chain_row_sparse_backward_matches_fp64_reference(B, N, M, K0, J1, J2, J3, relu_pool, mode):
     """`pooled_chain` (one node for conv -> conv -> conv + max-pool with the ROW-SPARSE backward: live rows compacted on the
     device, dgrad / wgrad on those rows only) vs fp64 torch autograd of the same three layers, and vs the layer-wise HIP ops
-    it replaces.  The forward outputs come from the layer-wise ops (what the fused kernels save)."""
+    it replaces.  The forward outputs come from the layer-wise ops (what the fused kernels save).  Modes bf16 / split: the
+    same GEMM kernels with a device-side row count on the reduced-precision pipes, against fp64 at the mode's own precision."""
     from catre_amd import train_ops as T
+
+    tol64 = {"fp32": 2e-4, "split": 1e-3, "bf16": 4e-2}[mode]
 
     g = _gen(B * 7 + N + J2)
     R = B * (N + M)
@@ -489,30 +493,39 @@ def test_pooled_chain_row_sparse_backward_matches_fp64_reference(B, N, M, K0, J1
     lx = x.grad.clone() if x.requires_grad else None
     for t in (w1, b1, w2, b2, w3, b3) + ((x,) if x.requires_grad else ()):
         t.grad = None
-    # recover (g without the pooled ReLU, idx) the way the fused kernels hand them over
+    # (g without the pooled ReLU, idx) the way the fused kernels hand them over.  The arg-max rows are the fp64 reference's:
+    # in the reduced-precision modes a rounded product can flip single decisions, and this test is about the backward
     with torch.no_grad():
+        ypre_r = F.linear(y2r.detach(), w3r.detach()[:, :, 0], b3r.detach())
+        idx_o = ypre_r[: B * N].view(B, N, -1).argmax(1).int() + (torch.arange(B).int() * N)[:, None]
+        idx_p = ypre_r[B * N:].view(B, M, -1).argmax(1).int() + (B * N + torch.arange(B).int() * M)[:, None]
+        idx = torch.cat([idx_o, idx_p], 0).contiguous().to(DEV)
         ypre = F.linear(y2.detach().double(), w3.detach().double()[:, :, 0], b3.detach().double())
-        gp = cloud_max(ypre).float()
-        idx_o = ypre[: B * N].view(B, N, -1).argmax(1).int() + (torch.arange(B, device=DEV).int() * N)[:, None]
-        idx_p = ypre[B * N:].view(B, M, -1).argmax(1).int() + (B * N + torch.arange(B, device=DEV).int() * M)[:, None]
-        idx = torch.cat([idx_o, idx_p], 0).contiguous()
+        gp = ypre.gather(0, idx.long()).float().contiguous()
+    # the saved activations are the fp32 ops' in every mode (a rounded forward would flip ReLU masks next to zero, which is
+    # not what this test is about); the chain's GEMMs run on the pipe of `mode`
+    ctx_mode = T.amp_mode(mode)
+    ctx_mode.__enter__()
     assert T.pooled_chain_ok(x, w1, w2, w3, N, M)
     gc = T.pooled_chain(x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, (y1.detach(), y2.detach(), gp, idx))
-    _cmp(gc, gr, "pooled output", atol=1e-4, rtol=1e-4)
+    _cmp(gc, gr, "pooled output", atol=1e-4 if mode == "fp32" else 5e-2, rtol=1e-4 if mode == "fp32" else 5e-2)
     (gc * Gd.to(DEV)).sum().backward()
+    ctx_mode.__exit__(None, None, None)
     for name, t, tr in (("w1", w1, w1r), ("b1", b1, b1r), ("w2", w2, w2r), ("b2", b2, b2r), ("w3", w3, w3r), ("b3", b3, b3r)):
         scale = float(tr.grad.abs().max()) + 1e-12
         err = float((t.grad.cpu().double() - tr.grad).abs().max()) / scale
-        assert err <= 2e-4, (name, err)
-        errl = float((t.grad - lw[name]).abs().max()) / scale
-        assert errl <= 2e-4, (name, "vs layer-wise", errl)
+        assert err <= tol64, (name, err)
+        if mode == "fp32":
+            errl = float((t.grad - lw[name]).abs().max()) / scale
+            assert errl <= 2e-4, (name, "vs layer-wise", errl)
     if x.requires_grad:
         scale = float(xr.grad.abs().max()) + 1e-12
-        assert float((x.grad.cpu().double() - xr.grad).abs().max()) / scale <= 2e-4
+        assert float((x.grad.cpu().double() - xr.grad).abs().max()) / scale <= tol64
         # rows that are nobody's arg-max get EXACT zeros, the others the layer-wise values up to re-association
         live = torch.zeros(R, dtype=torch.bool, device=DEV)
         live[idx.long().reshape(-1)] = True
         assert float(x.grad[~live].abs().max()) == 0.0
-        assert float((x.grad - lx).abs().max()) / scale <= 2e-4
+        if mode == "fp32":
+            assert float((x.grad - lx).abs().max()) / scale <= 2e-4
     else:
         assert x.grad is None
