@@ -963,6 +963,56 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
   }
   if (threadIdx.x == 0 && db) db[j] = sb;
 }
+// The same gradient for K % 4 == 0, K <= 1024 with the workgroup split into CL = 256 / (K/4) CLOUD LANES: lane l walks the
+// clouds l, l + CL, ... with eight of them in flight, a thread owns one float4 column of its lane's rows, and the lanes'
+// partial sums are merged through LDS in lane order (deterministic).  The walk above is one chain of C / 8 steps of two
+// dependent global round trips whatever K is (150 us for K = 128 as for K = 512); here it is C / (8 CL) steps.
+__global__ __launch_bounds__(256) void k_maxlin_bwd_w4(const float* __restrict__ dg, const int* __restrict__ idx,
+                                                       const float* __restrict__ X, int ldx, float* __restrict__ dW,
+                                                       float* __restrict__ db, int C, int J, int K) {
+  __shared__ f32x4 red[256];
+  __shared__ float reds[256];
+  const int j = blockIdx.x, Q = K >> 2, CL = 256 / Q, q = threadIdx.x % Q, cl = threadIdx.x / Q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  if (cl < CL) {
+    for (int c0 = cl; c0 < C; c0 += 8 * CL) {
+      float g[8];
+      int row[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u * CL, cc = min(c, C - 1);
+        g[u] = c < C ? dg[(size_t)cc * J + j] : 0.f;
+        row[u] = idx[(size_t)cc * J + j];
+      }
+      f32x4 xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const f32x4*>(X + (size_t)row[u] * ldx + 4 * q);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sb += g[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[u], xv[u][e], acc[e]);
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  reds[threadIdx.x] = sb;
+  __syncthreads();
+  if (cl == 0) {
+    for (int l = 1; l < CL; ++l) {
+      const f32x4 o = red[l * Q + q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += o[e];
+    }
+    *reinterpret_cast<f32x4*>(dW + (size_t)j * K + 4 * q) = acc;
+    if (q == 0 && db) {
+      for (int l = 1; l < CL; ++l) sb += reds[l * Q];
+      db[j] = sb;
+    }
+  }
+}
+
 // dX of linear + max-pool for one cloud per workgroup, every row written exactly once (no read-modify-write, no
 // pre-zeroed buffer, no barrier per channel):
 //   1. histogram of the arg-max rows of the cloud's J channels (LDS), exclusive scan -> bucket offsets
