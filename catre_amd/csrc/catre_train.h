@@ -915,11 +915,12 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ Y
 
 // scatter: dY[idx[c][j]][j] = dout[c][j] on a zeroed dY (dense form, for the narrow pools)
 __global__ void k_maxpool_scatter(const float* __restrict__ dout, const int* __restrict__ idx, float* __restrict__ dY,
-                                  int ld, int C, int J) {
+                                  int ld, int C, int J, int accumulate = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * J) return;
   const int j = i % J;
-  dY[(size_t)idx[i] * ld + j] = dout[i];
+  float* d = dY + (size_t)idx[i] * ld + j;  // (cloud, channel) -> one (row, column): no two threads share a target
+  *d = accumulate ? *d + dout[i] : dout[i];
 }
 
 // Sparse backward of  Y = X W^T + b ; g = max_rows Y  without materialising dY:
@@ -1245,16 +1246,32 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
   }
 }
 
-// dense[r][:cols] = rowpos[r] >= 0 ? srcc[rowpos[r]][:cols] : 0 for every r < R: every row written once, no memset
+// dense[r][:cols] = rowpos[r] >= 0 ? srcc[rowpos[r]][:cols] : 0 for every r < R: every row written once, no memset.
+// objsrc (optional, [B (N + M)][cols] in OBJECT-major row order): added on the way - the gradient the rotation heads send
+// to the same cloud-major rows (train_ops.object_major), so that the sum of a tensor's consumers' gradients is one pass.
 __global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ srcc, int lds_, const int* __restrict__ rowpos,
-                                                      float* __restrict__ dst, int ldd, int cols, int R) {
+                                                      float* __restrict__ dst, int ldd, int cols, int R,
+                                                      const float* __restrict__ objsrc = nullptr, int ldo = 0, int B = 0,
+                                                      int N = 0, int M = 0) {
   const int lane = threadIdx.x & 63, q = cols >> 2;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
     const int p = rowpos[r];
     float* d = dst + (size_t)r * ldd;
+    const float* o = nullptr;
+    if (objsrc) {
+      const int ro = r < B * N ? (r / N) * (N + M) + r % N : ((r - B * N) / M) * (N + M) + N + (r - B * N) % M;
+      o = objsrc + (size_t)ro * ldo;
+    }
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int c4 = lane; c4 < q; c4 += 64)
-      *reinterpret_cast<f32x4*>(d + 4 * c4) = p >= 0 ? reinterpret_cast<const f32x4*>(srcc + (size_t)p * lds_)[c4] : z;
+    for (int c4 = lane; c4 < q; c4 += 64) {
+      f32x4 v = p >= 0 ? reinterpret_cast<const f32x4*>(srcc + (size_t)p * lds_)[c4] : z;
+      if (o) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(o)[c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += a[e];
+      }
+      *reinterpret_cast<f32x4*>(d + 4 * c4) = v;
+    }
   }
 }
 

@@ -59,13 +59,16 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
     rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode)
     pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
     if T.pooled_chain_ok(pf, w("conv2.weight"), w("conv3.weight"), w("conv4.weight"), N, M):
-        g = T.pooled_chain(pf, w("conv2.weight"), w("conv2.bias"), w("conv3.weight"), w("conv3.bias"), w("conv4.weight"),
-                           w("conv4.bias"), False, B, N, M, (buf["c2"], buf["c3"], buf["g"], buf["i"]))
-    else:
-        h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
-        h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
-        g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
-    return g, pf
+        # the conv stack with its row-sparse backward AND pointfeat's two other consumers (max over points, the rotation
+        # heads' object-major copy) as one node: their three gradients meet in one pass (train_ops._PointfeatHub)
+        g, pfmax, pf_obj = T.pointfeat_hub(pf, w("conv2.weight"), w("conv2.bias"), w("conv3.weight"), w("conv3.bias"),
+                                           w("conv4.weight"), w("conv4.bias"), B, N, M,
+                                           (buf["c2"], buf["c3"], buf["g"], buf["i"]))
+        return g, pf, (pfmax, pf_obj)
+    h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
+    h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
+    g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
+    return g, pf, None
 
 
 def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
@@ -126,10 +129,12 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
     if rt is not None and T._amp() in (0, 1) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
-        g, pf = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp())
+        g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp())
     else:
-        g, pf = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform))
-    pfmax = T.maxpool_points(pf, B, N, M)                                     # max_n pointfeat (flat_pcl_feat tail)
+        (g, pf), hub = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform)), None
+    # max_n pointfeat (flat_pcl_feat tail) and the rot heads' input in object-major order: [N observed | M prior] per object
+    # (CATRE_disR_shared.py:69, :86)
+    pfmax, pf_obj = hub if hub is not None else (T.maxpool_points(pf, B, N, M), T.object_major(pf, B, N, M))
 
     feats = [g[:B], pfmax[:B]]
     if opts.with_kps_feature:
@@ -146,8 +151,6 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     dt = T.linear(h, p["ts_head.fc_t.weight"], p["ts_head.fc_t.bias"])
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
-    # rot head input in object-major order: [N observed | M prior] per object (CATRE_disR_shared.py:86)
-    pf_obj = T.object_major(pf, B, N, M)
     rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
     ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
     rot6d = torch.cat([rx, ry], 1)

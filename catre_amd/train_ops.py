@@ -414,48 +414,100 @@ class _PooledChain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dg):
-        x, w1, w2, w3, y1, y2, idx, gout = ctx.saved_tensors
-        B, N, M = ctx.dims
-        lib = hip.load()
-        dg = _c(dg)
-        if ctx.relu_pool:
-            t = torch.empty_like(dg)
-            hip.check(lib.catre_op_relu_bwd(hip.ptr(dg), hip.ptr(gout), hip.ptr(t), dg.numel(), _st(dg)), "catre_op_relu_bwd")
-            dg = t
-        C, J3 = dg.shape
-        w1m, w2m, w3m = (_c(w.reshape(w.shape[0], -1)) for w in (w1, w2, w3))
-        K3, K2 = w3m.shape[1], w2m.shape[1]
-        y1, y2 = _c(y1), _c(y2)
-        # pooled layer: its own weight / bias gradient gathers the arg-max rows of y2 (unchanged)
-        dw3 = torch.empty(J3, K3, dtype=torch.float32, device=dg.device)
-        db3 = torch.empty(J3, dtype=torch.float32, device=dg.device)
-        hip.check(lib.catre_op_maxlin_bwd_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(y2), y2.stride(0), hip.ptr(dw3), hip.ptr(db3),
-                                            C, J3, K3, _st(dg)), "catre_op_maxlin_bwd_w")
-        rows, rowpos, count = _rows_compact(dg, idx, B, N, M)
-        cap = rows.shape[0]
-        # dy2 on the live rows, with y2's own ReLU applied on the way out
-        dy2 = torch.empty(cap, K3, dtype=torch.float32, device=dg.device)
-        hip.check(lib.catre_op_maxlin_bwd_x_compact(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2),
-                                                    y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
-                  "catre_op_maxlin_bwd_x_compact")
-        y1c = _gather_rows(y1, rows, count)
-        amp = ctx.amp
-        dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
-        dy1 = _dgrad_n(dy2, w2m, None, count, amp)                  # [cap, K2], y1's ReLU still to apply: folded below
-        xk = x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4))
-        xc = _gather_rows(_c(xk), rows, count)
-        dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
-        dw1 = dw1[:, : w1m.shape[1]]
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dxc = _dgrad_n(dy1, w1m, y1c, count, amp)               # [cap, K1]
+        return _pooled_chain_backward(ctx, dg, None) + (None,) * 8
+
+
+def _pooled_chain_backward(ctx, dg, merge):
+    """Shared by _PooledChain and _PointfeatHub.  merge = (dobj, dmax, idx_max) or None: the other gradients x receives -
+    from the rotation heads (object-major rows) and from max over points - added while dx is scattered to dense rows.
+    -> (dx, dw1, db1, dw2, db2, dw3, db3)."""
+    x, w1, w2, w3, y1, y2, idx, gout = ctx.saved_tensors[:8]
+    B, N, M = ctx.dims
+    lib = hip.load()
+    dg = _c(dg)
+    if ctx.relu_pool:
+        t = torch.empty_like(dg)
+        hip.check(lib.catre_op_relu_bwd(hip.ptr(dg), hip.ptr(gout), hip.ptr(t), dg.numel(), _st(dg)), "catre_op_relu_bwd")
+        dg = t
+    C, J3 = dg.shape
+    w1m, w2m, w3m = (_c(w.reshape(w.shape[0], -1)) for w in (w1, w2, w3))
+    K3 = w3m.shape[1]
+    y1, y2 = _c(y1), _c(y2)
+    # pooled layer: its own weight / bias gradient gathers the arg-max rows of y2 (unchanged)
+    dw3 = torch.empty(J3, K3, dtype=torch.float32, device=dg.device)
+    db3 = torch.empty(J3, dtype=torch.float32, device=dg.device)
+    hip.check(lib.catre_op_maxlin_bwd_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(y2), y2.stride(0), hip.ptr(dw3), hip.ptr(db3),
+                                        C, J3, K3, _st(dg)), "catre_op_maxlin_bwd_w")
+    rows, rowpos, count = _rows_compact(dg, idx, B, N, M)
+    cap = rows.shape[0]
+    # dy2 on the live rows, with y2's own ReLU applied on the way out
+    dy2 = torch.empty(cap, K3, dtype=torch.float32, device=dg.device)
+    hip.check(lib.catre_op_maxlin_bwd_x_compact(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2),
+                                                y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
+              "catre_op_maxlin_bwd_x_compact")
+    amp = ctx.amp
+    y1c = _gather_rows(y1, rows, count)
+    dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
+    dy1 = _dgrad_n(dy2, w2m, None, count, amp)                      # [cap, K2], y1's ReLU still to apply: folded below
+    xk = x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4))
+    xc = _gather_rows(_c(xk), rows, count)
+    dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
+    dw1 = dw1[:, : w1m.shape[1]]
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dxc = _dgrad_n(dy1, w1m, y1c, count, amp)                   # [cap, K1]
+        if merge is None:
             dx = _scatter_rows(dxc, rowpos, dxc.shape[1])
-            if dx.shape[1] != x.shape[1]:
-                dx = _c(dx[:, : x.shape[1]])
-        hb = ctx.has_b
-        return (dx, _c(dw1).reshape(w1.shape), _c(db1) if hb[0] else None, _c(dw2).reshape(w2.shape),
-                _c(db2) if hb[1] else None, dw3.reshape(w3.shape), db3 if hb[2] else None,
-                None, None, None, None, None, None, None, None)
+        else:
+            dobj, dmax, idx_max = merge
+            cols = dxc.shape[1]
+            dx = torch.empty(rowpos.shape[0], cols, dtype=torch.float32, device=dg.device)
+            dobj = _c(dobj) if dobj is not None else None
+            dmax = _c(dmax) if dmax is not None else None
+            hip.check(lib.catre_op_scatter_rows_merge(
+                hip.ptr(dxc), dxc.stride(0), hip.ptr(rowpos), hip.ptr(dobj), dobj.stride(0) if dobj is not None else 0,
+                hip.ptr(dmax), hip.ptr(idx_max), dmax.shape[1] if dmax is not None else 0, hip.ptr(dx), cols, cols, B, N, M,
+                _st(dg)), "catre_op_scatter_rows_merge")
+        if dx.shape[1] != x.shape[1]:
+            dx = _c(dx[:, : x.shape[1]])
+    hb = ctx.has_b
+    return (dx, _c(dw1).reshape(w1.shape), _c(db1) if hb[0] else None, _c(dw2).reshape(w2.shape),
+            _c(db2) if hb[1] else None, dw3.reshape(w3.shape), db3 if hb[2] else None)
+
+
+class _PointfeatHub(torch.autograd.Function):
+    """The trunk's conv stack (_PooledChain on x = pointfeat) TOGETHER with pointfeat's two other consumers - max over the
+    points of each cloud (the tail of flat_pcl_feat, CATRE_disR_shared.py:69) and the object-major copy the rotation heads
+    read (:86) - as one node: -> (g, pfmax, pf_obj).  Its backward adds the three gradients pointfeat receives while the
+    row-sparse one is scattered back to dense rows: one pass over [rows, 64] instead of a zero-fill + scatter, two strided
+    copies + cat, and two full-size adds by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx):
+        lib = hip.load()
+        xc = _c(x)
+        J, C = xc.shape[1], (2 * B if M > 0 else B)
+        pfmax = torch.empty(C, J, dtype=torch.float32, device=x.device)
+        idx_max = torch.empty(C, J, dtype=torch.int32, device=x.device)
+        hip.check(lib.catre_op_maxpool_fwd(hip.ptr(xc), J, hip.ptr(pfmax), hip.ptr(idx_max), J, B, N, M, _st(x)),
+                  "catre_op_maxpool_fwd")
+        pf_obj = torch.cat([xc[: B * N].view(B, N, J), xc[B * N:].view(B, M, J)], 1).reshape(B * (N + M), J)
+        ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, None, idx_max)
+        ctx.dims, ctx.relu_pool, ctx.amp = (B, N, M), False, _amp()
+        ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
+        return g, pfmax, pf_obj
+
+    @staticmethod
+    def backward(ctx, dg, dmax, dobj):
+        idx_max = ctx.saved_tensors[8]
+        if dg is None:
+            raise RuntimeError("pointfeat hub: the pooled trunk feature received no gradient")
+        return _pooled_chain_backward(ctx, dg, (dobj, dmax, idx_max)) + (None,) * 7
+
+
+def pointfeat_hub(x, w1, b1, w2, b2, w3, b3, B, N, M, pre):
+    y1, y2, g, idx = pre
+    return _PointfeatHub.apply(x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx)
 
 
 def pooled_chain_ok(x, w1, w2, w3, N, M):

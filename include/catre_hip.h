@@ -398,6 +398,12 @@ int catre_op_gather_rows(const float* src, int lds, const int32_t* rows, const i
                          int cap, void* stream);
 int catre_op_scatter_rows(const float* srcc, int lds, const int32_t* rowpos, float* dst, int ldd, int cols, int R,
                           void* stream);
+/* catre_op_scatter_rows plus objsrc[object-major row of r] (the rows of B objects, [N observed | M prior] each - the order
+ * the rotation heads work in, CATRE_disR_shared.py:86) and then dst[idx_max[c][j]][j] += dmax[c][j] (the backward of
+ * max over points, :69): the three gradients pointfeat receives summed in two launches.  objsrc / dmax may be NULL. */
+int catre_op_scatter_rows_merge(const float* srcc, int lds, const int32_t* rowpos, const float* objsrc, int ldo,
+                                const float* dmax, const int32_t* idx_max, int Jm, float* dst, int ldd, int cols, int B, int N,
+                                int M, void* stream);
 int catre_op_gemm_rows_n(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
                          const float* mask, int ldm, float* Y, int ldy, int R, int J, int K, int relu,
                          const int32_t* nrows_dev, int compute_dtype, void* stream);

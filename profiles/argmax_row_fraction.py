@@ -22,7 +22,7 @@ from catre_amd import train_forward as TF, train_ops as T
 p = dict(model.named_parameters())
 pts = torch.cat([TF._points_rows(b["x"]), TF._points_rows(b["tfd_kps"])], 0)
 with torch.no_grad():
-    g, pf = TF.pointnet_rows_fused(pts, desc, rt, p, B, N, M)
+    g, pf, _ = TF.pointnet_rows_fused(pts, desc, rt, p, B, N, M)
 torch.cuda.synchronize()
 R = B * (N + M)
 # re-run to fetch buffers: pointnet_rows_fused allocates its own buf; replicate to read indices
