@@ -529,3 +529,27 @@ def test_pooled_chain_row_sparse_backward_matches_fp64_reference(B, N, M, K0, J1
             assert float((x.grad - lx).abs().max()) / scale <= 2e-4
     else:
         assert x.grad is None
+
+
+def test_pooled_chain_with_no_live_row_returns_exact_zeros():
+    """Upstream gradient identically zero: no row is live, the device-side count is 0, every tile / split of the row GEMMs
+    leaves at once - all gradients are exact zeros (nothing uninitialised leaks out of the worst-case-sized buffers)."""
+    from catre_amd import train_ops as T
+
+    B, N, M, K0, J1, J2, J3 = 3, 128, 64, 64, 128, 512, 1024
+    g = _gen(5)
+    R = B * (N + M)
+    x = torch.randn(R, K0, generator=g).to(DEV).requires_grad_(True)
+    ws = [torch.randn(j, k, 1, generator=g).div(k ** 0.5).to(DEV).requires_grad_(True) for (j, k) in ((J1, K0), (J2, J1), (J3, J2))]
+    bs = [(0.1 * torch.randn(j, generator=g)).to(DEV).requires_grad_(True) for j in (J1, J2, J3)]
+    with torch.no_grad():
+        y1 = T.linear(x, ws[0], bs[0], relu=True)
+        y2 = T.linear(y1, ws[1], bs[1], relu=True)
+        gp = T.linear_maxpool(y2, ws[2], bs[2], False, B, N, M)
+    idx = torch.zeros(2 * B, J3, dtype=torch.int32, device=DEV)
+    idx[:B] = (torch.arange(B, device=DEV).int() * N)[:, None]
+    idx[B:] = (B * N + torch.arange(B, device=DEV).int() * M)[:, None]
+    out = T.pooled_chain(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], False, B, N, M, (y1, y2, gp, idx))
+    (out * 0.0).sum().backward()
+    for t in [x] + ws + bs:
+        assert t.grad is not None and float(t.grad.abs().max()) == 0.0 and torch.isfinite(t.grad).all()
