@@ -133,11 +133,32 @@ __device__ __forceinline__ void store_tile_split(const f32x16 (&acc)[MB][NB], u3
     }
 }
 
+// Training forward (SAVE instances): hi + lo images [ROWS][C] -> fp32 rows dst[row][C] in channel order (the value the
+// three-product arithmetic works with: hi + lo, 16-17 bits of mantissa), rows >= valid skipped.
+template <int C, int NT, int ROWS>
+__device__ __forceinline__ void save_tile_rows_split(const u32x4* __restrict__ ih, const u32x4* __restrict__ il,
+                                                     float* __restrict__ dst, int valid, int tid) {
+  constexpr int CP = C / 8;
+#pragma unroll
+  for (int u = 0; u < ROWS * CP / NT; ++u) {
+    const int i = tid + NT * u, row = i / CP, c = i % CP;
+    if (row >= valid) continue;
+    const u32x4 a = ih[bf_off<CP>(row, c)], b = il[bf_off<CP>(row, c)];
+    const f32x4 lo = {bf_lo(a[0]) + bf_lo(b[0]), bf_hi(a[0]) + bf_hi(b[0]), bf_lo(a[1]) + bf_lo(b[1]), bf_hi(a[1]) + bf_hi(b[1])};
+    const f32x4 hi = {bf_lo(a[2]) + bf_lo(b[2]), bf_hi(a[2]) + bf_hi(b[2]), bf_lo(a[3]) + bf_lo(b[3]), bf_hi(a[3]) + bf_hi(b[3])};
+    float* d = dst + (size_t)row * C + 16 * (c >> 1) + 4 * (c & 1);
+    *reinterpret_cast<f32x4*>(d) = lo;
+    *reinterpret_cast<f32x4*>(d + 8) = hi;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // trunk: k_trunk with conv3 and conv4 on GemmPipeS (conv2 / conv3 epilogues write split images).  512 threads, 160 KiB.
 //   a3 hi [64][512 ch] 64 KiB | a3 lo 64 KiB | a2 hi [64][128 ch] 16 KiB | a2 lo 16 KiB
 // ------------------------------------------------------------------------------------------
-template <int RS>
+// SAVE (training forward in split mode, catre_train_trunk_fwd): x1 (sv.s1), h1 (sv.s2), conv2 / conv3 outputs (sv.s3, sv.s4)
+// as fp32 rows and the per-tile (max, arg-max row) pairs; pointfeat is the fp32 row output it always was.
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float* __restrict__ trans3,
                                                      const float* __restrict__ trans64, const float* __restrict__ Wc1,
                                                      const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
                                                      const float* __restrict__ b3, const u32x4* __restrict__ wp4,
                                                      const float* __restrict__ b4, float* __restrict__ pm,
                                                      float* __restrict__ pointfeat, int B, int N, int M,
-                                                     unsigned long long* __restrict__ trace) {
+                                                     unsigned long long* __restrict__ trace, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
   float* h1 = smem;                      // [64][68]
   float* t64 = smem + TP * LD64;         // [64][64]
@@ -174,6 +195,12 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
     float x, y, z;
     load_point(P, ti, lane, x, y, z);
     apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    if (SAVE && wave == 0 && lane < ti.valid) {
+      const size_t r = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0 + lane;
+      const f32x4 lo = {x, y, z, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(sv.s1 + r * 8) = lo;
+      *reinterpret_cast<f32x4*>(sv.s1 + r * 8 + 4) = hi;
+    }
     conv3_relu_row<8>(x, y, z, Wc1, bc1, wave * 8, h1 + lane * LD64);
     if (ft) {
       const f32x4* src = reinterpret_cast<const f32x4*>(trans64 + (size_t)ti.cloud * 4096);
@@ -184,6 +211,8 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   }
   __syncthreads();
   TRUNKS_STAMP(1);
+  const size_t srow0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows<64, 512, false>(h1, LD64, sv.s2 + srow0 * 64, tid);
   if (ft) {
     if (wave < 4) {
       const int mblk = wave >> 1, nb = wave & 1;
@@ -240,11 +269,12 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   }
   __syncthreads();
   TRUNKS_STAMP(3);
+  if (SAVE) save_tile_rows_split<128, 512, TP>(a2h, a2l, sv.s3 + srow0 * 128, ti.valid, tid);
   // conv4 512->1024 on the split pipe: wave owns m-blocks [4*wave, +4) in two passes of 2; K = 512 = 32 steps of 16.
   // RS workgroups per tile: 4/RS m-blocks from mb0 (one pass of 2, or of 1)
   constexpr int MB4 = RS == 4 ? 1 : 2;
   const int mb0 = part * (32 / RS) + wave * (4 / RS);
-  GemmPipeS<MB4, 2, true, 64, 3> g4a, g4b;
+  GemmPipeS<MB4, 2, true, 64, SAVE ? 2 : 3> g4a, g4b;  // SAVE: the arg-max epilogue needs the registers of a ring slot
   {
     f32x16 acc3[2][2];
 #pragma unroll
@@ -262,6 +292,7 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   TRUNKS_STAMP(5);
+  if (SAVE) save_tile_rows_split<512, 512, TP>(a3h, a3l, sv.s4 + srow0 * 512, ti.valid, tid);
   {
     float* dstbase = pointfeat + (ti.is_obs ? ((size_t)ti.obj * N + ti.p0) * 64
                                             : ((size_t)B * N + (size_t)ti.obj * M + ti.p0) * 64);
@@ -278,8 +309,15 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
 #pragma unroll
     for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
     g4a.run(acc4, a3h, a3l, lane);
-    if (RS == 1) g4b.prefetch(wp4 + ((size_t)(mb0 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
-    max_tile_store_pre<MB4, 2>(acc4, out, mb0 * 32, bl4[0], false, lane);
+    if (RS == 1 && !SAVE) g4b.prefetch(wp4 + ((size_t)(mb0 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
+    if (SAVE) {
+      argmax_tile_store<MB4, 2>(acc4, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl4[0],
+                                (int)srow0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (RS == 1) g4b.prefetch(wp4 + ((size_t)(mb0 + 2) * 32) * 64 + lane, 32 * 64, 1024 * 512 / 8);
+    } else {
+      max_tile_store_pre<MB4, 2>(acc4, out, mb0 * 32, bl4[0], false, lane);
+    }
     TRUNKS_STAMP(6);
   }
   if (RS == 1) {
@@ -287,7 +325,13 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
 #pragma unroll
     for (int mb = 0; mb < MB4; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
     g4b.run(acc4, a3h, a3l, lane);
-    max_tile_store_pre<MB4, 2>(acc4, out, (mb0 + 2) * 32, bl4[1], false, lane);
+    if (SAVE) {
+      int lane2 = lane;  // opaque: keeps the epilogue's store addresses from being computed (and spilled) before the sweep
+      asm volatile("" : "+v"(lane2));
+      argmax_tile_store<MB4, 2>(acc4, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, (mb0 + 2) * 32, bl4[1],
+                                (int)srow0, lane2);
+    } else
+      max_tile_store_pre<MB4, 2>(acc4, out, (mb0 + 2) * 32, bl4[1], false, lane);
   }
   TRUNKS_STAMP(7);
 #undef TRUNKS_STAMP
@@ -298,9 +342,11 @@ __global__ __launch_bounds__(512) void k_trunk_split(catre_points P, const float
 // (128 -> 1024, 92 % of the kernels' FLOPs) in four passes of 2 m-blocks per wave.  Structure of k_stn3d / k_stnkd.
 // ------------------------------------------------------------------------------------------
 // RS workgroups per tile (small grids, see k_trunk): the wave owns 8/RS m-blocks from mb0 = 4/RS passes.
-template <int RS, typename Img>
+template <int RS, typename Img, bool SAVE = false>
 __device__ __forceinline__ void stn_conv3_split(const u32x4* __restrict__ wp3, const float* __restrict__ b3, Img a2h,
-                                                Img a2l, float* __restrict__ out, int part, int wave, int lane) {
+                                                Img a2l, float* __restrict__ out, int part, int wave, int lane,
+                                                float* __restrict__ pmax = nullptr, int* __restrict__ pidx = nullptr,
+                                                int row0 = 0) {
   constexpr int NPS = 4 / RS;
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
   GemmPipeS<2, 2, true, 16, 2> g[2];
@@ -314,7 +360,10 @@ __device__ __forceinline__ void stn_conv3_split(const u32x4* __restrict__ wp3, c
     for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g[ps & 1].run(acc, a2h, a2l, lane);
     if (ps < NPS - 1) g[(ps + 1) & 1].prefetch(wp3 + ((size_t)(mb0 + (ps + 1) * 2) * 8) * 64 + lane, 8 * 64, 1024 * 128 / 8);
-    max_tile_store_pre<2, 2>(acc, out, (mb0 + ps * 2) * 32, bl, true, lane);
+    if (SAVE)
+      argmax_tile_store<2, 2>(acc, pmax, pidx, (mb0 + ps * 2) * 32, bl, row0, lane);
+    else
+      max_tile_store_pre<2, 2>(acc, out, (mb0 + ps * 2) * 32, bl, true, lane);
   }
 }
 
@@ -342,12 +391,12 @@ __device__ __forceinline__ void conv3_relu_chunks_split(float x, float y, float 
   rl[(2 * grp + 1) ^ key] = lo;
 }
 
-template <int RS>
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, const u32x4* __restrict__ wp2,
                                                         const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                         const float* __restrict__ b3, float* __restrict__ pm, int B,
-                                                        int N, int M) {
+                                                        int N, int M, TrainSave sv = TrainSave{}) {
   __shared__ u32x4 smem[2 * TP * 8 + 2 * TP * 16];  // a1 hi/lo [64][64 ch] 16 KiB + a2 hi/lo [64][128 ch] 32 KiB
   u32x4* a1h = smem;
   u32x4* a1l = smem + TP * 8;
@@ -367,22 +416,28 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_split(catre_points P, const fl
     conv3_relu_chunks_split(x, y, z, W1, b1, wave, a1h + lane * 8, a1l + lane * 8, bf_key<8>(lane));
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_split<64, 256, TP>(a1h, a1l, sv.s1 + row0 * 64, ti.valid, tid);
   {
     f32x16 acc[1][2] = {{zero16(), zero16()}};
     g2.run(acc, a1h, a1l, lane);
     store_tile_split<1, 2, true, 16>(acc, a2h, a2l, wave, bv2, lane);
   }
   __syncthreads();
-  stn_conv3_split<RS>(wp3, b3, a2h, a2l, pm + (size_t)tile * PMW, part, wave, lane);
+  if (SAVE) save_tile_rows_split<128, 256, TP>(a2h, a2l, sv.s2 + row0 * 128, ti.valid, tid);
+  stn_conv3_split<RS, u32x4*, SAVE>(wp3, b3, a2h, a2l, pm + (size_t)tile * PMW, part, wave, lane,
+                                    SAVE ? sv.pmax + (size_t)tile * 1024 : nullptr, SAVE ? sv.pidx + (size_t)tile * 1024 : nullptr,
+                                    (int)row0);
 }
 
-template <int RS>
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const float* __restrict__ trans3,
                                                         const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                         const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                         const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                         const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
-                                                        float* __restrict__ pm, int B, int N, int M) {
+                                                        float* __restrict__ pm, int B, int N, int M,
+                                                        TrainSave sv = TrainSave{}) {
   __shared__ u32x4 smem[4 * TP * 8 + 2 * TP * 16];  // h1, f1 hi/lo 32 KiB + f2 hi/lo 32 KiB
   u32x4* h1h = smem;
   u32x4* h1l = smem + TP * 8;
@@ -417,13 +472,18 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
     store_tile_split<1, 1, true, 8>(acc, f1h + nb1 * 32 * 8, f1l + nb1 * 32 * 8, mblk1, bv1, lane);
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_split<64, 256, TP>(f1h, f1l, sv.s1 + row0 * 64, ti.valid, tid);
   {
     f32x16 acc[1][2] = {{zero16(), zero16()}};
     g2.run(acc, f1h, f1l, lane);
     store_tile_split<1, 2, true, 16>(acc, f2h, f2l, wave, bv2, lane);
   }
   __syncthreads();
-  stn_conv3_split<RS>(wpf3, bf3, f2h, f2l, pm + (size_t)tile * PMW, part, wave, lane);
+  if (SAVE) save_tile_rows_split<128, 256, TP>(f2h, f2l, sv.s2 + row0 * 128, ti.valid, tid);
+  stn_conv3_split<RS, u32x4*, SAVE>(wpf3, bf3, f2h, f2l, pm + (size_t)tile * PMW, part, wave, lane,
+                                    SAVE ? sv.pmax + (size_t)tile * 1024 : nullptr, SAVE ? sv.pidx + (size_t)tile * 1024 : nullptr,
+                                    (int)row0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -41,7 +41,8 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
     """The same graph as :func:`pointnet_rows` (feature_transform=True), but the three conv stacks run as the FUSED encoder
     kernels with extra stores (``catre_train_{stn3d,stnkd,trunk}_fwd``): one launch per block instead of a row GEMM per
     layer.  Every layer op becomes a graph node around an output that exists already (``pre=``); the backward is the
-    layer-wise one, unchanged.  N, M multiples of 64.  mode 0: the fp32 kernels; mode 1 (autocast): the bf16-operand kernels -
+    layer-wise one, unchanged.  N, M multiples of 64.  mode 0: the fp32 kernels; mode 2: the split kernels (rows hold hi + lo);
+    mode 1 (autocast): the bf16-operand kernels -
     the rows they save are the bf16-rounded activations, which is what the reduced-precision dgrad / wgrad kernels of the
     backward make of their operands anyway."""
     w = lambda n: p[f"{prefix}.{n}"]
@@ -127,7 +128,7 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
     hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)
     pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
-    if rt is not None and T._amp() in (0, 1) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
+    if rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
         g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp())
     else:

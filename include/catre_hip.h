@@ -421,7 +421,9 @@ int catre_op_gemm_tn_bias_n(const float* dY, int ldy, const float* ymask, int ld
  * N and M multiples of 64; `workspace` as catre_workspace_bytes.  compute_dtype = CATRE_DTYPE_F32 (fp32 packs,
  * CATRE_PACK_F32_ENCODER, in `packed`) or CATRE_DTYPE_BF16 (what torch.autocast selects, engine.py:304: the bf16-operand
  * kernels, CATRE_PACK_BF16 packs; the saved rows then hold the bf16-rounded activations as fp32 - the reduced-precision
- * dgrad / wgrad ops round their operands the same way when they stage them; trans64 required). */
+ * dgrad / wgrad ops round their operands the same way when they stage them; trans64 required) or CATRE_DTYPE_SPLIT (the
+ * split-bf16 kernels, CATRE_PACK_SPLIT | CATRE_PACK_F32_ENCODER packs - conv2 of the trunk stays an fp32 MFMA layer; the saved rows
+ * hold hi + lo; trans64 required). */
 int catre_train_stn3d_fwd(const catre_points* pts, const float* const* params, const float* packed, float* a1, float* a2,
                           float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, int compute_dtype,
                           void* stream);

@@ -174,7 +174,8 @@ def test_amp_training_iteration_tracks_fp32():
     assert checked >= 20
 
 
-def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path():
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path(mode):
     """Under autocast the encoder forward of the training path runs on SAVE instances of the bf16-operand inference kernels
     (`catre_train_*_fwd`, compute_dtype = bf16: k_stn3d_bf / k_stnkd_bf / k_trunk_bf2 with fp32 row saves + arg-max) instead of
     one bf16 row GEMM per layer.  Same operand rounding (weights at pack time, activations when they are staged), so against the
@@ -200,7 +201,7 @@ def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path():
 
     def run(rt):
         model.zero_grad(set_to_none=True)
-        with train_ops.amp_mode("bf16"):
+        with train_ops.amp_mode(mode):
             pose, scale, _ = forward_train(p, model._opts, b["x"], b["tfd_kps"], b["obj_pose_est"], b["obj_scale_est"], b["K"],
                                            b["obj_mean_scales"], rt=rt)
             ((pose * Gp).sum() + (scale * Gs).sum()).backward()
@@ -209,43 +210,46 @@ def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path():
     rt = model._runtime()
     pose_l, g_l = run(None)
     pose_f, g_f = run(rt)
-    assert not torch.equal(pose_l, pose_f), "the fused bf16 forward was not taken"
-    assert (pose_l - pose_f).abs().max() < 2e-3
+    assert not torch.equal(pose_l, pose_f), "the fused reduced-precision forward was not taken"
+    assert (pose_l - pose_f).abs().max() < (2e-3 if mode == "bf16" else 2e-5)
     assert set(g_l) == set(g_f) and len(g_f) == 68
     for k, g in g_l.items():
         if g.numel() < 1024 or float(g.norm()) < 1e-8:
             continue
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), g_f[k].reshape(-1), dim=0))
         # two bf16 pipelines flip single arg-max decisions in front of the pools: the fp32-vs-autocast test above holds 0.98
-        assert cos >= 0.97 and 0.9 <= float(g_f[k].norm() / g.norm()) <= 1.1, (k, cos)
+        if mode == "bf16":
+            assert cos >= 0.97 and 0.9 <= float(g_f[k].norm() / g.norm()) <= 1.1, (k, cos)
+        else:   # split: fp32-grade on both sides (the test against the fp32 iteration holds 5e-2 relative L2)
+            assert cos >= 0.995 and 0.98 <= float(g_f[k].norm() / g.norm()) <= 1.02, (k, cos)
     # the saved rows themselves: fused (bf16-rounded) vs the fp32 kernels' saves rounded the same way
     desc = __import__("catre_amd.hip", fromlist=["points_desc"]).points_desc(b["x"], b["tfd_kps"])
     bufs = {}
-    for mode in (0, 1):
+    mi = {"bf16": 1, "split": 2}[mode]
+    rel = 1e-2 if mode == "bf16" else 1e-4
+    for m_ in (0, mi):
         buf = rt.train_encoder_buffers(B, N, M, torch.device(DEV))
         for v in buf.values():
             v.fill_(0) if v.dtype == torch.int32 else v.fill_(float("nan"))
-        rt.train_stn3d(desc, buf, B, N, M, torch.device(DEV), mode)
+        rt.train_stn3d(desc, buf, B, N, M, torch.device(DEV), m_)
         trans3 = torch.eye(3, device=DEV).reshape(1, 9).repeat(2 * B, 1).contiguous()
-        rt.train_stnkd(desc, trans3, buf, B, N, M, torch.device(DEV), mode)
+        rt.train_stnkd(desc, trans3, buf, B, N, M, torch.device(DEV), m_)
         trans64 = torch.eye(64, device=DEV).reshape(1, 4096).repeat(2 * B, 1).contiguous()
-        rt.train_trunk(desc, trans3, trans64, buf, B, N, M, torch.device(DEV), mode)
+        rt.train_trunk(desc, trans3, trans64, buf, B, N, M, torch.device(DEV), m_)
         torch.cuda.synchronize()
-        bufs[mode] = buf
-    for k in ("a1", "x1", "h1", "pf"):   # inputs of the first bf16 GEMMs: exactly the fp32 values rounded to bf16
-        want = bufs[0][k].to(torch.bfloat16).float()
-        assert torch.isfinite(bufs[1][k]).all(), k
-        assert torch.equal(bufs[1][k], want) or (bufs[1][k] - want).abs().max() <= 1e-2 * want.abs().max(), k
-    for k in ("a2", "f1", "f2", "c2", "c3"):
-        assert torch.isfinite(bufs[1][k]).all(), k
-        err = (bufs[1][k] - bufs[0][k]).abs().max() / bufs[0][k].abs().max()
-        assert err <= 2e-2, (k, float(err))
-    for k in ("g_stn", "g_fstn", "g"):
-        err = (bufs[1][k] - bufs[0][k]).abs().max() / bufs[0][k].abs().max()
-        assert err <= 2e-2, (k, float(err))
+        bufs[m_] = buf
+    got, ref = bufs[mi], bufs[0]
+    for k in ("a1", "x1", "h1", "pf"):   # inputs of the first reduced GEMMs: the fp32 values (bf16: rounded to bf16)
+        want = ref[k].to(torch.bfloat16).float() if mode == "bf16" else ref[k]
+        assert torch.isfinite(got[k]).all(), k
+        assert torch.equal(got[k], want) or (got[k] - want).abs().max() <= rel * want.abs().max(), k
+    for k in ("a2", "f1", "f2", "c2", "c3", "g_stn", "g_fstn", "g"):
+        assert torch.isfinite(got[k]).all(), k
+        err = (got[k] - ref[k]).abs().max() / ref[k].abs().max()
+        assert err <= 2 * rel, (k, float(err))
     for k in ("i_stn", "i_fstn", "i"):
-        assert (bufs[1][k] >= 0).all() and (bufs[1][k] < B * (N + M)).all(), k
-        assert float((bufs[1][k] == bufs[0][k]).float().mean()) >= 0.9, k
+        assert (got[k] >= 0).all() and (got[k] < B * (N + M)).all(), k
+        assert float((got[k] == ref[k]).float().mean()) >= (0.9 if mode == "bf16" else 0.995), k
 
 
 def test_split_training_iteration_matches_fp32():
