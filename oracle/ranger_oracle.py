@@ -19,8 +19,12 @@ def radam_terms(step, beta1, beta2, threshold=5):
 
 
 def ranger_step(p, grad, state, lr, betas=(0.95, 0.999), eps=1e-5, weight_decay=0.0, alpha=0.5, k=6, threshold=5,
-                use_gc=True, gc_threshold=1):
-    """One update of one tensor; ``state`` is a dict that this function creates / advances in place."""
+                use_gc=True, gc_threshold=1, storage=None):
+    """One update of one tensor; ``state`` is a dict that this function creates / advances in place.
+    ``storage`` (e.g. torch.float32): round the parameter and the slow weights to that dtype where the reference, whose
+    tensors ARE fp32, stores them (after the RAdam update, after the lookahead merge) - arithmetic stays in p's dtype."""
+    def stored(t):
+        return t if storage is None else t.to(storage).to(t.dtype)
     if not state:
         state.update(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), slow_buffer=p.clone())
     beta1, beta2 = betas
@@ -37,8 +41,9 @@ def ranger_step(p, grad, state, lr, betas=(0.95, 0.999), eps=1e-5, weight_decay=
         p = p - size * lr * state["exp_avg"] / (state["exp_avg_sq"].sqrt() + eps)
     else:
         p = p - size * lr * state["exp_avg"]
+    p = stored(p)
     if state["step"] % k == 0:
-        state["slow_buffer"] = state["slow_buffer"] + alpha * (p - state["slow_buffer"])
+        state["slow_buffer"] = stored(state["slow_buffer"] + alpha * (p - state["slow_buffer"]))
         p = state["slow_buffer"].clone()
     return p
 
