@@ -2444,16 +2444,18 @@ __global__ __launch_bounds__(64) void k_ranger_rowmean(const RangerTensor* __res
 
 #define RANGER_CHUNK 4096
 __global__ __launch_bounds__(256) void k_ranger_update(const RangerTensor* __restrict__ T, const int2* __restrict__ chunks,
-                                                       const float* __restrict__ rowmean, float beta1, float beta2,
-                                                       float eps, float alpha, int clean, float lim) {
+                                                       const float* __restrict__ rowmean, float beta1, float omb1,
+                                                       float beta2, float omb2, float eps, float alpha, int clean,
+                                                       float lim) {
   const int2 c = chunks[blockIdx.x];
   const RangerTensor t = T[c.x];
   const int end = min(t.numel, c.y + RANGER_CHUNK);
   for (int i = c.y + threadIdx.x; i < end; i += 256) {
     float g = ranger_clean(t.g[i], clean, lim);
     if (t.row_len > 0) g -= rowmean[t.row_off + i / t.row_len];
-    const float v = t.v[i] * beta2 + (1.f - beta2) * g * g;
-    const float m = t.m[i] * beta1 + (1.f - beta1) * g;
+    // omb = fp32(1 - beta) formed in double on the host like the reference's `1 - beta2` (1.f - 0.999f is off by 4.7e-5)
+    const float v = t.v[i] * beta2 + omb2 * g * g;
+    const float m = t.m[i] * beta1 + omb1 * g;
     t.v[i] = v;
     t.m[i] = m;
     float p = t.p[i];

@@ -440,9 +440,11 @@ int catre_train_trunk_fwd(const catre_points* pts, const float* trans3, const fl
  * (core/catre/engine/engine.py:351-353).  `tensors`: device array of n_tensors 72-byte records
  * {float* p; const float* g; float* exp_avg; float* exp_avg_sq; float* slow; int numel, row_len, row_off;
  *  float lr_step, wd_lr; int adaptive, lookahead, pad;}; `chunks`: device array of {int tensor, offset} pairs
- * (4096 elements each); `row_tensor[total_rows]`: tensor index of every centralized gradient row. */
+ * (4096 elements each); `row_tensor[total_rows]`: tensor index of every centralized gradient row.
+ * beta1 / beta2 are doubles: the reference forms `1 - beta` in Python double precision before torch rounds it to the
+ * tensors' fp32 (ranger.py:141-143), so the decay and the (1 - beta) weights are rounded separately here too. */
 int catre_op_ranger_step(const void* tensors, int n_tensors, const void* chunks, int n_chunks, const int* row_tensor,
-                         int total_rows, float* rowmean_ws, float beta1, float beta2, float eps, float alpha,
+                         int total_rows, float* rowmean_ws, double beta1, double beta2, float eps, float alpha,
                          int clean_grads, float grad_limit, void* stream);
 
 /* Build identification: "catre_hip gfx950 <version>" */

@@ -47,14 +47,15 @@ def test_hip_ranger_matches_reference_class():
             p.grad = g.clone().cuda()   # NaN / inf left in: the fused step cleans them
         opt.step()
         for i, p in enumerate(ps):
-            np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"p{i}_step{t + 1}"], rtol=3e-5, atol=3e-6,
+            # measured 1.5e-7 (profiles/ranger_dev.py): the kernel rounds beta and 1 - beta separately like the reference
+            np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"p{i}_step{t + 1}"], rtol=2e-6, atol=2e-9,
                                        err_msg=f"p{i} step {t + 1}")
     for i, p in enumerate(ps):
         st = opt.state[p]
         assert st["step"] == RANGER_STEPS and set(st) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"}
         np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), z[f"exp_avg{i}"], rtol=3e-5, atol=1e-6)
-        np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), z[f"exp_avg_sq{i}"], rtol=3e-5, atol=1e-7)
-        np.testing.assert_allclose(st["slow_buffer"].cpu().numpy(), z[f"slow{i}"], rtol=3e-5, atol=3e-6)
+        np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), z[f"exp_avg_sq{i}"], rtol=3e-6, atol=1e-12)
+        np.testing.assert_allclose(st["slow_buffer"].cpu().numpy(), z[f"slow{i}"], rtol=2e-6, atol=2e-9)
     # state_dict round trip keeps the reference's layout
     sd = opt.state_dict()
     assert sd["param_groups"][0]["k"] == 6 and sd["param_groups"][1]["weight_decay"] == 0.1
