@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
                                                           int ldw, int coloff, const float* __restrict__ bias0,
                                                           const float* __restrict__ gamx, const float* __restrict__ betx,
                                                           const float* __restrict__ gamy, const float* __restrict__ bety,
-                                                          float* __restrict__ aff, int B, int N, int M) {
+                                                          float* __restrict__ aff, int B, int N, int M,
+                                                          float* __restrict__ stat0 = nullptr /*[2][B][32][2]*/) {
   __shared__ __attribute__((aligned(16))) float S[2][64 * GN0_SLD];
   __shared__ __attribute__((aligned(16))) float Wl[64 * GN0_WLD];
   __shared__ float mu[2][64];
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(256) void k_gn0_from_moments(const float* __restric
       const float rstd = 1.0f / sqrtf(m2 / ntot + 1e-5f);
       const float sc = rstd * gam;
       const float sh0 = bet - gmean * sc;
+      if (stat0 && (lane & 7) == 0) {  // training forward: (mean, rstd) of y0 per (head, object, group) for the backward
+        float* so = stat0 + (((size_t)hd * B + obj) * 32 + (ch >> 3)) * 2;
+        so[0] = gmean;
+        so[1] = rstd;
+      }
 #pragma unroll
       for (int cl = 0; cl < 2; ++cl) {
         float* o = aff + ((((size_t)obj * 2 + hd) * 2 + cl) * 2) * 256;

@@ -75,14 +75,23 @@ __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ point
 // Small grids (tiles * RS <= #CUs, like the encoder kernels): RS = 2 puts the two heads of a tile on two workgroups,
 // RS = 4 additionally halves layer 1's output channels (each workgroup repeats layer 0 + GELU, 20 % of the MFMAs, and
 // sweeps 128 of the 256 layer-1 channels: one m-block per wave).  Every output sees the same K order for any RS.
-template <int RS>
+//
+// SAVE (training forward, catre_train_rot_fwd; N and M multiples of 64): additionally stores what the backward kernels
+// read - y0 = layer 0's output WITH its per-cloud bias (the GroupNorm-0 input) and a0 = gelu(GN0(y0)) - straight from the
+// layer-0 epilogue's registers (a lane holds 4 consecutive channels of a point: 16-byte stores, a wave completes a
+// 128-byte line of every row in four epilogue steps), and lays y0 / a0 / y1 / the GN1 partials out HEAD-major
+// ([2][B*P][256], [2][B*P/64][32][2]) so that each head's slice is the [rows,256] matrix the per-head backward ops take.
+template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
                                                    const f32x4* __restrict__ wpl0y,
                                                    const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
                                                    const f32x4* __restrict__ wpl1x, const f32x4* __restrict__ wpl1y,
                                                    const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                    float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
-                                                   int M, unsigned long long* __restrict__ trace) {
+                                                   int M, unsigned long long* __restrict__ trace,
+                                                   const float* __restrict__ bias0 = nullptr /*[2][2B][256]*/,
+                                                   float* __restrict__ y0s = nullptr, float* __restrict__ a0s = nullptr) {
+  static_assert(!SAVE || RS == 1, "the training instance takes both heads of a tile");
   __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
   int stamp_i = 0;
 #define ROT_STAMP()                                                                                      \
@@ -116,10 +125,21 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
       // epilogue step i = (mb, g) = (i >> 2, i & 3) needs the sc/sh quads of channels mb*32 + 8g + 4h ..+3; a ring of
       // three keeps two steps in flight (the first two are requested before the GEMM)
       f32x4 scr[3], shr[3];
+      // SAVE: the bias quads of the same channels (y0 = acc + b0), and this lane's row in the head-major save buffers
+      const float* bq = nullptr;
+      f32x4 b0r[3];
+      float *y0p = nullptr, *a0p = nullptr;
+      if constexpr (SAVE) {
+        bq = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + 4 * h;
+        const size_t row = ((size_t)hd * B + rt.obj) * P + rt.gp0 + n;
+        y0p = y0s + row * 256 + wave * 64 + 4 * h;
+        a0p = a0s + row * 256 + wave * 64 + 4 * h;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
         shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
+        if constexpr (SAVE) b0r[i] = *reinterpret_cast<const f32x4*>(bq + (i >> 2) * 32 + 8 * (i & 3));
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
@@ -134,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
           const int j = i + 2;
           scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
           shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
+          if constexpr (SAVE) b0r[j % 3] = *reinterpret_cast<const f32x4*>(bq + (j >> 2) * 32 + 8 * (j & 3));
         }
         __builtin_amdgcn_sched_barrier(0);
         const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
@@ -144,6 +165,12 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
                        scr[i % 3], shr[i % 3], zz);
           const f32x4 z = {zz[0], zz[1], zz[2], zz[3]};
           *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
+          if constexpr (SAVE) {
+            const f32x4 y = {acc[mb][nb][4 * g] + b0r[i % 3][0], acc[mb][nb][4 * g + 1] + b0r[i % 3][1],
+                             acc[mb][nb][4 * g + 2] + b0r[i % 3][2], acc[mb][nb][4 * g + 3] + b0r[i % 3][3]};
+            *reinterpret_cast<f32x4*>(y0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = y;
+            *reinterpret_cast<f32x4*>(a0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = z;
+          }
         }
       }
     }
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 #pragma unroll
       for (int mb = 0; mb < MB1; ++mb) {
         const int ch = (mblk1 + mb) * 32 + n;
-        float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+        float* dst = y1 + ((SAVE ? (size_t)hd * B + rt.obj : (size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
         if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
           float* dh = dst + (size_t)(4 * h) * 256;
@@ -226,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
         m2 += __shfl_xor(m2, 4);
         m2 += __shfl_xor(m2, 32);
         if ((lane & 7) == 0 && h == 0) {
-          float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
+          float* out = gn1 + ((SAVE ? (size_t)hd * B + rt.obj : (size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
           out[0] = mean;
           out[1] = m2;
         }

@@ -212,9 +212,11 @@ class HipRuntime:
             x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128), c3=e(R, 512), g=e(C, 1024), i=e(C, 1024, dt=torch.int32))
 
     def _train_packs(self, device, mode):
-        """(params, packed) for the fused training forward in `mode` (0 = fp32 kernels, 1 = bf16-operand kernels, 2 = split:
-        its trunk keeps conv2 as an fp32 MFMA layer, so it reads the fp32 encoder image as well)."""
-        return self.params(device, {0: hip.PACK_F32_ENCODER, 1: hip.PACK_BF16, 2: hip.PACK_SPLIT | hip.PACK_F32_ENCODER}[int(mode)])
+        """(params, packed) for the fused training forward in `mode` (0 = fp32 kernels: encoder AND head images, the rotation
+        heads' fused forward reads the latter; 1 = bf16-operand kernels; 2 = split: its trunk keeps conv2 as an fp32 MFMA
+        layer, so it reads the fp32 encoder image as well)."""
+        return self.params(device, {0: hip.PACK_F32_ENCODER | hip.PACK_F32_HEADS, 1: hip.PACK_BF16,
+                                    2: hip.PACK_SPLIT | hip.PACK_F32_ENCODER}[int(mode)])
 
     def train_stn3d(self, pts, buf, B, N, M, device, mode=0):
         lib = hip.load()

@@ -121,6 +121,37 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
 
 
+_ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
+
+
+def _rot_heads_fused_ok(p, pf_obj, N, M):
+    return (T.rot_heads_ok(pf_obj, N, M) and all(p.get(f"{pre}.layers.3.bias") is not None
+                                                 and tuple(p[f"{pre}.layers.0.weight"].shape[:2]) == (256, 1088)
+                                                 and tuple(p[f"{pre}.layers.3.weight"].shape[:2]) == (256, 256)
+                                                 for pre in _ROT_PREFIX))
+
+
+def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
+    """Both RotHeads (heads/conv_out_per_rot_head.py:126-140) with the fused forward (train_ops._RotHeads, fp32)."""
+    from .heads import neck_weight3
+
+    heads = []
+    for pre in _ROT_PREFIX:
+        w = lambda n: p[f"{pre}.{n}"]
+        W0 = w("layers.0.weight").reshape(256, 1088)
+        bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))   # [2B,256]: global half + conv bias
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        heads.append((bias0, W0[:, 1024:].contiguous(), w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
+                      w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn))
+    prm, packed = rt._train_packs(pf.device, 0)
+    y3x, y3y = T.rot_heads(pf.detach(), pf_obj, prm, packed, B, N, M, heads[0], heads[1])
+    out = []
+    for pre, y3 in zip(_ROT_PREFIX, (y3x, y3y)):
+        rd = p[f"{pre}.neck.0.weight"].shape[0]
+        out.append(T.weighted_point_sum(y3, p[f"{pre}.conv_p.weight"], p.get(f"{pre}.conv_p.bias"), B, N + M)[:, :rd])
+    return out
+
+
 def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None, rt=None):
     """p: {state_dict key: live parameter}.  Returns (pose [B,3,4], scale [B,3], aux dict) - autograd-connected.
     ``rt``: the model's :class:`~catre_amd.runtime.HipRuntime`; with it the fp32 encoder forward takes the fused kernels."""
@@ -152,8 +183,11 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     dt = T.linear(h, p["ts_head.fc_t.weight"], p["ts_head.fc_t.bias"])
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
-    rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
-    ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
+    if hub is not None and _rot_heads_fused_ok(p, pf_obj, N, M):
+        rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
+    else:
+        rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
+        ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
     rot6d = torch.cat([rx, ry], 1)
 
     pose, scale = T.pose_update_autograd(rot6d, dt, ds, init_pose, init_scale, mean_scales, K_zoom, opts)

@@ -949,6 +949,115 @@ def rot_l1_block(a, w, b, gamma, beta, wn, bn, B, N, M):
     return _RotL1Block.apply(a, w, b, gamma, beta, wn, bn, B, N, M)
 
 
+def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P):
+    """_RotL1Block's backward on explicit tensors -> (da, dW [256,256], db [256], dpar [5,256])."""
+    lib = hip.load()
+    dy3 = _c(dy3)
+    dev = dy3.device
+    da = torch.empty_like(a)
+    dwb = torch.empty(256 * 256 + 256, dtype=torch.float32, device=dev)
+    dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
+    ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
+    hip.check(lib.catre_op_rot_l1_bwd(hip.ptr(dy3), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                      hip.ptr(a), hip.ptr(w2), hip.ptr(da), hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws),
+                                      ws.numel(), B, P, _st(dy3)), "catre_op_rot_l1_bwd")
+    return da, dwb[: 256 * 256].view(256, 256), dwb[256 * 256:], dpar
+
+
+def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M):
+    """_RotL0Block's backward on explicit tensors -> (dx [R,64], dW [256,64], dbias2d [2B,256], dgamma, dbeta)."""
+    lib = hip.load()
+    da = _c(da)
+    dev = da.device
+    dx = torch.empty(x.shape[0], 64, dtype=torch.float32, device=dev)
+    dw = torch.empty(256, 64, dtype=torch.float32, device=dev)
+    db = torch.empty(2 * B if M > 0 else B, 256, dtype=torch.float32, device=dev)
+    dg, dbe = torch.empty_like(gamma), torch.empty_like(beta)
+    ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
+    hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
+                                      x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
+                                      hip.ptr(dbe), hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
+    return dx, dw, db, dg, dbe
+
+
+class _RotHeads(torch.autograd.Function):
+    """BOTH RotHeads up to the neck output (conv_out_per_rot_head.py:126-137) as one graph node in fp32.  Forward on the
+    fused inference kernels with saves (``catre_train_rot_fwd``: GroupNorm-0 statistics from second moments of pointfeat,
+    then layer 0 + GN0 + GELU + layer 1 per 64-point tile for both heads - no pass re-reads a [rows,256] matrix between the
+    two linears), then each head's GroupNorm-1 + GELU + neck kernel.  Backward: the per-head passes of _RotL1Block and
+    _RotL0Block on the saved head slices; the two pointfeat gradients are summed here.
+
+    Per head h in (x, y) the inputs are: bias0 [2B,256] (global half of layer 0 + conv bias, per cloud), w0 [256,64] (local
+    half), GN0 gamma/beta, w1 [256,256], b1, GN1 gamma/beta, wn [3,256], bn [3] or None.  ``pf_cm`` is pointfeat cloud-major
+    (what the kernels read); ``pf_obj`` the same rows object-major - the differentiable input and what the backward reads.
+    ``prm`` / ``packed``: the runtime's parameter pointer array and fp32 weight image (heads included)."""
+
+    NH = 10  # tensors per head
+
+    @staticmethod
+    def forward(ctx, pf_cm, pf_obj, prm, packed, B, N, M, *heads):
+        lib = hip.load()
+        hx, hy = heads[: _RotHeads.NH], heads[_RotHeads.NH:]
+        dev = pf_obj.device
+        R, P = B * (N + M), N + M
+        pf_cm, pf_obj = _c(pf_cm), _c(pf_obj)
+        bias0 = torch.stack([_c(hx[0]), _c(hy[0])])                               # [2, 2B, 256]
+        y0 = torch.empty(2, R, 256, dtype=torch.float32, device=dev)
+        a0, y1 = torch.empty_like(y0), torch.empty_like(y0)
+        part = torch.empty(2, R // 64, 32, 2, dtype=torch.float32, device=dev)
+        stat0 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
+        ws = _ws(lib.catre_train_rot_fwd_ws_bytes(B), dev)
+        hip.check(lib.catre_train_rot_fwd(hip.ptr(pf_cm), hip.ptr(bias0), prm, hip.ptr(packed), hip.ptr(y0), hip.ptr(a0),
+                                          hip.ptr(y1), hip.ptr(part), hip.ptr(stat0), hip.ptr(ws), ws.numel(), B, N, M,
+                                          _st(pf_obj)), "catre_train_rot_fwd")
+        stat1 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
+        outs, keep = [], []
+        for h, hd in enumerate((hx, hy)):
+            _, w0, g0, be0, w1, b1, g1, be1, wn, bn = hd
+            wn = _c(wn)
+            bnc = _c(bn) if bn is not None else None
+            y3 = torch.empty(R, 3, dtype=torch.float32, device=dev)
+            hip.check(lib.catre_op_gnp_gelu_neck_fwd(hip.ptr(y1[h]), hip.ptr(part[h]), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
+                                                     hip.ptr(bnc), hip.ptr(y3), hip.ptr(stat1[h]), B, P, _st(pf_obj)),
+                      "catre_op_gnp_gelu_neck_fwd")
+            outs.append(y3)
+            keep += [_c(w0.reshape(256, -1)), g0, be0, _c(w1.reshape(256, -1)), g1, be1, wn]
+        ctx.save_for_backward(pf_obj, y0, a0, y1, stat0, stat1, *keep)
+        ctx.dims = (B, N, M)
+        ctx.has_bn = (hx[9] is not None, hy[9] is not None)
+        ctx.wshapes = (hx[1].shape, hx[4].shape, hy[1].shape, hy[4].shape)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dy3x, dy3y):
+        pf_obj, y0, a0, y1, stat0, stat1, *keep = ctx.saved_tensors
+        B, N, M = ctx.dims
+        P = N + M
+        grads, dxs = [], []
+        for h, dy3 in enumerate((dy3x, dy3y)):
+            w0, g0, be0, w1, g1, be1, wn = keep[7 * h: 7 * h + 7]
+            dy3 = _c(dy3)
+            da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P)
+            dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M)
+            del da
+            dxs.append(dx)
+            dbn = _colsum(dy3) if ctx.has_bn[h] else None
+            grads += [dbias0, dw0.view(ctx.wshapes[2 * h]), dg0, dbe0, dw1.view(ctx.wshapes[2 * h + 1]), db1, dpar[0], dpar[1],
+                      dpar[2:5], dbn]
+        dxs[0].add_(dxs[1])
+        return (None, dxs[0], None, None, None, None, None) + tuple(grads)
+
+
+def rot_heads_ok(pf_obj, N, M):
+    return _amp() == 0 and pf_obj.shape[1] == 64 and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0
+
+
+def rot_heads(pf_cm, pf_obj, prm, packed, B, N, M, head_x, head_y):
+    """head_* = (bias0, w0_local, gn0_w, gn0_b, w1, b1, gn1_w, gn1_b, wn3, bn3) -> (y3x, y3y), each [B*(N+M), 3]."""
+    assert len(head_x) == _RotHeads.NH and len(head_y) == _RotHeads.NH
+    return _RotHeads.apply(pf_cm, pf_obj, prm, packed, B, N, M, *head_x, *head_y)
+
+
 class _GNRowsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) on a [R,256] matrix (groups of 8 channels inside each row; ts head)."""
 

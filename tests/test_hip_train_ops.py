@@ -553,3 +553,57 @@ def test_pooled_chain_with_no_live_row_returns_exact_zeros():
     (out * 0.0).sum().backward()
     for t in [x] + ws + bs:
         assert t.grad is not None and float(t.grad.abs().max()) == 0.0 and torch.isfinite(t.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 64, 192), (5, 256, 256)])
+def test_fused_rot_heads_forward_matches_the_per_head_blocks(B, N, M):
+    """train_ops._RotHeads (both RotHeads' forward on the fused inference kernels with saves, `catre_train_rot_fwd`:
+    GroupNorm-0 statistics from pointfeat moments, layer 0 + GN0 + GELU + layer 1 per tile) against the per-head
+    block path (`_rot_head`: row GEMM -> GroupNorm/GELU pass -> row GEMM -> neck), heads/conv_out_per_rot_head.py:126-140:
+    the 6-d rotation output and every gradient (all 20 head parameters, the global feature, pointfeat)."""
+    from catre_amd import synth, train_forward as TF
+    from catre_amd import train_ops as T
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+
+    cfg = default_cfg(num_pcl=N, num_kps=M, device="cuda:0")
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    model.load_state_dict({k: v.cuda() for k, v in synth.recipe_state_dict(expected_state_shapes(cfg)).items()})
+    model.train()
+    rt = model._runtime()
+    p = dict(model.named_parameters())
+    gen = torch.Generator().manual_seed(B * 1000 + N + M)
+    R = B * (N + M)
+    pf0 = (torch.randn(R, 64, generator=gen) * 0.7).cuda()
+    g0 = torch.randn(2 * B, 1024, generator=gen).cuda().relu()
+    w6 = torch.randn(B, 6, generator=gen).cuda()
+
+    def run(fused):
+        for q in p.values():
+            q.grad = None
+        pf = pf0.clone().requires_grad_(True)
+        g = g0.clone().requires_grad_(True)
+        pf_obj = T.object_major(pf, B, N, M)
+        if fused:
+            rt._fingerprint = None   # what the first encoder kernel of a training forward does: re-pack the weight image
+            rx, ry = TF._rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
+        else:
+            rx = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
+            ry = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
+        out = torch.cat([rx, ry], 1)
+        (out * w6).sum().backward()
+        grads = {k: q.grad.clone() for k, q in p.items() if q.grad is not None}
+        grads["pointfeat"], grads["g"] = pf.grad.clone(), g.grad.clone()
+        return out.detach(), grads
+
+    assert TF._rot_heads_fused_ok(p, pf0, N, M)
+    want, gw = run(False)
+    got, gg = run(True)
+    assert torch.isfinite(got).all()
+    # forward: same arithmetic except GN0 statistics (moment form vs tile partials): 1e-5 relative to the output scale
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max().clamp_min(1.0), (got - want).abs().max()
+    assert set(gg) == set(gw) and len(gg) >= 2 * 10 + 2, sorted(gg)
+    for k in gw:
+        err = float((gg[k] - gw[k]).norm() / gw[k].norm().clamp_min(1e-12))
+        assert err <= 2e-4, (k, err)
