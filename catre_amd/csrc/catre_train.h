@@ -1740,6 +1740,132 @@ __global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd(const float* __restri
   }
 }
 
+// The same forward that ALSO leaves what the GroupNorm-1 backward's reduction pass would have to recompute from Y.  The
+// neck output feeds only conv_p (out[b][j] = sum_p wp[p] Y3[b,p,j] + b, conv_out_per_rot_head.py:138-140), so the gradient
+// of every row is dY3[b,p,:] = wp[p] dout[b,:] and, with u[b][c] = sum_j Wn[j][c] dout[b][j], everything that pass sums over
+// the points factors through three per-(object, channel) moments that do not depend on dout:
+//   S1 = sum_p wp[p] gelu'(z[p,c]),   S2 = sum_p wp[p] gelu'(z[p,c]) xhat[p,c],   S3 = sum_p wp[p] gelu(z[p,c])
+//   sum dxhat = gamma_c u S1,  sum dxhat xhat = gamma_c u S2,  dgamma_c = sum_b u S2,  dbeta_c = sum_b u S1,
+//   dWn[j][c] = sum_b dout[b][j] S3
+// Spart [tile = 64 rows][3][256]: this workgroup's share; k_neck_sums_from_s finishes them in the backward - which then
+// never reads Y for the sums (k_gnp_neck_bwd_sums: a 0.5 GiB pass per head).
+__global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd_s(const float* __restrict__ Y, const float* __restrict__ stat,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ Wn, const float* __restrict__ bn,
+                                                             const float* __restrict__ wp, float* __restrict__ Y3,
+                                                             float* __restrict__ Spart, int P) {
+  __shared__ float red[4][3][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t r0 = (size_t)blockIdx.x * 64;
+  const int obj = (int)(r0 / P), c0 = lane * 4;
+  const int p0 = (int)(r0 - (size_t)obj * P);
+  const float* st = stat + ((size_t)obj * 32 + (c0 >> 3)) * 2;
+  const float mean = st[0], rstd = st[1];
+  f32x4 sc, sh;
+  float nk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * gamma[c0 + q];
+    sh[q] = beta[c0 + q] - mean * sc[q];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nk[k][q] = Wn[k * 256 + c0 + q];
+  }
+  const float b0 = bn ? bn[0] : 0.f, b1 = bn ? bn[1] : 0.f, b2 = bn ? bn[2] : 0.f;
+  const float* src = Y + (r0 + wave) * 256 + c0;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < 4; ++it) {
+    f32x4 v[4];
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(16 * it + 4 * u) * 256));
+      wv[u] = wp[p0 + wave + 16 * it + 4 * u];
+    }
+    float t[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float z[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float dg;
+        gelu_both(fmaf(v[u][q], sc[q], sh[q]), z[q], dg);
+        const float wd = wv[u] * dg;
+        s1[q] += wd;
+        s2[q] = fmaf(wd, (v[u][q] - mean) * rstd, s2[q]);
+        s3[q] = fmaf(wv[u], z[q], s3[q]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float a = nk[k][0] * z[0];
+        a = fmaf(nk[k][1], z[1], a);
+        a = fmaf(nk[k][2], z[2], a);
+        a = fmaf(nk[k][3], z[3], a);
+        t[u][k] = a;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[u][k] = wave_sum(t[u][k]);
+    if (lane < 4) {
+      float o0 = t[0][0], o1 = t[0][1], o2 = t[0][2];
+#pragma unroll
+      for (int u = 1; u < 4; ++u)
+        if (lane == u) {
+          o0 = t[u][0];
+          o1 = t[u][1];
+          o2 = t[u][2];
+        }
+      float* dst = Y3 + (r0 + wave + 16 * it + 4 * lane) * 3;
+      dst[0] = o0 + b0;
+      dst[1] = o1 + b1;
+      dst[2] = o2 + b2;
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[wave][0][c0]) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+  *reinterpret_cast<f32x4*>(&red[wave][1][c0]) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+  *reinterpret_cast<f32x4*>(&red[wave][2][c0]) = f32x4{s3[0], s3[1], s3[2], s3[3]};
+  __syncthreads();
+  float* o = Spart + (size_t)blockIdx.x * 768;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[k * 256 + tid] = (red[0][k][tid] + red[1][k][tid]) + (red[2][k][tid] + red[3][k][tid]);
+}
+
+// backward of the above: the GroupNorm sums [B][32][2] and the per-object (dgamma, dbeta, dWn[0..2]) partials
+// dgb [B][5][256] (slot layout of k_gnp_neck_bwd_sums with one chunk per object) from dout [B][3] and the tile moments.
+__global__ __launch_bounds__(256) void k_neck_sums_from_s(const float* __restrict__ dout, const float* __restrict__ Spart,
+                                                          const float* __restrict__ gamma, const float* __restrict__ Wn,
+                                                          float* __restrict__ sums, float* __restrict__ dgb, int T) {
+  const int obj = blockIdx.x, ch = threadIdx.x;
+  const float* sp = Spart + (size_t)obj * T * 768 + ch;
+  float S1 = 0.f, S2 = 0.f, S3 = 0.f;
+  for (int t = 0; t < T; ++t) {  // tile order: fixed
+    S1 += sp[(size_t)t * 768];
+    S2 += sp[(size_t)t * 768 + 256];
+    S3 += sp[(size_t)t * 768 + 512];
+  }
+  const float d0 = dout[obj * 3], d1 = dout[obj * 3 + 1], d2 = dout[obj * 3 + 2];
+  const float u = fmaf(Wn[512 + ch], d2, fmaf(Wn[256 + ch], d1, Wn[ch] * d0));
+  const float ga = gamma[ch];
+  float s1 = ga * u * S1, s2 = ga * u * S2;
+  s1 += __shfl_xor(s1, 1);
+  s1 += __shfl_xor(s1, 2);
+  s1 += __shfl_xor(s1, 4);
+  s2 += __shfl_xor(s2, 1);
+  s2 += __shfl_xor(s2, 2);
+  s2 += __shfl_xor(s2, 4);
+  if ((ch & 7) == 0) {
+    sums[((size_t)obj * 32 + (ch >> 3)) * 2] = s1;
+    sums[((size_t)obj * 32 + (ch >> 3)) * 2 + 1] = s2;
+  }
+  float* o = dgb + (size_t)obj * 5 * 256 + ch;
+  o[0] = u * S2;
+  o[256] = u * S1;
+  o[512] = d0 * S3;
+  o[768] = d1 * S3;
+  o[1024] = d2 * S3;
+}
+
 // backward pass 1: k_gnp_bwd_sums with d a rebuilt from dY3, plus the neck's weight-gradient partials.
 // dgb_part [slot][5][256] = dgamma, dbeta, dWn[0..2] of the chunk.
 __global__ __launch_bounds__(256) void k_gnp_neck_bwd_sums(const float* __restrict__ dY3, const float* __restrict__ Y,

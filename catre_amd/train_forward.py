@@ -142,14 +142,11 @@ def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
         bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))   # [2B,256]: global half + conv bias
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         heads.append((bias0, W0[:, 1024:].contiguous(), w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
-                      w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn))
+                      w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                      p.get(f"{pre}.conv_p.bias")))
     prm, packed = rt._train_packs(pf.device, 0)
-    y3x, y3y = T.rot_heads(pf.detach(), pf_obj, prm, packed, B, N, M, heads[0], heads[1])
-    out = []
-    for pre, y3 in zip(_ROT_PREFIX, (y3x, y3y)):
-        rd = p[f"{pre}.neck.0.weight"].shape[0]
-        out.append(T.weighted_point_sum(y3, p[f"{pre}.conv_p.weight"], p.get(f"{pre}.conv_p.bias"), B, N + M)[:, :rd])
-    return out
+    outs = T.rot_heads(pf.detach(), pf_obj, prm, packed, B, N, M, heads[0], heads[1])
+    return [o[:, :p[f"{pre}.neck.0.weight"].shape[0]] for pre, o in zip(_ROT_PREFIX, outs)]
 
 
 def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None, rt=None):

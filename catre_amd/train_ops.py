@@ -949,8 +949,9 @@ def rot_l1_block(a, w, b, gamma, beta, wn, bn, B, N, M):
     return _RotL1Block.apply(a, w, b, gamma, beta, wn, bn, B, N, M)
 
 
-def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P):
-    """_RotL1Block's backward on explicit tensors -> (da, dW [256,256], db [256], dpar [5,256])."""
+def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spart=None):
+    """_RotL1Block's backward on explicit tensors -> (da, dW [256,256], db [256], dpar [5,256]).  With (dout [B,3], spart):
+    the GroupNorm sums come from the forward's tile moments (catre_op_gnp_gelu_neck_fwd_s) instead of a pass over y."""
     lib = hip.load()
     dy3 = _c(dy3)
     dev = dy3.device
@@ -958,9 +959,15 @@ def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P):
     dwb = torch.empty(256 * 256 + 256, dtype=torch.float32, device=dev)
     dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
     ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
-    hip.check(lib.catre_op_rot_l1_bwd(hip.ptr(dy3), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
-                                      hip.ptr(a), hip.ptr(w2), hip.ptr(da), hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws),
-                                      ws.numel(), B, P, _st(dy3)), "catre_op_rot_l1_bwd")
+    if spart is not None:
+        hip.check(lib.catre_op_rot_l1_bwd_s(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
+                                            hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(a), hip.ptr(w2), hip.ptr(da),
+                                            hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws), ws.numel(), B, P, _st(dy3)),
+                  "catre_op_rot_l1_bwd_s")
+    else:
+        hip.check(lib.catre_op_rot_l1_bwd(hip.ptr(dy3), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                          hip.ptr(a), hip.ptr(w2), hip.ptr(da), hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws),
+                                          ws.numel(), B, P, _st(dy3)), "catre_op_rot_l1_bwd")
     return da, dwb[: 256 * 256].view(256, 256), dwb[256 * 256:], dpar
 
 
@@ -984,15 +991,18 @@ class _RotHeads(torch.autograd.Function):
     """BOTH RotHeads up to the neck output (conv_out_per_rot_head.py:126-137) as one graph node in fp32.  Forward on the
     fused inference kernels with saves (``catre_train_rot_fwd``: GroupNorm-0 statistics from second moments of pointfeat,
     then layer 0 + GN0 + GELU + layer 1 per 64-point tile for both heads - no pass re-reads a [rows,256] matrix between the
-    two linears), then each head's GroupNorm-1 + GELU + neck kernel.  Backward: the per-head passes of _RotL1Block and
-    _RotL0Block on the saved head slices; the two pointfeat gradients are summed here.
+    two linears), then each head's GroupNorm-1 + GELU + neck kernel and conv_p (the weighted sum over the points).  Because
+    the node ends behind conv_p, every row's neck gradient is wp[p] * dout[b]: the neck kernel also leaves three per-channel
+    moments per tile from which the backward gets the GroupNorm-1 sums / dgamma / dbeta / dWn without its reduction pass
+    over y1 (catre_op_gnp_gelu_neck_fwd_s, catre_op_rot_l1_bwd_s).  Backward: conv_p, then the per-head passes of
+    _RotL1Block and _RotL0Block on the saved head slices; the two pointfeat gradients are summed here.
 
     Per head h in (x, y) the inputs are: bias0 [2B,256] (global half of layer 0 + conv bias, per cloud), w0 [256,64] (local
-    half), GN0 gamma/beta, w1 [256,256], b1, GN1 gamma/beta, wn [3,256], bn [3] or None.  ``pf_cm`` is pointfeat cloud-major
+    half), GN0 gamma/beta, w1 [256,256], b1, GN1 gamma/beta, wn [3,256], bn [3] or None, conv_p weight [1,P,1] and bias.  ``pf_cm`` is pointfeat cloud-major
     (what the kernels read); ``pf_obj`` the same rows object-major - the differentiable input and what the backward reads.
     ``prm`` / ``packed``: the runtime's parameter pointer array and fp32 weight image (heads included)."""
 
-    NH = 10  # tensors per head
+    NH = 12  # tensors per head
 
     @staticmethod
     def forward(ctx, pf_cm, pf_obj, prm, packed, B, N, M, *heads):
@@ -1012,38 +1022,54 @@ class _RotHeads(torch.autograd.Function):
                                           _st(pf_obj)), "catre_train_rot_fwd")
         stat1 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
         outs, keep = [], []
+        spart = torch.empty(2, R // 64, 3, 256, dtype=torch.float32, device=dev)
+        y3 = torch.empty(2, R, 3, dtype=torch.float32, device=dev)
         for h, hd in enumerate((hx, hy)):
-            _, w0, g0, be0, w1, b1, g1, be1, wn, bn = hd
-            wn = _c(wn)
+            _, w0, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp = hd
+            wn, wv = _c(wn), _c(wp.reshape(-1))
             bnc = _c(bn) if bn is not None else None
-            y3 = torch.empty(R, 3, dtype=torch.float32, device=dev)
-            hip.check(lib.catre_op_gnp_gelu_neck_fwd(hip.ptr(y1[h]), hip.ptr(part[h]), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
-                                                     hip.ptr(bnc), hip.ptr(y3), hip.ptr(stat1[h]), B, P, _st(pf_obj)),
-                      "catre_op_gnp_gelu_neck_fwd")
-            outs.append(y3)
-            keep += [_c(w0.reshape(256, -1)), g0, be0, _c(w1.reshape(256, -1)), g1, be1, wn]
-        ctx.save_for_backward(pf_obj, y0, a0, y1, stat0, stat1, *keep)
+            hip.check(lib.catre_op_gnp_gelu_neck_fwd_s(hip.ptr(y1[h]), hip.ptr(part[h]), hip.ptr(g1), hip.ptr(be1),
+                                                       hip.ptr(wn), hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3[h]),
+                                                       hip.ptr(stat1[h]), hip.ptr(spart[h]), B, P, _st(pf_obj)),
+                      "catre_op_gnp_gelu_neck_fwd_s")
+            out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+            hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3[h]), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, _st(pf_obj)),
+                      "catre_op_wsum_fwd")
+            outs.append(out)
+            keep += [_c(w0.reshape(256, -1)), g0, be0, _c(w1.reshape(256, -1)), g1, be1, wn, wv]
+        ctx.save_for_backward(pf_obj, y0, a0, y1, stat0, stat1, spart, y3, *keep)
         ctx.dims = (B, N, M)
         ctx.has_bn = (hx[9] is not None, hy[9] is not None)
-        ctx.wshapes = (hx[1].shape, hx[4].shape, hy[1].shape, hy[4].shape)
+        ctx.has_bp = (hx[11] is not None, hy[11] is not None)
+        ctx.wshapes = (hx[1].shape, hx[4].shape, hy[1].shape, hy[4].shape, hx[10].shape, hy[10].shape)
         return outs[0], outs[1]
 
     @staticmethod
-    def backward(ctx, dy3x, dy3y):
-        pf_obj, y0, a0, y1, stat0, stat1, *keep = ctx.saved_tensors
+    def backward(ctx, doutx, douty):
+        pf_obj, y0, a0, y1, stat0, stat1, spart, y3, *keep = ctx.saved_tensors
         B, N, M = ctx.dims
         P = N + M
+        lib = hip.load()
+        dev = pf_obj.device
         grads, dxs = [], []
-        for h, dy3 in enumerate((dy3x, dy3y)):
-            w0, g0, be0, w1, g1, be1, wn = keep[7 * h: 7 * h + 7]
-            dy3 = _c(dy3)
-            da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P)
+        for h, dout in enumerate((doutx, douty)):
+            w0, g0, be0, w1, g1, be1, wn, wv = keep[8 * h: 8 * h + 8]
+            dout = _c(dout)
+            # conv_p backward: dy3[b,p,:] = wp[p] dout[b,:], dwp, dbias (train_ops._WSum)
+            dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
+            dwp = torch.empty(P, dtype=torch.float32, device=dev)
+            dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp[h] else None
+            ws = _ws(B * P * 4, dev)
+            hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3[h]), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp),
+                                            0, hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+            da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P, dout=dout,
+                                                  spart=spart[h])
             dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M)
             del da
             dxs.append(dx)
             dbn = _colsum(dy3) if ctx.has_bn[h] else None
             grads += [dbias0, dw0.view(ctx.wshapes[2 * h]), dg0, dbe0, dw1.view(ctx.wshapes[2 * h + 1]), db1, dpar[0], dpar[1],
-                      dpar[2:5], dbn]
+                      dpar[2:5], dbn, dwp.view(ctx.wshapes[4 + h]), dbp]
         dxs[0].add_(dxs[1])
         return (None, dxs[0], None, None, None, None, None) + tuple(grads)
 
@@ -1053,7 +1079,8 @@ def rot_heads_ok(pf_obj, N, M):
 
 
 def rot_heads(pf_cm, pf_obj, prm, packed, B, N, M, head_x, head_y):
-    """head_* = (bias0, w0_local, gn0_w, gn0_b, w1, b1, gn1_w, gn1_b, wn3, bn3) -> (y3x, y3y), each [B*(N+M), 3]."""
+    """head_* = (bias0, w0_local, gn0_w, gn0_b, w1, b1, gn1_w, gn1_b, wn3, bn3, conv_p_w, conv_p_b) -> the two heads'
+    conv_p outputs, each [B, 3] (columns >= rot_dim are zero)."""
     assert len(head_x) == _RotHeads.NH and len(head_y) == _RotHeads.NH
     return _RotHeads.apply(pf_cm, pf_obj, prm, packed, B, N, M, *head_x, *head_y)
 

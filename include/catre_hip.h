@@ -368,6 +368,16 @@ size_t catre_op_rot_l1_bwd_ws_bytes(int B, int P);
 int catre_op_rot_l1_bwd(const float* dY3, const float* Y, const float* stat, const float* gamma, const float* beta,
                         const float* Wn, const float* A, const float* W, float* dA, float* dWb, float* dparams, void* ws,
                         size_t ws_bytes, int B, int P, void* stream);
+/* The pair used when the neck output feeds conv_p only (out[b][j] = sum_p wp[p] Y3[b,p,j] + b, conv_out_per_rot_head.py:
+ * 138-140, so dY3[b,p,:] = wp[p] dout[b,:]): the forward also leaves per-tile moments Spart [B*P/64][3][256]
+ * (sum_p wp gelu', sum_p wp gelu' xhat, sum_p wp gelu per channel); the backward takes the GroupNorm-1 sums and dgamma /
+ * dbeta / dWn from them and dout [B][3] instead of a reduction pass over Y.  dY3 must be catre_op_wsum_bwd's dY. */
+int catre_op_gnp_gelu_neck_fwd_s(const float* Y, const float* part64, const float* gamma, const float* beta,
+                                 const float* Wn, const float* bn, const float* wp, float* Y3, float* stat, float* Spart,
+                                 int B, int P, void* stream);
+int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
+                          const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
+                          float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
 int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
 int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);
