@@ -1592,39 +1592,69 @@ __global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ 
                                                       const float* __restrict__ stat, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ sums_part,
                                                       float* __restrict__ dgb_part, int P) {
-  // workgroup = (object, chunk of GNP_CH rows); thread = channel.  Partials are merged in chunk order.
-  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, ch = threadIdx.x, g = ch >> 3;
+  // workgroup = (object, chunk of GNP_CH rows); wave = every fourth row, lane = 4 channels (16-byte loads, eight of them
+  // in flight per lane: the one-channel-per-thread form of round 2 kept 256 B per wave in flight and ran at 4.4 TB/s).
+  // Partials are merged in wave order here and in chunk order by the finalize kernels.
+  __shared__ float red[4][4][256];
+  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = lane * 4, g = c0 >> 3;
   const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
-  const float ga = gamma[ch], be = beta[ch];
-  const float sc = rstd * ga, sh = be - mean * sc;
-  float s1 = 0.f, s2 = 0.f, dga = 0.f, dbe = 0.f;
-  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
-  const float* y = Y + (size_t)obj * P * 256 + ch;
-  const float* da = dA + (size_t)obj * P * 256 + ch;
-  for (int p = p0; p < p1; ++p) {
-    const float yv = y[(size_t)p * 256];
-    const float xh = (yv - mean) * rstd;
-    const float dyh = da[(size_t)p * 256] * gelu_grad(fmaf(yv, sc, sh));
-    dga = fmaf(dyh, xh, dga);
-    dbe += dyh;
-    const float dxh = dyh * ga;
-    s1 += dxh;
-    s2 = fmaf(dxh, xh, s2);
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
   }
-  // group = 8 consecutive lanes
-  s1 += __shfl_xor(s1, 1);
-  s1 += __shfl_xor(s1, 2);
-  s1 += __shfl_xor(s1, 4);
-  s2 += __shfl_xor(s2, 1);
-  s2 += __shfl_xor(s2, 2);
-  s2 += __shfl_xor(s2, 4);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, dga[4] = {0.f, 0.f, 0.f, 0.f}, dbe[4] = {0.f, 0.f, 0.f, 0.f};
+  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
+  const f32x4* y = reinterpret_cast<const f32x4*>(Y + (size_t)obj * P * 256) + lane;
+  const f32x4* da = reinterpret_cast<const f32x4*>(dA + (size_t)obj * P * 256) + lane;
+  for (int p = p0 + wave; p < p1; p += 16) {
+    f32x4 yv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = min(p + 4 * u, p1 - 1);
+      yv[u] = __builtin_nontemporal_load(y + (size_t)pp * 64);
+      dv[u] = __builtin_nontemporal_load(da + (size_t)pp * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p + 4 * u >= p1) break;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (yv[u][q] - mean) * rstd;
+        const float dyh = dv[u][q] * gelu_grad(fmaf(yv[u][q], sc[q], sh[q]));
+        dga[q] = fmaf(dyh, xh, dga[q]);
+        dbe[q] += dyh;
+        const float dxh = dyh * ga[q];
+        s1[q] += dxh;
+        s2[q] = fmaf(dxh, xh, s2[q]);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[wave][0][c0]) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+  *reinterpret_cast<f32x4*>(&red[wave][1][c0]) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+  *reinterpret_cast<f32x4*>(&red[wave][2][c0]) = f32x4{dga[0], dga[1], dga[2], dga[3]};
+  *reinterpret_cast<f32x4*>(&red[wave][3][c0]) = f32x4{dbe[0], dbe[1], dbe[2], dbe[3]};
+  __syncthreads();
+  const int ch = tid;
+  float t1 = (red[0][0][ch] + red[1][0][ch]) + (red[2][0][ch] + red[3][0][ch]);
+  float t2 = (red[0][1][ch] + red[1][1][ch]) + (red[2][1][ch] + red[3][1][ch]);
+  // group = 8 consecutive channels = 8 consecutive lanes
+  t1 += __shfl_xor(t1, 1);
+  t1 += __shfl_xor(t1, 2);
+  t1 += __shfl_xor(t1, 4);
+  t2 += __shfl_xor(t2, 1);
+  t2 += __shfl_xor(t2, 2);
+  t2 += __shfl_xor(t2, 4);
   const size_t slot = (size_t)obj * nch + chunk;
   if ((ch & 7) == 0) {
-    sums_part[(slot * 32 + g) * 2] = s1;
-    sums_part[(slot * 32 + g) * 2 + 1] = s2;
+    sums_part[(slot * 32 + (ch >> 3)) * 2] = t1;
+    sums_part[(slot * 32 + (ch >> 3)) * 2 + 1] = t2;
   }
-  dgb_part[(slot * 2) * 256 + ch] = dga;
-  dgb_part[(slot * 2 + 1) * 256 + ch] = dbe;
+  dgb_part[(slot * 2) * 256 + ch] = (red[0][2][ch] + red[1][2][ch]) + (red[2][2][ch] + red[3][2][ch]);
+  dgb_part[(slot * 2 + 1) * 256 + ch] = (red[0][3][ch] + red[1][3][ch]) + (red[2][3][ch] + red[3][3][ch]);
 }
 
 // sums[obj][32][2] = sum over chunks of sums_part[obj][chunk][32][2]
@@ -1873,32 +1903,69 @@ __global__ __launch_bounds__(256) void k_gnp_neck_bwd_sums(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ Wn,
                                                            float* __restrict__ sums_part, float* __restrict__ dgb_part,
                                                            int P) {
-  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, ch = threadIdx.x, g = ch >> 3;
+  // workgroup = (object, chunk of GNP_CH rows); wave = every fourth row, lane = 4 channels (16-byte loads: see
+  // k_gnp_bwd_sums); partials merged in wave order
+  __shared__ float red[4][7][256];
+  const int obj = blockIdx.x, chunk = blockIdx.y, nch = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = lane * 4, g = c0 >> 3;
   const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
-  const float ga = gamma[ch], be = beta[ch];
-  const float sc = rstd * ga, sh = be - mean * sc;
-  const float w0 = Wn[ch], w1 = Wn[256 + ch], w2 = Wn[512 + ch];
-  float s1 = 0.f, s2 = 0.f, dga = 0.f, dbe = 0.f, dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
-  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
-  const float* y = Y + (size_t)obj * P * 256 + ch;
-  const float* d3 = dY3 + (size_t)obj * P * 3;
-  for (int p = p0; p < p1; ++p) {
-    const float d0 = d3[p * 3], d1 = d3[p * 3 + 1], d2 = d3[p * 3 + 2];  // uniform over the workgroup
-    const float yv = y[(size_t)p * 256];
-    const float xh = (yv - mean) * rstd;
-    float a, dg;
-    gelu_both(fmaf(yv, sc, sh), a, dg);
-    const float da = fmaf(w2, d2, fmaf(w1, d1, w0 * d0));
-    const float dyh = da * dg;
-    dga = fmaf(dyh, xh, dga);
-    dbe += dyh;
-    const float dxh = dyh * ga;
-    s1 += dxh;
-    s2 = fmaf(dxh, xh, s2);
-    dw0 = fmaf(d0, a, dw0);
-    dw1 = fmaf(d1, a, dw1);
-    dw2 = fmaf(d2, a, dw2);
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  const f32x4 w0 = reinterpret_cast<const f32x4*>(Wn)[lane], w1 = reinterpret_cast<const f32x4*>(Wn)[64 + lane],
+              w2 = reinterpret_cast<const f32x4*>(Wn)[128 + lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
   }
+  float acc[7][4];
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[k][q] = 0.f;
+  const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
+  const f32x4* y = reinterpret_cast<const f32x4*>(Y + (size_t)obj * P * 256) + lane;
+  const float* d3 = dY3 + (size_t)obj * P * 3;
+  for (int p = p0 + wave; p < p1; p += 16) {
+    f32x4 yv[4];
+    float d[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = min(p + 4 * u, p1 - 1);
+      yv[u] = __builtin_nontemporal_load(y + (size_t)pp * 64);
+      d[u][0] = d3[pp * 3];  // uniform over the wave
+      d[u][1] = d3[pp * 3 + 1];
+      d[u][2] = d3[pp * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p + 4 * u >= p1) break;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (yv[u][q] - mean) * rstd;
+        float a, dg;
+        gelu_both(fmaf(yv[u][q], sc[q], sh[q]), a, dg);
+        const float da = fmaf(w2[q], d[u][2], fmaf(w1[q], d[u][1], w0[q] * d[u][0]));
+        const float dyh = da * dg;
+        acc[2][q] = fmaf(dyh, xh, acc[2][q]);  // dgamma
+        acc[3][q] += dyh;                      // dbeta
+        const float dxh = dyh * ga[q];
+        acc[0][q] += dxh;
+        acc[1][q] = fmaf(dxh, xh, acc[1][q]);
+        acc[4][q] = fmaf(d[u][0], a, acc[4][q]);  // dWn rows
+        acc[5][q] = fmaf(d[u][1], a, acc[5][q]);
+        acc[6][q] = fmaf(d[u][2], a, acc[6][q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) *reinterpret_cast<f32x4*>(&red[wave][k][c0]) = f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+  __syncthreads();
+  const int ch = tid;
+  float t[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]);
+  float s1 = t[0], s2 = t[1];
   s1 += __shfl_xor(s1, 1);
   s1 += __shfl_xor(s1, 2);
   s1 += __shfl_xor(s1, 4);
@@ -1907,15 +1974,15 @@ __global__ __launch_bounds__(256) void k_gnp_neck_bwd_sums(const float* __restri
   s2 += __shfl_xor(s2, 4);
   const size_t slot = (size_t)obj * nch + chunk;
   if ((ch & 7) == 0) {
-    sums_part[(slot * 32 + g) * 2] = s1;
-    sums_part[(slot * 32 + g) * 2 + 1] = s2;
+    sums_part[(slot * 32 + (ch >> 3)) * 2] = s1;
+    sums_part[(slot * 32 + (ch >> 3)) * 2 + 1] = s2;
   }
   float* o = dgb_part + slot * 5 * 256 + ch;
-  o[0] = dga;
-  o[256] = dbe;
-  o[512] = dw0;
-  o[768] = dw1;
-  o[1024] = dw2;
+  o[0] = t[2];
+  o[256] = t[3];
+  o[512] = t[4];
+  o[768] = t[5];
+  o[1024] = t[6];
 }
 
 // backward pass 2: dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat)) with d a rebuilt from dY3

@@ -44,7 +44,8 @@ def test_headline_kernels_keep_their_occupancy_shape():
     by = {r["kernel"]: r for r in _rows()}
     t = by["k_trunk<1, false>"]
     assert t["lds"] == 160 * 1024 and t["vgpr"] <= 256           # one 512-thread workgroup per CU
-    for k in ("k_stn3d<1, false>", "k_stnkd<1, false>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1>", "k_rot_l1_split"):
+    for k in ("k_stn3d<1, false>", "k_stnkd<1, false>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, false>", "k_rot_l1<1, true>",
+              "k_rot_l1_split"):
         assert by[k]["lds"] <= 80 * 1024 and by[k]["vgpr"] <= 256, k  # two 256-thread workgroups per CU
 
 
