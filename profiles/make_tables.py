@@ -29,9 +29,9 @@ STN3D = 2 * (64 * 128 + 128 * 1024) + 2 * 3 * 64
 STNKD = 2 * (64 * 64 + 64 * 128 + 128 * 1024) + 2 * 3 * 64 + 18
 ROT_L1 = 2 * 2 * (64 * 256 + 256 * 256)          # both heads: layer 0 recomputed + layer 1
 ALGO = {
-    "k_trunk<1, false>": (TRUNK, "a3+a5 trunk, conv4 + max", FP32_PEAK),
-    "k_stn3d<1, false>": (STN3D, "a2 STN3d conv stack + max", FP32_PEAK),
-    "k_stnkd<1, false>": (STNKD, "a4 STNkd conv stack + max", FP32_PEAK),
+    "k_trunk<1>": (TRUNK, "a3+a5 trunk, conv4 + max", FP32_PEAK),
+    "k_stn3d<1>": (STN3D, "a2 STN3d conv stack + max", FP32_PEAK),
+    "k_stnkd<1>": (STNKD, "a4 STNkd conv stack + max", FP32_PEAK),
     "k_rot_l1<1>": (ROT_L1, "a9 rot heads: layer 0 (recomputed) + GN0 + GELU + layer 1", FP32_PEAK),
     "k_trunk_split<1>": (TRUNK, "trunk, conv3/conv4 as split-bf16 (3 products)", SPLIT_PEAK),
     "k_rot_l1_split": (ROT_L1, "rot heads, split-bf16", SPLIT_PEAK),
@@ -42,24 +42,36 @@ ALGO = {
     "k_rot_l1_bf": (ROT_L1, "rot heads, bf16 operands", BF16_PEAK),
     "k_stn3d_bf": (STN3D, "STN3d, bf16 operands", BF16_PEAK),
     "k_stnkd_bf": (STNKD, "STNkd, bf16 operands", BF16_PEAK),
+    "k_stn3d_bf2": (STN3D, "STN3d, bf16 operands, 128-point pairs", BF16_PEAK),
+    "k_stnkd_bf2": (STNKD, "STNkd, bf16 operands, 128-point pairs", BF16_PEAK),
     # training (config 3): dense GEMM FLOPs of the op, per row of the [rows, C] activation
     "k_trunk<1, true>": (TRUNK, "training forward: trunk + activation saves", FP32_PEAK),
     "k_stn3d<1, true>": (STN3D, "training forward: STN3d + saves", FP32_PEAK),
     "k_stnkd<1, true>": (STNKD, "training forward: STNkd + saves", FP32_PEAK),
+    "k_rot_l1<1, true>": (ROT_L1, "training forward: both rot heads (layer 0 + GN0 + GELU + layer 1) + saves of y0 / a0 / y1", FP32_PEAK),
     "k_rot_l1_bwd": (2 * 2 * 256 * 256, "rot head layer-1 backward (dgrad + wgrad), one head, rows = B*(N+M)", FP32_PEAK),
     "k_rot_l0_bwd": (2 * 2 * 64 * 256, "rot head layer-0 backward (dgrad + wgrad), one head", FP32_PEAK),
     # the row GEMMs serve several layers: FLOPs = what the launches issued on average (PMC: MFMA ops x 512), None here
-    "k_gemm_rows<1, 32, false>": (None, "row GEMM, K = 256 / 512 (rot layer-1 forward 256 -> 256, conv3 dgrad 512 -> 128)", FP32_PEAK),
-    "k_gemm_rows<1, 8, false>": (None, "row GEMM, K = 64 (rot layer-0 forward, conv2-class dgrads)", FP32_PEAK),
-    "k_gemm_rows<1, 16, false>": (None, "row GEMM, K = 128 (conv2-class dgrads)", FP32_PEAK),
+    "k_gemm_rows<1, 32>": (None, "row GEMM, K = 512 (conv3 dgrad 512 -> 128 on the live rows)", FP32_PEAK),
+    "k_gemm_rows<1, 8>": (None, "row GEMM, K = 64 (conv2-class dgrads on the live rows)", FP32_PEAK),
+    "k_gemm_rows<1, 16>": (None, "row GEMM, K = 128 (conv2-class dgrads)", FP32_PEAK),
     "k_gemm_tn<2>": (None, "weight gradients, 128 x 128 tiles", FP32_PEAK),
     "k_gemm_tn<1>": (None, "weight gradients, 128 x 64 tiles (K <= 64)", FP32_PEAK),
 }
 
 
+def canon(n):
+    """Instances that differ only by a trailing `false` template argument (the non-SAVE forms; the argument was added in
+    round 3, so older summaries spell them without it) get one name: k_trunk<1, false> -> k_trunk<1>, k_trunk_bf2<false>
+    -> k_trunk_bf2.  `true` (training SAVE) instances keep theirs."""
+    n = n.strip()
+    n = re.sub(r",\s*false>$", ">", n)
+    return re.sub(r"<false>$", "", n)
+
+
 def short(name):
     n = name.replace("void ", "").strip()
-    return n.split("(")[0].strip()
+    return canon(n.split("(")[0].strip())
 
 
 def stats(path):
@@ -83,7 +95,7 @@ def pmc(path):
             simd_cycles = gui / 8 * 1024 if gui else None     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
             fetch, write = g("mean_FETCH_SIZE"), g("mean_WRITE_SIZE")
             mops = g("mean_SQ_INSTS_VALU_MFMA_MOPS_F32")
-            out[r["Kernel"].strip()] = dict(
+            out[canon(r["Kernel"])] = dict(
                 gflop=mops * 512 / 1e9 if mops else None,
                 busy=busy / simd_cycles if busy and simd_cycles else None,
                 rd_mb=fetch * 1024 * 2 / 1e6 if fetch is not None else None,   # gfx950 FETCH_SIZE x2 correction (guide)
@@ -123,15 +135,15 @@ def render(tag="r03"):
     out = [f"<!-- BEGIN GENERATED by profiles/make_tables.py {tag} -->"]
     out += block(tag, "fp32 headline path, B=256, N=M=1024, one refine iteration per row",
                  f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv",
-                 ["k_trunk<1, false>", "k_stn3d<1, false>", "k_stnkd<1, false>", "k_rot_l1<1>"], "")
+                 ["k_trunk<1>", "k_stn3d<1>", "k_stnkd<1>", "k_rot_l1<1>"], "")
     out += block(tag, "split mode (opt-in)", f"{tag}_split_kernel_stats.csv", f"{tag}_pmc_summary.csv",
                  ["k_trunk_split<1>", "k_stn3d_split<1>", "k_stnkd_split<1>", "k_rot_l1_split"],
                  "; peak = a third of the bf16 dense peak (three products per fp32-grade product)")
     out += block(tag, "bf16 operands (BASELINE config 5 arithmetic)", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv",
-                 ["k_trunk_bf2", "k_trunk_bf", "k_stn3d_bf", "k_stnkd_bf", "k_rot_l1_bf"], "")
+                 ["k_trunk_bf2", "k_trunk_bf", "k_stn3d_bf2", "k_stnkd_bf2", "k_stn3d_bf", "k_stnkd_bf", "k_rot_l1_bf"], "")
     out += block(tag, "training iteration (BASELINE config 3), fp32", f"{tag}_train_kernel_stats.csv", f"{tag}_train_pmc_summary.csv",
-                 ["k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
-                  "k_gemm_rows<1, 32, false>", "k_gemm_rows<1, 8, false>", "k_gemm_rows<1, 16, false>", "k_gemm_tn<2>",
+                 ["k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
+                  "k_gemm_rows<1, 32>", "k_gemm_rows<1, 8>", "k_gemm_rows<1, 16>", "k_gemm_tn<2>",
                   "k_gemm_tn<1>"],
                  "; GFLOP = the op's dense GEMM work on B*(N+M) rows")
     out.append("<!-- END GENERATED -->")
