@@ -1649,7 +1649,7 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
     if (split)
-      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, pointfeat, pkb(packed, L.sp_rot_l0[0]),
+      hipLaunchKernelGGL(k_rot_l1_split<false>, dim3(B * T), dim3(256), 0, st, pointfeat, pkb(packed, L.sp_rot_l0[0]),
                          pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
                          prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
                          g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
@@ -1942,7 +1942,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   {
     ProfScope ps(CATRE_K_ROT_L1, st);
     if (split)
-      hipLaunchKernelGGL(k_rot_l1_split, dim3(B * T), dim3(256), 0, st, ws + W.pointfeat, pkb(packed, L.sp_rot_l0[0]),
+      hipLaunchKernelGGL(k_rot_l1_split<false>, dim3(B * T), dim3(256), 0, st, ws + W.pointfeat, pkb(packed, L.sp_rot_l0[0]),
                          pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
                          prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
                          g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);

@@ -78,8 +78,8 @@ __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ point
 //
 // SAVE (training forward, catre_train_rot_fwd; N and M multiples of 64): additionally stores what the backward kernels
 // read - y0 = layer 0's output WITH its per-cloud bias (the GroupNorm-0 input) and a0 = gelu(GN0(y0)) - straight from the
-// layer-0 epilogue's registers (a lane holds 4 consecutive channels of a point: 16-byte stores, a wave completes a
-// 128-byte line of every row in four epilogue steps), and lays y0 / a0 / y1 / the GN1 partials out HEAD-major
+// layer-0 epilogue's registers (layer 0 runs in the swapped orientation in this instance: whole-line stores, see the head
+// loop), and lays y0 / a0 / y1 / the GN1 partials out HEAD-major
 // ([2][B*P][256], [2][B*P/64][32][2]) so that each head's slice is the [rows,256] matrix the per-head backward ops take.
 template <int RS, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
@@ -118,28 +118,56 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
   const int hd_lo = RS == 1 ? 0 : (part & 1), hd_hi = RS == 1 ? 2 : hd_lo + 1;
 #pragma unroll 1
   for (int hd = hd_lo; hd < hd_hi; ++hd) {
-    {
+    if constexpr (SAVE) {
+      // Training instance: layer 0 in the SWAPPED orientation (lane owns channel wave*64 + mb*32 + n and 32 of the tile's
+      // points, like layer 1): y0 / a0 then leave as 4-byte stores whose 32 lanes cover 128 consecutive bytes of a row -
+      // whole L2 lines.  (The normal orientation's 16-byte stores put 32 rows x 32 bytes into one instruction: the same
+      // 3.2 GB took 0.9 ms of L2 request time, k_rot_l1_split<true> is bound by exactly that.)  The a0 image layer 1 reads
+      // is the same; it is written with ds_write_b32 here (lanes along channels: conflict-free up to the two half-waves).
+      const float* afb = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + n;
+      const float* bqb = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + n;
+      float scv[2], shv[2], b0v[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        scv[mb] = afb[mb * 32];
+        shv[mb] = afb[256 + mb * 32];
+        b0v[mb] = bqb[mb * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+      gemm_core<2, 2, true, true, 8, 2>(acc, (hd ? wpl0y : wpl0x) + (wave * 2 * 8) * 64 + lane, 8 * 64, pf, 64, lane);
+      ROT_STAMP();
+      const size_t rowg = ((size_t)hd * B + rt.obj) * P + rt.gp0 + 4 * h;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int c = wave * 64 + mb * 32 + n;
+        float* yp = y0s + rowg * 256 + c;
+        float* ap = a0s + rowg * 256 + c;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = nb * 32 + (r & 3) + 8 * (r >> 2);  // + 4 h: in rowg / below
+            const float v = acc[mb][nb][r];
+            const float z = gelu_erf(fmaf(v, scv[mb], shv[mb]));
+            yp[row * 256] = v + b0v[mb];
+            ap[row * 256] = z;
+            a0[swz_off(row + 4 * h, c >> 2, 256) + (c & 3)] = z;
+          }
+      }
+    } else {
       // layer 0 recompute: wave -> channels [wave*64, +64), "normal" orientation.  The fused bias+GN affine
       // of this (object, head, cloud) is requested before the GEMM so the epilogue never waits on HBM/L2.
       const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
       // epilogue step i = (mb, g) = (i >> 2, i & 3) needs the sc/sh quads of channels mb*32 + 8g + 4h ..+3; a ring of
       // three keeps two steps in flight (the first two are requested before the GEMM)
       f32x4 scr[3], shr[3];
-      // SAVE: the bias quads of the same channels (y0 = acc + b0), and this lane's row in the head-major save buffers
-      const float* bq = nullptr;
-      f32x4 b0r[3];
-      float *y0p = nullptr, *a0p = nullptr;
-      if constexpr (SAVE) {
-        bq = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + 4 * h;
-        const size_t row = ((size_t)hd * B + rt.obj) * P + rt.gp0 + n;
-        y0p = y0s + row * 256 + wave * 64 + 4 * h;
-        a0p = a0s + row * 256 + wave * 64 + 4 * h;
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
         shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
-        if constexpr (SAVE) b0r[i] = *reinterpret_cast<const f32x4*>(bq + (i >> 2) * 32 + 8 * (i & 3));
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
@@ -154,7 +182,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
           const int j = i + 2;
           scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
           shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
-          if constexpr (SAVE) b0r[j % 3] = *reinterpret_cast<const f32x4*>(bq + (j >> 2) * 32 + 8 * (j & 3));
         }
         __builtin_amdgcn_sched_barrier(0);
         const int c = wave * 64 + mb * 32 + 8 * g + 4 * h;  // first of 4 consecutive channels
@@ -165,12 +192,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
                        scr[i % 3], shr[i % 3], zz);
           const f32x4 z = {zz[0], zz[1], zz[2], zz[3]};
           *reinterpret_cast<f32x4*>(a0 + swz_off(nb * 32 + n, c >> 2, 256)) = z;
-          if constexpr (SAVE) {
-            const f32x4 y = {acc[mb][nb][4 * g] + b0r[i % 3][0], acc[mb][nb][4 * g + 1] + b0r[i % 3][1],
-                             acc[mb][nb][4 * g + 2] + b0r[i % 3][2], acc[mb][nb][4 * g + 3] + b0r[i % 3][3]};
-            *reinterpret_cast<f32x4*>(y0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = y;
-            *reinterpret_cast<f32x4*>(a0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = z;
-          }
         }
       }
     }

@@ -490,13 +490,19 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
 // rotation head: pointfeat tile -> split images -> layer 0 (recomputed) on GemmPipeS -> fused bias+GN affine + GELU ->
 // split image -> layer 1 on GemmPipeS -> y1 + GN1 partials.  Otherwise k_rot_l1.  256 threads, 80 KiB LDS.
 // ------------------------------------------------------------------------------------------
+// SAVE: the training forward of the split mode (catre_train_rot_fwd, as k_rot_l1<1, true>): y0 = layer 0's output with its
+// per-cloud bias and a0 = gelu(GN0(y0)) stored as fp32 from the layer-0 epilogue, all outputs head-major.
+template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict__ pointfeat,
                                                          const u32x4* __restrict__ wpl0x, const u32x4* __restrict__ wpl0y,
                                                          const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
                                                          const u32x4* __restrict__ wpl1x, const u32x4* __restrict__ wpl1y,
                                                          const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                          float* __restrict__ y1, float* __restrict__ gn1, int B, int N,
-                                                         int M, unsigned long long* __restrict__ trace) {
+                                                         int M, unsigned long long* __restrict__ trace,
+                                                         const float* __restrict__ bias0 = nullptr /*[2][2B][256]*/,
+                                                         float* __restrict__ y0s = nullptr,
+                                                         float* __restrict__ a0s = nullptr) {
   __shared__ __attribute__((aligned(16))) float smem[TP * 64 + TP * 256];  // 80 KiB exactly
   int stamp_i = 0;
 #define ROTS_STAMP()                                                                                     \
@@ -533,10 +539,20 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
     {
       const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
       f32x4 scr[3], shr[3];
+      const float* bq = nullptr;
+      f32x4 b0r[3];
+      float *y0p = nullptr, *a0p = nullptr;
+      if constexpr (SAVE) {
+        bq = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + 4 * h;
+        const size_t row = ((size_t)hd * B + rt.obj) * P + rt.gp0 + n;
+        y0p = y0s + row * 256 + wave * 64 + 4 * h;
+        a0p = a0s + row * 256 + wave * 64 + 4 * h;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
         shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
+        if constexpr (SAVE) b0r[i] = *reinterpret_cast<const f32x4*>(bq + (i >> 2) * 32 + 8 * (i & 3));
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
@@ -557,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           const int j = i + 2;
           scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
           shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
+          if constexpr (SAVE) b0r[j % 3] = *reinterpret_cast<const f32x4*>(bq + (j >> 2) * 32 + 8 * (j & 3));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -564,6 +581,13 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           float z[4];
           gelu_affine4(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
                        scr[i % 3], shr[i % 3], z);
+          if constexpr (SAVE) {
+            const f32x4 y = {acc[mb][nb][4 * g] + b0r[i % 3][0], acc[mb][nb][4 * g + 1] + b0r[i % 3][1],
+                             acc[mb][nb][4 * g + 2] + b0r[i % 3][2], acc[mb][nb][4 * g + 3] + b0r[i % 3][3]};
+            const f32x4 zz = {z[0], z[1], z[2], z[3]};
+            *reinterpret_cast<f32x4*>(y0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = y;
+            *reinterpret_cast<f32x4*>(a0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = zz;
+          }
           if ((g & 1) == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) zprev[nb][q] = z[q];
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
-        float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+        float* dst = y1 + ((SAVE ? (size_t)hd * B + rt.obj : (size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
         float s = 0.f;
         if (rt.valid == TP) {
           float* dh = dst + (size_t)(4 * h) * 256;
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
         m2 += __shfl_xor(m2, 4);
         m2 += __shfl_xor(m2, 32);
         if ((lane & 7) == 0 && h == 0) {
-          float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
+          float* out = gn1 + ((SAVE ? (size_t)hd * B + rt.obj : (size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
           out[0] = mean;
           out[1] = m2;
         }

@@ -167,7 +167,7 @@ _SIGS = {
     "catre_op_wsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _P]),
     "catre_op_pose_update_bwd": (_I, [_P] * 13 + [_I, _P]),
     "catre_train_rot_fwd_ws_bytes": (_SZ, [_I]),
-    "catre_train_rot_fwd": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _P]),
+    "catre_train_rot_fwd": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _I, _P]),
     "catre_op_ranger_step": (_I, [_P, _I, _P, _I, _P, _I, _P, ctypes.c_double, ctypes.c_double, ctypes.c_float,
                                   ctypes.c_float, _I, ctypes.c_float, _P]),
     "catre_aug_points": (_I, [_P] * 10 + [_I, _I, _P]),

@@ -124,11 +124,44 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
 
 
+def _rot_heads_shapes_ok(p, pf_obj, N, M):
+    return (pf_obj.shape[1] == 64 and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0
+            and all(p.get(f"{pre}.layers.3.bias") is not None
+                    and tuple(p[f"{pre}.layers.0.weight"].shape[:2]) == (256, 1088)
+                    and tuple(p[f"{pre}.layers.3.weight"].shape[:2]) == (256, 256) for pre in _ROT_PREFIX))
+
+
 def _rot_heads_fused_ok(p, pf_obj, N, M):
-    return (T.rot_heads_ok(pf_obj, N, M) and all(p.get(f"{pre}.layers.3.bias") is not None
-                                                 and tuple(p[f"{pre}.layers.0.weight"].shape[:2]) == (256, 1088)
-                                                 and tuple(p[f"{pre}.layers.3.weight"].shape[:2]) == (256, 256)
-                                                 for pre in _ROT_PREFIX))
+    return T.rot_heads_ok(pf_obj, N, M) and _rot_heads_shapes_ok(p, pf_obj, N, M)
+
+
+def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
+    """Both RotHeads in split mode: ONE fused forward launch chain (`catre_train_rot_fwd`, k_rot_l1_split<true>) computes what
+    the per-head ops would - y0, a0 = gelu(GN0(y0)), y1 and the GroupNorm partials - and the per-head ops become graph nodes
+    around those buffers (`pre=`); their backward is unchanged (split dgrad / wgrad GEMMs, fp32 GroupNorm / GELU passes)."""
+    from .heads import neck_weight3
+
+    P = N + M
+    W0s, b0s = [], []
+    for pre in _ROT_PREFIX:
+        W0 = p[f"{pre}.layers.0.weight"].reshape(256, 1088)
+        W0s.append(W0)
+        b0s.append(T.linear(g, W0[:, :1024].contiguous(), p[f"{pre}.layers.0.bias"]))   # [2B,256]
+    prm, packed = rt._train_packs(pf.device, 2)
+    buf = T.rot_heads_forward(pf.detach(), b0s[0], b0s[1], prm, packed, B, N, M, 2)
+    out = []
+    for h, pre in enumerate(_ROT_PREFIX):
+        w = lambda n: p[f"{pre}.{n}"]
+        y, _ = T.linear_cloudbias(pf_obj, W0s[h][:, 1024:].contiguous(), b0s[h], B, N, M, with_gn_partials=True,
+                                  pre=(buf["y0"][h], None))
+        a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, None, pre=(buf["a0"][h], buf["stat0"][h]))
+        y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
+                                         pre=(buf["y1"][h], buf["part1"][h]))
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        y3 = T.gn_points_gelu_neck(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, B, P, part1)
+        rd = w("neck.0.weight").shape[0]
+        out.append(T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, P)[:, :rd])
+    return out
 
 
 def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
@@ -182,6 +215,8 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
 
     if hub is not None and _rot_heads_fused_ok(p, pf_obj, N, M):
         rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
+    elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):
+        rx, ry = _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M)
     else:
         rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
         ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)

@@ -671,13 +671,20 @@ class _RotLinear(torch.autograd.Function):
     a statistics pass over y).  Backward: dbias = column sums of dy (per cloud or total), dx / dW like a plain linear."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, per_cloud, B, N, M):
+    def forward(ctx, x, w, bias, per_cloud, B, N, M, pre=None):
         lib = hip.load()
         w2 = _c(w.reshape(w.shape[0], -1))
         J, K = w2.shape
         amp = _amp()
         if amp and K not in (64, 128, 256, 512):
             amp = 0
+        if pre is not None:  # (y, partials) already computed by a fused forward (rot_heads_forward): only the graph node
+            y, part = pre
+            ctx.save_for_backward(x, w)
+            ctx.dims, ctx.amp, ctx.per_cloud, ctx.has_b = (B, N, M), amp, bool(per_cloud), bias is not None
+            part = part if part is not None else torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(part)
+            return y, part
         xc, bc = _c(x), (_c(bias) if bias is not None else None)
         if amp == 1:
             wp = _pack_bf16(w2, J, K, x.device)
@@ -723,31 +730,33 @@ class _RotLinear(torch.autograd.Function):
             dw = _c(dw).reshape(w.shape)
         elif want_db and not ctx.per_cloud:
             db = _colsum(dy)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def _rot_linear_ok(R, J, K, N, M):
     return N % 64 == 0 and M % 64 == 0 and _tiled_gemm_ok(R, J, K, min_rows=64) and K % 8 == 0
 
 
-def linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=False):
+def linear_cloudbias(x, w, bias, B, N, M, with_gn_partials=False, pre=None):
     """x [B*(N+M), K] object-major rows, w [J,K], bias [2B,J] -> x w^T + bias[cloud(row)].  One fused kernel when the
     tiles cannot straddle clouds (N, M multiples of 64) and the shape is tiled; else linear + rowbias_add.  With
     with_gn_partials returns (y, partials or None)."""
     J, K = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
     if _rot_linear_ok(x.shape[0], J, K, N, M):
-        y, part = _RotLinear.apply(x, w, bias, True, B, N, M)
+        y, part = _RotLinear.apply(x, w, bias, True, B, N, M, pre)
         return (y, part if part.numel() else None) if with_gn_partials else y
+    assert pre is None
     y = rowbias_add(linear(x, w, None), bias, B, N, M)
     return (y, None) if with_gn_partials else y
 
 
-def linear_gn_partials(x, w, bias, B, N, M):
+def linear_gn_partials(x, w, bias, B, N, M, pre=None):
     """y = x w^T + bias plus the GroupNorm(32,256) tile partials of y from the same kernel -> (y, partials or None)."""
     J, K = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
     if J == 256 and _rot_linear_ok(x.shape[0], J, K, N, M):
-        y, part = _RotLinear.apply(x, w, bias, False, B, N, M)
+        y, part = _RotLinear.apply(x, w, bias, False, B, N, M, pre)
         return y, part
+    assert pre is None
     return linear(x, w, bias), None
 
 
@@ -761,9 +770,14 @@ class _GNPointsGelu(torch.autograd.Function):
     """gelu(GroupNorm(32,256)(y)) with statistics over the P points of each object (rows object-major)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, B, P, part):
+    def forward(ctx, y, gamma, beta, B, P, part, pre=None):
         lib = hip.load()
         y = _c(y)
+        if pre is not None:  # (a, stat) from a fused forward
+            a, stat = pre
+            ctx.save_for_backward(y, gamma, beta, stat)
+            ctx.dims = (B, P)
+            return a
         a = torch.empty_like(y)
         stat = torch.empty(B, 32, 2, dtype=torch.float32, device=y.device)
         if part is not None and P % 64 == 0:  # statistics from the producing GEMM's tile partials: no pass over y
@@ -789,13 +803,13 @@ class _GNPointsGelu(torch.autograd.Function):
         hip.check(lib.catre_op_gnp_gelu_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta),
                                             hip.ptr(dy), hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), ws.numel(), B, P,
                                             _st(y)), "catre_op_gnp_gelu_bwd")
-        return dy, dg, db, None, None, None
+        return dy, dg, db, None, None, None, None
 
 
-def gn_points_gelu(y, gamma, beta, B, P, part=None):
+def gn_points_gelu(y, gamma, beta, B, P, part=None, pre=None):
     """part: optional per-64-row-tile GroupNorm partials of y ([B*P/64, 32, 2], from linear_cloudbias /
-    linear_gn_partials)."""
-    return _GNPointsGelu.apply(y, gamma, beta, B, P, part)
+    linear_gn_partials).  pre: (a, stat [B,32,2]) already computed by a fused forward."""
+    return _GNPointsGelu.apply(y, gamma, beta, B, P, part, pre)
 
 
 class _GNPointsGeluNeck(torch.autograd.Function):
@@ -1018,7 +1032,7 @@ class _RotHeads(torch.autograd.Function):
         stat0 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
         ws = _ws(lib.catre_train_rot_fwd_ws_bytes(B), dev)
         hip.check(lib.catre_train_rot_fwd(hip.ptr(pf_cm), hip.ptr(bias0), prm, hip.ptr(packed), hip.ptr(y0), hip.ptr(a0),
-                                          hip.ptr(y1), hip.ptr(part), hip.ptr(stat0), hip.ptr(ws), ws.numel(), B, N, M,
+                                          hip.ptr(y1), hip.ptr(part), hip.ptr(stat0), hip.ptr(ws), ws.numel(), B, N, M, 0,
                                           _st(pf_obj)), "catre_train_rot_fwd")
         stat1 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
         outs, keep = [], []
@@ -1072,6 +1086,26 @@ class _RotHeads(torch.autograd.Function):
                       dpar[2:5], dbn, dwp.view(ctx.wshapes[4 + h]), dbp]
         dxs[0].add_(dxs[1])
         return (None, dxs[0], None, None, None, None, None) + tuple(grads)
+
+
+def rot_heads_forward(pf_cm, bias0x, bias0y, prm, packed, B, N, M, mode):
+    """The fused forward of both RotHeads up to the GroupNorm-1 input WITHOUT graph nodes (`catre_train_rot_fwd` in
+    `mode`: 0 fp32, 2 split) -> dict of head-major buffers y0, a0, y1 [2,R,256], part1 [2,R/64,32,2], stat0 [2,B,32,2] for
+    the per-head ops' `pre=` arguments (the split mode's graph: its backward stays the layer-wise split dgrad / wgrad)."""
+    lib = hip.load()
+    dev = pf_cm.device
+    R = B * (N + M)
+    pf_cm = _c(pf_cm)
+    bias0 = torch.stack([_c(bias0x.detach()), _c(bias0y.detach())])
+    y0 = torch.empty(2, R, 256, dtype=torch.float32, device=dev)
+    a0, y1 = torch.empty_like(y0), torch.empty_like(y0)
+    part = torch.empty(2, R // 64, 32, 2, dtype=torch.float32, device=dev)
+    stat0 = torch.empty(2, B, 32, 2, dtype=torch.float32, device=dev)
+    ws = _ws(lib.catre_train_rot_fwd_ws_bytes(B), dev)
+    hip.check(lib.catre_train_rot_fwd(hip.ptr(pf_cm), hip.ptr(bias0), prm, hip.ptr(packed), hip.ptr(y0), hip.ptr(a0),
+                                      hip.ptr(y1), hip.ptr(part), hip.ptr(stat0), hip.ptr(ws), ws.numel(), B, N, M, int(mode),
+                                      _st(pf_cm)), "catre_train_rot_fwd")
+    return dict(y0=y0, a0=a0, y1=y1, part1=part, stat0=stat0)
 
 
 def rot_heads_ok(pf_obj, N, M):

@@ -448,14 +448,15 @@ int catre_train_trunk_fwd(const catre_points* pts, const float* trans3, const fl
 /* Training forward of both rotation heads up to the GroupNorm-1 input (heads/conv_out_per_rot_head.py:126-134) on the fused
  * inference kernels with saves: GN0 statistics from second moments of pointfeat, then layer 0 + GN0 + GELU + layer 1 per
  * 64-point tile.  pointfeat: cloud-major [B*N + B*M][64]; bias0 [2 heads][2B clouds][256] = W0[:, :1024] g_cloud + b0;
- * prm / packed: the parameter pointer array and a weight image holding CATRE_PACK_F32_HEADS.  Outputs, head-major:
+ * prm / packed: the parameter pointer array and a weight image holding CATRE_PACK_F32_HEADS (compute_dtype CATRE_DTYPE_F32)
+ * or CATRE_PACK_SPLIT (CATRE_DTYPE_SPLIT: the two linears as split-bf16 MFMAs, everything stored is fp32).  Outputs, head-major:
  * y0, a0, y1 [2][B*(N+M)][256] (rows object-major), gn1_part [2][B*(N+M)/64][32][2] (what catre_op_gnp_gelu_neck_fwd takes),
  * stat0 [2][B][32][2] (mean, rstd).  N and M multiples of 64.  The per-head backward ops (catre_op_rot_l1_bwd,
  * catre_op_rot_l0_bwd) consume the head slices unchanged. */
 size_t catre_train_rot_fwd_ws_bytes(int B);
 int catre_train_rot_fwd(const float* pointfeat, const float* bias0, const float* const* params, const float* packed, float* y0,
                         float* a0, float* y1, float* gn1_part, float* stat0, void* workspace, size_t ws_bytes, int B, int N,
-                        int M, void* stream);
+                        int M, int compute_dtype, void* stream);
 
 /* f4: one fused multi-tensor Ranger step = RAdam + Lookahead + gradient centralization
  * (lib/torch_utils/solver/ranger.py:102-202) with the train loop's grad nan_to_num folded in

@@ -556,12 +556,14 @@ def test_pooled_chain_with_no_live_row_returns_exact_zeros():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "split"])
 @pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 64, 192), (5, 256, 256)])
-def test_fused_rot_heads_forward_matches_the_per_head_blocks(B, N, M):
-    """train_ops._RotHeads (both RotHeads' forward on the fused inference kernels with saves, `catre_train_rot_fwd`:
-    GroupNorm-0 statistics from pointfeat moments, layer 0 + GN0 + GELU + layer 1 per tile) against the per-head
-    block path (`_rot_head`: row GEMM -> GroupNorm/GELU pass -> row GEMM -> neck), heads/conv_out_per_rot_head.py:126-140:
-    the 6-d rotation output and every gradient (all 20 head parameters, the global feature, pointfeat)."""
+def test_fused_rot_heads_forward_matches_the_per_head_blocks(B, N, M, mode):
+    """Both RotHeads' forward on the fused inference kernels with saves (`catre_train_rot_fwd`: GroupNorm-0 statistics from
+    pointfeat moments, layer 0 + GN0 + GELU + layer 1 per tile) against the per-head path (`_rot_head`: row GEMM ->
+    GroupNorm/GELU pass -> row GEMM -> neck), heads/conv_out_per_rot_head.py:126-140: the 6-d rotation output and every
+    gradient (all head parameters, the global feature, pointfeat).  fp32: one graph node (train_ops._RotHeads, GroupNorm-1
+    sums from forward-side moments); split: the per-head nodes around the fused kernel's buffers (`pre=`)."""
     from catre_amd import synth, train_forward as TF
     from catre_amd import train_ops as T
     from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
@@ -584,20 +586,23 @@ def test_fused_rot_heads_forward_matches_the_per_head_blocks(B, N, M):
             q.grad = None
         pf = pf0.clone().requires_grad_(True)
         g = g0.clone().requires_grad_(True)
-        pf_obj = T.object_major(pf, B, N, M)
-        if fused:
-            rt._fingerprint = None   # what the first encoder kernel of a training forward does: re-pack the weight image
-            rx, ry = TF._rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
-        else:
-            rx = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
-            ry = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
-        out = torch.cat([rx, ry], 1)
-        (out * w6).sum().backward()
+        with T.amp_mode(mode):
+            pf_obj = T.object_major(pf, B, N, M)
+            if fused:
+                rt._fingerprint = None   # what the first encoder kernel of a training forward does: re-pack the weight image
+                fn = TF._rot_heads_fused if mode == "fp32" else TF._rot_heads_split
+                rx, ry = fn(g, pf, pf_obj, p, rt, B, N, M)
+            else:
+                rx = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
+                ry = TF._rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
+            out = torch.cat([rx, ry], 1)
+            (out * w6).sum().backward()
         grads = {k: q.grad.clone() for k, q in p.items() if q.grad is not None}
         grads["pointfeat"], grads["g"] = pf.grad.clone(), g.grad.clone()
         return out.detach(), grads
 
-    assert TF._rot_heads_fused_ok(p, pf0, N, M)
+    with T.amp_mode(mode):
+        assert TF._rot_heads_fused_ok(p, pf0, N, M) == (mode == "fp32") and TF._rot_heads_shapes_ok(p, pf0, N, M)
     want, gw = run(False)
     got, gg = run(True)
     assert torch.isfinite(got).all()
