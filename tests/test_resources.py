@@ -45,7 +45,7 @@ def test_headline_kernels_keep_their_occupancy_shape():
     t = by["k_trunk<1, false>"]
     assert t["lds"] == 160 * 1024 and t["vgpr"] <= 256           # one 512-thread workgroup per CU
     for k in ("k_stn3d<1, false>", "k_stnkd<1, false>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, false>", "k_rot_l1<1, true>",
-              "k_rot_l1_split"):
+              "k_rot_l1_split<false>", "k_rot_l1_split<true>"):
         assert by[k]["lds"] <= 80 * 1024 and by[k]["vgpr"] <= 256, k  # two 256-thread workgroups per CU
 
 
