@@ -2115,6 +2115,8 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
       asm volatile("" : "+v"(lane_o));
       gp.prefetch(WpT + ((size_t)mbk * 32) * 64 + lane_o, 0);
       gp.run(acc, dys + nb * 32 * 256, 256, lane);
+      // (the swapped orientation - whole-line stores, as in k_rot_l1_bwd - needs 16 store addresses here and spills; dX is
+      // 134 MB per head, its 16-byte stores are not what bounds this kernel)
       float* o = dX + (row0 + (size_t)t * TP + nb * 32 + i) * lddx + mbk * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -2284,22 +2286,22 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
     {  // dA tile = dY W: m-blocks 2 wave, 2 wave + 1 of the 256 input channels, both 32-row halves
       f32x16 acc[2][2];
       acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16();
-      GemmPipe<2, 2, false, false, 32, 2, 1> gp;
+      // "swapped" MFMA orientation: a lane owns input channel (2 wave + mb) * 32 + i and 32 of the tile's rows, so the
+      // stores below put 32 lanes on 128 consecutive bytes of a row - whole L2 lines (16-byte stores with the lanes along
+      // the rows cost four times the L2 requests: see k_rot_l1<1, true>)
+      GemmPipe<2, 2, true, false, 32, 2, 1> gp;
       unsigned lane_o = lane;  // opaque per tile: keeps the 64 fragment addresses of the sweep out of the tile loop's preheader
       asm volatile("" : "+v"(lane_o));
       gp.prefetch(WpT + ((size_t)(2 * wave) * 32) * 64 + lane_o, 32 * 64);
       gp.run(acc, dys, L1B_LDY, lane);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 2; ++mb) {
+        float* o = dA + (r0 + 4 * h) * 256 + (2 * wave + mb) * 32 + i;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          float* o = dA + (r0 + nb * 32 + i) * 256 + (2 * wave + mb) * 32 + 4 * h;
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(o + 8 * g) = v;
-          }
-        }
+          for (int r = 0; r < 16; ++r) o[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = acc[mb][nb][r];
+      }
     }
     {  // dW += dY^T A: j-blocks 2 wave, 2 wave + 1 x all eight k-blocks; operands two steps ahead, pinned
       const float* pa = dys + h * L1B_LDY + (2 * wave) * 32 + i;
