@@ -557,7 +557,7 @@ def test_pooled_chain_with_no_live_row_returns_exact_zeros():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["fp32", "split"])
-@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 64, 192), (5, 256, 256)])
+@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (2, 64, 192), (5, 256, 256), (1, 64, 64), (2, 2048, 1024)])
 def test_fused_rot_heads_forward_matches_the_per_head_blocks(B, N, M, mode):
     """Both RotHeads' forward on the fused inference kernels with saves (`catre_train_rot_fwd`: GroupNorm-0 statistics from
     pointfeat moments, layer 0 + GN0 + GELU + layer 1 per tile) against the per-head path (`_rot_head`: row GEMM ->
