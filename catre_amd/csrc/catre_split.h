@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_split(catre_points P, const fl
 // split image -> layer 1 on GemmPipeS -> y1 + GN1 partials.  Otherwise k_rot_l1.  256 threads, 80 KiB LDS.
 // ------------------------------------------------------------------------------------------
 // SAVE: the training forward of the split mode (catre_train_rot_fwd, as k_rot_l1<1, true>): y0 = layer 0's output with its
-// per-cloud bias and a0 = gelu(GN0(y0)) stored as fp32 from the layer-0 epilogue, all outputs head-major.
+// per-cloud bias and a0 = gelu(GN0(y0)) stored as fp32 (from an extra sweep of layer 0, see the head loop), all outputs
+// head-major.
 template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict__ pointfeat,
                                                          const u32x4* __restrict__ wpl0x, const u32x4* __restrict__ wpl0y,
@@ -538,21 +539,51 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
   for (int hd = 0; hd < 2; ++hd) {
     {
       const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
-      f32x4 scr[3], shr[3];
-      const float* bq = nullptr;
-      f32x4 b0r[3];
-      float *y0p = nullptr, *a0p = nullptr;
       if constexpr (SAVE) {
-        bq = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + 4 * h;
-        const size_t row = ((size_t)hd * B + rt.obj) * P + rt.gp0 + n;
-        y0p = y0s + row * 256 + wave * 64 + 4 * h;
-        a0p = a0s + row * 256 + wave * 64 + 4 * h;
+        // Saves first, from a sweep of layer 0 in the SWAPPED orientation (lane = channel wave*64 + mb*32 + n): y0 and a0
+        // leave as 4-byte stores covering 128 consecutive bytes of a row per half-wave - whole L2 lines.  The hi / lo LDS
+        // image below needs 8 channels of a point in one lane, which only the normal orientation has, so layer 0 (K = 64,
+        // a fifth of layer 1) runs twice in this instance.  (Storing from the normal orientation - 16 bytes per lane, 32
+        // rows per instruction - made this kernel L2-request-bound: 1.65 ms against 0.6 ms without saves.)
+        const float* afb = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + n;
+        const float* bqb = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 64 + n;
+        float scv[2], shv[2], b0v[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          scv[mb] = afb[mb * 32];
+          shv[mb] = afb[256 + mb * 32];
+          b0v[mb] = bqb[mb * 32];
+        }
+        f32x16 accs[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) accs[mb][0] = accs[mb][1] = zero16();
+        {
+          GemmPipeS<2, 2, true, 8, 2> gs;
+          gs.prefetch((hd ? wpl0y : wpl0x) + ((wave * 2) * 4) * 64 + lane, 4 * 64, 256 * 64 / 8);
+          gs.run(accs, pfh, pfl, lane);
+        }
+        const size_t rowg = ((size_t)hd * B + rt.obj) * P + rt.gp0 + 4 * h;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const int c = wave * 64 + mb * 32 + n;
+          float* yp = y0s + rowg * 256 + c;
+          float* ap = a0s + rowg * 256 + c;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = nb * 32 + (r & 3) + 8 * (r >> 2);
+              const float v = accs[mb][nb][r];
+              yp[row * 256] = v + b0v[mb];
+              ap[row * 256] = gelu_erf(fmaf(v, scv[mb], shv[mb]));
+            }
+        }
       }
+      f32x4 scr[3], shr[3];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         scr[i] = *reinterpret_cast<const f32x4*>(af + (i >> 2) * 32 + 8 * (i & 3));
         shr[i] = *reinterpret_cast<const f32x4*>(af + 256 + (i >> 2) * 32 + 8 * (i & 3));
-        if constexpr (SAVE) b0r[i] = *reinterpret_cast<const f32x4*>(bq + (i >> 2) * 32 + 8 * (i & 3));
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
@@ -573,7 +604,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           const int j = i + 2;
           scr[j % 3] = *reinterpret_cast<const f32x4*>(af + (j >> 2) * 32 + 8 * (j & 3));
           shr[j % 3] = *reinterpret_cast<const f32x4*>(af + 256 + (j >> 2) * 32 + 8 * (j & 3));
-          if constexpr (SAVE) b0r[j % 3] = *reinterpret_cast<const f32x4*>(bq + (j >> 2) * 32 + 8 * (j & 3));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -581,13 +611,6 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
           float z[4];
           gelu_affine4(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
                        scr[i % 3], shr[i % 3], z);
-          if constexpr (SAVE) {
-            const f32x4 y = {acc[mb][nb][4 * g] + b0r[i % 3][0], acc[mb][nb][4 * g + 1] + b0r[i % 3][1],
-                             acc[mb][nb][4 * g + 2] + b0r[i % 3][2], acc[mb][nb][4 * g + 3] + b0r[i % 3][3]};
-            const f32x4 zz = {z[0], z[1], z[2], z[3]};
-            *reinterpret_cast<f32x4*>(y0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = y;
-            *reinterpret_cast<f32x4*>(a0p + (size_t)nb * 32 * 256 + mb * 32 + 8 * g) = zz;
-          }
           if ((g & 1) == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) zprev[nb][q] = z[q];

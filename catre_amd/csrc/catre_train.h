@@ -29,7 +29,7 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 
 // ------------------------------------------------------------------------------------------------
 // gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
-// wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "normal" orientation: 4 consecutive channels/lane.
+// wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "swapped" orientation: a lane owns one channel of a block.
 // ------------------------------------------------------------------------------------------------
 // optional per-cloud bias of the row GEMMs (rot-head layer 0: the global-feature half of the 1088 -> 256 conv is a bias
 // that depends on the cloud a row belongs to): rows object-major [N observed | M prior] per object, N and M multiples
@@ -87,6 +87,77 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
     }
     return;
   }
+  // Store form - also in the "swapped" orientation (lane owns channel blk*32 + n and rows (r&3) + 8(r>>2) + 4h + 32nb): Y
+  // leaves as 4-byte stores whose 32 lanes cover 128 consecutive bytes of a row, whole L2 lines.  (Until round 3 this was
+  // the normal orientation with 16-byte stores, lanes along the rows: 32 rows x 32 bytes per instruction, four times the
+  // L2 write requests - what bounded the [rows,256] GEMMs of the reduced-precision training modes.)
+  const bool full = r0 + TP <= R;  // wave-uniform: no per-row predicates on full tiles
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int blk = blk_off + wave + 8 * mb;
+    if (blk >= nblk) break;
+    const int ch = blk * 32 + n;
+    const float bv = bias ? bias[ch] : 0.f;
+    float* yo = Y + (size_t)(r0 + 4 * h) * ldy + ch;
+    const float* mo = mask ? mask + (size_t)(r0 + 4 * h) * ldm + ch : nullptr;
+    int lim = R - r0 - 4 * h;  // row (nb, r) of this half-wave exists iff its in-tile index < lim
+    asm volatile("" : "+v"(lim));
+    float s = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = nb * 32 + (r & 3) + 8 * (r >> 2);
+        float t = acc[mb][nb][r] + bv;
+        t = relu ? fmaxf(t, 0.f) : t;
+        if (full || row < lim) {
+          if (mo) t = mo[(size_t)row * ldm] > 0.f ? t : 0.f;
+          yo[(size_t)row * ldy] = t;
+          s += t;
+        } else {
+          t = 0.f;
+        }
+        acc[mb][nb][r] = t;
+      }
+    if (gn_part) {
+      // GroupNorm(32, 256) partials of this 64-row tile for group blk*4 + (n>>3) (8 consecutive lanes, both half-waves):
+      // (mean, M2), merged per object by k_gnp_stats_final in tile order
+      const float cnt = 8.f * (float)min(TP, R - r0);
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 32);
+      const float mean = s / cnt;
+      float m2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[mb][nb][r] - mean;
+          m2 += (full || nb * 32 + (r & 3) + 8 * (r >> 2) < lim) ? d * d : 0.f;
+        }
+      m2 += __shfl_xor(m2, 1);
+      m2 += __shfl_xor(m2, 2);
+      m2 += __shfl_xor(m2, 4);
+      m2 += __shfl_xor(m2, 32);
+      if ((lane & 7) == 0 && h == 0) {
+        float* o = gn_part + ((size_t)blockIdx.x * 32 + blk * 4 + (n >> 3)) * 2;
+        o[0] = mean;
+        o[1] = m2;
+      }
+    }
+  }
+}
+
+// The store epilogue in the NORMAL orientation (lane owns a row and 4 consecutive channels per register quad: 16-byte
+// stores) - kept for k_gemm_rows_sp only: its three-product sweep in the swapped orientation spills ~120 SGPRs and ran
+// 15-60 % slower than the L2 requests it saved (one-box A/B, round 3).
+template <int MB>
+__device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
+                                                     const float* __restrict__ mask, int ldm, float* __restrict__ Y,
+                                                     int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
+                                                     int blk_off = 0, float* __restrict__ gn_part = nullptr) {
+  const int n = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int blk = blk_off + wave + 8 * mb;
@@ -225,7 +296,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
       // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
       // two weight chunks in flight, except the widest instance (4 m-blocks x K-chunk 256): 32 MFMAs per chunk cover
       // one chunk's L2 round trip, and the third ring slot would not fit 256 VGPRs (2 spills)
-      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;
+      GemmPipe<MB, 2, true, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;  // swapped: lane = channel
       // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
       g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
       g.run(acc, xs, LDX, lane);
@@ -295,7 +366,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   f32x16 acc[MB][2];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-  GemmPipeB<MB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1), 1> g;
+  GemmPipeB<MB, 2, true, CP, (NKC >= 4 ? 2 : 1), 1> g;  // swapped: lane = channel (gemm_rows_epilogue)
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
   gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
@@ -373,8 +444,12 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
     GemmPipeS<PMB, 2, MAXP, CP, (NKC >= 4 ? 2 : 1)> g;
     g.prefetch(Wp + ((size_t)(blk0 + wave) * NKC) * 64 + lane, 8 * NKC * 64, lo_off);
     g.run(acc, xs[0], xs[1], lane);
-    gemm_rows_epilogue<PMB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0,
-                                  cb.gn_part);
+    if constexpr (MAXP)
+      gemm_rows_epilogue<PMB, true>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0,
+                                    cb.gn_part);
+    else
+      gemm_rows_epilogue_n<PMB>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0,
+                                cb.gn_part);
   }
 }
 
