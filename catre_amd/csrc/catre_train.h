@@ -29,7 +29,8 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 
 // ------------------------------------------------------------------------------------------------
 // gemm_rows: 512 threads, 64 rows per workgroup, K processed in chunks of 8*NKC staged in LDS (swizzled),
-// wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  "swapped" orientation: a lane owns one channel of a block.
+// wave w owns m-blocks {w + 8*i}, i < MB (J <= 256*MB).  Store form: "normal" orientation (4 consecutive channels/lane)
+// in the fp32 and split kernels, "swapped" (lane = channel, whole-line stores) in the bf16-operand kernel.
 // ------------------------------------------------------------------------------------------------
 // optional per-cloud bias of the row GEMMs (rot-head layer 0: the global-feature half of the 1088 -> 256 conv is a bias
 // that depends on the cloud a row belongs to): rows object-major [N observed | M prior] per object, N and M multiples
@@ -150,8 +151,8 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
 }
 
 // The store epilogue in the NORMAL orientation (lane owns a row and 4 consecutive channels per register quad: 16-byte
-// stores) - kept for k_gemm_rows_sp only: its three-product sweep in the swapped orientation spills ~120 SGPRs and ran
-// 15-60 % slower than the L2 requests it saved (one-box A/B, round 3).
+// stores) - for k_gemm_rows (fp32: the requests hide under the slower MFMAs) and k_gemm_rows_sp (its three-product sweep in
+// the swapped orientation spills ~120 SGPRs and ran 15-60 % slower than the L2 requests it saved; one-box A/B, round 3).
 template <int MB>
 __device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                      const float* __restrict__ mask, int ldm, float* __restrict__ Y,
@@ -296,15 +297,21 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
       // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
       // two weight chunks in flight, except the widest instance (4 m-blocks x K-chunk 256): 32 MFMAs per chunk cover
       // one chunk's L2 round trip, and the third ring slot would not fit 256 VGPRs (2 spills)
-      GemmPipe<MB, 2, true, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;  // swapped: lane = channel
+      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;
       // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
       g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
       g.run(acc, xs, LDX, lane);
     }
   }
   if (!active) return;
-  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
-                               cb.gn_part);
+  // (store form: normal orientation - at the fp32 MFMA rate the L2 write requests of its 16-byte stores are hidden, and
+  // the swapped form measured 3-10 % slower on the training shapes; the bf16-operand kernel below is the one that needs it)
+  if constexpr (MAXP)
+    gemm_rows_epilogue<MB, true>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
+                                 cb.gn_part);
+  else
+    gemm_rows_epilogue_n<MB>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
+                             cb.gn_part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1395,8 +1402,8 @@ __global__ __launch_bounds__(256) void k_cloud_matmul(const float* __restrict__ 
   }
 }
 
-// kd = 64 on the matrix pipe (the VALU form above ran at 0.9 TB/s): 64 rows of one cloud per workgroup, Y^T tile
-// D[j][row] = sum_i T[i][j] X[row][i] with T (or T^T) as the A operand straight from LDS, wave -> (32 channels, 32 rows)
+// kd = 64 on the matrix pipe (the VALU form above ran at 0.9 TB/s): 64 rows of one cloud per workgroup,
+// D[row][j] = sum_i X[row][i] T[i][j] with T (or T^T) as the B operand straight from LDS, wave -> (32 channels, 32 rows)
 __global__ __launch_bounds__(256) void k_cloud_matmul64(const float* __restrict__ X, int ldx, const float* __restrict__ T,
                                                         float* __restrict__ Y, int ldy, int B, int N, int M,
                                                         int transpose) {
@@ -1434,16 +1441,16 @@ __global__ __launch_bounds__(256) void k_cloud_matmul64(const float* __restrict_
   for (int kc = 0; kc < 8; ++kc) {
     const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc = mfma32(ts[(kc * 8 + 4 * h + q) * 64 + mblk * 32 + nn], bx[q], acc);
+    // swapped operand order: D[row][j] - the lane owns channel mblk*32 + nn and 16 of the tile's rows, so that the stores
+    // below cover 128 consecutive bytes of a row per half-wave (whole L2 lines; see k_rot_l1<1, true>)
+    for (int q = 0; q < 4; ++q) acc = mfma32(bx[q], ts[(kc * 8 + 4 * h + q) * 64 + mblk * 32 + nn], acc);
   }
-  const int row = rb + nb * 32 + nn;
-  if (row < n) {
-    float* dst = Y + (size_t)(r0 + row) * ldy + mblk * 32 + 4 * h;
+  float* dst = Y + (size_t)(r0 + rb + nb * 32 + 4 * h) * ldy + mblk * 32 + nn;
+  const int lim = n - rb - nb * 32 - 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    if (row < lim) dst[(size_t)row * ldy] = acc[r];
   }
 }
 
