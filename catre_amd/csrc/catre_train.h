@@ -1406,51 +1406,62 @@ __global__ __launch_bounds__(256) void k_cloud_matmul(const float* __restrict__ 
 // D[row][j] = sum_i X[row][i] T[i][j] with T (or T^T) as the B operand straight from LDS, wave -> (32 channels, 32 rows)
 __global__ __launch_bounds__(256) void k_cloud_matmul64(const float* __restrict__ X, int ldx, const float* __restrict__ T,
                                                         float* __restrict__ Y, int ldy, int B, int N, int M,
-                                                        int transpose) {
+                                                        int transpose, int tpw) {
+  // a workgroup takes `tpw` consecutive 64-row tiles of one cloud: the 16 KiB transform is staged once, and the next
+  // tile's rows are requested before the current tile's MFMAs (one tile per workgroup re-read the transform for every
+  // tile and waited for each of its three dependent phases: 126 us for 0.4 GB at B = 256)
   __shared__ __attribute__((aligned(16))) float ts[64 * 64];
   __shared__ __attribute__((aligned(16))) float xs[64 * 68];
   const int c = blockIdx.y;
   int r0, n;
   cloud_rows(c, B, N, M, r0, n);
-  const int rb = blockIdx.x * 64;
-  if (rb >= n) return;
+  const int rb0 = blockIdx.x * tpw * 64;
+  if (rb0 >= n) return;
+  const int rb1 = min(n, rb0 + tpw * 64);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float* Tc = T + (size_t)c * 4096;
+  const int srow = tid >> 2, c0 = (tid & 3) * 16;
+  f32x4 v[4];
+  auto fetch = [&](int rb) {
+    const bool ok = rb + srow < n;
+    const float* src = X + (size_t)(r0 + rb + (ok ? srow : 0)) * ldx + c0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) v[u] = *reinterpret_cast<const f32x4*>(src + 4 * u);
+    }
+  };
+  fetch(rb0);
   if (transpose) {
     for (int i = tid; i < 4096; i += 256) ts[i] = Tc[(i & 63) * 64 + (i >> 6)];
   } else {
     for (int i = tid; i < 1024; i += 256) reinterpret_cast<f32x4*>(ts)[i] = reinterpret_cast<const f32x4*>(Tc)[i];
   }
-  {
-    const int row = tid >> 2, c0 = (tid & 3) * 16;
-    const bool ok = rb + row < n;
-    const float* src = X + (size_t)(r0 + rb + (ok ? row : 0)) * ldx + c0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(src + 4 * u);
-      *reinterpret_cast<f32x4*>(xs + row * 68 + c0 + 4 * u) = v;
-    }
-  }
-  __syncthreads();
   const int mblk = wave >> 1, nb = wave & 1, nn = lane & 31, h = lane >> 5;
-  f32x16 acc = zero16();
-  const float* xr = xs + (nb * 32 + nn) * 68 + 4 * h;
+  for (int rb = rb0; rb < rb1; rb += 64) {
 #pragma unroll
-  for (int kc = 0; kc < 8; ++kc) {
-    const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(xs + srow * 68 + c0 + 4 * u) = v[u];
+    __syncthreads();
+    if (rb + 64 < rb1) fetch(rb + 64);
+    f32x16 acc = zero16();
+    const float* xr = xs + (nb * 32 + nn) * 68 + 4 * h;
 #pragma unroll
-    // swapped operand order: D[row][j] - the lane owns channel mblk*32 + nn and 16 of the tile's rows, so that the stores
-    // below cover 128 consecutive bytes of a row per half-wave (whole L2 lines; see k_rot_l1<1, true>)
-    for (int q = 0; q < 4; ++q) acc = mfma32(bx[q], ts[(kc * 8 + 4 * h + q) * 64 + mblk * 32 + nn], acc);
-  }
-  float* dst = Y + (size_t)(r0 + rb + nb * 32 + 4 * h) * ldy + mblk * 32 + nn;
-  const int lim = n - rb - nb * 32 - 4 * h;
+    for (int kc = 0; kc < 8; ++kc) {
+      const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2);
-    if (row < lim) dst[(size_t)row * ldy] = acc[r];
+      // swapped operand order: D[row][j] - the lane owns channel mblk*32 + nn and 16 of the tile's rows, so that the
+      // stores below cover 128 consecutive bytes of a row per half-wave (whole L2 lines; see k_rot_l1<1, true>)
+      for (int q = 0; q < 4; ++q) acc = mfma32(bx[q], ts[(kc * 8 + 4 * h + q) * 64 + mblk * 32 + nn], acc);
+    }
+    float* dst = Y + (size_t)(r0 + rb + nb * 32 + 4 * h) * ldy + mblk * 32 + nn;
+    const int lim = n - rb - nb * 32 - 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      if (row < lim) dst[(size_t)row * ldy] = acc[r];
+    }
+    __syncthreads();  // xs is rewritten for the next tile
   }
 }
 
