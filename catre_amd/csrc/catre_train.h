@@ -2125,7 +2125,7 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ X, int ldx, const f32x4* __restrict__ WpT,
                                                     float* __restrict__ dX, int lddx, float* __restrict__ wpart,
-                                                    float* __restrict__ dbias, int B, int N, int M) {
+                                                    float* __restrict__ dbias, int B, int N, int M, int acc_dx) {
   __shared__ __attribute__((aligned(16))) float dys[TP * 256];
   __shared__ __attribute__((aligned(16))) float pfs[TP * L0B_LDP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2213,7 +2213,8 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
       float* o = dX + (row0 + (size_t)t * TP + nb * 32 + i) * lddx + mbk * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
+        f32x4 v = {acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
+        if (acc_dx) v += *reinterpret_cast<const f32x4*>(o + 8 * g);  // second head of a pair: dX += (the heads share X)
         *reinterpret_cast<f32x4*>(o + 8 * g) = v;
       }
     } else {

@@ -892,7 +892,7 @@ class _RotL0Block(torch.autograd.Function):
         ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
         hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
                                           x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
-                                          hip.ptr(dbe), hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
+                                          hip.ptr(dbe), 0, hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
         return dx, dw.view(ctx.wshape), db, dg, dbe, None, None, None
 
 
@@ -985,19 +985,21 @@ def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spar
     return da, dwb[: 256 * 256].view(256, 256), dwb[256 * 256:], dpar
 
 
-def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M):
-    """_RotL0Block's backward on explicit tensors -> (dx [R,64], dW [256,64], dbias2d [2B,256], dgamma, dbeta)."""
+def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M, dx_acc=None):
+    """_RotL0Block's backward on explicit tensors -> (dx [R,64], dW [256,64], dbias2d [2B,256], dgamma, dbeta).  dx_acc: a
+    [R,64] tensor the data gradient is ADDED to (and returned) instead of a fresh one."""
     lib = hip.load()
     da = _c(da)
     dev = da.device
-    dx = torch.empty(x.shape[0], 64, dtype=torch.float32, device=dev)
+    dx = dx_acc if dx_acc is not None else torch.empty(x.shape[0], 64, dtype=torch.float32, device=dev)
     dw = torch.empty(256, 64, dtype=torch.float32, device=dev)
     db = torch.empty(2 * B if M > 0 else B, 256, dtype=torch.float32, device=dev)
     dg, dbe = torch.empty_like(gamma), torch.empty_like(beta)
     ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
     hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
                                       x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
-                                      hip.ptr(dbe), hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
+                                      hip.ptr(dbe), int(dx_acc is not None), hip.ptr(ws), ws.numel(), B, N, M, _st(da)),
+              "catre_op_rot_l0_bwd")
     return dx, dw, db, dg, dbe
 
 
@@ -1078,13 +1080,13 @@ class _RotHeads(torch.autograd.Function):
                                             0, hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
             da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P, dout=dout,
                                                   spart=spart[h])
-            dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M)
+            dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M,
+                                                          dx_acc=dxs[0] if dxs else None)   # the second head adds into the first's dx
             del da
             dxs.append(dx)
             dbn = _colsum(dy3) if ctx.has_bn[h] else None
             grads += [dbias0, dw0.view(ctx.wshapes[2 * h]), dg0, dbe0, dw1.view(ctx.wshapes[2 * h + 1]), db1, dpar[0], dpar[1],
                       dpar[2:5], dbn, dwp.view(ctx.wshapes[4 + h]), dbp]
-        dxs[0].add_(dxs[1])
         return (None, dxs[0], None, None, None, None, None) + tuple(grads)
 
 
