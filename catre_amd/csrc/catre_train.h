@@ -845,8 +845,19 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, in
   const int j = blockIdx.x * 256 + col;
   const int lo = blockIdx.y * rows_per_split, hi = min(R, lo + rows_per_split);
   float s = 0.f;
-  if (rl < RL && j < J)
-    for (int r = lo + rl; r < hi; r += RL) s += dY[(size_t)r * ld + j];
+  if (rl < RL && j < J) {
+    // eight rows requested before the first add (same order of additions): as a plain loop every load was waited for
+    // before the next was issued - 2.3 TB/s on the 67 MB partial buffers of the rot-head weight gradients
+    int r = lo + rl;
+    for (; r + 7 * RL < hi; r += 8 * RL) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(dY + (size_t)(r + u * RL) * ld + j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < hi; r += RL) s += dY[(size_t)r * ld + j];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (rl == 0 && j < J) {
@@ -1756,6 +1767,7 @@ __global__ void k_gnp_bwd_sums_finalize(const float* __restrict__ sums_part, flo
   if (i >= B * 64) return;
   const int obj = i / 64, e = i % 64;
   float s = 0.f;
+#pragma unroll 8
   for (int c = 0; c < nch; ++c) s += sums_part[((size_t)obj * nch + c) * 64 + e];
   sums[i] = s;
 }
@@ -1962,6 +1974,7 @@ __global__ __launch_bounds__(256) void k_neck_sums_from_s(const float* __restric
   const int obj = blockIdx.x, ch = threadIdx.x;
   const float* sp = Spart + (size_t)obj * T * 768 + ch;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
+#pragma unroll 8
   for (int t = 0; t < T; ++t) {  // tile order: fixed
     S1 += sp[(size_t)t * 768];
     S2 += sp[(size_t)t * 768 + 256];
