@@ -835,6 +835,16 @@ __global__ void k_reduce_splits_p(const float* __restrict__ part, float* __restr
   out[i] = s;
 }
 
+// dst [rows][cols_pad] = src [rows][cols] (element strides sr, sc: transposed views too) with zero columns behind: the
+// zero-padding of small operands to the GEMM kernels' granularity in ONE launch (torch's F.pad is a fill plus a copy)
+__global__ void k_pad_cols(const float* __restrict__ src, long sr, long sc, int rows, int cols, float* __restrict__ dst,
+                           int cols_pad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols_pad) return;
+  const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+  dst[i] = c < cols ? src[(size_t)r * sr + (size_t)c * sc] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
                                                 int J, int rows_per_split) {
   // a block covers JB = min(J, 256) columns with 256/JB row lanes, so narrow matrices still use every thread

@@ -45,9 +45,19 @@ def _c(t):
 
 
 def _pad_cols(t, mult):
+    """t [..., k] with zero columns appended up to a multiple of `mult` (data movement only; called on tensors outside the
+    autograd graph - inside Function.forward / backward).  2-D fp32 device tensors: one launch (catre_op_pad_cols), any
+    strides; everything else through F.pad."""
     k = t.shape[-1]
     r = (-k) % mult
-    return t if r == 0 else F.pad(t, (0, r))
+    if r == 0:
+        return t
+    if t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and not t.requires_grad and t.numel() > 0:
+        out = torch.empty(t.shape[0], k + r, dtype=torch.float32, device=t.device)
+        hip.check(hip.load().catre_op_pad_cols(hip.ptr(t), t.stride(0), t.stride(1), t.shape[0], k, hip.ptr(out), k + r,
+                                               _st(t)), "catre_op_pad_cols")
+        return out
+    return F.pad(t, (0, r))
 
 
 # ------------------------------------------------------------------------------------------------- GEMMs

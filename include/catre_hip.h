@@ -380,6 +380,10 @@ int catre_op_gnp_gelu_neck_fwd_s(const float* Y, const float* part64, const floa
 int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
                           const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
                           float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* dst [rows][cols_pad] (contiguous) = src [rows][cols] (element strides: transposed views too) followed by zero columns:
+ * the padding of small operands to the GEMM kernels' granularity in one launch (F.pad of the reference-side glue). */
+int catre_op_pad_cols(const float* src, long stride_row, long stride_col, int rows, int cols, float* dst, int cols_pad,
+                      void* stream);
 int catre_op_gnr_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, int R, void* stream);
 int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, const float* beta, float* dY,
                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int R, void* stream);
