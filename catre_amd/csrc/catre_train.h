@@ -663,6 +663,98 @@ __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict_
   }
 }
 
+// Whole backward of a 64-channel layer fed by 3-d points (conv1 of the trunk: x1 [R,8] -> h1 [R,64] + ReLU) in ONE pass
+// over the rows: the output gradient arrives as up to two tensors (h1 feeds the STNkd stack and the feature transform; the
+// node adds them here instead of autograd), the ReLU mask is applied on load, and the same registers feed
+//   dW[j][k] = sum_r dv[r][j] X[r][k],  db[j] = sum_r dv[r][j]   (partials per workgroup, merged like k_gemm_tn_skinny's)
+//   dX[r][k] = sum_j dv[r][j] W[j][k]   (16 lanes of a row hold 4 channels each: xor-butterfly over the lane group)
+// instead of add + relu-backward + a K=64 row GEMM with 3 live outputs + pad + skinny wgrad (0.27 ms -> 0.07 ms at
+// R = 524 k; the op is bound by its 3 x 134 MB of operand reads).  J = 64 only (one 16-lane group per row), K <= 4.
+__global__ __launch_bounds__(256) void k_skinny_bwd(const float* __restrict__ dY, int ldy, const float* __restrict__ dY2,
+                                                    int ldy2, const float* __restrict__ ymask, int ldym,
+                                                    const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                    int ldw, int Kw, float* __restrict__ part, float* __restrict__ colpart,
+                                                    size_t pitch, float* __restrict__ dX, int lddx, int dxcols, int R,
+                                                    int rows_per_split) {
+  constexpr int KS = 4, JQ = 16, RL = 16, E = 4 * KS + 4;
+  __shared__ float red[RL * JQ * E];  // [row lane][column quad][4 * KS products + 4 column sums]
+  const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+  const int lo = blockIdx.x * rows_per_split, hi = min(R, lo + rows_per_split);
+  float acc[4][KS], cs[4], wv[4][KS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cs[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      acc[c][k] = 0.f;
+      wv[c][k] = (W && k < Kw) ? W[(size_t)(4 * q + c) * ldw + k] : 0.f;
+    }
+  }
+  for (int r = lo + rl; r < hi; r += 4 * RL) {
+    f32x4 d[4], d2[4], m[4], xa[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = min(r + u * RL, hi - 1);
+      d[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)rr * ldy + 4 * q);
+      if (dY2) d2[u] = *reinterpret_cast<const f32x4*>(dY2 + (size_t)rr * ldy2 + 4 * q);
+      if (ymask) m[u] = *reinterpret_cast<const f32x4*>(ymask + (size_t)rr * ldym + 4 * q);
+      xa[u] = *reinterpret_cast<const f32x4*>(X + (size_t)rr * ldx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = r + u * RL < hi;  // uniform over the 16 lanes of a row
+      float dx[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dx[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float dv = dY2 ? d[u][c] + d2[u][c] : d[u][c];
+        if ((ymask && !(m[u][c] > 0.f)) || !live) dv = 0.f;
+        cs[c] += dv;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          acc[c][k] = fmaf(dv, xa[u][k], acc[c][k]);
+          dx[k] = fmaf(dv, wv[c][k], dx[k]);
+        }
+      }
+      if (dX) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          dx[k] += __shfl_xor(dx[k], 1);
+          dx[k] += __shfl_xor(dx[k], 2);
+          dx[k] += __shfl_xor(dx[k], 4);
+          dx[k] += __shfl_xor(dx[k], 8);
+        }
+        if (live && q == 0) {
+          float* o = dX + (size_t)(r + u * RL) * lddx;
+          const f32x4 v = {dx[0], dx[1], dx[2], dx[3]}, z = {0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(o) = v;
+          if (dxcols > 4) *reinterpret_cast<f32x4*>(o + 4) = z;
+        }
+      }
+    }
+  }
+  float* o = red + (size_t)(rl * JQ + q) * E;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) o[c * KS + k] = acc[c][k];
+    o[4 * KS + c] = cs[c];
+  }
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * pitch;
+  for (int e = tid; e < JQ * E; e += 256) {
+    float sum = 0.f;
+    for (int l = 0; l < RL; ++l) sum += red[(size_t)l * JQ * E + e];  // fixed order
+    const int qq = e / E, i = e % E;
+    if (i < 4 * KS)
+      out[(size_t)(4 * qq + i / KS) * KS + (i % KS)] = sum;
+    else if (colpart)
+      colpart[(size_t)blockIdx.x * pitch + 4 * qq + (i - 4 * KS)] = sum;
+  }
+}
+
 // (Tried in round 2: 256 x 256 / 256 x 128 output tiles per workgroup for the big layers - each operand read once instead
 // of twice, half the LDS reads per MFMA: 0.72 ms for the 256 x 256 x 524 k weight gradient either way, no gain.)
 // ------------------------------------------------------------------------------------------------

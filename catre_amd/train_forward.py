@@ -53,9 +53,9 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
     trans3 = trans.detach().reshape(-1, 9).contiguous()
     # x1 / h1 are written by the trunk kernel further down (same stream, before anything reads them)
     x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8, pre=buf["x1"])
-    h1 = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True, pre=buf["h1"])
+    h1, h1s = T.linear_fan2(x1, w("conv1.weight"), w("conv1.bias"), relu=True, pre=buf["h1"])  # two consumers, one backward pass
     rt.train_stnkd(desc, trans3, buf, B, N, M, dev, mode)
-    trans_feat = _stn(h1, p, f"{prefix}.fstn", 64, B, N, M, pre=(buf["f1"], buf["f2"], buf["g_fstn"], buf["i_fstn"]))
+    trans_feat = _stn(h1s, p, f"{prefix}.fstn", 64, B, N, M, pre=(buf["f1"], buf["f2"], buf["g_fstn"], buf["i_fstn"]))
     trans64 = trans_feat.detach().reshape(-1, 4096).contiguous()
     rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode)
     pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
@@ -77,12 +77,12 @@ def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
     w = lambda n: p[f"{prefix}.{n}"]
     trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M)
     x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8)                    # x^T @ trans, zero-padded to 8 columns
-    h1 = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True)         # [R,64]
     if feature_transform:
-        trans_feat = _stn(h1, p, f"{prefix}.fstn", 64, B, N, M)
+        h1, h1s = T.linear_fan2(x1, w("conv1.weight"), w("conv1.bias"), relu=True)   # [R,64], two consumers
+        trans_feat = _stn(h1s, p, f"{prefix}.fstn", 64, B, N, M)
         pf = T.cloud_matmul(h1, trans_feat, B, N, M)
     else:
-        pf = h1
+        pf = T.linear(x1, w("conv1.weight"), w("conv1.bias"), relu=True)
     h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True)
     h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True)
     g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M)   # conv4 has no ReLU (:114)

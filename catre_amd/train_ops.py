@@ -203,51 +203,109 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
-        lib = hip.load()
-        dy = _c(dy)
-        w2 = w.reshape(w.shape[0], -1)
-        ymask = None
-        if ctx.relu:
-            # ReLU backward: folded into the operand loads of the two GEMMs below when both take the tiled kernels,
-            # else as its own pass
-            R, J = dy.shape
-            if J % 8 == 0 and (not ctx.needs_input_grad[0] or _tiled_gemm_ok(R, w2.shape[1], J)):
-                ymask = _c(y)
-            else:
-                g = torch.empty_like(dy)
-                hip.check(lib.catre_op_relu_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(g), dy.numel(), _st(dy)),
-                          "catre_op_relu_bwd")
-                dy = g
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
-            if dy.shape[1] % 8 == 0:
-                dx = _gemm_nt(dy, None, None, False, xmask=ymask, amp=ctx.amp, wT=_c(w2))     # [R, K]
-            else:
-                wt = _c(_pad_cols(w2.t(), 8))      # [K, J8]
-                dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)
-            if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
-                dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
-            elif x.shape[1] < dx.shape[1]:
-                dx = _c(dx[:, : x.shape[1]])
-        want_db = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            kw = min(w2.shape[1], x.shape[1])
-            if want_db:
-                dw, db = _gemm_tn(dy, _c(x), with_bias=True, ymask=ymask, amp=ctx.amp)
-                db = _c(db)
-            else:
-                dw = _gemm_tn(dy, _c(x), ymask=ymask, amp=ctx.amp)
-            dw = dw[:, :kw]
-            if kw < w2.shape[1]:
-                dw = F.pad(dw, (0, w2.shape[1] - kw))
-            dw = _c(dw).reshape(w.shape)
-        elif want_db:
-            if ymask is not None:
-                dy = dy * (ymask > 0)
-            db = _colsum(dy)
-        return dx, dw, db, None, None, None
+        return _linear_backward(ctx, dy)
+
+
+def _skinny_bwd_ok(dy, x, w2):
+    """Shapes catre_op_skinny_bwd takes: 64 output channels, <= 4 live input columns in rows of 4 or 8 floats."""
+    return dy.shape[1] == 64 and w2.shape[0] == 64 and w2.shape[1] <= 4 and x.shape[1] in (4, 8) and dy.shape[0] > 0
+
+
+def _skinny_backward(dy, dy2, ymask, x, w2, need_dx):
+    lib = hip.load()
+    R = dy.shape[0]
+    dev = dy.device
+    Kw = w2.shape[1]
+    buf = torch.empty(64 * 4 + 64, dtype=torch.float32, device=dev)
+    dx = torch.empty(R, x.shape[1], dtype=torch.float32, device=dev) if need_dx else None
+    wc = _c(w2)
+    ws = _ws(lib.catre_op_gemm_tn_bias_ws_bytes(64, 4, R), dev)
+    hip.check(lib.catre_op_skinny_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(dy2), dy2.stride(0) if dy2 is not None else 0,
+                                      hip.ptr(ymask), ymask.stride(0) if ymask is not None else 0, hip.ptr(x), x.stride(0),
+                                      hip.ptr(wc), wc.stride(0), Kw, hip.ptr(buf), hip.ptr(buf[256:]), hip.ptr(dx),
+                                      x.shape[1] if need_dx else 0, x.shape[1], R, hip.ptr(ws), ws.numel(), _st(dy)),
+              "catre_op_skinny_bwd")
+    return dx, _c(buf[:256].view(64, 4)[:, :Kw]), buf[256:]
+
+
+def _linear_backward(ctx, dy, dy2=None):
+    x, w, y = ctx.saved_tensors
+    lib = hip.load()
+    w2 = w.reshape(w.shape[0], -1)
+    if dy is None:
+        dy, dy2 = dy2, None
+    dy = _c(dy)
+    if _skinny_bwd_ok(dy, x, w2):
+        # conv1 on 3-d points: add of the two gradient streams, ReLU mask, dgrad, wgrad and bias gradient in one pass
+        dx, dw, db = _skinny_backward(dy, _c(dy2) if dy2 is not None else None, _c(y) if ctx.relu else None, _c(x), w2,
+                                      ctx.needs_input_grad[0])
+        return (dx, dw.reshape(w.shape) if ctx.needs_input_grad[1] else None,
+                db if ctx.has_b and ctx.needs_input_grad[2] else None, None, None, None)
+    if dy2 is not None:
+        dy = dy + dy2
+    ymask = None
+    if ctx.relu:
+        # ReLU backward: folded into the operand loads of the two GEMMs below when both take the tiled kernels,
+        # else as its own pass
+        R, J = dy.shape
+        if J % 8 == 0 and (not ctx.needs_input_grad[0] or _tiled_gemm_ok(R, w2.shape[1], J)):
+            ymask = _c(y)
+        else:
+            g = torch.empty_like(dy)
+            hip.check(lib.catre_op_relu_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(g), dy.numel(), _st(dy)),
+                      "catre_op_relu_bwd")
+            dy = g
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
+        if dy.shape[1] % 8 == 0:
+            dx = _gemm_nt(dy, None, None, False, xmask=ymask, amp=ctx.amp, wT=_c(w2))     # [R, K]
+        else:
+            wt = _c(_pad_cols(w2.t(), 8))      # [K, J8]
+            dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)
+        if x.shape[1] > dx.shape[1]:           # x carried zero padding columns beyond K
+            dx = F.pad(dx, (0, x.shape[1] - dx.shape[1]))
+        elif x.shape[1] < dx.shape[1]:
+            dx = _c(dx[:, : x.shape[1]])
+    want_db = ctx.has_b and ctx.needs_input_grad[2]
+    if ctx.needs_input_grad[1]:
+        kw = min(w2.shape[1], x.shape[1])
+        if want_db:
+            dw, db = _gemm_tn(dy, _c(x), with_bias=True, ymask=ymask, amp=ctx.amp)
+            db = _c(db)
+        else:
+            dw = _gemm_tn(dy, _c(x), ymask=ymask, amp=ctx.amp)
+        dw = dw[:, :kw]
+        if kw < w2.shape[1]:
+            dw = F.pad(dw, (0, w2.shape[1] - kw))
+        dw = _c(dw).reshape(w.shape)
+    elif want_db:
+        if ymask is not None:
+            dy = dy * (ymask > 0)
+        db = _colsum(dy)
+    return dx, dw, db, None, None, None
+
+
+class _LinearFan2(torch.autograd.Function):
+    """:class:`_Linear` whose output feeds TWO consumers (h1 = relu(conv1(x1)): the STNkd stack and the feature transform,
+    pointnet.py:103-109): returned as two tensors on one buffer, so that the two gradient streams arrive separately and the
+    backward adds them inside its own first pass instead of autograd running an add over [rows,64] before it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, pre):
+        ctx.set_materialize_grads(False)
+        y = _Linear.forward(ctx, x, w, b, relu, 0, pre)
+        return y, y.detach()
+
+    @staticmethod
+    def backward(ctx, dy_a, dy_b):
+        if dy_a is None and dy_b is None:
+            return None, None, None, None, None
+        return _linear_backward(ctx, dy_a, dy_b)[:5]
+
+
+def linear_fan2(x, w, b=None, relu=False, pre=None):
+    return _LinearFan2.apply(x, w, b, relu, pre)
 
 
 def linear(x, w, b=None, relu=False, identity_k=0, pre=None):

@@ -320,6 +320,13 @@ int catre_op_gemm_tn_bias_m(const float* dY, int ldy, const float* ymask, int ld
 int catre_op_gemm_tn_bias_lp(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx, float* dW,
                              float* db, int J, int K, int R, int accumulate, void* ws, size_t ws_bytes,
                              int compute_dtype, void* stream);
+/* whole backward of a 64-channel layer fed by <= 4 live input columns (conv1 on 3-d points; the reference's autograd of
+ * pointnet.py:103 `F.relu(self.conv1(x))`) in one pass over the rows: dv = (dY (+ dY2)) .* (ymask > 0); dW[64,4] = dv^T X,
+ * db[64] = column sums (db must be dW + 256), dX[R,dxcols] = dv W[64,Kw] (columns >= Kw zero, dxcols 4 or 8).  dY2, ymask
+ * and dX optional; ws >= catre_op_gemm_tn_bias_ws_bytes(64, 4, R) */
+int catre_op_skinny_bwd(const float* dY, int ldy, const float* dY2, int ldy2, const float* ymask, int ldym, const float* X,
+                        int ldx, const float* W, int ldw, int Kw, float* dW, float* db, float* dX, int lddx, int dxcols,
+                        int R, void* ws, size_t ws_bytes, void* stream);
 int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);

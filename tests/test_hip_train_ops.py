@@ -55,6 +55,37 @@ def test_linear_fwd_bwd(R, K, J, relu, mode):
     _cmp(b.grad, br.grad, "db", atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("R,cols,Kw,relu,two", [(524, 8, 3, True, True), (64, 8, 3, True, False), (5000, 4, 4, False, True),
+                                               (33, 8, 1, True, True), (70000, 8, 3, True, True)])
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_two_consumer_point_layer_backward_in_one_pass(R, cols, Kw, relu, two, mode):
+    """h1 = relu(conv1(x1)) with its two consumers (pointnet.py:103-109): linear_fan2 hands the buffer out twice and its
+    backward (catre_op_skinny_bwd) adds the two gradient streams, masks, and produces dx (zero in the padding columns),
+    dW and db in one pass - against fp64 autograd of the same graph; fp32 FMAs in every compute mode."""
+    from catre_amd import train_ops as T
+
+    g = _gen(R + cols + Kw)
+    x0 = torch.randn(R, cols, generator=g)
+    x0[:, Kw:] = 0
+    x, xr = _leaf(x0)
+    w, wr = _leaf(torch.randn(64, Kw, 1, generator=g))
+    b, br = _leaf(torch.randn(64, generator=g) * 0.1)
+    with T.amp_mode(mode):
+        ya, yb = T.linear_fan2(x, w, b, relu=relu)
+    assert ya.data_ptr() == yb.data_ptr()
+    yr = F.linear(xr[:, :Kw], wr[:, :, 0], br)
+    yr = yr * (ya.detach() > 0).double().cpu() if relu else yr
+    _cmp(ya, yr, "y")
+    da, db_ = torch.randn(R, 64, generator=g), torch.randn(R, 64, generator=g)
+    loss = (ya * da.to(DEV)).sum() + ((yb * db_.to(DEV)).sum() if two else 0)
+    loss.backward()
+    ((yr * da.double()).sum() + ((yr * db_.double()).sum() if two else 0)).backward()
+    assert float(x.grad[:, Kw:].abs().max()) == 0 if Kw < cols else True
+    _cmp(x.grad[:, :Kw], xr.grad[:, :Kw], "dx", atol=1e-4)
+    _cmp(w.grad, wr.grad, "dw", atol=2e-3 if R > 10000 else 2e-4, rtol=2e-5)
+    _cmp(b.grad, br.grad, "db", atol=2e-3 if R > 10000 else 2e-4, rtol=2e-5)
+
+
 @pytest.mark.parametrize("R,K,J,masked", [(700, 128, 512, True), (1000, 512, 1024, False), (5000, 64, 256, True),
                                           (333, 256, 64, False), (4096, 1024, 512, False), (520, 132, 36, True)])
 @pytest.mark.parametrize("mode", ["bf16", "split"])
