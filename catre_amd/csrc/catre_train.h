@@ -663,11 +663,17 @@ __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict_
   }
 }
 
+// cross-lane move inside a 16-lane row on the VALU (DPP), no LDS round trip like ds_bpermute
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // Whole backward of a 64-channel layer fed by 3-d points (conv1 of the trunk: x1 [R,8] -> h1 [R,64] + ReLU) in ONE pass
 // over the rows: the output gradient arrives as up to two tensors (h1 feeds the STNkd stack and the feature transform; the
 // node adds them here instead of autograd), the ReLU mask is applied on load, and the same registers feed
 //   dW[j][k] = sum_r dv[r][j] X[r][k],  db[j] = sum_r dv[r][j]   (partials per workgroup, merged like k_gemm_tn_skinny's)
-//   dX[r][k] = sum_j dv[r][j] W[j][k]   (16 lanes of a row hold 4 channels each: xor-butterfly over the lane group)
+//   dX[r][k] = sum_j dv[r][j] W[j][k]   (16 lanes of a row hold 4 channels each: DPP reduction over the 16-lane row)
 // instead of add + relu-backward + a K=64 row GEMM with 3 live outputs + pad + skinny wgrad (0.27 ms -> 0.07 ms at
 // R = 524 k; the op is bound by its 3 x 134 MB of operand reads).  J = 64 only (one 16-lane group per row), K <= 4.
 __global__ __launch_bounds__(256) void k_skinny_bwd(const float* __restrict__ dY, int ldy, const float* __restrict__ dY2,
@@ -721,10 +727,10 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(const float* __restrict__ dY
       if (dX) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          dx[k] += __shfl_xor(dx[k], 1);
-          dx[k] += __shfl_xor(dx[k], 2);
-          dx[k] += __shfl_xor(dx[k], 4);
-          dx[k] += __shfl_xor(dx[k], 8);
+          dx[k] += dpp_move<0xB1>(dx[k]);   // quad_perm [1,0,3,2]
+          dx[k] += dpp_move<0x4E>(dx[k]);   // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+          dx[k] += dpp_move<0x124>(dx[k]);  // row_ror:4
+          dx[k] += dpp_move<0x128>(dx[k]);  // row_ror:8: all four quads of the 16-lane row
         }
         if (live && q == 0) {
           float* o = dX + (size_t)(r + u * RL) * lddx;
