@@ -157,8 +157,12 @@ template <int MB>
 __device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                      const float* __restrict__ mask, int ldm, float* __restrict__ Y,
                                                      int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
-                                                     int blk_off = 0, float* __restrict__ gn_part = nullptr) {
+                                                     int blk_off = 0, float* __restrict__ gn_part = nullptr,
+                                                     int mr0 = -1, int mr1 = -1) {
   const int n = lane & 31, h = lane >> 5;
+  // mr0 / mr1 >= 0: the rows of `mask` that output rows r0 + n and r0 + 32 + n take their mask from (row-compacted outputs
+  // against a dense mask; looked up by the kernel before its sweep)
+  const size_t mr[2] = {mr0 >= 0 ? (size_t)mr0 : (size_t)(r0 + n), mr1 >= 0 ? (size_t)mr1 : (size_t)(r0 + 32 + n)};
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int blk = blk_off + wave + 8 * mb;
@@ -179,7 +183,7 @@ __device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const
             v[q] = relu ? fmaxf(t, 0.f) : t;
           }
           if (mask) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (size_t)r * ldm + ch);
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + mr[nb] * ldm + ch);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
           }
@@ -223,7 +227,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
                                                    int relu, const float* __restrict__ xmask, int ldxm, CloudBias cb,
-                                                   const int* __restrict__ Rdev = nullptr) {
+                                                   const int* __restrict__ Rdev = nullptr,
+                                                   const int* __restrict__ mrows = nullptr) {
   constexpr int KC = 8 * NKC;                       // floats per chunk (64, 128 or 256)
   constexpr int LDX = KC < 64 ? 64 : KC;            // swizzle needs a row pitch that is a multiple of 64 floats
   __shared__ __attribute__((aligned(16))) float xs[TP * LDX];
@@ -235,6 +240,12 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
     if (r0 >= R) return;
   }
   const int nblk = J / 32, nkc_total = K / 8, nchunks = K / KC;
+  // mask rows of this lane's two output rows (row-compacted outputs against a dense mask): requested before the sweep
+  int mr0 = -1, mr1 = -1;
+  if (mrows) {
+    mr0 = mrows[min(r0 + (lane & 31), R - 1)];
+    mr1 = mrows[min(r0 + 32 + (lane & 31), R - 1)];
+  }
   f32x16 acc[MB][2];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
                                  cb.gn_part);
   else
     gemm_rows_epilogue_n<MB>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
-                             cb.gn_part);
+                             cb.gn_part, mr0, mr1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,7 +486,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
                                                  int ldx, float* __restrict__ part, int J, int K, int R,
                                                  int rows_per_split, float* __restrict__ colpart,
                                                  const float* __restrict__ ymask, int ldym, size_t pitch,
-                                                 const int* __restrict__ Rdev = nullptr) {
+                                                 const int* __restrict__ Rdev = nullptr,
+                                                 const int* __restrict__ xrows = nullptr) {
+  // xrows: row r of the contraction takes its X row from xrows[r] (dY row-compacted, X dense: no gathered copy of X)
   if (Rdev) {  // device-side row count: the splits share the rows that exist (empty splits write zero partials)
     R = min(R, *Rdev);
     rows_per_split = (int)((R + gridDim.z * TN_ROWS - 1) / (gridDim.z * TN_ROWS)) * TN_ROWS;
@@ -500,6 +513,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
   float csum = 0.f;
   // staging: float4 slot e = tid + 512*u  ->  dY: row e>>5, float4 column e&31 (u = 0..3); X: row e / XQ, column e % XQ
   f32x4 vy[4], vx[XU];
+  int xi[XU];
+#pragma unroll
+  for (int u = 0; u < XU; ++u) xi[u] = 0;
   auto fetch = [&](int rs) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -521,10 +537,25 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
       const int e = tid + 512 * u, row = e / XQ, c4 = e % XQ, gr = rs + row;
       vx[u] = z;
       const int kc = k0 + c4 * 4;
-      if (gr < row_hi && kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
+      if (gr < row_hi && kc < K) {
+        const size_t xr = xrows ? (size_t)xi[u] : (size_t)gr;
+        vx[u] = *reinterpret_cast<const f32x4*>(X + xr * ldx + kc);
+      }
     }
   };
+  // row indices of the step AFTER the one being fetched: requested a whole MFMA phase before the X loads that need them
+  // (loaded inside fetch, every step would wait one L2 round trip for them before it could issue its X loads)
+  auto fetch_idx = [&](int rs) {
+    if (!xrows) return;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int gr = rs + (tid + 512 * u) / XQ;
+      xi[u] = gr < row_hi ? xrows[gr] : 0;
+    }
+  };
+  fetch_idx(row_lo);
   fetch(row_lo);
+  fetch_idx(row_lo + TN_ROWS);
   for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
     __syncthreads();  // the previous step's reads are done
 #pragma unroll
@@ -532,7 +563,10 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const float* __restrict__ dY, i
 #pragma unroll
     for (int u = 0; u < XU; ++u) *reinterpret_cast<f32x4*>(xs + (tid + 512 * u) * 4) = vx[u];
     __syncthreads();
-    if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);  // in flight during the MFMAs below
+    if (rs + TN_ROWS < row_hi) {
+      fetch(rs + TN_ROWS);  // in flight during the MFMAs below
+      fetch_idx(rs + 2 * TN_ROWS);
+    }
     if (do_col) {
       const float* yc = ys + (tid >> 7) * 16 * 128 + (tid & 127);
       float t = 0.f;
@@ -594,7 +628,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict_
                                                         int ldx, float* __restrict__ part, int J, int K, int R,
                                                         int rows_per_split, float* __restrict__ colpart,
                                                         const float* __restrict__ ymask, int ldym, size_t pitch,
-                                                        const int* __restrict__ Rdev = nullptr) {
+                                                        const int* __restrict__ Rdev = nullptr,
+                                                        const int* __restrict__ xrows = nullptr) {
   if (Rdev) {
     R = min(R, *Rdev);
     rows_per_split = (int)((R + gridDim.x * 32 - 1) / (gridDim.x * 32)) * 32;
@@ -619,8 +654,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict_
         const int rr = min(r + u * RL, hi - 1);
         d[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)rr * ldy + 4 * q);
         if (ymask) m[u] = *reinterpret_cast<const f32x4*>(ymask + (size_t)rr * ldym + 4 * q);
-        xa[u] = *reinterpret_cast<const f32x4*>(X + (size_t)rr * ldx);
-        if (KS == 8) xb[u] = *reinterpret_cast<const f32x4*>(X + (size_t)rr * ldx + 4);
+        const size_t xr = xrows ? (size_t)xrows[rr] : (size_t)rr;
+        xa[u] = *reinterpret_cast<const f32x4*>(X + xr * ldx);
+        if (KS == 8) xb[u] = *reinterpret_cast<const f32x4*>(X + xr * ldx + 4);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -424,9 +424,11 @@ def _scatter_rows(srcc, rowpos, cols):
     return dst
 
 
-def _dgrad_n(dy, w2, xmask, count, amp=0):
+def _dgrad_n(dy, w2, xmask, count, amp=0, mask=None, mask_rows=None):
     """dx[:n] = (dy[:n] .* (xmask[:n] > 0)) W  for the n = count[0] compact rows; w2: the layer's [J,K] weight; amp: the
-    matrix pipe (0 fp32, 1 bf16 operands, 2 split) - the reduced-precision kernels want J in {64, 128, 256, 512}."""
+    matrix pipe (0 fp32, 1 bf16 operands, 2 split) - the reduced-precision kernels want J in {64, 128, 256, 512}.
+    mask / mask_rows (fp32 pipe only): dx row r is zeroed where row mask_rows[r] of the DENSE tensor `mask` is <= 0 - the
+    ReLU of the layer in front, applied as the gradient is produced instead of on a gathered copy of its output."""
     lib = hip.load()
     cap, J = dy.shape
     K = w2.shape[1]
@@ -439,14 +441,22 @@ def _dgrad_n(dy, w2, xmask, count, amp=0):
         wp = torch.empty(J * K, dtype=torch.float32, device=dev)
         hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
     dx = torch.empty(cap, K, dtype=torch.float32, device=dev)
+    if mask is not None:
+        assert amp == 0 and mask.shape[1] == K
+        hip.check(lib.catre_op_gemm_rows_nr(hip.ptr(dy), dy.stride(0), hip.ptr(xmask),
+                                            xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), None, hip.ptr(mask),
+                                            mask.stride(0), hip.ptr(mask_rows), hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count),
+                                            _st(dy)), "catre_op_gemm_rows_nr")
+        return dx
     hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0,
                                        hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), int(amp),
                                        _st(dy)), "catre_op_gemm_rows_n")
     return dx
 
 
-def _wgrad_n(dy, x, ymask, count, amp=0):
-    """(dW [J,K], db [J]) = ((dy .* (ymask > 0))[:n]^T x[:n], column sums) over the n = count[0] compact rows."""
+def _wgrad_n(dy, x, ymask, count, amp=0, x_rows=None):
+    """(dW [J,K], db [J]) = ((dy .* (ymask > 0))[:n]^T x[:n], column sums) over the n = count[0] compact rows.
+    x_rows (fp32 pipe, or K <= 8): x is the DENSE tensor and compact row r pairs with its row x_rows[r]."""
     lib = hip.load()
     cap, J = dy.shape
     K = x.shape[1]
@@ -454,6 +464,12 @@ def _wgrad_n(dy, x, ymask, count, amp=0):
     buf = torch.empty(J * K + J, dtype=torch.float32, device=dy.device)
     dw, db = buf[: J * K].view(J, K), buf[J * K:]
     ws = _ws(lib.catre_op_gemm_tn_bias_ws_bytes(J, K, cap), dy.device)
+    if x_rows is not None:
+        hip.check(lib.catre_op_gemm_tn_bias_nr(hip.ptr(dy), dy.stride(0), hip.ptr(ymask),
+                                               ymask.stride(0) if ymask is not None else 0, hip.ptr(x), x.stride(0),
+                                               hip.ptr(x_rows), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws), ws.numel(),
+                                               hip.ptr(count), int(amp), _st(dy)), "catre_op_gemm_tn_bias_nr")
+        return dw, db
     hip.check(lib.catre_op_gemm_tn_bias_n(hip.ptr(dy), dy.stride(0), hip.ptr(ymask), ymask.stride(0) if ymask is not None else 0,
                                           hip.ptr(x), x.stride(0), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws),
                                           ws.numel(), hip.ptr(count), int(amp), _st(dy)), "catre_op_gemm_tn_bias_n")
@@ -514,12 +530,20 @@ def _pooled_chain_backward(ctx, dg, merge):
                                                 y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
               "catre_op_maxlin_bwd_x_compact")
     amp = ctx.amp
-    y1c = _gather_rows(y1, rows, count)
-    dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
-    dy1 = _dgrad_n(dy2, w2m, None, count, amp)                      # [cap, K2], y1's ReLU still to apply: folded below
-    xk = x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4))
-    xc = _gather_rows(_c(xk), rows, count)
-    dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
+    xk = _c(x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4)))
+    if amp == 0:
+        # fp32 pipe: no gathered copies of the saved activations - the weight-gradient GEMMs read the dense y1 / x through
+        # the live-row list, and y1's ReLU is applied where dy1 is produced (mask rows through the same list)
+        dw2, db2 = _wgrad_n(dy2, y1, None, count, 0, x_rows=rows)
+        dy1 = _dgrad_n(dy2, w2m, None, count, 0, mask=y1, mask_rows=rows)   # [cap, K2], y1's ReLU applied
+        dw1, db1 = _wgrad_n(dy1, xk, None, count, 0, x_rows=rows)
+        y1c = None
+    else:
+        y1c = _gather_rows(y1, rows, count)
+        dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
+        dy1 = _dgrad_n(dy2, w2m, None, count, amp)                  # [cap, K2], y1's ReLU still to apply: folded below
+        xc = _gather_rows(xk, rows, count)
+        dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
     dw1 = dw1[:, : w1m.shape[1]]
     dx = None
     if ctx.needs_input_grad[0]:
