@@ -2304,6 +2304,9 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
     sh[q] = be[q] - mean * sc[q];
   }
   f32x4 vd[8], vy[8], vp[2];
+  // X rows of this cloud: object-major like everything else here, or (acc_dx & 2) cloud-major - pointfeat as the encoder
+  // wrote it, so that the training forward needs no object-major copy of it
+  const size_t xrow0 = (acc_dx & 2) ? (prior ? (size_t)B * N + (size_t)obj * M : (size_t)obj * N) : row0;
   auto fetch = [&](int t) {
     const size_t r = row0 + (size_t)t * TP;
 #pragma unroll
@@ -2315,7 +2318,7 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + 512 * u;
-      vp[u] = *reinterpret_cast<const f32x4*>(X + (r + (e >> 4)) * ldx + 4 * (e & 15));
+      vp[u] = *reinterpret_cast<const f32x4*>(X + (xrow0 + (size_t)t * TP + (e >> 4)) * ldx + 4 * (e & 15));
     }
   };
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2371,7 +2374,7 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd(const float* __restrict__ dA
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v = {acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
-        if (acc_dx) v += *reinterpret_cast<const f32x4*>(o + 8 * g);  // second head of a pair: dX += (the heads share X)
+        if (acc_dx & 1) v += *reinterpret_cast<const f32x4*>(o + 8 * g);  // second head of a pair: dX += (the heads share X)
         *reinterpret_cast<f32x4*>(o + 8 * g) = v;
       }
     } else {

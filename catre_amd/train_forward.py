@@ -37,7 +37,7 @@ def _stn(rows, p, prefix, k, B, N, M, pre=None):
     return t.view(-1, k, k)
 
 
-def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
+def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0, obj_copy=True):
     """The same graph as :func:`pointnet_rows` (feature_transform=True), but the three conv stacks run as the FUSED encoder
     kernels with extra stores (``catre_train_{stn3d,stnkd,trunk}_fwd``): one launch per block instead of a row GEMM per
     layer.  Every layer op becomes a graph node around an output that exists already (``pre=``); the backward is the
@@ -64,7 +64,7 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0):
         # heads' object-major copy) as one node: their three gradients meet in one pass (train_ops._PointfeatHub)
         g, pfmax, pf_obj = T.pointfeat_hub(pf, w("conv2.weight"), w("conv2.bias"), w("conv3.weight"), w("conv3.bias"),
                                            w("conv4.weight"), w("conv4.bias"), B, N, M,
-                                           (buf["c2"], buf["c3"], buf["g"], buf["i"]))
+                                           (buf["c2"], buf["c3"], buf["g"], buf["i"]), obj_copy=obj_copy)
         return g, pf, (pfmax, pf_obj)
     h = T.linear(pf, w("conv2.weight"), w("conv2.bias"), relu=True, pre=buf["c2"])
     h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
@@ -122,6 +122,14 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 
 
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
+
+
+def _rot_heads_shapes_ok_p(p, N, M):
+    """:func:`_rot_heads_shapes_ok` before pointfeat exists (its width is pcl_net.conv1's: 64)."""
+    return (tuple(p["pcl_net.conv1.weight"].shape[:1]) == (64,) and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0
+            and all(p.get(f"{pre}.layers.3.bias") is not None
+                    and tuple(p[f"{pre}.layers.0.weight"].shape[:2]) == (256, 1088)
+                    and tuple(p[f"{pre}.layers.3.weight"].shape[:2]) == (256, 256) for pre in _ROT_PREFIX))
 
 
 def _rot_heads_shapes_ok(p, pf_obj, N, M):
@@ -191,7 +199,10 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
     if rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
-        g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp())
+        # the fused fp32 rotation heads read pointfeat cloud-major (forward AND backward): no object-major copy for them
+        fused_rot = T._amp() == 0 and _rot_heads_shapes_ok_p(p, N, M)
+        g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
+                                         obj_copy=not fused_rot)
     else:
         (g, pf), hub = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform)), None
     # max_n pointfeat (flat_pcl_feat tail) and the rot heads' input in object-major order: [N observed | M prior] per object
@@ -213,6 +224,8 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     dt = T.linear(h, p["ts_head.fc_t.weight"], p["ts_head.fc_t.bias"])
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
+    if hub is not None and pf_obj.data_ptr() == pf.data_ptr() and not _rot_heads_fused_ok(p, pf_obj, N, M):
+        raise RuntimeError("pointfeat was handed out cloud-major for rotation heads that read it object-major")
     if hub is not None and _rot_heads_fused_ok(p, pf_obj, N, M):
         rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
     elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):

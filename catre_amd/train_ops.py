@@ -575,7 +575,7 @@ class _PointfeatHub(torch.autograd.Function):
     copies + cat, and two full-size adds by autograd."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx, obj_copy=True):
         lib = hip.load()
         xc = _c(x)
         J, C = xc.shape[1], (2 * B if M > 0 else B)
@@ -583,7 +583,12 @@ class _PointfeatHub(torch.autograd.Function):
         idx_max = torch.empty(C, J, dtype=torch.int32, device=x.device)
         hip.check(lib.catre_op_maxpool_fwd(hip.ptr(xc), J, hip.ptr(pfmax), hip.ptr(idx_max), J, B, N, M, _st(x)),
                   "catre_op_maxpool_fwd")
-        pf_obj = torch.cat([xc[: B * N].view(B, N, J), xc[B * N:].view(B, M, J)], 1).reshape(B * (N + M), J)
+        if obj_copy:
+            pf_obj = torch.cat([xc[: B * N].view(B, N, J), xc[B * N:].view(B, M, J)], 1).reshape(B * (N + M), J)
+        else:
+            # the consumer (train_ops._RotHeads) reads pointfeat in its cloud-major order: no copy, the third output is the
+            # input's buffer; its GRADIENT still arrives object-major, like the copy's would
+            pf_obj = xc.detach()
         ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, None, idx_max)
         ctx.dims, ctx.relu_pool, ctx.amp = (B, N, M), False, _amp()
         ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
@@ -594,12 +599,14 @@ class _PointfeatHub(torch.autograd.Function):
         idx_max = ctx.saved_tensors[8]
         if dg is None:
             raise RuntimeError("pointfeat hub: the pooled trunk feature received no gradient")
-        return _pooled_chain_backward(ctx, dg, (dobj, dmax, idx_max)) + (None,) * 7
+        return _pooled_chain_backward(ctx, dg, (dobj, dmax, idx_max)) + (None,) * 8
 
 
-def pointfeat_hub(x, w1, b1, w2, b2, w3, b3, B, N, M, pre):
+def pointfeat_hub(x, w1, b1, w2, b2, w3, b3, B, N, M, pre, obj_copy=True):
+    """obj_copy=False: the third output is pointfeat itself (cloud-major rows, no copy) - for a consumer that reads it in
+    that order and returns an object-major gradient (the fused fp32 rotation heads)."""
     y1, y2, g, idx = pre
-    return _PointfeatHub.apply(x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx)
+    return _PointfeatHub.apply(x, w1, b1, w2, b2, w3, b3, B, N, M, y1, y2, g, idx, obj_copy)
 
 
 def pooled_chain_ok(x, w1, w2, w3, N, M):
@@ -1077,9 +1084,10 @@ def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spar
     return da, dwb[: 256 * 256].view(256, 256), dwb[256 * 256:], dpar
 
 
-def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M, dx_acc=None):
+def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M, dx_acc=None, x_cloud_major=False):
     """_RotL0Block's backward on explicit tensors -> (dx [R,64], dW [256,64], dbias2d [2B,256], dgamma, dbeta).  dx_acc: a
-    [R,64] tensor the data gradient is ADDED to (and returned) instead of a fresh one."""
+    [R,64] tensor the data gradient is ADDED to (and returned) instead of a fresh one.  x_cloud_major: the rows of x are
+    cloud-major (dx stays object-major)."""
     lib = hip.load()
     da = _c(da)
     dev = da.device
@@ -1090,7 +1098,8 @@ def _rot_l0_backward(da, x, w2, y, stat, gamma, beta, B, N, M, dx_acc=None):
     ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
     hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
                                       x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
-                                      hip.ptr(dbe), int(dx_acc is not None), hip.ptr(ws), ws.numel(), B, N, M, _st(da)),
+                                      hip.ptr(dbe), int(dx_acc is not None) | (2 if x_cloud_major else 0), hip.ptr(ws),
+                                      ws.numel(), B, N, M, _st(da)),
               "catre_op_rot_l0_bwd")
     return dx, dw, db, dg, dbe
 
@@ -1116,6 +1125,9 @@ class _RotHeads(torch.autograd.Function):
     def forward(ctx, pf_cm, pf_obj, prm, packed, B, N, M, *heads):
         lib = hip.load()
         hx, hy = heads[: _RotHeads.NH], heads[_RotHeads.NH:]
+        # pf_obj on pf_cm's own buffer: the hub handed out pointfeat itself (cloud-major rows) instead of an object-major
+        # copy - only the backward reads it (k_rot_l0_bwd's X operand), and it can walk either row order
+        ctx.x_cm = pf_obj.data_ptr() == pf_cm.data_ptr()
         dev = pf_obj.device
         R, P = B * (N + M), N + M
         pf_cm, pf_obj = _c(pf_cm), _c(pf_obj)
@@ -1173,7 +1185,8 @@ class _RotHeads(torch.autograd.Function):
             da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P, dout=dout,
                                                   spart=spart[h])
             dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M,
-                                                          dx_acc=dxs[0] if dxs else None)   # the second head adds into the first's dx
+                                                          dx_acc=dxs[0] if dxs else None,   # the second head adds into the first's dx
+                                                          x_cloud_major=ctx.x_cm)
             del da
             dxs.append(dx)
             dbn = _colsum(dy3) if ctx.has_bn[h] else None

@@ -364,7 +364,9 @@ int catre_op_gnp_gelu_neck_bwd(const float* dY3, const float* Y, const float* st
 /* Backward of a RotHead's first block - Conv1d(1088 -> 256) on cat(point feature, global feature) = a 64 -> 256 linear with
  * a per-cloud bias, GroupNorm(32,256), GELU (conv_out_per_rot_head.py:126-131) - from dA [R,256] in two passes over (dA, Y):
  * the [R,256] gradient of the linear's output stays in LDS.  X [R,64], W [256][64], rows object-major, N, M % 64 == 0.
- * accumulate_dx != 0: dX += (the two RotHeads share X; the second head's call adds into the first one's result). */
+ * accumulate_dx bit 0: dX += (the two RotHeads share X; the second head's call adds into the first one's result);
+ * bit 1: the rows of X are cloud-major (B*N observed rows, then B*M prior rows - pointfeat as the encoder writes it), dX
+ * stays object-major. */
 size_t catre_op_rot_l0_bwd_ws_bytes(int B, int N, int M);
 int catre_op_rot_l0_bwd(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
                         const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
