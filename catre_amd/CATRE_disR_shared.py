@@ -139,7 +139,7 @@ class CATRE_disR_shared(nn.Module):
 
         loss_dict, vis = catre_loss(self.cfg, out_rot=pose[:, :3, :3], out_trans=pose[:, :3, 3], out_scale=scale,
                                     gt_rot=gt_ego_rot, gt_trans=gt_trans, gt_scale=gt_scale, obj_kps=obj_kps,
-                                    sym_info=sym_info, trans_deltas=aux["trans_deltas"], return_vis=True)
+                                    sym_info=sym_info, trans_deltas=aux["trans_deltas"], return_vis=True, pose=pose)
         # The reference pushes 14 `.item()` scalars per call into detectron2's EventStorage (:127-164: vis/error_R,
         # vis/error_t, object 0's translation / deltas / ground truth).  Here the loss kernels write them into ONE device
         # tensor; `self.vis_scalars` exposes it (no copy until read) and, when an EventStorage is active, the same keys

@@ -159,9 +159,11 @@ class VisScalars:
 
 
 def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, obj_kps, sym_info, trans_deltas=None,
-               return_vis=False):
+               return_vis=False, pose=None):
     """-> the reference's loss dict (same keys, same values).  Gradients flow to out_rot / out_trans / out_scale.
-    ``return_vis``: also return the 14 logging scalars (device tensor, see :class:`VisScalars`)."""
+    ``return_vis``: also return the 14 logging scalars (device tensor, see :class:`VisScalars`).
+    ``pose``: the [B,3,4] tensor out_rot / out_trans are the slices of (the model's own call): the kernels take it as it is
+    instead of a cat of the two slices, and its gradient arrives whole instead of through two zero-fill + copy + add chains."""
     lc = cfg.MODEL.CATRE.LOSS_CFG
     B = out_rot.shape[0]
     dev = out_rot.device
@@ -176,7 +178,11 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
         n_sym = sum(1 for s in sym_info if s is not None)
         n_nonsym = B - n_sym
     lcfg = _loss_cfg_struct(cfg)
-    pose = torch.cat([out_rot, out_trans.unsqueeze(-1)], -1).contiguous()
+    if pose is None:
+        pose = torch.cat([out_rot, out_trans.unsqueeze(-1)], -1).contiguous()
+    else:
+        assert tuple(pose.shape) == (B, 3, 4)
+        pose = pose.contiguous()
     f32 = lambda t: hip.require_dev_f32(t.contiguous(), "loss input") if t is not None else None
     gs = f32(gt_scale) if gt_scale is not None else torch.zeros(B, 3, dtype=torch.float32, device=dev)
     td = f32(trans_deltas.detach()) if trans_deltas is not None else None

@@ -52,7 +52,8 @@ def _pad_cols(t, mult):
     r = (-k) % mult
     if r == 0:
         return t
-    if t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and not t.requires_grad and t.numel() > 0:
+    if (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0
+            and (not t.requires_grad or not torch.is_grad_enabled())):  # (grad mode is off inside Function.forward / backward)
         out = torch.empty(t.shape[0], k + r, dtype=torch.float32, device=t.device)
         hip.check(hip.load().catre_op_pad_cols(hip.ptr(t), t.stride(0), t.stride(1), t.shape[0], k, hip.ptr(out), k + r,
                                                _st(t)), "catre_op_pad_cols")
@@ -530,7 +531,7 @@ def _pooled_chain_backward(ctx, dg, merge):
                                                 y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
               "catre_op_maxlin_bwd_x_compact")
     amp = ctx.amp
-    xk = _c(x if x.shape[1] % 4 == 0 else F.pad(x, (0, (-x.shape[1]) % 4)))
+    xk = _c(_pad_cols(x, 4))
     if amp == 0:
         # fp32 pipe: no gathered copies of the saved activations - the weight-gradient GEMMs read the dense y1 / x through
         # the live-row list, and y1's ReLU is applied where dy1 is produced (mask rows through the same list)
