@@ -619,7 +619,10 @@ __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm,
 // k_heads_a, catre_small.h) - the same fragment addressing, the same MFMA sequence, the same bits either way.
 // `stage()` runs after the first trip's weight fragments have been requested and before X is read: the LDS-staged callers
 // fill X there (+ barrier), so that their weight round trip overlaps the staging instead of following it.
-template <class StageF>
+// TW: W is given TRANSPOSED - element (output j, input k) at W[k * ldw + j] - and read with four 4-byte loads per chunk
+// (consecutive lanes, consecutive j) instead of one 16-byte load: the dgrad of a small linear (dx = dy W) straight from
+// the layer's own [J][K] weight, no transposed copy.
+template <bool TW = false, class StageF>
 __device__ __forceinline__ void linear_body(const float* X, int ldx, const float* __restrict__ W, int ldw,
                                             const float* __restrict__ bias, float* __restrict__ Y, int ldy, int R, int J,
                                             int K, int relu, int iden_k, int bx, int by, float (*part)[16][64],
@@ -632,6 +635,15 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
   const int r = min(bx * 32 + i, R - 1), j = min(by * 32 + i, J - 1);
   const f32x4* xa = reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + 4 * h);
   const f32x4* wb = reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + 4 * h);
+  const float* wt = W + (size_t)(4 * h) * ldw + j;  // TW: chunk c of this lane = wt[(8 c + s) * ldw], s = 0..3
+  auto wload = [&](int c) -> f32x4 {
+    if constexpr (TW) {
+      const float* q = wt + (size_t)(8 * c) * ldw;
+      return f32x4{q[0], q[ldw], q[2 * (size_t)ldw], q[3 * (size_t)ldw]};
+    } else {
+      return wb[c * 2];
+    }
+  };
   f32x16 acc = zero16();
   const int nkc = K / 8;
   int kc = wave;
@@ -639,7 +651,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
   const bool first = kc + 7 * LIN_WAVES < nkc;
   if (first) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) b[u] = wb[(kc + LIN_WAVES * u) * 2];
+    for (int u = 0; u < 8; ++u) b[u] = wload(kc + LIN_WAVES * u);
   }
   __builtin_amdgcn_sched_barrier(0);
   stage();
@@ -648,7 +660,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       a[u] = xa[(kc + LIN_WAVES * u) * 2];
-      if (kc != wave) b[u] = wb[(kc + LIN_WAVES * u) * 2];
+      if (kc != wave) b[u] = wload(kc + LIN_WAVES * u);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -660,7 +672,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u] = xa[(kc + LIN_WAVES * u) * 2];
-      b[u] = wb[(kc + LIN_WAVES * u) * 2];
+      b[u] = wload(kc + LIN_WAVES * u);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -668,7 +680,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
       for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);
   }
   for (; kc < nkc; kc += LIN_WAVES) {
-    const f32x4 a = xa[kc * 2], b = wb[kc * 2];
+    const f32x4 a = xa[kc * 2], b = wload(kc);
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
   }
@@ -710,6 +722,14 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
   }
   __shared__ float part[LIN_WAVES][16][64];
   linear_body(X, ldx, W, ldw, bias, Y, ldy, R, J, K, relu, iden_k, blockIdx.x, blockIdx.y, part, [] {});
+}
+
+// Y = X W for W [K][J] row-major (the transposed-weight form of k_linear: dgrad of the FC tails / ts head in training)
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_linear_t(const float* __restrict__ X, int ldx,
+                                                              const float* __restrict__ W, int ldw,
+                                                              float* __restrict__ Y, int ldy, int R, int J, int K) {
+  __shared__ float part[LIN_WAVES][16][64];
+  linear_body<true>(X, ldx, W, ldw, nullptr, Y, ldy, R, J, K, 0, 0, blockIdx.x, blockIdx.y, part, [] {});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1571,6 +1591,14 @@ int catre_linear(const float* x, int ldx, const float* Wt, int ldw, const float*
   REQUIRE(x && Wt && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0);
   hipLaunchKernelGGL(k_linear, dim3((R + 31) / 32, (J + 31) / 32), dim3(64 * LIN_WAVES), 0, (hipStream_t)stream, x, ldx, Wt, ldw,
                      bias, y, ldy, R, J, K, relu, add_identity_k);
+  return check_launch();
+}
+
+// y[R,J] = x[R,K] W for W [K][J] row-major (ldw): the data gradient of a small linear from its own weight, no transposed copy
+int catre_linear_t(const float* x, int ldx, const float* W, int ldw, float* y, int ldy, int R, int J, int K, void* stream) {
+  REQUIRE(x && W && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && ldw >= J);
+  hipLaunchKernelGGL(k_linear_t, dim3((R + 31) / 32, (J + 31) / 32), dim3(64 * LIN_WAVES), 0, (hipStream_t)stream, x, ldx, W,
+                     ldw, y, ldy, R, J, K);
   return check_launch();
 }
 

@@ -179,10 +179,10 @@ def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
     heads = []
     for pre in _ROT_PREFIX:
         w = lambda n: p[f"{pre}.{n}"]
-        W0 = w("layers.0.weight").reshape(256, 1088)
-        bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))   # [2B,256]: global half + conv bias
+        W0g, W0l = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)   # global half | point half
+        bias0 = T.linear(g, W0g, w("layers.0.bias"))                              # [2B,256]: global half + conv bias
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
-        heads.append((bias0, W0[:, 1024:].contiguous(), w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
+        heads.append((bias0, W0l, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
                       w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
                       p.get(f"{pre}.conv_p.bias")))
     prm, packed = rt._train_packs(pf.device, 0)

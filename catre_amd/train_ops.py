@@ -128,6 +128,11 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False, w
     if wT is not None:
         if big:
             w, tr = wT, 1
+        elif K % 8 == 0 and bias is None and not relu and mask is None and xmask is None and identity_k == 0:
+            # small dgrad: the kernel reads the layer's own [K_contraction][J] weight, no transposed copy
+            hip.check(lib.catre_linear_t(hip.ptr(x), x.stride(0), hip.ptr(wT), wT.stride(0), hip.ptr(y), J, R, J, K, _st(x)),
+                      "catre_linear_t")
+            return y
         else:
             w = _c(wT.t())
     if big and amp in (1, 2) and K in (64, 128, 256, 512):
@@ -311,6 +316,32 @@ def linear_fan2(x, w, b=None, relu=False, pre=None):
 
 def linear(x, w, b=None, relu=False, identity_k=0, pre=None):
     return _Linear.apply(x, w, b, relu, identity_k, pre)
+
+
+class _SplitCols(torch.autograd.Function):
+    """w [J, K] -> (w[:, :k0], w[:, k0:]) as two contiguous matrices (rot-head layer 0: the global and the point half of its
+    1088-wide weight, conv_out_per_rot_head.py:126).  Backward: ONE cat of the two gradients - autograd's own slice backward
+    is a zero-fill + copy per half and an add over [J, K]."""
+
+    @staticmethod
+    def forward(ctx, w, k0):
+        ctx.k0, ctx.K = k0, w.shape[1]
+        return w[:, :k0].contiguous(), w[:, k0:].contiguous()
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None and db is None:
+            return None, None
+        ref = da if da is not None else db
+        if da is None:
+            da = ref.new_zeros(ref.shape[0], ctx.k0)
+        if db is None:
+            db = ref.new_zeros(ref.shape[0], ctx.K - ctx.k0)
+        return torch.cat([da, db], 1), None
+
+
+def split_cols(w, k0):
+    return _SplitCols.apply(w, k0)
 
 
 # ------------------------------------------------------------------------------------------------- linear + max-pool
