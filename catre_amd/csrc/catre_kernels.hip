@@ -622,11 +622,12 @@ __global__ __launch_bounds__(256) void k_reduce_pm(const float* __restrict__ pm,
 // TW: W is given TRANSPOSED - element (output j, input k) at W[k * ldw + j] - and read with four 4-byte loads per chunk
 // (consecutive lanes, consecutive j) instead of one 16-byte load: the dgrad of a small linear (dx = dy W) straight from
 // the layer's own [J][K] weight, no transposed copy.
+// XM (TW instances only): a matrix laid out like X; X is zeroed where XM <= 0 as it is loaded (ReLU backward folded in).
 template <bool TW = false, class StageF>
 __device__ __forceinline__ void linear_body(const float* X, int ldx, const float* __restrict__ W, int ldw,
                                             const float* __restrict__ bias, float* __restrict__ Y, int ldy, int R, int J,
                                             int K, int relu, int iden_k, int bx, int by, float (*part)[16][64],
-                                            StageF stage) {
+                                            StageF stage, const float* __restrict__ XM = nullptr) {
   // 8 waves split K (interleaved 8-wide chunks), each with up to 8 chunk pairs in flight - the kernel is a chain of
   // L2 round trips, so the trip count (K/8/8/8 = 2 for K = 1024) is what sets its time; partial 32x32 blocks are
   // summed through LDS in wave order (deterministic).
@@ -634,6 +635,18 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = min(bx * 32 + i, R - 1), j = min(by * 32 + i, J - 1);
   const f32x4* xa = reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + 4 * h);
+  const f32x4* xm = reinterpret_cast<const f32x4*>(XM + (size_t)r * ldx + 4 * h);
+  auto xload = [&](int c) -> f32x4 {
+    f32x4 v = xa[c * 2];
+    if constexpr (TW) {
+      if (XM) {
+        const f32x4 m = xm[c * 2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : 0.f;
+      }
+    }
+    return v;
+  };
   const f32x4* wb = reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + 4 * h);
   const float* wt = W + (size_t)(4 * h) * ldw + j;  // TW: chunk c of this lane = wt[(8 c + s) * ldw], s = 0..3
   auto wload = [&](int c) -> f32x4 {
@@ -659,7 +672,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
     f32x4 a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      a[u] = xa[(kc + LIN_WAVES * u) * 2];
+      a[u] = xload(kc + LIN_WAVES * u);
       if (kc != wave) b[u] = wload(kc + LIN_WAVES * u);
     }
 #pragma unroll
@@ -671,7 +684,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
     f32x4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      a[u] = xa[(kc + LIN_WAVES * u) * 2];
+      a[u] = xload(kc + LIN_WAVES * u);
       b[u] = wload(kc + LIN_WAVES * u);
     }
 #pragma unroll
@@ -680,7 +693,7 @@ __device__ __forceinline__ void linear_body(const float* X, int ldx, const float
       for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);
   }
   for (; kc < nkc; kc += LIN_WAVES) {
-    const f32x4 a = xa[kc * 2], b = wload(kc);
+    const f32x4 a = xload(kc), b = wload(kc);
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
   }
@@ -727,9 +740,10 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear(const float* __restri
 // Y = X W for W [K][J] row-major (the transposed-weight form of k_linear: dgrad of the FC tails / ts head in training)
 __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear_t(const float* __restrict__ X, int ldx,
                                                               const float* __restrict__ W, int ldw,
-                                                              float* __restrict__ Y, int ldy, int R, int J, int K) {
+                                                              float* __restrict__ Y, int ldy, int R, int J, int K,
+                                                              const float* __restrict__ XM) {
   __shared__ float part[LIN_WAVES][16][64];
-  linear_body<true>(X, ldx, W, ldw, nullptr, Y, ldy, R, J, K, 0, 0, blockIdx.x, blockIdx.y, part, [] {});
+  linear_body<true>(X, ldx, W, ldw, nullptr, Y, ldy, R, J, K, 0, 0, blockIdx.x, blockIdx.y, part, [] {}, XM);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1595,10 +1609,12 @@ int catre_linear(const float* x, int ldx, const float* Wt, int ldw, const float*
 }
 
 // y[R,J] = x[R,K] W for W [K][J] row-major (ldw): the data gradient of a small linear from its own weight, no transposed copy
-int catre_linear_t(const float* x, int ldx, const float* W, int ldw, float* y, int ldy, int R, int J, int K, void* stream) {
+// xmask (optional, [R,K] with x's row pitch): x .* (xmask > 0) replaces x - the ReLU backward of the layer's output
+int catre_linear_t(const float* x, int ldx, const float* xmask, const float* W, int ldw, float* y, int ldy, int R, int J,
+                   int K, void* stream) {
   REQUIRE(x && W && y && R > 0 && J > 0 && K > 0 && (K % 8) == 0 && (ldx % 4) == 0 && ldw >= J);
   hipLaunchKernelGGL(k_linear_t, dim3((R + 31) / 32, (J + 31) / 32), dim3(64 * LIN_WAVES), 0, (hipStream_t)stream, x, ldx, W,
-                     ldw, y, ldy, R, J, K);
+                     ldw, y, ldy, R, J, K, xmask);
   return check_launch();
 }
 

@@ -108,7 +108,7 @@ _SIGS = {
     "catre_pose_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "catre_stn3d_pool": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_linear": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "catre_linear_t": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "catre_linear_t": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "catre_stnkd_pool": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_trunk": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_ts_head": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),

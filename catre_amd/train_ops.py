@@ -128,10 +128,12 @@ def _gemm_nt(x, w, bias, relu, mask=None, identity_k=0, xmask=None, amp=False, w
     if wT is not None:
         if big:
             w, tr = wT, 1
-        elif K % 8 == 0 and bias is None and not relu and mask is None and xmask is None and identity_k == 0:
-            # small dgrad: the kernel reads the layer's own [K_contraction][J] weight, no transposed copy
-            hip.check(lib.catre_linear_t(hip.ptr(x), x.stride(0), hip.ptr(wT), wT.stride(0), hip.ptr(y), J, R, J, K, _st(x)),
-                      "catre_linear_t")
+        elif K % 8 == 0 and bias is None and not relu and mask is None and identity_k == 0 \
+                and (xmask is None or xmask.stride(0) == x.stride(0)):
+            # small dgrad: the kernel reads the layer's own [K_contraction][J] weight (no transposed copy) and applies the
+            # ReLU mask of the layer's output while it loads dy
+            hip.check(lib.catre_linear_t(hip.ptr(x), x.stride(0), hip.ptr(xmask), hip.ptr(wT), wT.stride(0), hip.ptr(y), J, R,
+                                         J, K, _st(x)), "catre_linear_t")
             return y
         else:
             w = _c(wT.t())
@@ -254,7 +256,10 @@ def _linear_backward(ctx, dy, dy2=None):
         # ReLU backward: folded into the operand loads of the two GEMMs below when both take the tiled kernels,
         # else as its own pass
         R, J = dy.shape
-        if J % 8 == 0 and (not ctx.needs_input_grad[0] or _tiled_gemm_ok(R, w2.shape[1], J)):
+        # (a small dgrad - under 2048 rows - takes catre_linear_t, which masks its operand as well)
+        if J % 8 == 0 and (not ctx.needs_input_grad[0] or _tiled_gemm_ok(R, w2.shape[1], J)
+                           or (not _tiled_gemm_ok(R, w2.shape[1], J) and w2.is_contiguous() and y.is_contiguous()
+                               and dy.stride(0) == y.stride(0))):
             ymask = _c(y)
         else:
             g = torch.empty_like(dy)

@@ -164,8 +164,10 @@ int catre_linear(const float* x, int ldx, const float* W, int ldw, const float* 
                  int R, int J, int K, int relu, int add_identity_k, void* stream);
 /* y[R,J] = x[R,K] W with W [K][J] row-major (ldw): catre_linear on the transposed weight without a transposed copy - the
  * data gradient of a small linear layer (autograd of the FC tails / FC_TransSizeHead, heads/fc_trans_size_head.py:98-116)
- * from the layer's own [out][in] weight.  K % 8 == 0. */
-int catre_linear_t(const float* x, int ldx, const float* W, int ldw, float* y, int ldy, int R, int J, int K, void* stream);
+ * from the layer's own [out][in] weight.  K % 8 == 0.  xmask (optional, laid out like x): x .* (xmask > 0) replaces x (the
+ * ReLU backward of the layer's output folded into the operand load). */
+int catre_linear_t(const float* x, int ldx, const float* xmask, const float* W, int ldw, float* y, int ldy, int R, int J,
+                   int K, void* stream);
 
 /* a3+a4: x' = x T3, relu(conv1), STNkd conv stack + max-pool (pointnet.py:98-103,57-62).
  * trans3 [2B,3,3] -> pooled [2B,1024]. */
