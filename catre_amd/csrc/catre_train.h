@@ -51,7 +51,10 @@ template <int MB, bool MAXP>
 __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                    const float* __restrict__ mask, int ldm, float* __restrict__ Y,
                                                    int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
-                                                   int blk_off = 0, float* __restrict__ gn_part = nullptr) {
+                                                   int blk_off = 0, float* __restrict__ gn_part = nullptr,
+                                                   int mri = -1) {
+  // mri >= 0 (all lanes): lane l holds the row of `mask` that output row r0 + l takes its mask from (row-compacted outputs
+  // against a dense mask, looked up by the kernel before its sweep); -1: output row = mask row
   const int n = lane & 31, h = lane >> 5;
   if constexpr (MAXP) {
     // D[row = point][col = channel]: lane owns channel blk*32 + n and points (r&3) + 8(r>>2) + 4h + 32nb
@@ -100,7 +103,7 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
     const int ch = blk * 32 + n;
     const float bv = bias ? bias[ch] : 0.f;
     float* yo = Y + (size_t)(r0 + 4 * h) * ldy + ch;
-    const float* mo = mask ? mask + (size_t)(r0 + 4 * h) * ldm + ch : nullptr;
+    const float* mo = mask ? mask + (mri >= 0 ? (size_t)0 : (size_t)(r0 + 4 * h) * ldm) + ch : nullptr;
     int lim = R - r0 - 4 * h;  // row (nb, r) of this half-wave exists iff its in-tile index < lim
     asm volatile("" : "+v"(lim));
     float s = 0.f;
@@ -111,8 +114,10 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
         const int row = nb * 32 + (r & 3) + 8 * (r >> 2);
         float t = acc[mb][nb][r] + bv;
         t = relu ? fmaxf(t, 0.f) : t;
+        size_t mrow = (size_t)row;
+        if (mri >= 0) mrow = (size_t)__shfl(mri, 4 * h + row);
         if (full || row < lim) {
-          if (mo) t = mo[(size_t)row * ldm] > 0.f ? t : 0.f;
+          if (mo) t = mo[mrow * ldm] > 0.f ? t : 0.f;
           yo[(size_t)row * ldy] = t;
           s += t;
         } else {
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
                                                       const float* __restrict__ xmask, int ldxm, CloudBias cb,
-                                                      const int* __restrict__ Rdev = nullptr) {
+                                                      const int* __restrict__ Rdev = nullptr,
+                                                      const int* __restrict__ mrows = nullptr) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   __shared__ u32x4 xs[TP * CP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
     R = min(R, *Rdev);
     if (r0 >= R) return;
   }
+  const int mri = mrows ? mrows[min(r0 + lane, R - 1)] : -1;  // mask row of output row r0 + lane (see gemm_rows_epilogue)
   const int nblk = J / 32;
   for (int i = tid; i < TP * CP; i += 512) {
     const int row = i / CP, ch = i % CP;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
   gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
-                               cb.gn_part);
+                               cb.gn_part, MAXP ? -1 : mri);
 }
 
 // ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
@@ -414,7 +421,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
                                                       const float* __restrict__ xmask, int ldxm, CloudBias cb,
-                                                      const int* __restrict__ Rdev = nullptr) {
+                                                      const int* __restrict__ Rdev = nullptr,
+                                                      const int* __restrict__ mrows = nullptr) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   constexpr int PMB = MB >= 2 ? 2 : 1;
   __shared__ u32x4 xs[2][TP * CP];
@@ -424,6 +432,11 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
   if (Rdev) {
     R = min(R, *Rdev);
     if (r0 >= R) return;
+  }
+  int mr0 = -1, mr1 = -1;  // mask rows of this lane's two output rows (gemm_rows_epilogue_n)
+  if (mrows) {
+    mr0 = mrows[min(r0 + (lane & 31), R - 1)];
+    mr1 = mrows[min(r0 + 32 + (lane & 31), R - 1)];
   }
   const int nblk = J / 32;
   for (int i = tid; i < TP * CP; i += 512) {
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_sp(const float* __restrict__ 
                                     cb.gn_part);
     else
       gemm_rows_epilogue_n<PMB>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, blk0,
-                                cb.gn_part);
+                                cb.gn_part, mr0, mr1);
   }
 }
 
@@ -819,7 +832,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
                                                        int ldx, float* __restrict__ part, int J, int K, int R,
                                                        int rows_per_split, float* __restrict__ colpart,
                                                        const float* __restrict__ ymask, int ldym, size_t pitch,
-                                                       const int* __restrict__ Rdev = nullptr) {
+                                                       const int* __restrict__ Rdev = nullptr,
+                                                       const int* __restrict__ xrows = nullptr) {
   if (Rdev) {
     R = min(R, *Rdev);
     rows_per_split = (int)((R + gridDim.z * 64 - 1) / (gridDim.z * 64)) * 64;
@@ -842,6 +856,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
   const int c4 = tid & 31, g = tid >> 5;
   const int jc = j0 + c4 * 4, kc = k0 + c4 * 4;
   f32x4 vy[8], vx[8];
+  int xi[8];  // xrows: the X rows of the NEXT fetch (k_gemm_tn: requested a step ahead of the loads that need them)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) xi[u] = 0;
+  auto fetch_idx = [&](int rs) {
+    if (!xrows) return;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gr = rs + g * 8 + u;
+      xi[u] = gr < row_hi ? xrows[gr] : 0;
+    }
+  };
   auto fetch = [&](int rs) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -857,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
             for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
           }
         }
-        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ldx + kc);
+        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (xrows ? (size_t)xi[u] : (size_t)gr) * ldx + kc);
       }
     }
   };
@@ -876,7 +901,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
       }
     }
   };
+  fetch_idx(row_lo);
   fetch(row_lo);
+  fetch_idx(row_lo + TN_ROWS);
   for (int rs = row_lo; rs < row_hi; rs += TN_ROWS) {
     __syncthreads();  // the previous slab's fragment reads are done
     if (do_col) {
@@ -891,7 +918,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
     stage(vy, ys);
     stage(vx, xs);
     __syncthreads();
-    if (rs + TN_ROWS < row_hi) fetch(rs + TN_ROWS);  // in flight during the MFMAs below
+    if (rs + TN_ROWS < row_hi) {
+      fetch(rs + TN_ROWS);  // in flight during the MFMAs below
+      fetch_idx(rs + 2 * TN_ROWS);
+    }
 #pragma unroll
     for (int ks = 0; ks < TN_ROWS / 16; ++ks) {
       u32x4 a[2], b[2], al[2], bl[2];

@@ -100,7 +100,7 @@ _SIGS = {
     "catre_op_scatter_rows_merge": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "catre_op_gemm_rows_n": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "catre_op_gemm_tn_bias_n": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _SZ, _P, _I, _P]),
-    "catre_op_gemm_rows_nr": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "catre_op_gemm_rows_nr": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "catre_op_gemm_tn_bias_nr": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P, _I, _P]),
     "catre_train_stn3d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_train_stnkd_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),

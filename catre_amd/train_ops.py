@@ -479,11 +479,11 @@ def _dgrad_n(dy, w2, xmask, count, amp=0, mask=None, mask_rows=None):
         hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
     dx = torch.empty(cap, K, dtype=torch.float32, device=dev)
     if mask is not None:
-        assert amp == 0 and mask.shape[1] == K
+        assert mask.shape[1] == K
         hip.check(lib.catre_op_gemm_rows_nr(hip.ptr(dy), dy.stride(0), hip.ptr(xmask),
                                             xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), None, hip.ptr(mask),
                                             mask.stride(0), hip.ptr(mask_rows), hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count),
-                                            _st(dy)), "catre_op_gemm_rows_nr")
+                                            int(amp), _st(dy)), "catre_op_gemm_rows_nr")
         return dx
     hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0,
                                        hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), int(amp),
@@ -568,23 +568,15 @@ def _pooled_chain_backward(ctx, dg, merge):
               "catre_op_maxlin_bwd_x_compact")
     amp = ctx.amp
     xk = _c(_pad_cols(x, 4))
-    if amp == 0:
-        # fp32 pipe: no gathered copies of the saved activations - the weight-gradient GEMMs read the dense y1 / x through
-        # the live-row list, and y1's ReLU is applied where dy1 is produced (mask rows through the same list)
-        dw2, db2 = _wgrad_n(dy2, y1, None, count, 0, x_rows=rows)
-        dy1 = _dgrad_n(dy2, w2m, None, count, 0, mask=y1, mask_rows=rows)   # [cap, K2], y1's ReLU applied
-        dw1, db1 = _wgrad_n(dy1, xk, None, count, 0, x_rows=rows)
-        y1c = None
-    else:
-        y1c = _gather_rows(y1, rows, count)
-        dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
-        dy1 = _dgrad_n(dy2, w2m, None, count, amp)                  # [cap, K2], y1's ReLU still to apply: folded below
-        xc = _gather_rows(xk, rows, count)
-        dw1, db1 = _wgrad_n(dy1, xc, y1c, count, amp)
+    # no gathered copies of the saved activations: the weight-gradient GEMMs read the dense y1 / x through the live-row list,
+    # and y1's ReLU is applied where dy1 is produced (mask rows through the same list) - every compute mode
+    dw2, db2 = _wgrad_n(dy2, y1, None, count, amp, x_rows=rows)
+    dy1 = _dgrad_n(dy2, w2m, None, count, amp, mask=y1, mask_rows=rows)     # [cap, K2], y1's ReLU applied
+    dw1, db1 = _wgrad_n(dy1, xk, None, count, amp, x_rows=rows)
     dw1 = dw1[:, : w1m.shape[1]]
     dx = None
     if ctx.needs_input_grad[0]:
-        dxc = _dgrad_n(dy1, w1m, y1c, count, amp)                   # [cap, K1]
+        dxc = _dgrad_n(dy1, w1m, None, count, amp)                  # [cap, K1]
         if merge is None:
             dx = _scatter_rows(dxc, rowpos, dxc.shape[1])
         else:

@@ -443,11 +443,10 @@ int catre_op_gemm_tn_bias_n(const float* dY, int ldy, const float* ymask, int ld
                             const int32_t* nrows_dev, int compute_dtype, void* stream);
 /* the two above with row indirection against DENSE tensors (no gathered copies of the saved activations in the row-sparse
  * backward): output row r of catre_op_gemm_rows_nr is masked with row mask_rows[r] of `mask`; catre_op_gemm_tn_bias_nr
- * contracts dY row r with row x_rows[r] of X.  fp32 kernels (and the K <= 8 skinny weight gradient of every compute_dtype);
- * a null index array is the identity */
+ * contracts dY row r with row x_rows[r] of X.  Every compute_dtype; a null index array is the identity */
 int catre_op_gemm_rows_nr(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
                           const float* mask, int ldm, const int32_t* mask_rows, float* Y, int ldy, int R, int J, int K,
-                          int relu, const int32_t* nrows_dev, void* stream);
+                          int relu, const int32_t* nrows_dev, int compute_dtype, void* stream);
 int catre_op_gemm_tn_bias_nr(const float* dY, int ldy, const float* ymask, int ldym, const float* X, int ldx,
                              const int32_t* x_rows, float* dW, float* db, int J, int K, int R, int accumulate, void* ws,
                              size_t ws_bytes, const int32_t* nrows_dev, int compute_dtype, void* stream);
