@@ -86,6 +86,38 @@ def test_two_consumer_point_layer_backward_in_one_pass(R, cols, Kw, relu, two, m
     _cmp(b.grad, br.grad, "db", atol=2e-3 if R > 10000 else 2e-4, rtol=2e-5)
 
 
+def test_row_list_ops_gather_scatter_and_indexed_gemms():
+    """The live-row list of the row-sparse backward: catre_op_gather_rows / scatter_rows against torch indexing, and the
+    indexed GEMMs (catre_op_gemm_tn_bias_nr reads X through the list, catre_op_gemm_rows_nr masks its output through it)
+    against the same GEMMs on gathered copies - bit for bit (same kernels, same order)."""
+    from catre_amd import train_ops as T
+
+    g = _gen(77)
+    R, K, J = 4096, 64, 128
+    live = torch.rand(R, generator=g) < 0.3
+    rows_h = torch.nonzero(live).flatten().to(torch.int32)
+    n = rows_h.numel()
+    rows = torch.zeros(R, dtype=torch.int32)
+    rows[:n] = rows_h
+    rows, count = rows.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
+    x = torch.randn(R, K, generator=g).to(DEV)
+    y1 = torch.randn(R, K, generator=g).to(DEV)           # a dense "ReLU output": its sign pattern is the mask
+    dy = torch.randn(R, J, generator=g).to(DEV)            # compact rows: only the first n are meaningful
+    w = (torch.randn(J, K, generator=g) / J ** 0.5).to(DEV)
+    xc = T._gather_rows(x, rows, count)
+    assert torch.equal(xc[:n].cpu(), x.cpu()[rows_h.long()])
+    for mode in ("fp32", "bf16", "split"):
+        amp = T._MODES[mode]
+        dw_a, db_a = T._wgrad_n(dy, xc, None, count, amp)
+        dw_b, db_b = T._wgrad_n(dy, x, None, count, amp, x_rows=rows)
+        assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b), mode
+        y1c = T._gather_rows(y1, rows, count)
+        dx_a = T._dgrad_n(dy, w, None, count, amp)
+        dx_a = torch.where(y1c > 0, dx_a, torch.zeros_like(dx_a))
+        dx_b = T._dgrad_n(dy, w, None, count, amp, mask=y1, mask_rows=rows)
+        assert torch.equal(dx_a[:n], dx_b[:n]), mode
+
+
 @pytest.mark.parametrize("R,K,J,masked", [(700, 128, 512, True), (1000, 512, 1024, False), (5000, 64, 256, True),
                                           (333, 256, 64, False), (4096, 1024, 512, False), (520, 132, 36, True)])
 @pytest.mark.parametrize("mode", ["bf16", "split"])
