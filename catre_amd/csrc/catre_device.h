@@ -75,42 +75,60 @@ __device__ __forceinline__ float erf_rational(float x) {
   return x * p * __builtin_amdgcn_rcpf(q);
 }
 
+// Phi(v) = 0.5 (1 + erf(v / sqrt 2)) from the same rational, with the argument scaling (1/sqrt 2), the x^2 = v^2 / 2 and the
+// final 0.5 (1 + .) folded into the coefficients (powers of two: exact; the common factor 0.5/sqrt 2 is one rounding per
+// numerator coefficient): clamp, square, 6 + 4 FMAs, v_rcp, one multiply, one FMA - two issue slots fewer per GELU than
+// 0.5 v (1 + erf_rational(v/sqrt 2)), same 1.5e-6 absolute accuracy over |v| <= 8 (checked against scipy in fp32 emulation).
+__device__ __forceinline__ float gelu_cdf(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -5.656854f, 5.656854f);
+  const float t = c * c;
+  float p = fmaf(t, -1.5059951e-12f, 3.0611993e-10f);
+  p = fmaf(t, p, -4.6426507e-08f);
+  p = fmaf(t, p, -2.515756e-06f);
+  p = fmaf(t, p, -6.496461e-05f);
+  p = fmaf(t, p, -5.223044e-04f);
+  p = fmaf(t, p, -5.690807e-03f);
+  float q = fmaf(t, -9.1037947e-07f, -2.6671756e-05f);
+  q = fmaf(t, q, -4.2070675e-04f);
+  q = fmaf(t, q, -3.6866646e-03f);
+  q = fmaf(t, q, -1.4264739e-02f);
+  return fmaf(c * p, __builtin_amdgcn_rcpf(q), 0.5f);
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
-  // nn.GELU() default: 0.5 * v * (1 + erf(v / sqrt(2)))
-  const float hv = 0.5f * v;
-  return fmaf(hv, erf_rational(v * 0.70710678118654752440f), hv);
+  // nn.GELU() default: 0.5 * v * (1 + erf(v / sqrt(2))) = v * Phi(v)
+  return v * gelu_cdf(v);
 }
 
 // Two GELUs per instruction stream: the same operation sequence as gelu_erf (bit-identical results) written on
-// float2 so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 - 17 packed ops + 2 v_rcp per PAIR instead of ~22 VALU ops
-// per element.  Used where GELU is the bottleneck (rotation head: 2 x 2 x 256 x (N+M) evaluations per object).
+// float2 (the packed-fp32 forms it once compiled to are disabled library-wide; the pairing still gives the
+// scheduler two independent chains).  Used where GELU is the bottleneck (rotation head: 2 x 2 x 256 x (N+M) evaluations per
+// object).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float a) {
   f32x2 v = {a, a};
   return v;
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 erf_rational2(f32x2 x) {
-  x[0] = __builtin_amdgcn_fmed3f(x[0], -4.f, 4.f);  // no packed min/max on gfx950: med3 halves the clamp
-  x[1] = __builtin_amdgcn_fmed3f(x[1], -4.f, 4.f);
-  const f32x2 x2 = x * x;
-  f32x2 p = pk_fma(x2, splat2(-2.72614225801306e-10f), splat2(2.77068142495902e-08f));
-  p = pk_fma(x2, p, splat2(-2.10102402082508e-06f));
-  p = pk_fma(x2, p, splat2(-5.69250639462346e-05f));
-  p = pk_fma(x2, p, splat2(-7.34990630326855e-04f));
-  p = pk_fma(x2, p, splat2(-2.95459980854025e-03f));
-  p = pk_fma(x2, p, splat2(-1.60960333262415e-02f));
-  f32x2 q = pk_fma(x2, splat2(-1.45660718464996e-05f), splat2(-2.13374055278905e-04f));
-  q = pk_fma(x2, q, splat2(-1.68282697438203e-03f));
-  q = pk_fma(x2, q, splat2(-7.37332916720468e-03f));
-  q = pk_fma(x2, q, splat2(-1.42647390514189e-02f));
+__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 v) {
+  f32x2 c;
+  c[0] = __builtin_amdgcn_fmed3f(v[0], -5.656854f, 5.656854f);
+  c[1] = __builtin_amdgcn_fmed3f(v[1], -5.656854f, 5.656854f);
+  const f32x2 t = c * c;
+  f32x2 p = pk_fma(t, splat2(-1.5059951e-12f), splat2(3.0611993e-10f));
+  p = pk_fma(t, p, splat2(-4.6426507e-08f));
+  p = pk_fma(t, p, splat2(-2.515756e-06f));
+  p = pk_fma(t, p, splat2(-6.496461e-05f));
+  p = pk_fma(t, p, splat2(-5.223044e-04f));
+  p = pk_fma(t, p, splat2(-5.690807e-03f));
+  f32x2 q = pk_fma(t, splat2(-9.1037947e-07f), splat2(-2.6671756e-05f));
+  q = pk_fma(t, q, splat2(-4.2070675e-04f));
+  q = pk_fma(t, q, splat2(-3.6866646e-03f));
+  q = pk_fma(t, q, splat2(-1.4264739e-02f));
   const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
-  return x * p * r;
+  return pk_fma(c * p, r, splat2(0.5f));
 }
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-  const f32x2 hv = v * splat2(0.5f);
-  return pk_fma(hv, erf_rational2(v * splat2(0.70710678118654752440f)), hv);
-}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) { return v * gelu_cdf2(v); }
 // z[0..3] = gelu(v * sc + sh) on a register quad
 __device__ __forceinline__ void gelu_affine4(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
                                              float (&z)[4]) {
@@ -128,16 +146,16 @@ __device__ __forceinline__ void gelu_affine4(float v0, float v1, float v2, float
 // (R, t, s), an order of magnitude inside what rounding the operands to bf16 costs; NOT used by the fp32 / split kernels,
 // whose 2e-5 bar it would eat).  The bf16 rotation-head kernels are VALU-bound on this function.
 __device__ __forceinline__ float gelu_erf_lp(float v) {
-  const float z = __builtin_amdgcn_fmed3f(v * 0.70710678118654752440f, -3.6f, 3.6f);
-  const float t = z * z;
-  float p = fmaf(t, 0.0006665938417427242f, 0.04241189360618591f);
-  p = fmaf(t, p, 0.1693669706583023f);
-  p = fmaf(t, p, 1.1281505823135376f);
-  float q = fmaf(t, 0.008663873188197613f, 0.09953298419713974f);
-  q = fmaf(t, q, 0.4826095402240753f);
+  // v * Phi(v) with the scalings folded into the coefficients like gelu_cdf: 15 issue slots instead of 18
+  const float c = __builtin_amdgcn_fmed3f(v, -5.091169f, 5.091169f);
+  const float t = c * c;
+  float p = fmaf(t, 2.9459565e-05f, 3.7487173e-03f);
+  p = fmaf(t, p, 2.9940134e-02f);
+  p = fmaf(t, p, 3.9886147e-01f);
+  float q = fmaf(t, 1.0829841e-03f, 2.4883246e-02f);
+  q = fmaf(t, q, 2.4130477e-01f);
   q = fmaf(t, q, 1.0f);
-  const float hv = 0.5f * v;
-  return fmaf(hv, z * p * __builtin_amdgcn_rcpf(q), hv);
+  return v * fmaf(c * p, __builtin_amdgcn_rcpf(q), 0.5f);
 }
 __device__ __forceinline__ void gelu_affine4_lp(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
                                                 float (&z)[4]) {

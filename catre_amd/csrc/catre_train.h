@@ -1748,8 +1748,7 @@ __global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict
 
 __device__ __forceinline__ float gelu_grad(float v) {
   // d/dv [0.5 v (1 + erf(v/sqrt2))] = 0.5 (1 + erf(v/sqrt2)) + v * exp(-v^2/2) / sqrt(2 pi)
-  const float cdf = 0.5f * (1.0f + erf_rational(v * 0.70710678118654752440f));
-  return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
+  return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), gelu_cdf(v));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1978,10 +1977,9 @@ __global__ void k_gnp_bwd_apply(const float* __restrict__ dA, const float* __res
 // 0.5 GiB loads forward and backward, and the two padded GEMMs (a 3 x 256 weight gradient on 128 x 128 MFMA tiles).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gelu_both(float v, float& g, float& dg) {
-  const float e = erf_rational(v * 0.70710678118654752440f);
-  const float hv = 0.5f * v;
-  g = fmaf(hv, e, hv);  // the operation sequences of gelu_erf / gelu_grad on one erf evaluation
-  dg = fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), 0.5f * (1.0f + e));
+  const float cdf = gelu_cdf(v);
+  g = v * cdf;  // the operation sequences of gelu_erf / gelu_grad on one evaluation of Phi
+  dg = fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
 }
 
 // workgroup = 64 consecutive rows of one object (P % 64 == 0); wave = row, lane = 4 channels; Y3 [R][3]
