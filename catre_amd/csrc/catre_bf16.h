@@ -967,7 +967,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// a9: rotation heads, bf16 operands: layer-0 statistics pass, then the structure of k_rot_l1 / k_rot_out.
+// a9: rotation heads, bf16 operands: the structure of k_rot_l1 / k_rot_out (GN0 statistics: k_pf_moments_bf, catre_gram.h).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_pf_tile_bf(const u32x4* __restrict__ pointfeat, const RotTile& rt, u32x4* pf, int tid,
                                                 int nthreads) {
@@ -975,63 +975,6 @@ __device__ __forceinline__ void load_pf_tile_bf(const u32x4* __restrict__ pointf
     const int row = i >> 3, c = i & 7;
     const int srow = min(row, rt.valid - 1);
     pf[bf_off<8>(row, c)] = pointfeat[(rt.pf_off / 64 + srow) * 8 + c];
-  }
-}
-
-__global__ __launch_bounds__(512) void k_rot_l0_stats_bf(const u32x4* __restrict__ pointfeat,
-                                                         const u32x4* __restrict__ wpl0x,
-                                                         const u32x4* __restrict__ wpl0y,
-                                                         const float* __restrict__ bias0 /*[2][2B][256]*/,
-                                                         float* __restrict__ gn0 /*[B][2][T][64]*/, int B, int N,
-                                                         int M) {
-  __shared__ u32x4 pf[TP * 8];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const RotTile rt = rot_tile(blockIdx.x, B, N, M);
-  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
-  load_pf_tile_bf(pointfeat, rt, pf, tid, 512);
-  __syncthreads();
-  const int n = lane & 31, h = lane >> 5;
-  const float cnt = 8.f * (float)rt.valid;
-#pragma unroll 1
-  for (int hd = 0; hd < 2; ++hd) {
-    f32x16 acc[1][2] = {{zero16(), zero16()}};
-    GemmPipeB<1, 2, false, 8, 2> g;
-    g.prefetch((hd ? wpl0y : wpl0x) + (wave * 4) * 64 + lane, 0);
-    g.run(acc, pf, lane);
-    const float* bz = bias0 + ((size_t)hd * 2 * B + rt.cloud) * 256 + wave * 32;
-    float* out = gn0 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bz + 8 * g4 + 4 * h);
-      float v[2][4];
-      float s = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const bool ok = nb * 32 + n < rt.valid;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[nb][q] = acc[0][nb][4 * g4 + q] + bv[q];
-          s += ok ? v[nb][q] : 0.f;
-        }
-      }
-      const float mean = wave_sum(s) / cnt;
-      float m2 = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const bool ok = nb * 32 + n < rt.valid;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float d = v[nb][q] - mean;
-          m2 += ok ? d * d : 0.f;
-        }
-      }
-      m2 = wave_sum(m2);
-      if (lane == 0) {
-        out[(wave * 4 + g4) * 2] = mean;
-        out[(wave * 4 + g4) * 2 + 1] = m2;
-      }
-    }
   }
 }
 

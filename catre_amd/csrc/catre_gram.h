@@ -12,8 +12,9 @@
 //                    (fp32 MFMA; operands read one float per lane from the point-major LDS tile, which is what 32x32x2
 //                    wants), tiles accumulated in order in the MFMA accumulators: deterministic
 //   k_gn0_from_moments  per (object, head, 64 channels): the quadratic forms w^T S w, group statistics over both
-//                    clouds, and the fused bias + GroupNorm affine table k_rot_l1 consumes (= k_gn0_affine's output).
-// Used by the fp32 path; the bf16 path keeps k_rot_l0_stats_bf (at bf16 MFMA rates the recompute is already cheap).
+//                    clouds, and the fused bias + GroupNorm affine table k_rot_l1 consumes.
+// Used by every compute mode (the bf16 path through k_pf_moments_bf, which reads its bf16 pointfeat buffer: the statistics
+// are then those of the fp32 W0 on the rounded pointfeat, ~1e-4 relative from what the bf16 layer 0 computes).
 // Everything is fp32; sums of squares are always taken about a mean (tile mean, then cloud mean), never raw.
 #pragma once
 
@@ -32,6 +33,9 @@
 #define PF_NG 4
 #define PF_MOM_SMEM (2 * TP * LD64 + 4 * 64 + 64)  // floats of LDS
 // body for cloud `cloud`, tile group by of gy (gy == 1: all four groups); 256 threads
+// BF: pointfeat is the bf16 point-major buffer of the reduced-precision path ([point][8 chunks of 8 bf16], channels in
+// k-slot order inside a chunk - catre_bf16.h); a thread then stages chunk tid & 7 of rows tid >> 3 and (tid >> 3) + 32.
+template <bool BF = false>
 __device__ __forceinline__ void pf_moments_body(const float* __restrict__ pointfeat,
                                                 float* __restrict__ Gc /*[2B][PF_NG][4096]*/,
                                                 float* __restrict__ s1c /*[2B][PF_NG][64]*/,
@@ -48,17 +52,48 @@ __device__ __forceinline__ void pf_moments_body(const float* __restrict__ pointf
   // staging map: thread -> rows {r0, r0+16, r0+32, r0+48}, float4 column c4 (coalesced 256 B per row)
   const int r0 = tid >> 4, c4 = tid & 15;
   f32x4 nxt[4];
+  // BF: rows rb, rb + 32, chunk cb -> channels [chb, chb + 4) and [chb + 8, chb + 12)
+  const int rb = tid >> 3, cb = tid & 7, chb = 16 * (cb >> 1) + 4 * (cb & 1);
+  u32x4 nxb[2];
+  const u32x4* srcb = reinterpret_cast<const u32x4*>(pointfeat) +
+                      (cloud < B ? (size_t)cloud * N : (size_t)B * N + (size_t)(cloud - B) * M) * 8;
   auto fetch = [&](int t) {
+    if constexpr (BF) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = t * TP + r0 + 16 * u;
-      nxt[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(p, n - 1) * 64 + c4 * 4);
+      for (int u = 0; u < 2; ++u) nxb[u] = srcb[(size_t)min(t * TP + rb + 32 * u, n - 1) * 8 + cb];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = t * TP + r0 + 16 * u;
+        nxt[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(p, n - 1) * 64 + c4 * 4);
+      }
+    }
+  };
+  // the fetched tile t -> LDS buffer, minus the shift (sa / sb: the shift of this thread's channels), rows past the cloud's
+  // end as zeros when `mask`
+  auto stage = [&](float* buf, int t, bool mask, const f32x4& sa, const f32x4& sb) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool ok = !mask || t * TP + rb + 32 * u < n;
+        const f32x4 a = {bf_lo(nxb[u][0]), bf_hi(nxb[u][0]), bf_lo(nxb[u][1]), bf_hi(nxb[u][1])};
+        const f32x4 b = {bf_lo(nxb[u][2]), bf_hi(nxb[u][2]), bf_lo(nxb[u][3]), bf_hi(nxb[u][3])};
+        *reinterpret_cast<f32x4*>(buf + (rb + 32 * u) * LD64 + chb) = ok ? a - sa : z;
+        *reinterpret_cast<f32x4*>(buf + (rb + 32 * u) * LD64 + chb + 8) = ok ? b - sb : z;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = !mask || t * TP + r0 + 16 * u < n;
+        *reinterpret_cast<f32x4*>(buf + (r0 + 16 * u) * LD64 + c4 * 4) = ok ? nxt[u] - sa : z;
+      }
     }
   };
   fetch(0);
   {  // the cloud's first tile as it is -> buffer 1 (scratch use); column means of its valid points = the shift
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(pf[1] + (r0 + 16 * u) * LD64 + c4 * 4) = nxt[u];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    stage(pf[1], 0, false, z4, z4);
     __syncthreads();
     const int ch = tid & 63, q = tid >> 6, v0 = min(TP, n);
     float s = 0.f;
@@ -72,7 +107,8 @@ __device__ __forceinline__ void pf_moments_body(const float* __restrict__ pointf
     }
     __syncthreads();
   }
-  const f32x4 sh4 = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+  const f32x4 sh4 = *reinterpret_cast<const f32x4*>(shift + (BF ? chb : c4 * 4));
+  const f32x4 sh4b = *reinterpret_cast<const f32x4*>(shift + (BF ? chb + 8 : c4 * 4));
   const int bi = wave >> 1, bj = wave & 1, i = lane & 31, h = lane >> 5;
   const int g_lo = gy == 1 ? 0 : by, g_hi = gy == 1 ? PF_NG : by + 1;
 #pragma unroll 1
@@ -83,15 +119,7 @@ __device__ __forceinline__ void pf_moments_body(const float* __restrict__ pointf
     if (t_lo < t_hi && !(g == g_lo && t_lo == 0)) fetch(t_lo);  // (tile 0 is still in registers for the first group)
     for (int t = t_lo; t < t_hi; ++t) {
       float* buf = pf[t & 1];
-      {  // shifted tile -> LDS, rows past the cloud's end as zeros (they then add nothing to G' or s1)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool ok = t * TP + r0 + 16 * u < n;
-          f32x4 v = nxt[u] - sh4;
-          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(buf + (r0 + 16 * u) * LD64 + c4 * 4) = v;
-        }
-      }
+      stage(buf, t, true, sh4, sh4b);  // shifted tile -> LDS, rows past the cloud's end as zeros (they add nothing to G' or s1)
       __syncthreads();  // also orders the previous tile's reads of the other buffer before its next overwrite
       if (t + 1 < t_hi) fetch(t + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -125,8 +153,17 @@ __global__ __launch_bounds__(256) void k_pf_moments(const float* __restrict__ po
   __shared__ __attribute__((aligned(16))) float lds[PF_MOM_SMEM];
   pf_moments_body(pointfeat, Gc, s1c, shc, B, N, M, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
+// the same moments from the bf16 pointfeat buffer of the reduced-precision path
+__global__ __launch_bounds__(256) void k_pf_moments_bf(const u32x4* __restrict__ pointfeat, float* __restrict__ Gc,
+                                                       float* __restrict__ s1c, float* __restrict__ shc, int B, int N,
+                                                       int M) {
+  __shared__ __attribute__((aligned(16))) float lds[PF_MOM_SMEM];
+  pf_moments_body<true>(reinterpret_cast<const float*>(pointfeat), Gc, s1c, shc, B, N, M, blockIdx.x, blockIdx.y,
+                        gridDim.y, lds);
+}
 
-// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256], as k_gn0_affine.  Workgroup = object x `gridDim.y`
+// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256]: gelu_in = acc * sc + sh with sc = rstd * gamma,
+// sh = beta + (bias0[cloud][ch] - mean) * sc.  Workgroup = object x `gridDim.y`
 // shares of the 8 (head, 64-channel block) combinations: 8 shares on small grids (one combination each: a single object
 // still gets eight CUs), one share on large ones (the object's two 64 x 64 scatter matrices are then fetched and centred
 // once instead of eight times - at B = 256 that traffic, 268 MB through L2, was the kernel's time).

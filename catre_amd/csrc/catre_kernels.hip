@@ -1835,12 +1835,20 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                      prm[CATRE_P_ROTX_L0_W], PMW, prm[CATRE_P_ROTX_L0_W + 1], bias0, 256, 2 * B, 256, 1024, 0, 0,
                      prm[CATRE_P_ROTY_L0_W], prm[CATRE_P_ROTY_L0_W + 1], bias0 + (size_t)2 * B * 256);
   {
+    // GN0 statistics from second moments of the (bf16) pointfeat like the fp32 path (catre_gram.h) instead of a recompute of
+    // layer 0 over every point: the statistics are those of W0 pf in fp32 on the bf16-rounded pointfeat - layer 0's own
+    // bf16 weight rounding moves them by ~1e-4 relative, a fraction of what rounding a0 to bf16 does next.  The moment
+    // buffers borrow y1, which k_rot_l1_bf writes afterwards.
+    float* Gc = ws + W.y1;
+    float* s1c = Gc + (size_t)2 * B * PF_NG * 4096;
+    float* shc = s1c + (size_t)2 * B * PF_NG * 64;
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
-    hipLaunchKernelGGL(k_rot_l0_stats_bf, dim3(B * T), dim3(512), 0, st, pointfeat, pkb(packed, L.bf_rot_l0[0]),
-                       pkb(packed, L.bf_rot_l0[1]), bias0, ws + W.gn0, B, N, M);
+    hipLaunchKernelGGL(k_pf_moments_bf, dim3(2 * B, 2 * B * PF_NG <= 256 ? PF_NG : 1), dim3(256), 0, st, pointfeat, Gc, s1c,
+                       shc, B, N, M);
+    hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, gn0_shares(B)), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
+                       prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
+                       prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   }
-  hipLaunchKernelGGL(k_gn0_affine, dim3(B * 2), dim3(256), 0, st, ws + W.gn0, bias0, prm[CATRE_P_ROTX_GN0_W],
-                     prm[CATRE_P_ROTX_GN0_B], prm[CATRE_P_ROTY_GN0_W], prm[CATRE_P_ROTY_GN0_B], ws + W.aff0, B, N, M);
   unsigned short* y1 = reinterpret_cast<unsigned short*>(ws + W.y1);
   {
     ProfScope ps(CATRE_K_ROT_L1, st);

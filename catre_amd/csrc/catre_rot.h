@@ -1,8 +1,8 @@
 // catre_rot.h - rotation-head kernels after the layer-0 statistics pass (included by catre_kernels.hip).
 //
 // a9 (heads/conv_out_per_rot_head.py:126-140) per (object, head), over the P = N+M concatenated points:
-//   y0 = W0[:,1024:] pointfeat + bias0(cloud)       -> GN0 statistics from the moments of pointfeat (catre_gram.h;
-//                                                      the bf16 path: k_rot_l0_stats_bf + k_gn0_affine)
+//   y0 = W0[:,1024:] pointfeat + bias0(cloud)       -> GN0 statistics from the moments of pointfeat (catre_gram.h,
+//                                                      every compute mode)
 //   a0 = gelu(GN0(y0));  y1 = W1 a0 + b1             -> y1 to HBM, GN1 partials (k_rot_l1)
 //   k_gn_finalize
 //   out[c] = sum_p w_p * (neck gelu(GN1(y1)))[c,p]                             (k_rot_out, HBM-bound)
@@ -28,35 +28,6 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
   merge_gn(sp, g, T, TN, N, M, mean, rstd);
   stat[((size_t)blockIdx.x * 32 + g) * 2] = mean;
   stat[((size_t)blockIdx.x * 32 + g) * 2 + 1] = rstd;
-}
-
-// GN0 statistics -> per-channel affine of the fused "bias + GroupNorm" that follows rot-head layer 0:
-//   gelu_in = (acc + bias0[cloud][ch]) * sc + (beta - mean*sc) = acc * sc + sh,   sc = rstd * gamma
-// aff [B*2 (object, head)][2 (observed, prior)][2 (sc, sh)][256].  One block of 256 threads per (object, head).
-__global__ __launch_bounds__(256) void k_gn0_affine(const float* __restrict__ part, const float* __restrict__ bias0,
-                                                    const float* __restrict__ gamx, const float* __restrict__ betx,
-                                                    const float* __restrict__ gamy, const float* __restrict__ bety,
-                                                    float* __restrict__ aff, int B, int N, int M) {
-  __shared__ float st[64];
-  const int TN = (N + TP - 1) / TP, T = TN + (M + TP - 1) / TP;
-  const int obj = blockIdx.x >> 1, hd = blockIdx.x & 1, ch = threadIdx.x;
-  if (ch < 32) {
-    float mean, rstd;
-    merge_gn(part + (size_t)blockIdx.x * T * 64, ch, T, TN, N, M, mean, rstd);
-    st[ch * 2] = mean;
-    st[ch * 2 + 1] = rstd;
-  }
-  __syncthreads();
-  const float mean = st[(ch >> 3) * 2], rstd = st[(ch >> 3) * 2 + 1];
-  const float sc = rstd * (hd ? gamy : gamx)[ch];
-  const float sh0 = (hd ? bety : betx)[ch] - mean * sc;
-#pragma unroll
-  for (int cl = 0; cl < 2; ++cl) {
-    const float b0 = bias0[((size_t)hd * 2 * B + (cl ? B + obj : obj)) * 256 + ch];
-    float* o = aff + (((size_t)blockIdx.x * 2 + cl) * 2) * 256;
-    o[ch] = sc;
-    o[256 + ch] = fmaf(b0, sc, sh0);
-  }
 }
 
 __device__ __forceinline__ void load_pf_tile_swz(const float* __restrict__ pointfeat, const RotTile& rt, float* pf,
