@@ -31,7 +31,11 @@ PER_OBJECT_KEYS = frozenset((
     "last_frame_poses", "obj_visib_mask", "obj_trunc_mask",       # batching.py:29-41 (concatenated over instances)
 ))
 # per-IMAGE entries (batching.py:12-27): never sliced, and never warned about when an image count happens to equal B
-PER_IMAGE_KEYS = frozenset(("img", "depth_obs", "roi_img", "roi_depth", "file_name", "scene_im_id", "cam", "im_H", "im_W"))
+# (plus the per-image meta entries of the reference's dataset dicts that evaluator-side code carries along:
+# core/catre/datasets/data_loader.py dataset_dict keys)
+PER_IMAGE_KEYS = frozenset(("img", "depth_obs", "roi_img", "roi_depth", "file_name", "scene_im_id", "cam", "im_H", "im_W",
+                            "depth_file", "depth_factor", "img_type", "dataset_name", "image_id", "width", "height",
+                            "time", "resize_ratio"))
 
 
 def shard_batch(batch, rank, world, extra_keys=(), per_image_keys=()):

@@ -196,15 +196,28 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     B, N, M = x.shape[0], x.shape[2], tfd_kps.shape[2]
     hip.require_dev_f32(x, "x", (B, 3, N), contiguous=False)
     hip.require_dev_f32(tfd_kps, "tfd_kps", (B, 3, M), contiguous=False)
-    pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)             # cloud-major rows
-    if rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
+    # one decision, taken once: the fused fp32 rotation heads read pointfeat cloud-major (forward AND backward), so no
+    # object-major copy is made for them
+    fused_rot = (rt is not None and T._amp() == 0 and bool(opts.feature_transform) and N + M == rt.N + rt.M
+                 and _rot_heads_shapes_ok_p(p, N, M))
+    enc_frozen = (not x.requires_grad and not tfd_kps.requires_grad
+                  and not any(v.requires_grad for k, v in p.items() if k.startswith("pcl_net.")))
+    if rt is not None and enc_frozen and T._amp() == 0 and N + M == rt.N + rt.M:
+        # PCLNET.FREEZE (CATRE_disR_shared.py:301-304): nothing in front of the heads needs a gradient, so the encoder runs
+        # on the INFERENCE kernels - no activation saves, no arg-max rows, no graph nodes (and no encoder backward)
+        st = rt.stage_pointnet(x, tfd_kps, feature_transform=bool(opts.feature_transform))
+        g, pfmax, pf = st["gfeat"][:, :1024], st["gfeat"][:, 1024:], st["pointfeat"]
+        hub = (pfmax, pf if fused_rot else T.object_major(pf, B, N, M))
+    elif rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
-        # the fused fp32 rotation heads read pointfeat cloud-major (forward AND backward): no object-major copy for them
-        fused_rot = T._amp() == 0 and _rot_heads_shapes_ok_p(p, N, M)
+        pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)         # cloud-major rows
         g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
                                          obj_copy=not fused_rot)
+        fused_rot = fused_rot and hub is not None
     else:
+        pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)
         (g, pf), hub = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform)), None
+        fused_rot = False
     # max_n pointfeat (flat_pcl_feat tail) and the rot heads' input in object-major order: [N observed | M prior] per object
     # (CATRE_disR_shared.py:69, :86)
     pfmax, pf_obj = hub if hub is not None else (T.maxpool_points(pf, B, N, M), T.object_major(pf, B, N, M))
@@ -224,9 +237,7 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     dt = T.linear(h, p["ts_head.fc_t.weight"], p["ts_head.fc_t.bias"])
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
-    if hub is not None and pf_obj.data_ptr() == pf.data_ptr() and not _rot_heads_fused_ok(p, pf_obj, N, M):
-        raise RuntimeError("pointfeat was handed out cloud-major for rotation heads that read it object-major")
-    if hub is not None and _rot_heads_fused_ok(p, pf_obj, N, M):
+    if fused_rot:
         rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
     elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):
         rx, ry = _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M)

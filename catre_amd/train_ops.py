@@ -644,6 +644,8 @@ def pooled_chain_ok(x, w1, w2, w3, N, M):
         return False
     j1, j2, j3 = w1.shape[0], w2.shape[0], w3.shape[0]
     k1 = w1.reshape(j1, -1).shape[1]
+    if x.requires_grad and not _tiled_gemm_ok(1, k1, j1, min_rows=0):
+        return False  # the chain's input gradient is a tiled row GEMM with K1 outputs: a differentiable 3-d input takes the layer-wise ops
     return (j1 in (64, 128) and j2 in (128, 512) and j3 <= 1024 and j3 % 32 == 0 and (k1 <= 8 or k1 in (64, 128)))
 
 
