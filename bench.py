@@ -182,6 +182,33 @@ def cpu_baseline(cfg_fn, sd):
             O.refine_k(batch, sd, cfg, n_iter=Ks)
             runs.append(time.perf_counter() - t0)
     dt = sorted(runs)[1]
+    # BASELINE config 1 (the reference's own CPU-runnable case: one object per call, catre_evaluator.py:292-311): B = 1
+    # at the same thread count, median of five K = 4 refines
+    one = synth.make_inputs(1, N_PTS, M_PTS, seed=124)
+    with torch.no_grad():
+        O.refine_k(one, sd, cfg, n_iter=1)
+        r1 = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            O.refine_k(one, sd, cfg, n_iter=Ks)
+            r1.append(time.perf_counter() - t0)
+    dt1 = sorted(r1)[2]
+    phys = None
+    try:  # physical cores = distinct (physical id, core id) pairs
+        ids, cur = set(), {}
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ":" in ln:
+                    k, v = (t.strip() for t in ln.split(":", 1))
+                    cur[k] = v
+                elif cur:
+                    ids.add((cur.get("physical id"), cur.get("core id")))
+                    cur = {}
+        if cur:
+            ids.add((cur.get("physical id"), cur.get("core id")))
+        phys = len(ids) if ids and (None, None) not in ids else None
+    except OSError:
+        pass
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -195,8 +222,12 @@ def cpu_baseline(cfg_fn, sd):
         "value": round(Bs * Ks / dt, 3),
         "unit": "object-iterations/s",
         "cores": torch.get_num_threads(),
+        "host_threads": cores,
+        "physical_cores": phys,
         "kind": "port",
         "cpu_model": model,
+        "config1_B1": {"value": round(Ks / dt1, 3), "unit": "object-iterations/s", "ms_per_refine": round(dt1 * 1e3, 1),
+                       "sample": f"B=1, N=M={N_PTS}, K={Ks}, median of 5 refines, {torch.get_num_threads()} threads"},
         "runs_s": [round(r, 2) for r in runs],
         "sample": f"oracle/catre_oracle.refine_k (torch CPU fp32), B={Bs}, N=M={N_PTS}, K={Ks}, median of 3 runs "
                   f"({dt:.1f} s), {torch.get_num_threads()} of {cores} host threads (best of a thread-count calibration) on {model}",
@@ -517,7 +548,7 @@ def main():
             "path_tflops": round(value * path_flops / 1e12, 2),
             "path_frac_of_mfma_peak": round(value * path_flops / 1e12 / (mfma_peak * world), 4),
             "roofline": {
-                "kernel": "k_trunk_bf" if bf16 else ("k_trunk_split" if split else "k_trunk"),
+                "kernel": "k_trunk_bf2" if bf16 else ("k_trunk_split" if split else "k_trunk"),  # (B=256: the 128-point pair form)
                 "bound": "mfma",
                 "achieved": round(achieved, 2) if achieved else None,
                 "peak": mfma_peak,

@@ -979,27 +979,47 @@ __device__ __forceinline__ void load_pf_tile_bf(const u32x4* __restrict__ pointf
 }
 
 // layer 0 recompute -> fused (bias + GN0) affine -> GELU -> bf16 image -> layer 1 -> y1 (bf16, HBM) + GN1 partials.
-// 256 threads, 40 KiB LDS, 2 workgroups per CU (the kernel is VALU-bound on the exact-erf GELU).
+// 256 threads, 50 KiB LDS (40 of images + a 2.5 KiB transposition stage per wave), 3 workgroups per CU.
+#ifndef ROTBF_PFD1
+#define ROTBF_PFD1 3  // layer-1 weight K-steps in flight per wave
+#endif
+#define ROTBF_PITCH 80                       // bytes per stage row: 32 points x 2 bytes + 16 (conflict-free 8-byte writes)
+#define ROTBF_STAGE (32 * ROTBF_PITCH / 16)  // u32x4 per wave: one 32-channel x 32-point block
 __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ pointfeat,
                                                       const u32x4* __restrict__ wpl0x, const u32x4* __restrict__ wpl0y,
                                                       const float* __restrict__ aff0 /*[B*2][2][2][256]*/,
                                                       const u32x4* __restrict__ wpl1x, const u32x4* __restrict__ wpl1y,
                                                       const float* __restrict__ b1x, const float* __restrict__ b1y,
                                                       unsigned short* __restrict__ y1, float* __restrict__ gn1, int B,
-                                                      int N, int M) {
-  __shared__ u32x4 smem[TP * 8 + TP * 32];
+                                                      int N, int M, unsigned long long* __restrict__ trace = nullptr) {
+  __shared__ u32x4 smem[TP * 8 + TP * 32 + 4 * ROTBF_STAGE];
+  int stamp_i = 0;
+#define ROTB_STAMP()                                                                                     \
+  do {                                                                                                   \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                              \
+      trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + stamp_i] = __builtin_readcyclecounter(); \
+    ++stamp_i;                                                                                           \
+  } while (0)
+  ROTB_STAMP();
+  int abl = 0;  // instrumented build: knob 1 switches phases off (timing only, results wrong)
+#ifdef CATRE_DEBUG_TRACE
+  abl = __builtin_amdgcn_readfirstlane(g_ablate);
+#endif
   u32x4* pf = smem;           // [64][64 ch]
   u32x4* a0 = smem + TP * 8;  // [64][256 ch]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave-private transposition stage of the y1 epilogue: [32 channels][32 points] bf16, rows of 80 bytes
+  unsigned* stage = reinterpret_cast<unsigned*>(smem + TP * 8 + TP * 32 + wave * ROTBF_STAGE);
   const RotTile rt = rot_tile(blockIdx.x, B, N, M);
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
-  const int P = N + M;
   load_pf_tile_bf(pointfeat, rt, pf, tid, 256);
   __syncthreads();
+  ROTB_STAMP();
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll 1
   for (int hd = 0; hd < 2; ++hd) {
+    GemmPipeB<2, 2, true, 32, ROTBF_PFD1> g1;
     {
       // wave -> channels [wave*64, +64) = m-blocks 2*wave, 2*wave+1
       const float* af = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + wave * 64 + 4 * h;
@@ -1015,7 +1035,10 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
       for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
       GemmPipeB<2, 2, false, 8, 2> g0;
       g0.prefetch((hd ? wpl0y : wpl0x) + (wave * 2 * 4) * 64 + lane, 4 * 64);
-      g0.run(acc, pf, lane);
+      if (!(abl & 64)) g0.run(acc, pf, lane);
+      ROTB_STAMP();
+      // layer 1's first weight fragments are requested now: their L2 round trip runs under the GELU epilogue and the barrier
+      g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64);
       const int key = bf_key<32>(n);
       float zprev[2][4];
 #pragma unroll
@@ -1030,8 +1053,13 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           float z[4];
-          gelu_affine4_lp(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
-                       scr[i % 3], shr[i % 3], z);
+          if (abl & 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] = fmaf(acc[mb][nb][4 * g + q], scr[i % 3][q], shr[i % 3][q]);
+          } else {
+            gelu_affine4_lp(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3],
+                            scr[i % 3], shr[i % 3], z);
+          }
           if ((g & 1) == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) zprev[nb][q] = z[q];
@@ -1043,61 +1071,86 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         }
       }
     }
+    ROTB_STAMP();
     __syncthreads();
+    ROTB_STAMP();
     {
       // layer 1 (256->256), "swapped": lane owns channel wave*64 + mb*32 + n and 32 of the tile's points
+      // (the accumulators start at the lane's channel bias - one value per lane in this orientation)
       f32x16 acc[2][2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-      GemmPipeB<2, 2, true, 32, 2> g1;
-      g1.prefetch((hd ? wpl1y : wpl1x) + (wave * 2 * 16) * 64 + lane, 16 * 64);
-      g1.run(acc, a0, lane);
+      for (int mb = 0; mb < 2; ++mb) {
+        const float bb = (hd ? b1y : b1x)[wave * 64 + mb * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = acc[mb][1][r] = bb;
+      }
+      if (!(abl & 32)) g1.run(acc, a0, lane);
+      ROTB_STAMP();
       const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
       int valid_h = rt.valid - 4 * h;
       asm volatile("" : "+v"(valid_h));
+      // y1 leaves in BLOCK order [object][head][tile][2 point halves][256 channels][32 points] (bf16): a wave's 32-channel x
+      // 32-point accumulator block is 2 KiB of consecutive bytes, written as two 1-KiB store instructions (16 bytes per
+      // lane, whole lines) after a transposition through 2.5 KiB of wave-private LDS.  Straight from the accumulators (lane =
+      // channel, registers = points) it took 64 two-byte stores per lane and head.  Points >= rt.valid hold clamped
+      // duplicates; k_rot_out_bf masks them.
+      u32x4* ytile = reinterpret_cast<u32x4*>(y1) + (((size_t)rt.obj * 2 + hd) * T + rt.t) * (2 * 256 * 4);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int ch = wave * 64 + mb * 32 + n;
-        const float bb = (hd ? b1y : b1x)[ch];
-        unsigned short* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
-        float s = 0.f;
-        unsigned short* dh = dst + (size_t)(4 * h) * 256;
-        if (rt.valid == TP) {  // full tile (wave-uniform): no per-store predication
+        if (!(abl & 16)) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            unsigned* srow = stage + n * (ROTBF_PITCH / 4) + 2 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const u32x2 d = {pack_bf2(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]),
+                               pack_bf2(acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3])};
+              *reinterpret_cast<u32x2*>(srow + 4 * g) = d;
+            }
+            const u32x4* sv = reinterpret_cast<const u32x4*>(stage);
+            u32x4* dst = ytile + ((size_t)nb * 256 + wave * 64 + mb * 32) * 4;
+            const u32x4 r0 = sv[(lane >> 2) * (ROTBF_PITCH / 16) + (lane & 3)];
+            const u32x4 r1 = sv[(16 + (lane >> 2)) * (ROTBF_PITCH / 16) + (lane & 3)];
+            __builtin_nontemporal_store(r0, dst + lane);
+            __builtin_nontemporal_store(r1, dst + 64 + lane);
+          }
+        }
+        if (abl & 8) continue;
+        float s = 0.f, m2 = 0.f;
+        if (rt.valid == TP) {  // full tile (wave-uniform): no predication
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
-              dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
-              s += v;
-            }
+            for (int r = 0; r < 16; ++r) s += acc[mb][nb][r];
         } else {  // ragged tile: see k_rot_l1
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[mb][nb][r] + bb;
-              acc[mb][nb][r] = v;
-              if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
-                dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = __builtin_bit_cast(unsigned short, (__bf16)v);
-                s += v;
-              }
-            }
+            for (int r = 0; r < 16; ++r) s += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? acc[mb][nb][r] : 0.f;
         }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 32);
         const float mean = s * inv_cnt;
-        float m2 = 0.f;
+        if (rt.valid == TP) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[mb][nb][r] - mean;
-            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[mb][nb][r] - mean;
+              m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
+            }
+        }
         m2 += __shfl_xor(m2, 1);
         m2 += __shfl_xor(m2, 2);
         m2 += __shfl_xor(m2, 4);
@@ -1109,11 +1162,18 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         }
       }
     }
+    ROTB_STAMP();
     __syncthreads();  // a0 is rewritten for the second head
+    ROTB_STAMP();
   }
+#undef ROTB_STAMP
 }
 
-// GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; reads the bf16 y1.
+// GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; reads the bf16 y1 in the block order
+// k_rot_l1_bf writes ([2 point halves][256 channels][32 points] per tile and head).  A lane takes 8 consecutive points
+// (16 bytes) of 4 channels in both halves: every load instruction of the workgroup is 4 KiB of consecutive bytes, the conv_p
+// weights of its 16 points stay in registers, and the neck is applied to the per-channel sums (sum_p w_p gelu(z_cp))
+// instead of to every point.
 __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __restrict__ y1,
                                                     const float* __restrict__ gn1stat, const float* __restrict__ gam1x,
                                                     const float* __restrict__ bet1x, const float* __restrict__ gam1y,
@@ -1121,48 +1181,61 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
                                                     const float* __restrict__ necky, const float* __restrict__ wpx,
                                                     const float* __restrict__ wpy, float* __restrict__ rpart, int B,
                                                     int N, int M, int rd) {
+  __shared__ float cst[5][256];  // per channel: GN1 scale, shift, the three neck weights
   __shared__ float red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, P = N + M;
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
   const int hd = blockIdx.y;
   const RotTile rt = rot_tile(blockIdx.x, B, N, M);
-  const int c0 = lane * 4;
-  const float* gam = hd ? gam1y : gam1x;
-  const float* bet = hd ? bet1y : bet1x;
-  const float* neck = hd ? necky : neckx;
-  const float* wp = hd ? wpy : wpx;
-  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (c0 >> 3) * 2;
-  const float mean = st[0], rstd = st[1];
-  f32x4 sc, sh;
-  float nk[3][4];
+  const u32x4* src = reinterpret_cast<const u32x4*>(y1) + (((size_t)rt.obj * 2 + hd) * T + rt.t) * (2 * 256 * 4);
+  u32x4 rows[8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    sc[q] = rstd * gam[c0 + q];
-    sh[q] = bet[c0 + q] - mean * sc[q];
+  for (int i = 0; i < 8; ++i) rows[i] = __builtin_nontemporal_load(src + i * 256 + tid);
+  {
+    const float* gam = hd ? gam1y : gam1x;
+    const float* bet = hd ? bet1y : bet1x;
+    const float* neck = hd ? necky : neckx;
+    const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (tid >> 3) * 2;
+    const float mean = st[0], rstd = st[1];
+    const float sc = rstd * gam[tid];
+    cst[0][tid] = sc;
+    cst[1][tid] = bet[tid] - mean * sc;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nk[c][q] = c < rd ? neck[c * 256 + c0 + q] : 0.f;
+    for (int c = 0; c < 3; ++c) cst[2 + c][tid] = c < rd ? neck[c * 256 + tid] : 0.f;
   }
-  const unsigned short* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
+  // conv_p weights of the lane's 2 x 8 points (zero past the ragged end: those slots hold clamped duplicates)
+  const float* wp = (hd ? wpy : wpx) + rt.gp0;
+  const int pbase = (tid & 3) * 8;
+  float w[2][8];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[nb][e] = nb * 32 + pbase + e < rt.valid ? wp[nb * 32 + pbase + e] : 0.f;
+  __syncthreads();
   float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int p = wave; p < rt.valid; p += 4) {
-    const u32x2 u = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src + (size_t)p * 256));
-    const float v[4] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
-    const float w = wp[rt.gp0 + p];
-    float z[4];
-    gelu_affine4_lp(v[0], v[1], v[2], v[3], sc, sh, z);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(z[q]));  // scalar neck sums on purpose: see rot_out_body
+  for (int k = 0; k < 4; ++k) {  // channel (k * 64 + tid / 4): chunks i = k (points 0..31) and i = 4 + k (points 32..63)
+    const int c = k * 64 + (tid >> 2);
+    const float sc1 = cst[0][c], sh1 = cst[1][c];
+    const f32x4 sc = {sc1, sc1, sc1, sc1}, sh = {sh1, sh1, sh1, sh1};
+    float t = 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float t = nk[c][0] * z[0];
-      t = fmaf(nk[c][1], z[1], t);
-      t = fmaf(nk[c][2], z[2], t);
-      t = fmaf(nk[c][3], z[3], t);
-      asm volatile("" : "+v"(t));
-      a3[c] = fmaf(w, t, a3[c]);
-      asm volatile("" : "+v"(a3[c]));
+    for (int nb = 0; nb < 2; ++nb) {
+      const u32x4 u = rows[nb * 4 + k];
+      float z[4];
+      gelu_affine4_lp(bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1]), sc, sh, z);
+      t = fmaf(w[nb][0], z[0], t);
+      t = fmaf(w[nb][1], z[1], t);
+      t = fmaf(w[nb][2], z[2], t);
+      t = fmaf(w[nb][3], z[3], t);
+      gelu_affine4_lp(bf_lo(u[2]), bf_hi(u[2]), bf_lo(u[3]), bf_hi(u[3]), sc, sh, z);
+      t = fmaf(w[nb][4], z[0], t);
+      t = fmaf(w[nb][5], z[1], t);
+      t = fmaf(w[nb][6], z[2], t);
+      t = fmaf(w[nb][7], z[3], t);
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a3[q] = fmaf(cst[2 + q][c], t, a3[q]);
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) a3[c] = wave_sum(a3[c]);

@@ -1263,7 +1263,8 @@ WsLayout ws_layout(int B, int N, int M) {
   L.gn1stat = take(b * 2 * 64);
   {  // y1 [b][2][P][256]; before it is written the region holds the pointfeat moments (catre_gram.h)
     const size_t y1n = b * 2 * P * 256, mom = b * 2 * (4 * (4096 + 64) + 64);  // PF_NG partial moments per cloud
-    L.y1 = take(y1n > mom ? y1n : mom);
+    const size_t y1t = b * 2 * T * 256 * 32;  // bf16 mode: [b][2][T tiles][256 channels][64 points] bf16 (whole tiles)
+    L.y1 = take(std::max(std::max(y1n, mom), y1t));
   }
   L.rpart = take(b * 2 * T * 4);
   L.total = o;
@@ -1855,7 +1856,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     hipLaunchKernelGGL(k_rot_l1_bf, dim3(B * T), dim3(256), 0, st, pointfeat, pkb(packed, L.bf_rot_l0[0]),
                        pkb(packed, L.bf_rot_l0[1]), ws + W.aff0, pkb(packed, L.bf_rot_l1[0]),
                        pkb(packed, L.bf_rot_l1[1]), prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], y1, ws + W.gn1, B,
-                       N, M);
+                       N, M, g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
   }
   hipLaunchKernelGGL(k_gn_finalize, dim3(B * 2), dim3(256), (size_t)T * 64 * sizeof(float), st, ws + W.gn1, ws + W.gn1stat,
                      N, M);
