@@ -151,6 +151,26 @@ def bench_dryrun(args, world, rank):
         dist.destroy_process_group()
 
 
+def train_flops_per_iteration():
+    """MFMA work of one fp32 training iteration (forward + loss + backward + step at B=256, N=M=1024) as COUNTED by the
+    committed PMC pass of the newest round (profiles/rNN_train_pmc_summary.csv: sum over kernels of dispatches x
+    SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOP, per iteration) -> (FLOP, source file) or (None, None)."""
+    import glob
+    import importlib.util
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_train_pmc_summary.csv")))
+    if not files:
+        return None, None
+    spec = importlib.util.spec_from_file_location("make_tables", os.path.join(ROOT, "profiles", "make_tables.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    pm = mt._raw_pmc(files[-1])
+    its = sum(r["n"] for r in pm if r["k"] == "k_trunk<1, true>")
+    if not its:
+        return None, None
+    return sum(r["n"] * r["flop"] for r in pm) / its, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(cfg_fn, sd):
     """Oracle (port of the reference's CPU path) on the host cores, bounded sample."""
     from catre_amd import synth
@@ -341,12 +361,16 @@ def main():
     ap.add_argument("--dtype", choices=("fp32", "split", "bf16"), default="fp32",
                     help="fp32: fp32 MFMA everywhere (the headline); split: the layers holding 98 %% of the FLOPs as split-bf16 "
                          "(hi+lo, 3 products) MFMAs, same 2e-5 parity; bf16: bf16 operands (BASELINE config 5)")
-    ap.add_argument("--shape", choices=("headline", "config5"), default="headline",
-                    help="headline: N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8")
+    ap.add_argument("--shape", choices=("headline", "config5", "config2"), default="headline",
+                    help="headline: B=256, N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8; config2: B=64 (BASELINE "
+                         "configs[1] as written - the headline metric is quoted at B=256)")
+    ap.add_argument("--no-split-extra", action="store_true", help="skip the split-mode measurement of the default line")
     args = ap.parse_args()
-    global N_PTS, K_ITER
+    global N_PTS, K_ITER, B_PER_GPU
     if args.shape == "config5":
         N_PTS, K_ITER = 2048, 8
+    if args.shape == "config2":
+        B_PER_GPU = 64
     bf16 = args.dtype == "bf16"
     split = args.dtype == "split"
     # split arithmetic spends three bf16 MFMAs per fp32-accurate product: its matrix ceiling is a third of the bf16 peak
@@ -444,7 +468,7 @@ def main():
     # the same batch through the split compute mode (outside the timed region, rank 0 only): throughput and its
     # deviation from the fp32 kernels' result - reported next to the headline, never as `value`
     split_extra = None
-    if rank == 0 and args.dtype == "fp32":
+    if rank == 0 and args.dtype == "fp32" and not args.no_split_extra:
         model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"
         for _ in range(2):
             osp = model.refine(batch, n_iter=K_ITER)
@@ -497,6 +521,12 @@ def main():
                        "value": round(B_PER_GPU * K_ITER * tsteps / tdt, 1), "unit": "training object-iterations/s (1 GPU)",
                        "ms_per_step": round(tdt / tsteps * 1e3, 3), "ms_per_iteration": round(tdt / tsteps / K_ITER * 1e3, 3)}
 
+        flop_it, src = train_flops_per_iteration()
+        if flop_it:
+            tfs = flop_it / (tdt / tsteps / K_ITER) / 1e12
+            train_extra.update({"mfma_gflop_per_iteration": round(flop_it / 1e9, 1), "mfma_gflop_source": src,
+                                "tflops": round(tfs, 1), "path_frac_of_mfma_peak": round(tfs / FP32_MFMA_PEAK_TFLOPS, 4)})
+
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     comm = comm_info(dist, dev, world, rank, local_rank)
 
@@ -519,7 +549,7 @@ def main():
                               f"bytes per launch = {B_PER_GPU * (N_PTS + M_PTS) * 12}")
         path_flops = flops_per_object_iteration(N_PTS, M_PTS)
         line = {
-            "metric": f"pose-refine iters/sec (B=256, N={N_PTS}, K={K_ITER})"
+            "metric": f"pose-refine iters/sec (B={B_PER_GPU}, N={N_PTS}, K={K_ITER})"
                       + (" [bf16 operands]" if bf16 else (" [split-bf16 GEMMs]" if split else "")),
             "value": round(value, 1),
             "unit": "object-iterations/s",
@@ -537,7 +567,7 @@ def main():
             "dtype": "bf16" if bf16 else ("f32+bf16x3" if split else "f32"),
             "data": "synthetic",
             "config": {
-                "workload": f"B=256 objects/GPU, N={N_PTS} observed + M={M_PTS} prior points, K={K_ITER} refine iterations, "
+                "workload": f"B={B_PER_GPU} objects/GPU, N={N_PTS} observed + M={M_PTS} prior points, K={K_ITER} refine iterations, "
                             "forward-only (eval loop of catre_evaluator.py:292-311), "
                             + ("bf16 MFMA operands / fp32 accumulate" if bf16 else
                                ("fp32 results; STN conv2/conv3 (+fstn conv1), trunk conv3/conv4 and rot-head layers 0/1 as split-bf16 (hi+lo, "

@@ -9,10 +9,13 @@
 No torch op is on the hot path: the only torch calls are ``torch.empty`` for outputs/workspace.
 """
 import ctypes
+import logging
 
 import torch
 
 from . import hip
+
+logger = logging.getLogger(__name__)
 
 
 def opts_from_cfg(cfg, feature_transform=True):
@@ -48,7 +51,13 @@ def opts_from_cfg(cfg, feature_transform=True):
 
 
 class HipRuntime:
-    """One per model instance (and device)."""
+    """One per model instance (and device).
+
+    One runtime serves ONE stream at a time for weight packing: the packed image is a single buffer that ``params``
+    rewrites in place, stream-ordered, whenever a parameter changed - and the training forward rewrites it on every
+    call (``train_stn3d``).  Inference calls on several streams may share a runtime (each stream has its own workspace,
+    the image is only read); a training stream next to a concurrent inference stream - or a ``GraphedRefine`` replay -
+    on the SAME runtime is not supported: use a second model instance (``copy.deepcopy`` drops the runtime)."""
 
     def __init__(self, named_params, N, M, ts_in_dim, root=None):
         """``named_params``: callable returning ``{state_dict key: tensor}`` of the LIVE parameters.  ``root`` (optional):
@@ -65,6 +74,7 @@ class HipRuntime:
         self._param_keep = None
         self._packed = None
         self._packed_sel = 0
+        self._capture_fp = None  # ((stream, fingerprint), sel) of the pack recorded by the capture in progress
         self._ws = None
 
     # ------------------------------------------------------------------ weights
@@ -94,6 +104,15 @@ class HipRuntime:
         lib = hip.load()
         tensors = self._live_params()
         fp = (hip.param_epoch(),) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and self._packed is not None and self._packed.device == device and self._capture_fp is not None \
+                and self._capture_fp[0] == (torch.cuda.current_stream(device).cuda_stream, fp) \
+                and not (sel & ~self._capture_fp[1]):
+            # this capture has already recorded a pack of these weights holding every image asked for: the later
+            # encoder / head entry points of the same captured forward reuse it (one pack node per replay, not one per call)
+            return self._param_arr, self._packed
+        if not capturing:
+            self._capture_fp = None
         if fp == self._fingerprint and self._packed is not None and self._packed.device == device \
                 and (sel & ~self._packed_sel):
             sel |= self._packed_sel  # same weights, more packs wanted: redo with the union
@@ -115,8 +134,10 @@ class HipRuntime:
             )
             # a pack issued while the stream is being captured is only RECORDED (GraphedTrainStep): the buffer still holds
             # whatever the last executed pack wrote, so the cache must not call it fresh
-            self._fingerprint = None if torch.cuda.is_current_stream_capturing() else fp
+            self._fingerprint = None if capturing else fp
             self._packed_sel = int(sel)
+            if capturing:
+                self._capture_fp = ((torch.cuda.current_stream(device).cuda_stream, fp), int(sel))
         return self._param_arr, self._packed
 
     # ------------------------------------------------------------------ workspace
@@ -130,11 +151,17 @@ class HipRuntime:
         if self._ws is None:
             self._ws = {}
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < need:
             if ws is None and len(self._ws) >= 16:
-                self._ws.clear()  # stale streams: the caching allocator keeps the blocks alive until their work is done
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+                # least recently used stream only (dicts keep insertion order; every use re-inserts): the caching
+                # allocator keeps the block alive until the work queued on it is done, and whoever captured an address
+                # (GraphedRefine / GraphedTrainStep) holds its own reference
+                old = next(iter(self._ws))
+                del self._ws[old]
+                logger.info("HipRuntime: workspace of stream %#x evicted (16 streams cached)", old[1])
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+        self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ drivers

@@ -6,12 +6,14 @@ Row orders used below: "cloud-major" = B*N observed rows then B*M prior rows; "o
 [N observed | M prior] per object.
 """
 import ctypes
+import logging
 
 import torch
 import torch.nn.functional as F
 
 from . import hip
 
+logger = logging.getLogger(__name__)
 _scratch = {}
 
 
@@ -22,12 +24,16 @@ def _ws(nbytes, device):
     only - whoever captured its address (``GraphedTrainStep``) keeps its own reference (``scratch_of``)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
-    buf = _scratch.get(key)
+    buf = _scratch.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         if buf is None and len(_scratch) >= 32:
-            _scratch.clear()  # stale streams: the caching allocator keeps a block alive until its queued work is done
+            # least recently used stream only (every use re-inserts its key at the end): the caching allocator keeps a
+            # block alive until its queued work is done; a capture that baked an address in keeps its own reference
+            old = next(iter(_scratch))
+            del _scratch[old]
+            logger.info("train_ops: scratch of stream %#x evicted (32 streams cached)", old[1])
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _scratch[key] = buf
+    _scratch[key] = buf
     return buf
 
 

@@ -131,6 +131,67 @@ def block(tag, title, stats_file, pmc_file, keys, note):
     return lines
 
 
+def _raw_stats(path):
+    out = []
+    if os.path.exists(path):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                out.append((short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]) / 1e3))
+    return out
+
+
+def _raw_pmc(path):
+    out = []
+    if os.path.exists(path):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                g = lambda k: float(r[k]) if r.get(k) not in (None, "") else 0.0
+                out.append(dict(k=canon(r["Kernel"]), n=int(r["Dispatches"]),
+                                flop=512.0 * (g("mean_SQ_INSTS_VALU_MFMA_MOPS_F32") + g("mean_SQ_INSTS_VALU_MFMA_MOPS_BF16")),
+                                hbm=1024.0 * (2 * g("mean_FETCH_SIZE") + g("mean_WRITE_SIZE"))))
+    return out
+
+
+def budget(title, stats_file, pmc_file, ref, peak, only=None):
+    """One line of iteration arithmetic per mode, every figure from the two committed files: MFMA work per iteration
+    (PMC MOPS counters x 512 FLOP), HBM bytes per iteration (FETCH_SIZE x 2 + WRITE_SIZE), kernel time per iteration
+    (kernel trace), the share of that time spent in launches that carry < 1 % of the FLOPs each (the non-MFMA tail), and the
+    fraction of the dense MFMA peak the iteration sustains.  `ref`: the kernel that runs once per iteration; `only`: keep the
+    kernels whose name matches (runs that also time another mode)."""
+    st, pm = _raw_stats(os.path.join(HERE, stats_file)), _raw_pmc(os.path.join(HERE, pmc_file))
+    keep = (lambda k: re.search(only, k) is not None) if only else (lambda k: True)
+    it_s = sum(c for k, c, _ in st if k == ref)
+    it_p = sum(r["n"] for r in pm if r["k"] == ref)
+    if not it_s or not it_p:
+        return f"| {title} | - | - | - | - | - | - | (`profiles/{stats_file}` / `profiles/{pmc_file}` not collected) |"
+    flop = sum(r["n"] * r["flop"] for r in pm if keep(r["k"])) / it_p
+    hbm = sum(r["n"] * r["hbm"] for r in pm if keep(r["k"])) / it_p
+    big = {r["k"] for r in pm if keep(r["k"]) and r["n"] * r["flop"] / it_p >= 0.01 * flop}
+    t_all = sum(c * us for k, c, us in st if keep(k)) / it_s
+    t_tail = sum(c * us for k, c, us in st if keep(k) and k not in big) / it_s
+    n_all = sum(c for k, c, _ in st if keep(k)) / it_s
+    n_tail = sum(c for k, c, _ in st if keep(k) and k not in big) / it_s
+    tf = flop / (t_all * 1e-6) / 1e12
+    return (f"| {title} | {flop / 1e9:.1f} | {hbm / 1e9:.2f} | {t_all / 1e3:.3f} | {n_all:.0f} | {t_tail / 1e3:.3f} ms in {n_tail:.0f} launches "
+            f"({100 * t_tail / t_all:.0f} %) | {tf:.1f} | {tf / peak:.3f} of {peak:.0f} |")
+
+
+def budgets(tag):
+    lines = ["**Iteration arithmetic per mode** (one refine iteration at B=256, N=M=1024; FLOPs and bytes are the PMC passes' counters, "
+             "time is the kernel trace's - profiled runs, a few % slower than the un-profiled bench; the tail is every launch that "
+             "carries < 1 % of the mode's FLOPs)", "",
+             "| mode | MFMA GFLOP / iteration (PMC) | HBM GB / iteration (PMC) | kernel ms / iteration | launches | non-MFMA tail | TFLOP/s | fraction of the dense peak |",
+             "|---|---|---|---|---|---|---|---|"]
+    no_other = r"^(?!.*(_split|_bf|k_colmax|distribution|reduce_kernel))"
+    lines.append(budget("fp32 inference", f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv", "k_trunk<1>", FP32_PEAK, only=no_other))
+    lines.append(budget("bf16 operands", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv", "k_trunk_bf2", BF16_PEAK,
+                        only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
+    lines.append(budget("fp32 training (forward + loss + backward + Ranger)", f"{tag}_train_kernel_stats.csv",
+                        f"{tag}_train_pmc_summary.csv", "k_trunk<1, true>", FP32_PEAK))
+    lines.append("")
+    return lines
+
+
 def render(tag="r03"):
     out = [f"<!-- BEGIN GENERATED by profiles/make_tables.py {tag} -->"]
     out += block(tag, "fp32 headline path, B=256, N=M=1024, one refine iteration per row",
@@ -146,6 +207,7 @@ def render(tag="r03"):
                   "k_gemm_rows<1, 32>", "k_gemm_rows<1, 8>", "k_gemm_rows<1, 16>", "k_gemm_tn<2>",
                   "k_gemm_tn<1>"],
                  "; GFLOP = the op's dense GEMM work on B*(N+M) rows")
+    out += budgets(tag)
     out.append("<!-- END GENERATED -->")
     return "\n".join(out)
 

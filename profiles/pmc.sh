@@ -9,10 +9,10 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$name" -- python "$root/bench.py" --steps 2 --warmup 1 \
-    --no-cpu-baseline --no-train-extra --no-small-extra "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || tail -3 "$out/$name.log"
+    --no-cpu-baseline --no-train-extra --no-small-extra --no-split-extra "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || tail -3 "$out/$name.log"
 }
 BENCH_ARGS=("$@")
-run sq SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
+run sq SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 find "$out" -name '*counter_collection.csv' | head
