@@ -1188,21 +1188,16 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
   const int hd = blockIdx.y;
   const RotTile rt = rot_tile(blockIdx.x, B, N, M);
   const u32x4* src = reinterpret_cast<const u32x4*>(y1) + (((size_t)rt.obj * 2 + hd) * T + rt.t) * (2 * 256 * 4);
-  u32x4 rows[8];
+  // The small (L2-resident) operands are requested BEFORE the tile: vmcnt retires in order, so behind the 32 KiB of HBM
+  // loads their consumers - the constant table and the barrier - would wait for the whole tile first.
+  const float* gam = hd ? gam1y : gam1x;
+  const float* bet = hd ? bet1y : bet1x;
+  const float* neck = hd ? necky : neckx;
+  const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (tid >> 3) * 2;
+  const float mean = st[0], rstd = st[1], gm = gam[tid], bt = bet[tid];
+  float nk[3];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) rows[i] = __builtin_nontemporal_load(src + i * 256 + tid);
-  {
-    const float* gam = hd ? gam1y : gam1x;
-    const float* bet = hd ? bet1y : bet1x;
-    const float* neck = hd ? necky : neckx;
-    const float* st = gn1stat + ((size_t)rt.obj * 2 + hd) * 64 + (tid >> 3) * 2;
-    const float mean = st[0], rstd = st[1];
-    const float sc = rstd * gam[tid];
-    cst[0][tid] = sc;
-    cst[1][tid] = bet[tid] - mean * sc;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) cst[2 + c][tid] = c < rd ? neck[c * 256 + tid] : 0.f;
-  }
+  for (int c = 0; c < 3; ++c) nk[c] = c < rd ? neck[c * 256 + tid] : 0.f;
   // conv_p weights of the lane's 2 x 8 points (zero past the ragged end: those slots hold clamped duplicates)
   const float* wp = (hd ? wpy : wpx) + rt.gp0;
   const int pbase = (tid & 3) * 8;
@@ -1211,6 +1206,18 @@ __global__ __launch_bounds__(256) void k_rot_out_bf(const unsigned short* __rest
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int e = 0; e < 8; ++e) w[nb][e] = nb * 32 + pbase + e < rt.valid ? wp[nb * 32 + pbase + e] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 rows[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rows[i] = __builtin_nontemporal_load(src + i * 256 + tid);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float sc = rstd * gm;
+    cst[0][tid] = sc;
+    cst[1][tid] = bt - mean * sc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cst[2 + c][tid] = nk[c];
+  }
   __syncthreads();
   float a3[3] = {0.f, 0.f, 0.f};
 #pragma unroll

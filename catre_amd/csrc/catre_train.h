@@ -1367,22 +1367,41 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
   // several workgroups (each repeats the cheap bucketing above) so that the row walk is not one long serial chain.
   // A row is a chain of dependent loads (bucket entry -> dg, W row): eight waves walk rows side by side and a lane's
   // two column slices are requested together - the walk is bound by that latency, not by the bytes it writes.
+  // (the channel gradients of the cloud sit in LDS - `fill` is free after the bucketing - so that a row's chain is bucket
+  // entry (LDS) -> W row (L2) and not bucket entry -> dg (L2) -> W row (L2); and a row's channels are fetched FOUR at a
+  // time: most rows own one to four channels, so a row costs one L2 round trip instead of one per channel.  The sums run
+  // in the same ascending channel order as before: not a bit changes.)
+  float* gl = reinterpret_cast<float*>(fill);
+  for (int j = tid; j < 1024; j += 512) gl[j] = j < J ? g[j] : 0.f;
+  __syncthreads();
   for (int r = blockIdx.y * 8 + wave; r < n; r += 8 * gridDim.y) {
     const int b = start[r], e = start[r + 1];
     if (rowpos && b == e) continue;  // compact destination: rows without a channel do not exist
     float* xr = dX + (size_t)(rowpos ? rowpos[r0 + r] : r0 + r) * ldx;
     const int q0 = lane, q1 = lane + 64;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    for (int t = b; t < e; ++t) {
-      const int j = lst[t];
-      const float gv = g[j];
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 w0 = q0 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q0 * 4) : z;
-      const f32x4 w1 = q1 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)j * ldw + q1 * 4) : z;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int t = b; t < e; t += 4) {
+      int jj[4];
+      float gv[4];
+      f32x4 w0[4], w1[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc0[u] = fmaf(gv, w0[u], acc0[u]);
-        acc1[u] = fmaf(gv, w1[u], acc1[u]);
+      for (int d = 0; d < 4; ++d) {
+        const bool on = t + d < e;  // wave-uniform
+        jj[d] = lst[min(t + d, e - 1)];
+        gv[d] = on ? gl[jj[d]] : 0.f;
+        w0[d] = on && q0 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)jj[d] * ldw + q0 * 4) : z;
+        w1[d] = on && q1 < nf4 ? *reinterpret_cast<const f32x4*>(W + (size_t)jj[d] * ldw + q1 * 4) : z;
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (t + d < e) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0[u] = fmaf(gv[d], w0[d][u], acc0[u]);
+            acc1[u] = fmaf(gv[d], w1[d][u], acc1[u]);
+          }
+        }
       }
     }
     if (ymask) {
