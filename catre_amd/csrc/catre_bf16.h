@@ -228,8 +228,8 @@ __device__ __forceinline__ void save_tile_rows_bf(const u32x4* __restrict__ img,
     const f32x4 lo = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
     const f32x4 hi = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
     float* d = dst + (size_t)row * C + 16 * (c >> 1) + 4 * (c & 1);
-    *reinterpret_cast<f32x4*>(d) = lo;
-    *reinterpret_cast<f32x4*>(d + 8) = hi;
+    st_stream(reinterpret_cast<f32x4*>(d), lo);
+    st_stream(reinterpret_cast<f32x4*>(d + 8), hi);
   }
 }
 

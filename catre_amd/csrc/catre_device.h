@@ -383,6 +383,22 @@ __device__ __forceinline__ void max_tile_store_pre(const f32x16 (&acc)[MB][NB], 
 }
 
 
+// Stores of large activation tensors that the next launch (or the backward, much later) reads back: non-temporal.  A plain
+// store leaves its line dirty in the 256 MiB Infinity Cache; behind > 256 MiB of them the NEXT kernel's reads run against
+// their write-back (profiles/ubench/mall_reread.hip: 1 GiB written with plain stores reads back at 4.1 TB/s, with
+// non-temporal stores at 5.7 TB/s; a 256 MiB buffer behind 1 GiB of other plain-store traffic at 2.5 TB/s).
+#ifndef CATRE_NT_SAVES
+#define CATRE_NT_SAVES 1
+#endif
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, const T& v) {
+#if CATRE_NT_SAVES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // ---- training forward of the fused encoder kernels (SAVE variants): what the layer-wise backward needs ----------------
 // LDS activation image [TP][ld] (point-major) -> global rows dst[TP][C], coalesced float4 stores by all NT threads
 template <int C, int NT, bool SWZ>
@@ -392,7 +408,7 @@ __device__ __forceinline__ void save_tile_rows(const float* __restrict__ img, in
   for (int u = 0; u < TP * F4 / NT; ++u) {
     const int i = tid + NT * u, row = i / F4, c4 = i % F4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(img + (SWZ ? swz_off(row, c4, ld) : row * ld + c4 * 4));
-    *reinterpret_cast<f32x4*>(dst + (size_t)row * C + c4 * 4) = v;
+    st_stream(reinterpret_cast<f32x4*>(dst + (size_t)row * C + c4 * 4), v);
   }
 }
 

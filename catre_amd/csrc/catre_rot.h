@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
             const int row = nb * 32 + (r & 3) + 8 * (r >> 2);  // + 4 h: in rowg / below
             const float v = acc[mb][nb][r];
             const float z = gelu_erf(fmaf(v, scv[mb], shv[mb]));
-            yp[row * 256] = v + b0v[mb];
-            ap[row * 256] = z;
+            st_stream(yp + row * 256, v + b0v[mb]);
+            st_stream(ap + row * 256, z);
             a0[swz_off(row + 4 * h, c >> 2, 256) + (c & 3)] = z;
           }
       }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float v = acc[mb][nb][r];
-              dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
+              st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
               s += v;
             }
         } else {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
             for (int r = 0; r < 16; ++r) {
               const float v = acc[mb][nb][r];
               if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
-                dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
+                st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
                 s += v;
               }
             }
@@ -289,7 +289,10 @@ __device__ __forceinline__ void rot_out_body(const float* __restrict__ y1, const
   }
   const float* src = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + c0;
   float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
+#ifndef ROT_OUT_UNROLL
+#define ROT_OUT_UNROLL 4
+#endif
+#pragma unroll ROT_OUT_UNROLL
   for (int p = wave; p < rt.valid; p += 4) {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)p * 256));
     const float w = wp[rt.gp0 + p];

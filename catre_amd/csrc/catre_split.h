@@ -147,8 +147,8 @@ __device__ __forceinline__ void save_tile_rows_split(const u32x4* __restrict__ i
     const f32x4 lo = {bf_lo(a[0]) + bf_lo(b[0]), bf_hi(a[0]) + bf_hi(b[0]), bf_lo(a[1]) + bf_lo(b[1]), bf_hi(a[1]) + bf_hi(b[1])};
     const f32x4 hi = {bf_lo(a[2]) + bf_lo(b[2]), bf_hi(a[2]) + bf_hi(b[2]), bf_lo(a[3]) + bf_lo(b[3]), bf_hi(a[3]) + bf_hi(b[3])};
     float* d = dst + (size_t)row * C + 16 * (c >> 1) + 4 * (c & 1);
-    *reinterpret_cast<f32x4*>(d) = lo;
-    *reinterpret_cast<f32x4*>(d + 8) = hi;
+    st_stream(reinterpret_cast<f32x4*>(d), lo);
+    st_stream(reinterpret_cast<f32x4*>(d + 8), hi);
   }
 }
 
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
             for (int r = 0; r < 16; ++r) {
               const int row = nb * 32 + (r & 3) + 8 * (r >> 2);
               const float v = accs[mb][nb][r];
-              yp[row * 256] = v + b0v[mb];
-              ap[row * 256] = gelu_erf(fmaf(v, scv[mb], shv[mb]));
+              st_stream(yp + row * 256, v + b0v[mb]);
+              st_stream(ap + row * 256, gelu_erf(fmaf(v, scv[mb], shv[mb])));
             }
         }
       }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float v = acc[mb][nb][r];
-              dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
+              st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
               s += v;
             }
         } else {
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_split(const float* __restrict
             for (int r = 0; r < 16; ++r) {
               const float v = acc[mb][nb][r];
               if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
-                dh[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = v;
+                st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
                 s += v;
               }
             }

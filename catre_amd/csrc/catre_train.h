@@ -2601,7 +2601,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[(nb * 32 + (r & 3) + 8 * (r >> 2)) * 256] = acc[mb][nb][r];
+          for (int r = 0; r < 16; ++r) st_stream(o + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, acc[mb][nb][r]);
       }
     }
     {  // dW += dY^T A: j-blocks 2 wave, 2 wave + 1 x all eight k-blocks; operands two steps ahead, pinned

@@ -186,6 +186,9 @@ def budgets(tag):
     lines.append(budget("fp32 inference", f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv", "k_trunk<1>", FP32_PEAK, only=no_other))
     lines.append(budget("bf16 operands", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv", "k_trunk_bf2", BF16_PEAK,
                         only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
+    lines.append(budget("split mode (issued bf16 products: three per fp32-grade product)", f"{tag}_split_kernel_stats.csv",
+                        f"{tag}_split_pmc_summary.csv", "k_trunk_split<1>", BF16_PEAK,
+                        only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
     lines.append(budget("fp32 training (forward + loss + backward + Ranger)", f"{tag}_train_kernel_stats.csv",
                         f"{tag}_train_pmc_summary.csv", "k_trunk<1, true>", FP32_PEAK))
     lines.append("")
@@ -197,7 +200,8 @@ def render(tag="r03"):
     out += block(tag, "fp32 headline path, B=256, N=M=1024, one refine iteration per row",
                  f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv",
                  ["k_trunk<1>", "k_stn3d<1>", "k_stnkd<1>", "k_rot_l1<1>"], "")
-    out += block(tag, "split mode (opt-in)", f"{tag}_split_kernel_stats.csv", f"{tag}_pmc_summary.csv",
+    out += block(tag, "split mode (opt-in)", f"{tag}_split_kernel_stats.csv",
+                 f"{tag}_split_pmc_summary.csv" if os.path.exists(os.path.join(HERE, f"{tag}_split_pmc_summary.csv")) else f"{tag}_pmc_summary.csv",
                  ["k_trunk_split<1>", "k_stn3d_split<1>", "k_stnkd_split<1>", "k_rot_l1_split"],
                  "; peak = a third of the bf16 dense peak (three products per fp32-grade product)")
     out += block(tag, "bf16 operands (BASELINE config 5 arithmetic)", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv",
