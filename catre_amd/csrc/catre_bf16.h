@@ -655,10 +655,15 @@ __device__ __forceinline__ void pair_info(int bid, int B, int N, int M, TileInfo
 // weight fragment feeds four MFMAs).  Same contraction order per output, exact maxima: the bits of k_stn3d_bf / k_stnkd_bf.
 // conv3 128 -> 1024 + ReLU + max: the wave owns m-blocks [8 wave, +8) in four passes of two.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stn_conv3_pair_bf(const u32x4* __restrict__ wp3, const float* __restrict__ b3, const u32x4* a2,
-                                                  float* __restrict__ out, float* __restrict__ out2, int wave, int lane) {
-  GemmPipeB<2, 4, true, 16, 3, 1, true> g[2];
+typedef GemmPipeB<2, 4, true, 16, 3, 1, true> StnConv3Pipe;
+// g[0] arrives with its first weight fragments already requested (stn_conv3_prefetch, issued by the caller BEFORE the conv2
+// phase: the L2 round trip then runs under conv2 and its barrier instead of after them)
+__device__ __forceinline__ void stn_conv3_prefetch(StnConv3Pipe (&g)[2], const u32x4* __restrict__ wp3, int wave, int lane) {
   g[0].prefetch(wp3 + ((size_t)(wave * 8) * 8) * 64 + lane, 8 * 64);
+}
+__device__ __forceinline__ void stn_conv3_pair_bf(StnConv3Pipe (&g)[2], const u32x4* __restrict__ wp3,
+                                                  const float* __restrict__ b3, const u32x4* a2,
+                                                  float* __restrict__ out, float* __restrict__ out2, int wave, int lane) {
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     f32x16 acc[2][4];
@@ -699,6 +704,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
     conv3_relu_chunks(x, y, z, W1, b1, g0 + 1, a1 + p * 8, bf_key<8>(p));
   }
   __syncthreads();
+  StnConv3Pipe g3[2];
+  stn_conv3_prefetch(g3, wp3, wave, lane);
   {
     f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
     g2.run(acc, a1, lane);
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
   }
   __syncthreads();
   float* out = pm + (size_t)tile0 * PMW;
-  stn_conv3_pair_bf(wp3, b3, a2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+  stn_conv3_pair_bf(g3, wp3, b3, a2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
 }
 
 __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const float* __restrict__ trans3,
@@ -750,6 +757,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
     store_tile_bf<1, 2, true, 8>(acc, f1 + half1 * TP * 8, mblk1, bv1, lane);
   }
   __syncthreads();
+  StnConv3Pipe g3[2];
+  stn_conv3_prefetch(g3, wpf3, wave, lane);
   {
     f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
     g2.run(acc, f1, lane);
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
   }
   __syncthreads();
   float* out = pm + (size_t)tile0 * PMW;
-  stn_conv3_pair_bf(wpf3, bf3, f2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+  stn_conv3_pair_bf(g3, wpf3, bf3, f2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
 }
 
 #define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)

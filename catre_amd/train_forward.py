@@ -93,10 +93,9 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     """RotHead.forward (heads/conv_out_per_rot_head.py:126-140) on the never-materialised cat(pcl_feat,kps_feat)."""
     w = lambda n: p[f"{prefix}.{n}"]
     P = N + M
-    W0 = w("layers.0.weight").reshape(256, 1088)
-    bias0 = T.linear(g, W0[:, :1024].contiguous(), w("layers.0.bias"))       # [2B,256]: global half + conv bias
+    W0g, W0b = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)   # global half (a view) | point half
+    bias0 = T.linear(g, W0g, w("layers.0.bias"))                              # [2B,256]: global half + conv bias
     # [B*P,256]; the per-cloud bias and the GroupNorm tile partials are epilogue work of the GEMMs
-    W0b = W0[:, 1024:].contiguous()
     if T.rot_l0_block_ok(pf_obj, W0b, N, M):
         a = T.rot_l0_block(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), B, N, M)
     else:
@@ -152,15 +151,15 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
     P = N + M
     W0s, b0s = [], []
     for pre in _ROT_PREFIX:
-        W0 = p[f"{pre}.layers.0.weight"].reshape(256, 1088)
-        W0s.append(W0)
-        b0s.append(T.linear(g, W0[:, :1024].contiguous(), p[f"{pre}.layers.0.bias"]))   # [2B,256]
+        W0g, W0l = T.split_cols(p[f"{pre}.layers.0.weight"].reshape(256, 1088), 1024)
+        W0s.append(W0l)
+        b0s.append(T.linear(g, W0g, p[f"{pre}.layers.0.bias"]))   # [2B,256]
     prm, packed = rt._train_packs(pf.device, 2)
     buf = T.rot_heads_forward(pf.detach(), b0s[0], b0s[1], prm, packed, B, N, M, 2)
     out = []
     for h, pre in enumerate(_ROT_PREFIX):
         w = lambda n: p[f"{pre}.{n}"]
-        y, _ = T.linear_cloudbias(pf_obj, W0s[h][:, 1024:].contiguous(), b0s[h], B, N, M, with_gn_partials=True,
+        y, _ = T.linear_cloudbias(pf_obj, W0s[h], b0s[h], B, N, M, with_gn_partials=True,
                                   pre=(buf["y0"][h], None))
         a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, None, pre=(buf["a0"][h], buf["stat0"][h]))
         y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,

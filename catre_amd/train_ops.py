@@ -209,7 +209,11 @@ class _Linear(torch.autograd.Function):
             # catre_train_*_fwd): this node only ties it into the graph; the backward below is the layer's own
             y = pre
         else:
-            xk, wk = _c(_pad_cols(x, 8)), _c(_pad_cols(w2, 8))
+            # (a weight that is a column slice of a wider matrix - rot-head layer 0's global half - is read in place: every
+            # kernel below takes its leading dimension)
+            xk, wk = _c(_pad_cols(x, 8)), _pad_cols(w2, 8)
+            if wk.stride(1) != 1 or wk.stride(0) % 4:
+                wk = _c(wk)
             y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k, amp=amp)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.K, ctx.has_b, ctx.amp = relu, K, b is not None, amp
@@ -276,7 +280,8 @@ def _linear_backward(ctx, dy, dy2=None):
     if ctx.needs_input_grad[0]:
         # dx[R,K] = dy[R,J] W[J,K]  ==  gemm_nt(dy, W^T[K,J]); the contraction length J is padded to 8
         if dy.shape[1] % 8 == 0:
-            dx = _gemm_nt(dy, None, None, False, xmask=ymask, amp=ctx.amp, wT=_c(w2))     # [R, K]
+            dx = _gemm_nt(dy, None, None, False, xmask=ymask, amp=ctx.amp,
+                          wT=w2 if (w2.stride(1) == 1 and w2.stride(0) % 4 == 0) else _c(w2))     # [R, K]
         else:
             wt = _c(_pad_cols(w2.t(), 8))      # [K, J8]
             dx = _gemm_nt(_c(_pad_cols(dy, 8)), wt, None, False, xmask=ymask, amp=ctx.amp)
@@ -330,14 +335,16 @@ def linear(x, w, b=None, relu=False, identity_k=0, pre=None):
 
 
 class _SplitCols(torch.autograd.Function):
-    """w [J, K] -> (w[:, :k0], w[:, k0:]) as two contiguous matrices (rot-head layer 0: the global and the point half of its
+    """w [J, K] -> (w[:, :k0] as a view, w[:, k0:] contiguous) (rot-head layer 0: the global and the point half of its
     1088-wide weight, conv_out_per_rot_head.py:126).  Backward: ONE cat of the two gradients - autograd's own slice backward
     is a zero-fill + copy per half and an add over [J, K]."""
 
     @staticmethod
     def forward(ctx, w, k0):
         ctx.k0, ctx.K = k0, w.shape[1]
-        return w[:, :k0].contiguous(), w[:, k0:].contiguous()
+        # the wide half stays a VIEW (the linear that consumes it reads it through its leading dimension: no 1 MB copy per
+        # head and iteration); the narrow half is packed by kernels that want it contiguous
+        return w[:, :k0], w[:, k0:].contiguous()
 
     @staticmethod
     def backward(ctx, da, db):
