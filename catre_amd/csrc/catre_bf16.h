@@ -1126,12 +1126,16 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
           }
         }
         if (abl & 8) continue;
-        float s = 0.f, m2 = 0.f;
-        if (rt.valid == TP) {  // full tile (wave-uniform): no predication
+        float s = 0.f, m2 = 0.f, q = 0.f;
+        if (rt.valid == TP) {  // full tile (wave-uniform): no predication; sum and sum of squares in ONE pass (VALU time
+                               // adds to MFMA time here): M2 = sum v^2 - n mean^2, fp32, 512 values of O(1)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += acc[mb][nb][r];
+            for (int r = 0; r < 16; ++r) {
+              s += acc[mb][nb][r];
+              q = fmaf(acc[mb][nb][r], acc[mb][nb][r], q);
+            }
         } else {  // ragged tile: see k_rot_l1
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
@@ -1144,13 +1148,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         s += __shfl_xor(s, 32);
         const float mean = s * inv_cnt;
         if (rt.valid == TP) {
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float d = acc[mb][nb][r] - mean;
-              m2 = fmaf(d, d, m2);
-            }
+          m2 = q;  // reduced over the group below like the ragged form's M2, then q_group - s_group * mean
         } else {
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
@@ -1164,6 +1162,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         m2 += __shfl_xor(m2, 2);
         m2 += __shfl_xor(m2, 4);
         m2 += __shfl_xor(m2, 32);
+        if (rt.valid == TP) m2 = fmaxf(m2 - s * mean, 0.f);
         if ((lane & 7) == 0 && h == 0) {
           float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
           out[0] = mean;
