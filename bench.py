@@ -540,12 +540,15 @@ def main():
         # rocprofv3): the figure is the one collected from this build by profiles/pmc.sh (separate --pmc passes, gfx950
         # FETCH_SIZE x2 correction) and committed next to its summary; `traffic_source` says so in the line itself
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_trunk_hbm_bytes.json")
-        if os.path.exists(pmc) and args.dtype == "fp32" and args.shape == "headline":
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_trunk_hbm_bytes.json")))  # newest round's pass
+        if pmcs and args.dtype == "fp32" and args.shape == "headline":
+            pmc = pmcs[-1]
+            tag = os.path.basename(pmc)[:3]
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-            traffic_source = ("profiles/r03_trunk_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "build (profiles/pmc.sh, profiles/r03_pmc_summary.csv), not measured in this run; algorithmic "
+            traffic_source = (f"profiles/{os.path.basename(pmc)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              f"build (profiles/pmc.sh, profiles/{tag}_pmc_summary.csv), not measured in this run; algorithmic "
                               f"bytes per launch = {B_PER_GPU * (N_PTS + M_PTS) * 12}")
         path_flops = flops_per_object_iteration(N_PTS, M_PTS)
         line = {

@@ -32,6 +32,11 @@
 // an object's result does not depend on how many objects share its batch.
 #define PF_NG 4
 #define PF_MOM_SMEM (2 * TP * LD64 + 4 * 64 + 64)  // floats of LDS
+#ifndef PF_SPLIT_ALWAYS
+#define PF_SPLIT_ALWAYS 0
+#endif
+// workgroups per cloud of k_pf_moments (gridDim.y): the four tile groups on four workgroups, or one workgroup for all
+inline int pf_groups(int B) { return (PF_SPLIT_ALWAYS || 2 * B * PF_NG <= 256) ? PF_NG : 1; }
 // body for cloud `cloud`, tile group by of gy (gy == 1: all four groups); 256 threads
 // BF: pointfeat is the bf16 point-major buffer of the reduced-precision path ([point][8 chunks of 8 bf16], channels in
 // k-slot order inside a chunk - catre_bf16.h); a thread then stages chunk tid & 7 of rows tid >> 3 and (tid >> 3) + 32.

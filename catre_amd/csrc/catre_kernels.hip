@@ -1685,7 +1685,7 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
   {
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
     // a handful of clouds: the four tile groups of a cloud on four workgroups (same partial sums, same result)
-    hipLaunchKernelGGL(k_pf_moments, dim3(2 * B, 2 * B * PF_NG <= 256 ? PF_NG : 1), dim3(256), 0, st, pointfeat, Gc, s1c,
+    hipLaunchKernelGGL(k_pf_moments, dim3(2 * B, pf_groups(B)), dim3(256), 0, st, pointfeat, Gc, s1c,
                        shc, B, N, M);
     hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, gn0_shares(B)), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
@@ -1844,7 +1844,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     float* s1c = Gc + (size_t)2 * B * PF_NG * 4096;
     float* shc = s1c + (size_t)2 * B * PF_NG * 64;
     ProfScope ps(CATRE_K_ROT_L0_STATS, st);
-    hipLaunchKernelGGL(k_pf_moments_bf, dim3(2 * B, 2 * B * PF_NG <= 256 ? PF_NG : 1), dim3(256), 0, st, pointfeat, Gc, s1c,
+    hipLaunchKernelGGL(k_pf_moments_bf, dim3(2 * B, pf_groups(B)), dim3(256), 0, st, pointfeat, Gc, s1c,
                        shc, B, N, M);
     hipLaunchKernelGGL(k_gn0_from_moments, dim3(B, gn0_shares(B)), dim3(256), 0, st, Gc, s1c, shc, prm[CATRE_P_ROTX_L0_W],
                        prm[CATRE_P_ROTY_L0_W], PMW, 1024, bias0, prm[CATRE_P_ROTX_GN0_W], prm[CATRE_P_ROTX_GN0_B],
