@@ -376,3 +376,17 @@ def test_design_roofline_table_is_generated_from_the_committed_profiles():
     assert m.group(0) == mt.render(m.group(1)), "DESIGN.md table is stale: python profiles/make_tables.py <tag> --write"
     for row in ("| `k_trunk<1>`", "| `k_rot_l1<1>`", "| `k_rot_l1<1, true>`", "| `k_rot_l1_bwd`", "| `k_trunk_bf2`", "| `k_trunk_split<1>`"):
         assert row in m.group(0), f"roofline table lost its {row} row (kernel renamed? see make_tables.canon)"
+
+
+def test_bench_train_flop_count_comes_from_the_committed_pmc_pass():
+    """`train_fp32.path_frac_of_mfma_peak` divides COUNTED MFMA work (newest profiles/rNN_train_pmc_summary.csv: dispatches x
+    SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOP per iteration) by measured time - no hand-written FLOP budget (VERDICT r3 #1)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    flop, src = bench.train_flops_per_iteration()
+    assert src and src.startswith("profiles/r") and src.endswith("_train_pmc_summary.csv")
+    # forward 1.10 TFLOP (SURVEY 8d: 4.315 GFLOP x 256) + rot-head backward 0.34 + row-sparse encoder backward < 0.1
+    assert 1.45e12 < flop < 1.65e12, flop
