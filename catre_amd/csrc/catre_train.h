@@ -2494,7 +2494,13 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ Wn, const float* __restrict__ A,
                                                     const f32x4* __restrict__ WpT, float* __restrict__ dA,
-                                                    float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
+                                                    float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw,
+                                                    unsigned long long* __restrict__ trace = nullptr) {
+#define L1B_STAMP(i)                                                                                       \
+  do {                                                                                                     \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                \
+      trace[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* dys = lds;                  // [64][260]
   float* as = lds + TP * L1B_LDY;    // [64][288]
@@ -2546,6 +2552,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
   if (t0 < t1) request_y(t0, 0);
   for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)obj * P + (size_t)t * TP;
+    L1B_STAMP(0);
     request_a(t, 0);
     request(t, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -2581,7 +2588,9 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
       if (bb < 2) request(t, bb + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    L1B_STAMP(1);
     __syncthreads();
+    L1B_STAMP(2);
     if (t + 1 < t1) request_y(t + 1, 0);  // (16 registers across the MFMA phases: the A rows too, or two batches, would spill)
     __builtin_amdgcn_sched_barrier(0);
     {  // dA tile = dY W: m-blocks 2 wave, 2 wave + 1 of the 256 input channels, both 32-row halves
@@ -2604,6 +2613,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
           for (int r = 0; r < 16; ++r) st_stream(o + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, acc[mb][nb][r]);
       }
     }
+    L1B_STAMP(3);
     {  // dW += dY^T A: j-blocks 2 wave, 2 wave + 1 x all eight k-blocks; operands two steps ahead, pinned
       const float* pa = dys + h * L1B_LDY + (2 * wave) * 32 + i;
       const float* pb = as + h * L1B_LDA + i;
@@ -2633,8 +2643,11 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    L1B_STAMP(4);
     __syncthreads();
+    L1B_STAMP(5);
   }
+#undef L1B_STAMP
   float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (256 * 256 + 256);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
