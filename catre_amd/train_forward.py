@@ -111,9 +111,11 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
         return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     if part is not None and P % 64 == 0:
-        # GroupNorm + GELU + neck in one op: the [B*P,256] activation in between is never stored
+        # GroupNorm + GELU + neck + conv_p as one node: the [B*P,256] activation in between is never stored and the backward
+        # needs no reduction pass over y (train_ops._NeckTail)
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
-        y3 = T.gn_points_gelu_neck(y, w("layers.4.weight"), w("layers.4.bias"), wn, bn, B, P, part)
+        return T.neck_tail(y, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                           p.get(f"{prefix}.conv_p.bias"), B, P, part)[:, :rd]
     else:
         a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
         y3 = neck_rows(a, w("neck.0.weight"), w("neck.0.bias"))              # [B*P,3] (columns >= rot_dim are zero)
@@ -165,9 +167,9 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
         y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
                                          pre=(buf["y1"][h], buf["part1"][h]))
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
-        y3 = T.gn_points_gelu_neck(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, B, P, part1)
         rd = w("neck.0.weight").shape[0]
-        out.append(T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, P)[:, :rd])
+        out.append(T.neck_tail(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                               p.get(f"{pre}.conv_p.bias"), B, P, part1)[:, :rd])
     return out
 
 

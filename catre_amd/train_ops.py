@@ -995,6 +995,62 @@ def gn_points_gelu_neck(y, gamma, beta, wn, bn, B, P, part):
     return _GNPointsGeluNeck.apply(y, gamma, beta, wn, bn, B, P, part)
 
 
+class _NeckTail(torch.autograd.Function):
+    """RotHead's tail - GroupNorm(32,256), GELU, neck conv 256 -> rot_dim and conv_p (the weighted sum over the points),
+    conv_out_per_rot_head.py:132-140 - as ONE node: y [B*P,256] (+ its tile partials) -> out [B,3].  Because the node ends
+    behind conv_p, every row's neck gradient is wp[p] * dout[b]: the forward also leaves three per-channel moments per tile
+    (catre_op_gnp_gelu_neck_fwd_s) and the backward takes the GroupNorm sums, dgamma, dbeta and dWn from them
+    (catre_op_gnp_gelu_neck_bwd_s) instead of a reduction pass over y (0.5 GiB per head).  Every compute mode: the block is
+    fp32 arithmetic in all of them; the fused fp32 heads (_RotHeads) have the same thing built in."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, wn, bn, wp, bp, B, P, part):
+        lib = hip.load()
+        y, wn = _c(y), _c(wn)
+        bnc = _c(bn) if bn is not None else None
+        wv = _c(wp.reshape(-1))
+        dev = y.device
+        y3 = torch.empty(y.shape[0], 3, dtype=torch.float32, device=dev)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=dev)
+        spart = torch.empty(y.shape[0] // 64, 3, 256, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_gnp_gelu_neck_fwd_s(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                                   hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat), hip.ptr(spart), B, P,
+                                                   _st(y)), "catre_op_gnp_gelu_neck_fwd_s")
+        out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, _st(y)), "catre_op_wsum_fwd")
+        ctx.save_for_backward(y, gamma, beta, wn, stat, spart, y3, wv)
+        ctx.dims, ctx.has_bn, ctx.has_bp, ctx.wp_shape = (B, P), bn is not None, bp is not None, wp.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, wn, stat, spart, y3, wv = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        dev = y.device
+        dout = _c(dout)
+        dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
+        dwp = torch.empty(P, dtype=torch.float32, device=dev)
+        dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp else None
+        ws = _ws(B * P * 4, dev)
+        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
+                                        hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+        dy = torch.empty_like(y)
+        dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
+        ws = _ws(lib.catre_op_gnp_gelu_neck_bwd_ws_bytes(B, P), dev)
+        hip.check(lib.catre_op_gnp_gelu_neck_bwd_s(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
+                                                   hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(dy), hip.ptr(dpar),
+                                                   hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_gnp_gelu_neck_bwd_s")
+        dbn = _colsum(dy3) if ctx.has_bn else None
+        return dy, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None
+
+
+def neck_tail(y, gamma, beta, wn, bn, wp, bp, B, P, part):
+    """y [B*P,256] with its tile partials ``part`` (linear_gn_partials; P % 64 == 0), wn [3,256], bn [3] or None, conv_p weight
+    [1,P,1] and bias -> [B,3] (columns >= rot_dim are zero)."""
+    return _NeckTail.apply(y, gamma, beta, wn, bn, wp, bp, B, P, part)
+
+
 class _RotL0Block(torch.autograd.Function):
     """A RotHead's first block in fp32 - 64 -> 256 linear with a per-cloud bias, GroupNorm(32,256), GELU
     (conv_out_per_rot_head.py:126-131) - as one graph node.  Forward: the two kernels of linear_cloudbias +

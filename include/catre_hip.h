@@ -395,6 +395,12 @@ int catre_op_gnp_gelu_neck_fwd_s(const float* Y, const float* part64, const floa
 int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
                           const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
                           float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* ... and the per-head form for the modes whose linear backward is not fused (autocast, split): sums and dparams from dout
+ * and Spart, then the apply pass -> dY [B*P,256] (what catre_op_gnp_gelu_neck_bwd returns, without its reduction pass over Y).
+ * ws as catre_op_gnp_gelu_neck_bwd_ws_bytes. */
+int catre_op_gnp_gelu_neck_bwd_s(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
+                                 const float* gamma, const float* beta, const float* Wn, float* dY, float* dparams, void* ws,
+                                 size_t ws_bytes, int B, int P, void* stream);
 /* dst [rows][cols_pad] (contiguous) = src [rows][cols] (element strides: transposed views too) followed by zero columns:
  * the padding of small operands to the GEMM kernels' granularity in one launch (F.pad of the reference-side glue). */
 int catre_op_pad_cols(const float* src, long stride_row, long stride_col, int rows, int cols, float* dst, int cols_pad,
