@@ -2665,6 +2665,200 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_rot_l1_bwd on the bf16 matrix pipe (torch.autocast: the backward of a bf16 linear runs in bf16 as well).  Same pass,
+// same fp32 GroupNorm / GELU' arithmetic, same outputs; the two GEMMs take bf16 operands (fp32 accumulation):
+//   * dY is written to LDS twice - row-major [64][256] in GemmPipeB's swizzled chunk layout (the dgrad contracts over the
+//     256 output channels: 8 consecutive channels per lane) and TRANSPOSED [256 columns][8 chunks of 8 rows] in
+//     k_gemm_tn_lp's tn_slot layout next to the transposed A tile (the wgrad contracts over the tile's rows, and
+//     v_mfma_f32_32x32x16_bf16 wants 8 consecutive contraction indices per lane);
+//   * a thread stages 4 columns x 8 consecutive rows per 32-row half (wave w: rows 8w..8w+7), in two batches of four rows:
+//     row-major 8-byte writes per row, one 16-byte transposed chunk per column and half.
+// 96 KiB of LDS, one wave per SIMD (256 weight-gradient accumulators per lane, as in the fp32 kernel).
+// WpT: bf16 fragments of W^T (k_op_pack_bf, transpose = 1: rows = input channels, K = output channels).
+// ------------------------------------------------------------------------------------------------
+#define L1L_IMG (TP * 32)  // 16-byte slots of one 64 x 256 bf16 image
+__global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__ dY3, const float* __restrict__ Y,
+                                                       const float* __restrict__ stat, const float* __restrict__ sums,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ Wn, const float* __restrict__ A,
+                                                       const u32x4* __restrict__ WpT, float* __restrict__ dA,
+                                                       float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 ldsq[];
+  u32x4* dys = ldsq;                // row-major, bf_off<32>(row, chunk)
+  u32x4* dyt = ldsq + L1L_IMG;      // transposed, tn_slot(column, chunk of 8 rows)
+  u32x4* ast = ldsq + 2 * L1L_IMG;  // transposed A tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int obj = blockIdx.x, T = P / TP;
+  const int t0 = blockIdx.y * tpw, t1 = min(T, t0 + tpw);
+  const int grp = lane >> 1;
+  const float mean = stat[((size_t)obj * 32 + grp) * 2], rstd = stat[((size_t)obj * 32 + grp) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + grp) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + grp) * 2 + 1] * inv_m;
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  const f32x4 w0 = reinterpret_cast<const f32x4*>(Wn)[lane], w1 = reinterpret_cast<const f32x4*>(Wn)[64 + lane],
+              w2 = reinterpret_cast<const f32x4*>(Wn)[128 + lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 wacc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) wacc[a][kb] = zero16();
+  const int i = lane & 31, h = lane >> 5;
+  // batch bb of a tile: rows (bb >> 1) * 32 + 8 wave + 4 (bb & 1) + u, u = 0..3; two batches of (Y, A) rows in flight while
+  // one is transformed, the first Y batch of the next tile across the MFMA phases (as in k_rot_l1_bwd)
+  auto row_of = [&](int bb, int u) { return (bb >> 1) * 32 + 8 * wave + 4 * (bb & 1) + u; };
+  f32x4 vy[2][4], va[2][4];
+  auto request_y = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      vy[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (rr + row_of(bb, u)) * 64 + lane);
+  };
+  auto request_a = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      va[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + (rr + row_of(bb, u)) * 64 + lane);
+  };
+  auto request = [&](int tt, int bb) {
+    request_y(tt, bb);
+    request_a(tt, bb);
+  };
+  u32x2* dys2 = reinterpret_cast<u32x2*>(dys);
+  if (t0 < t1) request_y(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const size_t r0 = (size_t)obj * P + (size_t)t * TP;
+    request_a(t, 0);
+    request(t, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // opaque per tile: keeps the ~70 LDS addresses of a tile (row-major and transposed staging slots, fragment slots) out
+    // of the tile loop's preheader, where they would sit in registers across all three phases
+    unsigned lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    unsigned hy[4][2], ha[4][2];  // rows 0..3 of the chunk, packed, until rows 4..7 arrive
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      float d3v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* d3 = dY3 + (r0 + row_of(bb, u)) * 3;
+        d3v[u][0] = d3[0];
+        d3v[u][1] = d3[1];
+        d3v[u][2] = d3[2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row_of(bb, u);
+        const float d0 = d3v[u][0], d1 = d3v[u][1], d2 = d3v[u][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float yv = vy[bb & 1][u][q];
+          const float xh = (yv - mean) * rstd;
+          const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
+          const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+          o[u][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
+          cs[q] += o[u][q];
+        }
+        const u32x2 pr = {pack_bf2(o[u][0], o[u][1]), pack_bf2(o[u][2], o[u][3])};
+        dys2[(row * 32 + ((lane_o >> 1) ^ (row & 15))) * 2 + (lane_o & 1)] = pr;
+      }
+      if ((bb & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hy[q][0] = pack_bf2(o[0][q], o[1][q]);
+          hy[q][1] = pack_bf2(o[2][q], o[3][q]);
+          ha[q][0] = pack_bf2(va[0][0][q], va[0][1][q]);
+          ha[q][1] = pack_bf2(va[0][2][q], va[0][3][q]);
+        }
+      } else {
+        const int chunk = (bb >> 1) * 4 + wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int slot = tn_slot(4 * (int)lane_o + q, chunk);
+          dyt[slot] = u32x4{hy[q][0], hy[q][1], pack_bf2(o[0][q], o[1][q]), pack_bf2(o[2][q], o[3][q])};
+          ast[slot] = u32x4{ha[q][0], ha[q][1], pack_bf2(va[1][0][q], va[1][1][q]), pack_bf2(va[1][2][q], va[1][3][q])};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (bb < 2) request(t, bb + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (t + 1 < t1) request_y(t + 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    {  // dA tile = dY W: input-channel blocks 2 wave, 2 wave + 1, both 32-row halves; a lane owns one input channel and
+       // 32 of the tile's rows (whole-line stores, see k_rot_l1_bwd)
+      f32x16 acc[2][2];
+      acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16();
+      GemmPipeB<2, 2, true, 32, 2, 1> gp;
+      gp.prefetch(WpT + ((size_t)(2 * wave) * 16) * 64 + lane_o, 16 * 64);
+      gp.run(acc, dys, (int)lane_o);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        float* o = dA + (r0 + 4 * h) * 256 + (2 * wave + mb) * 32 + i;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st_stream(o + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, acc[mb][nb][r]);
+      }
+    }
+    {  // dW += dY^T A: output-channel blocks 2 wave, 2 wave + 1 x all eight input-channel blocks; 16 rows per step.
+       // tn_slot(32 kb + i, 2 ks + h) = 256 kb + (b0 ^ (2 (kb ^ ks) & 7)) with b0 = tn_slot(i, h): one per-lane base, the
+       // block and the step only through compile-time (kb: wave-uniform) constants
+      const unsigned io = lane_o & 31, ho = lane_o >> 5;
+      const unsigned b0 = (io >> 1) * 16 + 8 * ((io ^ (io >> 2)) & 1) + ((ho ^ (io >> 1) ^ (io >> 4)) & 7);
+      u32x4 fa[2][2], fb[2][8];
+      auto frags = [&](int ks) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int jb = 2 * wave + a;
+          fa[ks & 1][a] = dyt[jb * 256 + (b0 ^ ((2 * (jb ^ ks)) & 7))];
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) fb[ks & 1][kb] = ast[kb * 256 + (b0 ^ ((2 * (kb ^ ks)) & 7))];
+      };
+      frags(0);
+#pragma unroll
+      for (int ks = 0; ks < TP / 16; ++ks) {
+        if (ks + 1 < TP / 16) frags(ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          wacc[0][kb] = mfma_bf(fa[ks & 1][0], fb[ks & 1][kb], wacc[0][kb]);
+          wacc[1][kb] = mfma_bf(fa[ks & 1][1], fb[ks & 1][kb], wacc[1][kb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (256 * 256 + 256);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = (2 * wave + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[(size_t)j * 256 + kb * 32 + i] = wacc[a][kb][reg];
+      }
+  // bias gradient partial (fp32 values, before the bf16 rounding): four row slices of 256 column sums, merged in wave order
+  float* red = reinterpret_cast<float*>(ldsq);
+  *reinterpret_cast<f32x4*>(red + wave * 256 + 4 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __syncthreads();
+  out[256 * 256 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm(32,256) + GELU on rows [R,256] (ts head): groups of 8 channels inside a row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gnr_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ gamma,

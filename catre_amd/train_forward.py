@@ -109,6 +109,11 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
         y3 = T.rot_l1_block(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
                             B, N, M)
         return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
+    if T.rot_l1_tail_lp_ok(a, w("layers.3.weight"), w("layers.3.bias"), N, M):
+        # autocast: the whole second half of the head as one node whose backward is one pass on the bf16 matrix pipe
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        return T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
+                                w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, N, M)[:, :rd]
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     if part is not None and P % 64 == 0:
         # GroupNorm + GELU + neck + conv_p as one node: the [B*P,256] activation in between is never stored and the backward

@@ -7,6 +7,7 @@ Row orders used below: "cloud-major" = B*N observed rows then B*M prior rows; "o
 """
 import ctypes
 import logging
+import os
 
 import torch
 import torch.nn.functional as F
@@ -1051,6 +1052,72 @@ def neck_tail(y, gamma, beta, wn, bn, wp, bp, B, P, part):
     return _NeckTail.apply(y, gamma, beta, wn, bn, wp, bp, B, P, part)
 
 
+class _RotL1TailLP(torch.autograd.Function):
+    """A RotHead from its second linear to the conv_p output under torch.autocast - Conv1d(256 -> 256) on bf16 operands,
+    GroupNorm(32,256), GELU, neck, conv_p (conv_out_per_rot_head.py:129-140) - as ONE node: a [B*P,256] -> out [B,3].
+    Forward: the bf16-operand row GEMM with the GroupNorm tile partials in its epilogue, then _NeckTail's two kernels.
+    Backward: conv_p, then catre_op_rot_l1_bwd_lp - the GroupNorm sums from the forward's moments and ONE pass over (y, a)
+    that rebuilds the linear's output gradient in LDS and takes da and dW from it on the bf16 matrix pipe (k_rot_l1_bwd_bf)
+    instead of the apply pass + a dgrad and a wgrad launch that each re-read a [B*P,256] fp32 matrix."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M):
+        lib = hip.load()
+        ac, w2, wn = _c(a), _c(w.reshape(256, -1)), _c(wn)
+        bc, bnc = _c(b), (_c(bn) if bn is not None else None)
+        wv = _c(wp.reshape(-1))
+        dev = a.device
+        R, P = ac.shape[0], N + M
+        pk = _pack_bf16(w2, 256, 256, dev)
+        y = torch.empty(R, 256, dtype=torch.float32, device=dev)
+        part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(ac), ac.stride(0), hip.ptr(pk), hip.ptr(bc), 0, hip.ptr(y), 256, 256, 256,
+                                            B, N, M, hip.ptr(part), 1, _st(a)), "catre_op_gemm_rows_gn")
+        y3 = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        stat = torch.empty(B, 32, 2, dtype=torch.float32, device=dev)
+        spart = torch.empty(R // 64, 3, 256, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_gnp_gelu_neck_fwd_s(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn),
+                                                   hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat), hip.ptr(spart), B, P,
+                                                   _st(a)), "catre_op_gnp_gelu_neck_fwd_s")
+        out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, _st(a)), "catre_op_wsum_fwd")
+        ctx.save_for_backward(ac, w2, y, stat, gamma, beta, wn, spart, y3, wv)
+        ctx.dims, ctx.wshape, ctx.wp_shape = (B, P), w.shape, wp.shape
+        ctx.has_bn, ctx.has_bp = bn is not None, bp is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, w2, y, stat, gamma, beta, wn, spart, y3, wv = ctx.saved_tensors
+        B, P = ctx.dims
+        lib = hip.load()
+        dev = a.device
+        dout = _c(dout)
+        dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
+        dwp = torch.empty(P, dtype=torch.float32, device=dev)
+        dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp else None
+        ws = _ws(B * P * 4, dev)
+        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
+                                        hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+        da, dw, db, dpar = _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=dout, spart=spart, lp=True)
+        dbn = _colsum(dy3) if ctx.has_bn else None
+        return (da, dw.view(ctx.wshape), db, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None)
+
+
+# CATRE_LP_ROT_FUSED=0: the layer-wise autocast rot heads (A/B measurements, tests/test_hip_rot_lp.py)
+FUSED_LP_ROT = os.environ.get("CATRE_LP_ROT_FUSED", "1") != "0"
+
+
+def rot_l1_tail_lp_ok(a, w, b, N, M):
+    return (FUSED_LP_ROT and _amp() == 1 and a.shape[1] == 256 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 256 and b is not None
+            and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
+
+
+def rot_l1_tail_lp(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M):
+    """conv_p(neck(gelu(GroupNorm(a w^T + b)))) -> [B,3] under autocast (rot_l1_tail_lp_ok); a [B*(N+M),256] object-major."""
+    return _RotL1TailLP.apply(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M)
+
+
 class _RotL0Block(torch.autograd.Function):
     """A RotHead's first block in fp32 - 64 -> 256 linear with a per-cloud bias, GroupNorm(32,256), GELU
     (conv_out_per_rot_head.py:126-131) - as one graph node.  Forward: the two kernels of linear_cloudbias +
@@ -1063,12 +1130,16 @@ class _RotL0Block(torch.autograd.Function):
         lib = hip.load()
         xc, w2, bc = _c(x), _c(w.reshape(256, -1)), _c(bias2d)
         R, P = xc.shape[0], N + M
-        wp = torch.empty(256 * 64, dtype=torch.float32, device=x.device)
-        hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), 256, 64, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
+        amp = 1 if _amp() == 1 else 0   # autocast: the forward linear on bf16 operands (what _RotLinear does there)
+        if amp:
+            wp = _pack_bf16(w2, 256, 64, x.device)
+        else:
+            wp = torch.empty(256 * 64, dtype=torch.float32, device=x.device)
+            hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), 256, 64, 0, hip.ptr(wp), _st(x)), "catre_op_pack")
         y = torch.empty(R, 256, dtype=torch.float32, device=x.device)
         part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=x.device)
         hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(xc), xc.stride(0), hip.ptr(wp), hip.ptr(bc), 1, hip.ptr(y), 256, 256, 64,
-                                            B, N, M, hip.ptr(part), 0, _st(x)), "catre_op_gemm_rows_gn")
+                                            B, N, M, hip.ptr(part), amp, _st(x)), "catre_op_gemm_rows_gn")
         a = torch.empty_like(y)
         stat = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
         hip.check(lib.catre_op_gnp_gelu_fwd_pre(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a),
@@ -1096,7 +1167,8 @@ class _RotL0Block(torch.autograd.Function):
 
 
 def rot_l0_block_ok(x, w, N, M):
-    return (_amp() == 0 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 64 and x.shape[1] == 64
+    # autocast takes the node too (FUSED_LP_ROT): bf16-operand forward, the one-pass backward
+    return ((_amp() == 0 or (_amp() == 1 and FUSED_LP_ROT)) and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 64 and x.shape[1] == 64
             and N % 64 == 0 and M % 64 == 0 and N > 0)
 
 
@@ -1162,9 +1234,10 @@ def rot_l1_block(a, w, b, gamma, beta, wn, bn, B, N, M):
     return _RotL1Block.apply(a, w, b, gamma, beta, wn, bn, B, N, M)
 
 
-def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spart=None):
+def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spart=None, lp=False):
     """_RotL1Block's backward on explicit tensors -> (da, dW [256,256], db [256], dpar [5,256]).  With (dout [B,3], spart):
-    the GroupNorm sums come from the forward's tile moments (catre_op_gnp_gelu_neck_fwd_s) instead of a pass over y."""
+    the GroupNorm sums come from the forward's tile moments (catre_op_gnp_gelu_neck_fwd_s) instead of a pass over y.
+    lp: the two GEMMs on the bf16 matrix pipe (autocast)."""
     lib = hip.load()
     dy3 = _c(dy3)
     dev = dy3.device
@@ -1172,7 +1245,12 @@ def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spar
     dwb = torch.empty(256 * 256 + 256, dtype=torch.float32, device=dev)
     dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
     ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
-    if spart is not None:
+    if lp:
+        hip.check(lib.catre_op_rot_l1_bwd_lp(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
+                                             hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(a), hip.ptr(w2), hip.ptr(da),
+                                             hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws), ws.numel(), B, P, _st(dy3)),
+                  "catre_op_rot_l1_bwd_lp")
+    elif spart is not None:
         hip.check(lib.catre_op_rot_l1_bwd_s(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
                                             hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(a), hip.ptr(w2), hip.ptr(da),
                                             hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws), ws.numel(), B, P, _st(dy3)),

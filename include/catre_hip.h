@@ -395,6 +395,12 @@ int catre_op_gnp_gelu_neck_fwd_s(const float* Y, const float* part64, const floa
 int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
                           const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
                           float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* catre_op_rot_l1_bwd / _s with the two GEMMs (dA = dY W, dW = dY^T A) on the bf16 matrix pipe: bf16 operands, fp32
+ * accumulation - the backward torch.autocast gives a bf16 Conv1d (engine.py:304); GroupNorm / GELU', the bias gradient and all
+ * outputs stay fp32.  dout and Spart: both (sums from the forward's moments) or both NULL (sums pass over Y). */
+int catre_op_rot_l1_bwd_lp(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
+                           const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
+                           float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
 /* ... and the per-head form for the modes whose linear backward is not fused (autocast, split): sums and dparams from dout
  * and Spart, then the apply pass -> dY [B*P,256] (what catre_op_gnp_gelu_neck_bwd returns, without its reduction pass over Y).
  * ws as catre_op_gnp_gelu_neck_bwd_ws_bytes. */

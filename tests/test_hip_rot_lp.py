@@ -1,0 +1,124 @@
+"""The autocast rotation heads' fused backward on the bf16 matrix pipe (k_rot_l1_bwd_bf, train_ops._RotL1TailLP) against the
+layer-wise autocast ops it replaces (same operand roundings: only the fp32 summation order differs) and against the fp32
+fused op (bf16-operand tolerance).  Reference behaviour: heads/conv_out_per_rot_head.py:129-140 under engine.py:304's
+autocast."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _head_tensors(B, N, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = N + M
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    t = dict(a=r(B * P, 256), w=r(256, 256, 1, sc=0.06), b=r(256, sc=0.1), gamma=1 + r(256, sc=0.1), beta=r(256, sc=0.1),
+             wn=r(3, 256, sc=0.1), bn=r(3, sc=0.1), wp=r(1, P, 1, sc=0.05), bp=r(1, sc=0.1), dout=r(B, 3))
+    for k in t:
+        if k != "dout":
+            t[k].requires_grad_(True)
+    return t
+
+
+def _run(fn, t):
+    for v in t.values():
+        v.grad = None
+    out = fn()
+    out.backward(t["dout"])
+    return out.detach().clone(), {k: v.grad.detach().clone() for k, v in t.items() if k != "dout"}
+
+
+@pytest.mark.parametrize("B,N,M", [(3, 128, 64), (5, 256, 192), (2, 1024, 1024)])
+def test_fused_lp_tail_matches_the_layerwise_autocast_ops(B, N, M):
+    from catre_amd import train_ops as T
+
+    t = _head_tensors(B, N, M, 100 + B)
+    P = N + M
+
+    def fused():
+        return T.rot_l1_tail_lp(t["a"], t["w"], t["b"], t["gamma"], t["beta"], t["wn"], t["bn"], t["wp"], t["bp"], B, N, M)
+
+    def layerwise():
+        y, part = T.linear_gn_partials(t["a"], t["w"], t["b"], B, N, M)
+        return T.neck_tail(y, t["gamma"], t["beta"], t["wn"], t["bn"], t["wp"], t["bp"], B, P, part)
+
+    with T.amp_mode("bf16"):
+        assert T.rot_l1_tail_lp_ok(t["a"], t["w"], t["b"], N, M)
+        of, gf = _run(fused, t)
+        ol, gl = _run(layerwise, t)
+    with T.amp_mode("fp32"):
+        o32, g32 = _run(layerwise, t)
+    assert torch.equal(of, ol), "the fused node's forward is the layer-wise autocast forward"
+    for k in gl:
+        scale = float(gl[k].abs().max()) + 1e-30
+        err = float((gf[k] - gl[k]).abs().max()) / scale
+        # same bf16 operands, fp32 accumulation in a different order (under 2048 rows the layer-wise data gradient is the
+        # fp32 split-K linear, not a bf16-operand GEMM: bf16-operand tolerance there)
+        tol = (5e-3 if B * P < 2048 else 2e-4) if k == "a" else (2e-4 if k in ("w", "b") else 1e-6)
+        assert err <= tol, (k, err)
+        err32 = float((gf[k] - g32[k]).abs().max()) / (float(g32[k].abs().max()) + 1e-30)
+        assert err32 <= 3e-2, (k, err32)
+
+
+def test_autocast_iteration_with_fused_lp_heads_tracks_the_layerwise_iteration():
+    """Whole training iteration under torch.autocast with and without the fused nodes: same losses (forward is the same
+    kernels), every gradient within 1e-2 of its largest entry."""
+    from catre_amd import train_ops as T
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 6, 256, 192
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 31, 1)
+    res = []
+    for fused in (True, False):
+        T.FUSED_LP_ROT = fused
+        try:
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                ld = _iteration(model, kw, sym)
+            res.append((ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            T.FUSED_LP_ROT = True
+    (lf, gf), (ll, gl) = res
+    for k in ll:
+        assert torch.equal(lf[k], ll[k]), k
+    assert gf.keys() == gl.keys()
+    for k in gl:
+        scale = float(gl[k].abs().max()) + 1e-30
+        # (the layer-0 block's backward runs on the fp32 pipe in the fused form: bf16-operand distance from the layer-wise one)
+        assert float((gf[k] - gl[k]).abs().max()) / scale <= 1e-2, k
+
+
+@pytest.mark.parametrize("B,N,M", [(5, 256, 192), (2, 1024, 1024)])
+def test_l0_block_under_autocast_matches_the_layerwise_autocast_ops(B, N, M):
+    """train_ops._RotL0Block under autocast (bf16-operand forward linear, one-pass backward) against linear_cloudbias +
+    gn_points_gelu in the same mode: identical forward, gradients within the bf16-operand tolerance of each other and of the
+    fp32 block."""
+    from catre_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(7 + B)
+    P = N + M
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    t = dict(x=r(B * P, 64), w=r(256, 64, 1, sc=0.1), bias=r(2 * B, 256, sc=0.3), gamma=1 + r(256, sc=0.1), beta=r(256, sc=0.1))
+    for v in t.values():
+        v.requires_grad_(True)
+    t["dout"] = r(B * P, 256)
+
+    def fused():
+        return T.rot_l0_block(t["x"], t["w"], t["bias"], t["gamma"], t["beta"], B, N, M)
+
+    def layerwise():
+        y, part = T.linear_cloudbias(t["x"], t["w"], t["bias"], B, N, M, with_gn_partials=True)
+        return T.gn_points_gelu(y, t["gamma"], t["beta"], B, P, part)
+
+    with T.amp_mode("bf16"):
+        assert T.rot_l0_block_ok(t["x"], t["w"], N, M)
+        of, gf = _run(fused, t)
+        ol, gl = _run(layerwise, t)
+    with T.amp_mode("fp32"):
+        o32, g32 = _run(fused, t)
+    assert torch.equal(of, ol)
+    for k in gl:
+        scale = float(g32[k].abs().max()) + 1e-30
+        assert float((gf[k] - gl[k]).abs().max()) / scale <= 8e-3, k
+        assert float((gf[k] - g32[k]).abs().max()) / scale <= 3e-2, k
