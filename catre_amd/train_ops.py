@@ -1119,7 +1119,7 @@ def rot_l1_tail_lp(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M):
 
 
 class _RotL0Block(torch.autograd.Function):
-    """A RotHead's first block in fp32 - 64 -> 256 linear with a per-cloud bias, GroupNorm(32,256), GELU
+    """A RotHead's first block (fp32, or bf16-operand GEMMs under autocast) - 64 -> 256 linear with a per-cloud bias, GroupNorm(32,256), GELU
     (conv_out_per_rot_head.py:126-131) - as one graph node.  Forward: the two kernels of linear_cloudbias +
     gn_points_gelu.  Backward: the GroupNorm sums, then ONE pass over (da, y) that rebuilds the linear's output gradient
     tile by tile in LDS and takes dx, dW and the per-cloud bias gradient from it (catre_op_rot_l0_bwd) - instead of
@@ -1145,7 +1145,7 @@ class _RotL0Block(torch.autograd.Function):
         hip.check(lib.catre_op_gnp_gelu_fwd_pre(hip.ptr(y), hip.ptr(part), hip.ptr(gamma), hip.ptr(beta), hip.ptr(a),
                                                 hip.ptr(stat), B, P, _st(x)), "catre_op_gnp_gelu_fwd_pre")
         ctx.save_for_backward(xc, w2, y, stat, gamma, beta)
-        ctx.dims, ctx.wshape = (B, N, M), w.shape
+        ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, amp
         return a
 
     @staticmethod
@@ -1160,9 +1160,10 @@ class _RotL0Block(torch.autograd.Function):
         db = torch.empty(2 * B if M > 0 else B, 256, dtype=torch.float32, device=dev)
         dg, dbe = torch.empty_like(gamma), torch.empty_like(beta)
         ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
-        hip.check(lib.catre_op_rot_l0_bwd(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
-                                          x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
-                                          hip.ptr(dbe), 0, hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
+        fn = lib.catre_op_rot_l0_bwd_lp if ctx.amp else lib.catre_op_rot_l0_bwd   # autocast: both GEMMs on the bf16 pipe
+        hip.check(fn(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
+                     x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
+                     hip.ptr(dbe), 0, hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
         return dx, dw.view(ctx.wshape), db, dg, dbe, None, None, None
 
 

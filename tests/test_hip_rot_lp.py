@@ -63,7 +63,7 @@ def test_fused_lp_tail_matches_the_layerwise_autocast_ops(B, N, M):
 
 def test_autocast_iteration_with_fused_lp_heads_tracks_the_layerwise_iteration():
     """Whole training iteration under torch.autocast with and without the fused nodes: same losses (forward is the same
-    kernels), every gradient within 1e-2 of its largest entry."""
+    kernels), every gradient within 2e-3 of its largest entry."""
     from catre_amd import train_ops as T
     from test_hip_train import _train_setup, _iteration
 
@@ -85,8 +85,7 @@ def test_autocast_iteration_with_fused_lp_heads_tracks_the_layerwise_iteration()
     assert gf.keys() == gl.keys()
     for k in gl:
         scale = float(gl[k].abs().max()) + 1e-30
-        # (the layer-0 block's backward runs on the fp32 pipe in the fused form: bf16-operand distance from the layer-wise one)
-        assert float((gf[k] - gl[k]).abs().max()) / scale <= 1e-2, k
+        assert float((gf[k] - gl[k]).abs().max()) / scale <= 2e-3, k
 
 
 @pytest.mark.parametrize("B,N,M", [(5, 256, 192), (2, 1024, 1024)])
@@ -120,5 +119,6 @@ def test_l0_block_under_autocast_matches_the_layerwise_autocast_ops(B, N, M):
     assert torch.equal(of, ol)
     for k in gl:
         scale = float(g32[k].abs().max()) + 1e-30
-        assert float((gf[k] - gl[k]).abs().max()) / scale <= 8e-3, k
+        # same bf16 operand roundings as the layer-wise GEMMs: only the fp32 summation order differs
+        assert float((gf[k] - gl[k]).abs().max()) / scale <= 5e-4, (k, float((gf[k] - gl[k]).abs().max()) / scale)
         assert float((gf[k] - g32[k]).abs().max()) / scale <= 3e-2, k
