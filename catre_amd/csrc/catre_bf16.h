@@ -52,6 +52,49 @@ __device__ __forceinline__ u32x4 pack_bf8(const float (&v)[8]) {
   return w;
 }
 
+// rows of 256 channels stored as fp32 (HB = false) or bf16 (HB = true): four consecutive channels of row-quad index i4
+// (= row * 64 + channel / 4).  The reduced-precision training heads keep their [rows,256] activations in bf16 - what
+// torch.autocast's Conv1d outputs are (engine.py:304) - and every pass over them moves half the bytes.
+template <bool HB>
+__device__ __forceinline__ f32x4 ld_row4(const void* __restrict__ p, size_t i4) {
+  if constexpr (HB) {
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p) + i4);
+    return f32x4{bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i4);
+  }
+}
+template <bool HB>
+__device__ __forceinline__ void st_row4(void* __restrict__ p, size_t i4, const f32x4& v) {
+  if constexpr (HB)
+    reinterpret_cast<u32x2*>(p)[i4] = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  else
+    reinterpret_cast<f32x4*>(p)[i4] = v;
+}
+
+// ... and the form for loads that are requested long before they are used (the prefetch rings of k_rot_l1_bwd_bf /
+// k_rot_l0_bwd_bf): the RAW quad stays in the ring - a conversion right behind the load would wait for it - and is widened
+// where it is consumed.  rowq_pair: column q of two rows as one packed bf16 pair (first row in the low half).
+template <bool HB>
+struct RowQ {
+  typedef f32x4 T;
+};
+template <>
+struct RowQ<true> {
+  typedef u32x2 T;
+};
+template <bool HB>
+__device__ __forceinline__ typename RowQ<HB>::T ld_rowq(const void* __restrict__ p, size_t i4) {
+  return __builtin_nontemporal_load(reinterpret_cast<const typename RowQ<HB>::T*>(p) + i4);
+}
+__device__ __forceinline__ f32x4 rowq_f32(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 rowq_f32(const u32x2& v) { return f32x4{bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])}; }
+__device__ __forceinline__ unsigned rowq_pair(const f32x4& a, const f32x4& b, int q) { return pack_bf2(a[q], b[q]); }
+__device__ __forceinline__ unsigned rowq_pair(const u32x2& a, const u32x2& b, int q) {
+  // v_perm_b32: bytes 4-7 = first operand, 0-3 = second
+  return (q & 1) ? __builtin_amdgcn_perm(b[q >> 1], a[q >> 1], 0x07060302u) : __builtin_amdgcn_perm(b[q >> 1], a[q >> 1], 0x05040100u);
+}
+
 template <int CP>
 __device__ __forceinline__ int bf_key(int row) {
   return CP >= 16 ? (row & 15) : ((row >> 1) & (CP - 1));

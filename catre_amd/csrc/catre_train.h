@@ -45,9 +45,15 @@ __device__ __forceinline__ const float* cloud_bias(const float* bias, CloudBias 
   return bias + (size_t)(within < cb.N ? obj : cb.B + obj) * J;
 }
 
+// cross-lane move inside a 16-lane row on the VALU (DPP), no LDS round trip like ds_bpermute
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // epilogue shared by the fp32 and bf16-operand row GEMMs: bias / ReLU / output mask -> Y, or (MAXP) the per-tile
 // max / arg-max over the 64 rows
-template <int MB, bool MAXP>
+template <int MB, bool MAXP, bool YB = false>  // YB: Y holds bf16 rows (ldy in elements; full tiles only)
 __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                    const float* __restrict__ mask, int ldm, float* __restrict__ Y,
                                                    int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
@@ -118,13 +124,27 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
         if (mri >= 0) mrow = (size_t)__shfl(mri, 4 * h + row);
         if (full || row < lim) {
           if (mo) t = mo[mrow * ldm] > 0.f ? t : 0.f;
-          yo[(size_t)row * ldy] = t;
+          if constexpr (!YB) yo[(size_t)row * ldy] = t;
           s += t;
         } else {
           t = 0.f;
         }
         acc[mb][nb][r] = t;
       }
+    if constexpr (YB) {
+      // bf16 rows: lane pairs (channels ch, ch + 1) exchange one value per pair of registers (rows row, row + 1); the even
+      // lane stores both channels of the first row, the odd lane of the second - one 4-byte store per two results
+      unsigned* yb = reinterpret_cast<unsigned*>(Y) + ((size_t)(r0 + 4 * h + (n & 1)) * ldy + (ch & ~1)) / 2;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float t0 = acc[mb][nb][r], t1 = acc[mb][nb][r + 1];
+          const float got = dpp_move<0xB1>((n & 1) ? t0 : t1);  // quad_perm [1,0,3,2]: the pair's other lane
+          const unsigned w = (n & 1) ? pack_bf2(got, t1) : pack_bf2(t0, got);
+          yb[(size_t)(nb * 32 + (r & 3) + 8 * (r >> 2)) * (ldy / 2)] = w;
+        }
+    }
     if (gn_part) {
       // GroupNorm(32, 256) partials of this 64-row tile for group blk*4 + (n>>3) (8 consecutive lanes, both half-waves):
       // (mean, M2), merged per object by k_gnp_stats_final in tile order
@@ -351,7 +371,9 @@ __global__ void k_op_pack_bf(const float* __restrict__ src, int ld, int J, int K
   dst[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
-template <int MB, int CP, bool MAXP>
+// IO bit 0: X holds bf16 rows (ldx in elements, already the operand format: staged with one 16-byte copy per chunk);
+// bit 1: Y holds bf16 rows (full tiles, no masks) - the all-bf16 activations of train_ops._RotHeadLP.
+template <int MB, int CP, bool MAXP, int IO = 0>
 __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
@@ -372,6 +394,11 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   for (int i = tid; i < TP * CP; i += 512) {
     const int row = i / CP, ch = i % CP;
     const int gr = min(r0 + row, R - 1);
+    if constexpr (IO & 1) {
+      xs[bf_off<CP>(row, ch)] = __builtin_nontemporal_load(
+          reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(X) + (size_t)gr * ldx) + ch);
+      continue;
+    }
     const float* src = X + (size_t)gr * ldx + ch * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -394,8 +421,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   GemmPipeB<MB, 2, true, CP, (NKC >= 4 ? 2 : 1), 1> g;  // swapped: lane = channel (gemm_rows_epilogue)
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
-  gemm_rows_epilogue<MB, MAXP>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane, 0,
-                               cb.gn_part, MAXP ? -1 : mri);
+  gemm_rows_epilogue<MB, MAXP, (IO & 2) != 0>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane,
+                                              0, cb.gn_part, MAXP ? -1 : mri);
 }
 
 // ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
@@ -710,12 +737,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn_skinny(const float* __restrict_
       colpart[(size_t)blockIdx.x * pitch + 4 * qq + (i - 4 * KS)] = sum;
     }
   }
-}
-
-// cross-lane move inside a 16-lane row on the VALU (DPP), no LDS round trip like ds_bpermute
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
 // Whole backward of a 64-channel layer fed by 3-d points (conv1 of the trunk: x1 [R,8] -> h1 [R,64] + ReLU) in ONE pass
@@ -1861,8 +1882,9 @@ __global__ __launch_bounds__(256) void k_gnp_stats(const float* __restrict__ Y, 
   }
 }
 
-__global__ void k_gnp_gelu_fwd(const float* __restrict__ Y, const float* __restrict__ stat,
-                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ A,
+template <bool HB = false>  // HB: Y and A are bf16 rows (ld_row4 / st_row4)
+__global__ void k_gnp_gelu_fwd(const void* __restrict__ Y, const float* __restrict__ stat,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, void* __restrict__ A,
                                int P, size_t total4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
@@ -1870,7 +1892,7 @@ __global__ void k_gnp_gelu_fwd(const float* __restrict__ Y, const float* __restr
   const size_t row = i >> 6;
   const int obj = row / P, g = c4 >> 1;
   const float mean = stat[((size_t)obj * 32 + g) * 2], rstd = stat[((size_t)obj * 32 + g) * 2 + 1];
-  const f32x4 y = reinterpret_cast<const f32x4*>(Y)[i];
+  const f32x4 y = HB ? ld_row4<HB>(Y, i) : reinterpret_cast<const f32x4*>(Y)[i];
   const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
   f32x4 a;
 #pragma unroll
@@ -1878,13 +1900,14 @@ __global__ void k_gnp_gelu_fwd(const float* __restrict__ Y, const float* __restr
     const float sc = rstd * ga[q];
     a[q] = gelu_erf(fmaf(y[q], sc, be[q] - mean * sc));
   }
-  reinterpret_cast<f32x4*>(A)[i] = a;
+  st_row4<HB>(A, i, a);
 }
 
 // pass 1 of the backward: per (object, group) sums S1 = sum dxhat, S2 = sum dxhat*xhat, and per-(object, channel)
 // partial dgamma / dbeta (summed over objects by k_reduce_splits)
 #define GNP_CH 128  // rows per workgroup in the backward reduction pass
-__global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ dA, const float* __restrict__ Y,
+template <bool HB = false>  // HB: dA and Y are bf16 rows
+__global__ __launch_bounds__(256) void k_gnp_bwd_sums(const void* __restrict__ dA, const void* __restrict__ Y,
                                                       const float* __restrict__ stat, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ sums_part,
                                                       float* __restrict__ dgb_part, int P) {
@@ -1904,15 +1927,14 @@ __global__ __launch_bounds__(256) void k_gnp_bwd_sums(const float* __restrict__ 
   }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, dga[4] = {0.f, 0.f, 0.f, 0.f}, dbe[4] = {0.f, 0.f, 0.f, 0.f};
   const int p0 = chunk * GNP_CH, p1 = min(P, p0 + GNP_CH);
-  const f32x4* y = reinterpret_cast<const f32x4*>(Y + (size_t)obj * P * 256) + lane;
-  const f32x4* da = reinterpret_cast<const f32x4*>(dA + (size_t)obj * P * 256) + lane;
+  const size_t q0 = (size_t)obj * P * 64 + lane;  // row-quad index of (first row of the object, this lane's channels)
   for (int p = p0 + wave; p < p1; p += 16) {
     f32x4 yv[4], dv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int pp = min(p + 4 * u, p1 - 1);
-      yv[u] = __builtin_nontemporal_load(y + (size_t)pp * 64);
-      dv[u] = __builtin_nontemporal_load(da + (size_t)pp * 64);
+      yv[u] = ld_row4<HB>(Y, q0 + (size_t)pp * 64);
+      dv[u] = ld_row4<HB>(dA, q0 + (size_t)pp * 64);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -2075,7 +2097,8 @@ __global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd(const float* __restri
 //   dWn[j][c] = sum_b dout[b][j] S3
 // Spart [tile = 64 rows][3][256]: this workgroup's share; k_neck_sums_from_s finishes them in the backward - which then
 // never reads Y for the sums (k_gnp_neck_bwd_sums: a 0.5 GiB pass per head).
-__global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd_s(const float* __restrict__ Y, const float* __restrict__ stat,
+template <bool HB = false>  // HB: Y is bf16 rows
+__global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd_s(const void* __restrict__ Y, const float* __restrict__ stat,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ Wn, const float* __restrict__ bn,
                                                              const float* __restrict__ wp, float* __restrict__ Y3,
@@ -2097,14 +2120,14 @@ __global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd_s(const float* __rest
     for (int k = 0; k < 3; ++k) nk[k][q] = Wn[k * 256 + c0 + q];
   }
   const float b0 = bn ? bn[0] : 0.f, b1 = bn ? bn[1] : 0.f, b2 = bn ? bn[2] : 0.f;
-  const float* src = Y + (r0 + wave) * 256 + c0;
+  const size_t src4 = (r0 + wave) * 64 + lane;  // row-quad index
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < 4; ++it) {
     f32x4 v[4];
     float wv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(16 * it + 4 * u) * 256));
+      v[u] = ld_row4<HB>(Y, src4 + (size_t)(16 * it + 4 * u) * 64);
       wv[u] = wp[p0 + wave + 16 * it + 4 * u];
     }
     float t[4][3];
@@ -2676,12 +2699,14 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd(const float* __restrict__ dY
 // 96 KiB of LDS, one wave per SIMD (256 weight-gradient accumulators per lane, as in the fp32 kernel).
 // WpT: bf16 fragments of W^T (k_op_pack_bf, transpose = 1: rows = input channels, K = output channels).
 // ------------------------------------------------------------------------------------------------
+// HB: Y, A and dA are bf16 rows (the all-bf16 activations of train_ops._RotHeadLP) instead of fp32 ones.
 #define L1L_IMG (TP * 32)  // 16-byte slots of one 64 x 256 bf16 image
-__global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__ dY3, const float* __restrict__ Y,
+template <bool HB>
+__global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__ dY3, const void* __restrict__ Y,
                                                        const float* __restrict__ stat, const float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ Wn, const float* __restrict__ A,
-                                                       const u32x4* __restrict__ WpT, float* __restrict__ dA,
+                                                       const float* __restrict__ Wn, const void* __restrict__ A,
+                                                       const u32x4* __restrict__ WpT, void* __restrict__ dA,
                                                        float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
   extern __shared__ __attribute__((aligned(16))) u32x4 ldsq[];
   u32x4* dys = ldsq;                // row-major, bf_off<32>(row, chunk)
@@ -2714,18 +2739,20 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
   // batch bb of a tile: rows (bb >> 1) * 32 + 8 wave + 4 (bb & 1) + u, u = 0..3; two batches of (Y, A) rows in flight while
   // one is transformed, the first Y batch of the next tile across the MFMA phases (as in k_rot_l1_bwd)
   auto row_of = [&](int bb, int u) { return (bb >> 1) * 32 + 8 * wave + 4 * (bb & 1) + u; };
-  f32x4 vy[2][4], va[2][4];
+  // (bf16 rows, whole-tile ring of four batches: measured, no gain - the sweeps wait for weight fragments, not for rows)
+  constexpr int RD = 2;
+  typename RowQ<HB>::T vy[RD][4], va[RD][4];
   auto request_y = [&](int tt, int bb) {
     const size_t rr = (size_t)obj * P + (size_t)tt * TP;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      vy[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (rr + row_of(bb, u)) * 64 + lane);
+      vy[bb % RD][u] = ld_rowq<HB>(Y, (rr + row_of(bb, u)) * 64 + lane);
   };
   auto request_a = [&](int tt, int bb) {
     const size_t rr = (size_t)obj * P + (size_t)tt * TP;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      va[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + (rr + row_of(bb, u)) * 64 + lane);
+      va[bb % RD][u] = ld_rowq<HB>(A, (rr + row_of(bb, u)) * 64 + lane);
   };
   auto request = [&](int tt, int bb) {
     request_y(tt, bb);
@@ -2745,47 +2772,55 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
     unsigned hy[4][2], ha[4][2];  // rows 0..3 of the chunk, packed, until rows 4..7 arrive
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
-      float d3v[4][3];
+      unsigned py[4][2];  // this batch's two row pairs per column
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* d3 = dY3 + (r0 + row_of(bb, u)) * 3;
-        d3v[u][0] = d3[0];
-        d3v[u][1] = d3[1];
-        d3v[u][2] = d3[2];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 o[4];
+      for (int up = 0; up < 2; ++up) {  // a pair of rows at a time: their temporaries do not overlap the next pair's
+        float d3v[2][3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = row_of(bb, u);
-        const float d0 = d3v[u][0], d1 = d3v[u][1], d2 = d3v[u][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float yv = vy[bb & 1][u][q];
-          const float xh = (yv - mean) * rstd;
-          const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
-          const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
-          o[u][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
-          cs[q] += o[u][q];
+        for (int w = 0; w < 2; ++w) {
+          const float* d3 = dY3 + (r0 + row_of(bb, 2 * up + w)) * 3;
+          d3v[w][0] = d3[0];
+          d3v[w][1] = d3[1];
+          d3v[w][2] = d3[2];
         }
-        const u32x2 pr = {pack_bf2(o[u][0], o[u][1]), pack_bf2(o[u][2], o[u][3])};
-        dys2[(row * 32 + ((lane_o >> 1) ^ (row & 15))) * 2 + (lane_o & 1)] = pr;
+        f32x4 o[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int u = 2 * up + w, row = row_of(bb, u);
+          const float d0 = d3v[w][0], d1 = d3v[w][1], d2 = d3v[w][2];
+          const f32x4 y4 = rowq_f32(vy[bb % RD][u]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float yv = y4[q];
+            const float xh = (yv - mean) * rstd;
+            const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
+            const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+            o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
+            cs[q] += o[w][q];
+          }
+          const u32x2 pr = {pack_bf2(o[w][0], o[w][1]), pack_bf2(o[w][2], o[w][3])};
+          dys2[(row * 32 + ((lane_o >> 1) ^ (row & 15))) * 2 + (lane_o & 1)] = pr;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) py[q][up] = pack_bf2(o[0][q], o[1][q]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if ((bb & 1) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          hy[q][0] = pack_bf2(o[0][q], o[1][q]);
-          hy[q][1] = pack_bf2(o[2][q], o[3][q]);
-          ha[q][0] = pack_bf2(va[0][0][q], va[0][1][q]);
-          ha[q][1] = pack_bf2(va[0][2][q], va[0][3][q]);
+          hy[q][0] = py[q][0];
+          hy[q][1] = py[q][1];
+          ha[q][0] = rowq_pair(va[bb % RD][0], va[bb % RD][1], q);
+          ha[q][1] = rowq_pair(va[bb % RD][2], va[bb % RD][3], q);
         }
       } else {
         const int chunk = (bb >> 1) * 4 + wave;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int slot = tn_slot(4 * (int)lane_o + q, chunk);
-          dyt[slot] = u32x4{hy[q][0], hy[q][1], pack_bf2(o[0][q], o[1][q]), pack_bf2(o[2][q], o[3][q])};
-          ast[slot] = u32x4{ha[q][0], ha[q][1], pack_bf2(va[1][0][q], va[1][1][q]), pack_bf2(va[1][2][q], va[1][3][q])};
+          dyt[slot] = u32x4{hy[q][0], hy[q][1], py[q][0], py[q][1]};
+          ast[slot] = u32x4{ha[q][0], ha[q][1], rowq_pair(va[bb % RD][0], va[bb % RD][1], q),
+                            rowq_pair(va[bb % RD][2], va[bb % RD][3], q)};
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -2799,16 +2834,33 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
        // 32 of the tile's rows (whole-line stores, see k_rot_l1_bwd)
       f32x16 acc[2][2];
       acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16();
-      GemmPipeB<2, 2, true, 32, 2, 1> gp;
+      GemmPipeB<2, 2, true, 32, 2, 1> gp;  // (weight fragments four K-steps ahead: measured, no gain)
       gp.prefetch(WpT + ((size_t)(2 * wave) * 16) * 64 + lane_o, 16 * 64);
       gp.run(acc, dys, (int)lane_o);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        float* o = dA + (r0 + 4 * h) * 256 + (2 * wave + mb) * 32 + i;
+        if constexpr (HB) {
+          // bf16 rows: a lane pair (channels c, c + 1) exchanges one value per pair of registers (rows r, r + 1) - the even
+          // lane stores both channels of row r, the odd lane of row r + 1: one 4-byte store per two results
+          unsigned* o = reinterpret_cast<unsigned*>(dA) + ((r0 + 4 * h + (i & 1)) * 256 + (2 * wave + mb) * 32 + (i & ~1)) / 2;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) st_stream(o + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, acc[mb][nb][r]);
+            for (int r = 0; r < 16; r += 2) {
+              const float t0 = acc[mb][nb][r], t1 = acc[mb][nb][r + 1];
+              const float got = dpp_move<0xB1>((i & 1) ? t0 : t1);  // quad_perm [1,0,3,2]: the pair's other lane
+              const unsigned w = (i & 1) ? pack_bf2(got, t1) : pack_bf2(t0, got);
+              // (plain stores: the two 32-channel blocks of a wave are the two halves of one 128-byte line, written by
+              // different instructions - streamed past the cache they leave as partial lines, 2x the kernel time)
+              o[(size_t)(nb * 32 + (r & 3) + 8 * (r >> 2)) * 128] = w;
+            }
+        } else {
+          float* o = reinterpret_cast<float*>(dA) + (r0 + 4 * h) * 256 + (2 * wave + mb) * 32 + i;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st_stream(o + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, acc[mb][nb][r]);
+        }
       }
     }
     {  // dW += dY^T A: output-channel blocks 2 wave, 2 wave + 1 x all eight input-channel blocks; 16 rows per step.
@@ -2866,8 +2918,10 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
 // Every thread also transposes two rows x four columns of the 64 x 64 X tile.  72 KiB of LDS.  WpT: bf16 fragments of W^T (rows = 64 input channels,
 // K = 256 output channels).  Same outputs and flags as k_rot_l0_bwd.
 // ------------------------------------------------------------------------------------------------
+// HB: dA and Y are bf16 rows.
 #define L0L_IMG (TP * 32)  // 16-byte slots of one 64 x 256 bf16 image
-__global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const float* __restrict__ dA, const float* __restrict__ Y,
+template <bool HB>
+__global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const void* __restrict__ dA, const void* __restrict__ Y,
                                                        const float* __restrict__ stat, const float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ X, int ldx, const u32x4* __restrict__ WpT,
@@ -2896,13 +2950,14 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const float* __restrict__
     sh[q] = be[q] - mean * sc[q];
   }
   // batch bb of a tile: rows 8 wave + 4 bb + u, u = 0..3
-  f32x4 vd[2][4], vy[2][4], vx[2];
+  typename RowQ<HB>::T vd[2][4], vy[2][4];
+  f32x4 vx[2];
   auto request = [&](int t, int bb) {
     const size_t r = row0 + (size_t)t * TP + 8 * wave + 4 * bb;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      vd[bb][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dA) + (r + u) * 64 + lane);
-      vy[bb][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (r + u) * 64 + lane);
+      vd[bb][u] = ld_rowq<HB>(dA, (r + u) * 64 + lane);
+      vy[bb][u] = ld_rowq<HB>(Y, (r + u) * 64 + lane);
     }
   };
   const int xc4 = tid & 15, xrp = tid >> 4;  // X tile: column quad and row pair (rows 2 xrp, 2 xrp + 1) of this thread
@@ -2933,11 +2988,12 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const float* __restrict__
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
           const int u = 2 * up + w, row = 8 * wave + 4 * bb + u;
+          const f32x4 y4 = rowq_f32(vy[bb][u]), d4 = rowq_f32(vd[bb][u]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float yv = vy[bb][u][q];
+            const float yv = y4[q];
             const float xh = (yv - mean) * rstd;
-            const float dxh = vd[bb][u][q] * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+            const float dxh = d4[q] * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
             o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_bwd_apply
             cs[q] += o[w][q];
           }

@@ -95,6 +95,13 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
     P = N + M
     W0g, W0b = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)   # global half (a view) | point half
     bias0 = T.linear(g, W0g, w("layers.0.bias"))                              # [2B,256]: global half + conv bias
+    if T.rot_head_lp_ok(pf_obj, W0b, w("layers.3.weight"), w("layers.3.bias"), N, M):
+        # autocast: the head as one node with bf16 [B*P,256] activations between its kernels
+        from .heads import neck_weight3
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        return T.rot_head_lp(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
+                             w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                             p.get(f"{prefix}.conv_p.bias"), B, N, M)[:, :w("neck.0.weight").shape[0]]
     # [B*P,256]; the per-cloud bias and the GroupNorm tile partials are epilogue work of the GEMMs
     if T.rot_l0_block_ok(pf_obj, W0b, N, M):
         a = T.rot_l0_block(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), B, N, M)

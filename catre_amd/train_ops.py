@@ -1104,6 +1104,101 @@ class _RotL1TailLP(torch.autograd.Function):
         return (da, dw.view(ctx.wshape), db, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None)
 
 
+class _RotHeadLP(torch.autograd.Function):
+    """A whole RotHead behind the per-cloud bias of its first layer under torch.autocast (conv_out_per_rot_head.py:126-140:
+    Conv1d 64 -> 256 + per-cloud bias, GroupNorm, GELU, Conv1d 256 -> 256, GroupNorm, GELU, neck, conv_p) as ONE node:
+    x [B*P,64] (pointfeat, object-major) -> out [B,3].  The three [B*P,256] activations the backward needs - y0, a0, y1 - and
+    the gradient that travels between the two backward passes are bf16 rows (what autocast's Conv1d outputs are): every pass
+    over them moves half the bytes of the fp32-row form (_RotL0Block + _RotL1TailLP), nothing else changes - bf16-operand
+    GEMMs with fp32 accumulation, fp32 GroupNorm statistics from the GEMM epilogues, fp32 GroupNorm / GELU arithmetic.
+    Forward: 2 x (row GEMM, GroupNorm + GELU pass), conv_p.  Backward: conv_p, k_rot_l1_bwd_bf, GroupNorm-0 sums,
+    k_rot_l0_bwd_bf (include/catre_hip.h: the catre_op_*_h entry points)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M):
+        lib = hip.load()
+        dev = x.device
+        xc, bc = _c(x), _c(bias2d)
+        w0c, w1c, wn = _c(w0.reshape(256, -1)), _c(w1.reshape(256, -1)), _c(wn)
+        b1c, bnc = _c(b1), (_c(bn) if bn is not None else None)
+        wv = _c(wp.reshape(-1))
+        R, P = xc.shape[0], N + M
+        st = _st(x)
+        h = lambda: torch.empty(R, 256, dtype=torch.bfloat16, device=dev)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        y0, a0, y1 = h(), h(), h()
+        part0, part1 = f(R // 64, 32, 2), f(R // 64, 32, 2)
+        stat0, stat1 = f(B, 32, 2), f(B, 32, 2)
+        pk0 = _pack_bf16(w0c, 256, 64, dev)
+        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 1, hip.ptr(y0), 256, 256, 64,
+                                              B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
+        hip.check(lib.catre_op_gnp_gelu_fwd_pre_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
+                                                  hip.ptr(stat0), B, P, st), "catre_op_gnp_gelu_fwd_pre_h")
+        pk1 = _pack_bf16(w1c, 256, 256, dev)
+        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(a0), 256, hip.ptr(pk1), hip.ptr(b1c), 0, hip.ptr(y1), 256, 256, 256,
+                                              B, N, M, hip.ptr(part1), 3, st), "catre_op_gemm_rows_gn_h")
+        y3, spart = f(R, 3), f(R // 64, 3, 256)
+        hip.check(lib.catre_op_gnp_gelu_neck_fwd_s_h(hip.ptr(y1), hip.ptr(part1), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
+                                                     hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat1), hip.ptr(spart), B, P,
+                                                     st), "catre_op_gnp_gelu_neck_fwd_s_h")
+        out = f(B, 3)
+        hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, st), "catre_op_wsum_fwd")
+        ctx.save_for_backward(xc, w0c, y0, stat0, g0, be0, a0, w1c, y1, stat1, g1, be1, wn, spart, y3, wv)
+        ctx.dims = (B, N, M)
+        ctx.shapes = (w0.shape, w1.shape, wp.shape)
+        ctx.has_bn, ctx.has_bp = bn is not None, bp is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w0, y0, stat0, g0, be0, a0, w1, y1, stat1, g1, be1, wn, spart, y3, wv = ctx.saved_tensors
+        B, N, M = ctx.dims
+        P = N + M
+        lib = hip.load()
+        dev = x.device
+        dout = _c(dout)
+        st = _st(dout)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dy3, dwp = f(B * P, 3), f(P)
+        dbp = f(1) if ctx.has_bp else None
+        ws = _ws(B * P * 4, dev)
+        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
+                                        hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd")
+        da0 = torch.empty(B * P, 256, dtype=torch.bfloat16, device=dev)
+        dwb1, dpar1 = f(256 * 256 + 256), f(5, 256)
+        ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
+        hip.check(lib.catre_op_rot_l1_bwd_h(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y1), hip.ptr(stat1), hip.ptr(g1),
+                                            hip.ptr(be1), hip.ptr(wn), hip.ptr(a0), hip.ptr(w1), hip.ptr(da0), hip.ptr(dwb1),
+                                            hip.ptr(dpar1), hip.ptr(ws), ws.numel(), B, P, st), "catre_op_rot_l1_bwd_h")
+        dx, dw0 = f(x.shape[0], 64), f(256, 64)
+        db0 = f(2 * B if M > 0 else B, 256)
+        dg0, dbe0 = torch.empty_like(g0), torch.empty_like(be0)
+        ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
+        hip.check(lib.catre_op_rot_l0_bwd_h(hip.ptr(da0), hip.ptr(y0), hip.ptr(stat0), hip.ptr(g0), hip.ptr(be0), hip.ptr(x),
+                                            x.stride(0), hip.ptr(w0), hip.ptr(dx), 64, hip.ptr(dw0), hip.ptr(db0), hip.ptr(dg0),
+                                            hip.ptr(dbe0), 0, hip.ptr(ws), ws.numel(), B, N, M, st), "catre_op_rot_l0_bwd_h")
+        dbn = _colsum(dy3) if ctx.has_bn else None
+        s0, s1, sp = ctx.shapes
+        return (dx, dw0.view(s0), db0, dg0, dbe0, dwb1[: 256 * 256].view(s1), dwb1[256 * 256:], dpar1[0], dpar1[1], dpar1[2:5],
+                dbn, dwp.view(sp), dbp, None, None, None)
+
+
+# CATRE_LP_ROT_ROWS=fp32: keep the autocast heads' [rows,256] activations in fp32 (_RotL0Block + _RotL1TailLP)
+LP_ROT_BF16_ROWS = os.environ.get("CATRE_LP_ROT_ROWS", "bf16") != "fp32"
+
+
+def rot_head_lp_ok(x, w0, w1, b1, N, M):
+    return (FUSED_LP_ROT and LP_ROT_BF16_ROWS and _amp() == 1 and x.shape[1] == 64 and w0.shape[0] == 256
+            and w0.reshape(256, -1).shape[1] == 64 and w1.shape[0] == 256 and w1.reshape(256, -1).shape[1] == 256
+            and b1 is not None and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
+
+
+def rot_head_lp(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M):
+    """The RotHead behind its per-cloud layer-0 bias under autocast -> [B,3] (rot_head_lp_ok); x [B*(N+M),64] object-major,
+    w0 [256,64] the point half of layers.0, bias2d [2B,256] its global half + bias, wn [3,256], bn [3] or None."""
+    return _RotHeadLP.apply(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M)
+
+
 # CATRE_LP_ROT_FUSED=0: the layer-wise autocast rot heads (A/B measurements, tests/test_hip_rot_lp.py)
 FUSED_LP_ROT = os.environ.get("CATRE_LP_ROT_FUSED", "1") != "0"
 

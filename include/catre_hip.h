@@ -407,6 +407,26 @@ int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spar
 int catre_op_rot_l1_bwd_lp(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
                            const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
                            float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* The all-bf16-activation form of the autocast rotation heads: the [rows,256] tensors that travel between these kernels -
+ * y0, a0, y1, dA - are bf16 rows (256 bf16 per row; `void*`), what torch.autocast's Conv1d outputs are (engine.py:304), so
+ * every pass over them moves half the bytes; statistics, GroupNorm / GELU arithmetic, accumulation and every other output
+ * stay fp32.  catre_op_gemm_rows_gn_h: catre_op_gemm_rows_gn on bf16 operands (Wp: catre_op_pack_bf16) with io bit 0: X is
+ * bf16 rows, bit 1: Y is bf16 rows (ldx / ldy in elements); J = 256, K in {64, 256}.  The others: the op of the same name
+ * without _h / with _lp, with the named tensors as bf16 rows (catre_op_rot_l1_bwd_h: Y, A, dA; catre_op_rot_l0_bwd_h: dA, Y). */
+int catre_op_gemm_rows_gn_h(const void* X, int ldx, const void* Wp, const float* bias, int per_cloud, void* Y, int ldy, int J,
+                            int K, int B, int N, int M, float* gn_part, int io, void* stream);
+int catre_op_gnp_gelu_fwd_pre_h(const void* Y, const float* part64, const float* gamma, const float* beta, void* A,
+                                float* stat, int B, int P, void* stream);
+int catre_op_gnp_gelu_neck_fwd_s_h(const void* Y, const float* part64, const float* gamma, const float* beta, const float* Wn,
+                                   const float* bn, const float* wp, float* Y3, float* stat, float* Spart, int B, int P,
+                                   void* stream);
+int catre_op_rot_l1_bwd_h(const float* dY3, const float* dout, const float* Spart, const void* Y, const float* stat,
+                          const float* gamma, const float* beta, const float* Wn, const void* A, const float* W, void* dA,
+                          float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+int catre_op_rot_l0_bwd_h(const void* dA, const void* Y, const float* stat, const float* gamma, const float* beta,
+                          const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
+                          float* dgamma, float* dbeta, int accumulate_dx, void* ws, size_t ws_bytes, int B, int N, int M,
+                          void* stream);
 /* ... and the per-head form for the modes whose linear backward is not fused (autocast, split): sums and dparams from dout
  * and Spart, then the apply pass -> dY [B*P,256] (what catre_op_gnp_gelu_neck_bwd returns, without its reduction pass over Y).
  * ws as catre_op_gnp_gelu_neck_bwd_ws_bytes. */

@@ -71,14 +71,14 @@ def test_autocast_iteration_with_fused_lp_heads_tracks_the_layerwise_iteration()
     cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 31, 1)
     res = []
     for fused in (True, False):
-        T.FUSED_LP_ROT = fused
+        T.FUSED_LP_ROT, T.LP_ROT_BF16_ROWS = fused, False   # the fp32-row form: the layer-wise path's own tensors
         try:
             opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 ld = _iteration(model, kw, sym)
             res.append((ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
         finally:
-            T.FUSED_LP_ROT = True
+            T.FUSED_LP_ROT = T.LP_ROT_BF16_ROWS = True
     (lf, gf), (ll, gl) = res
     for k in ll:
         assert torch.equal(lf[k], ll[k]), k
@@ -122,3 +122,91 @@ def test_l0_block_under_autocast_matches_the_layerwise_autocast_ops(B, N, M):
         # same bf16 operand roundings as the layer-wise GEMMs: only the fp32 summation order differs
         assert float((gf[k] - gl[k]).abs().max()) / scale <= 5e-4, (k, float((gf[k] - gl[k]).abs().max()) / scale)
         assert float((gf[k] - g32[k]).abs().max()) / scale <= 3e-2, k
+
+
+@pytest.mark.parametrize("B,N,M", [(5, 256, 192), (2, 1024, 1024)])
+def test_head_with_bf16_rows_tracks_the_fp32_row_form(B, N, M):
+    """train_ops._RotHeadLP (y0 / a0 / y1 / dA as bf16 rows) against the same head with fp32 rows (_RotL0Block + _RotL1TailLP,
+    same bf16-operand GEMMs) and against the fp32 head: a0 is rounded to bf16 by the next GEMM in both forms, so only the
+    rounding of y0, y1 and dA is new - output within 2e-2 of the output range, every gradient with cosine >= 0.999 to the
+    fp32-row form and no further from the fp32 head than 1.5x the fp32-row form is (+1e-3 of the gradient's range)."""
+    from catre_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(41 + B)
+    P = N + M
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    t = dict(x=r(B * P, 64), w0=r(256, 64, 1, sc=0.1), bias=r(2 * B, 256, sc=0.3), g0=1 + r(256, sc=0.1), be0=r(256, sc=0.1),
+             w1=r(256, 256, 1, sc=0.06), b1=r(256, sc=0.1), g1=1 + r(256, sc=0.1), be1=r(256, sc=0.1), wn=r(3, 256, sc=0.1),
+             bn=r(3, sc=0.1), wp=r(1, P, 1, sc=0.05), bp=r(1, sc=0.1))
+    for v in t.values():
+        v.requires_grad_(True)
+    t["dout"] = r(B, 3)
+
+    def rows_bf16():
+        return T.rot_head_lp(t["x"], t["w0"], t["bias"], t["g0"], t["be0"], t["w1"], t["b1"], t["g1"], t["be1"], t["wn"], t["bn"],
+                             t["wp"], t["bp"], B, N, M)
+
+    def rows_fp32():
+        a = T.rot_l0_block(t["x"], t["w0"], t["bias"], t["g0"], t["be0"], B, N, M)
+        return T.rot_l1_tail_lp(a, t["w1"], t["b1"], t["g1"], t["be1"], t["wn"], t["bn"], t["wp"], t["bp"], B, N, M)
+
+    def fp32_head():
+        a = T.rot_l0_block(t["x"], t["w0"], t["bias"], t["g0"], t["be0"], B, N, M)
+        y3 = T.rot_l1_block(a, t["w1"], t["b1"], t["g1"], t["be1"], t["wn"], t["bn"], B, N, M)
+        return T.weighted_point_sum(y3, t["wp"], t["bp"], B, P)
+
+    with T.amp_mode("bf16"):
+        assert T.rot_head_lp_ok(t["x"], t["w0"], t["w1"], t["b1"], N, M)
+        oh, gh = _run(rows_bf16, t)
+        of, gf = _run(rows_fp32, t)
+    with T.amp_mode("fp32"):
+        o32, g32 = _run(fp32_head, t)
+    rng = float(o32.abs().max())
+    assert float((oh - of).abs().max()) <= 2e-2 * rng
+    for k in g32:
+        a, b, c = gh[k].reshape(-1), gf[k].reshape(-1), g32[k].reshape(-1)
+        if float(c.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos >= 0.999, (k, cos)
+        scale = float(c.abs().max())
+        eh, ef = float((a - c).abs().max()) / scale, float((b - c).abs().max()) / scale
+        assert eh <= 1.5 * ef + 1e-3, (k, eh, ef)
+
+
+def test_autocast_iteration_with_bf16_rows_tracks_the_fp32_iteration():
+    """The default autocast training iteration (heads with bf16 rows) against the fp32 iteration, with the criteria of
+    test_hip_train.test_amp_training_iteration_tracks_fp32, and against the fp32-row form of the same iteration."""
+    from catre_amd import train_ops as T
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 6, 256, 192
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 33, 1)
+
+    def run(autocast, rows):
+        T.LP_ROT_BF16_ROWS = rows
+        try:
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                ld = _iteration(model, kw, sym)
+            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            T.LP_ROT_BF16_ROWS = True
+
+    l32, g32 = run(False, True)
+    lh, gh = run(True, True)
+    lf, gf = run(True, False)
+    for k in l32:
+        assert abs(float(lh[k]) - float(l32[k])) <= 3e-2 * abs(float(l32[k])) + 1e-3, (k, float(lh[k]), float(l32[k]))
+    checked = 0
+    for k, g in g32.items():
+        if g.numel() < 4096 or float(g.norm()) < 1e-8:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), gh[k].reshape(-1), dim=0))
+        ratio = float(gh[k].norm() / g.norm())
+        assert cos >= 0.98 and 0.9 <= ratio <= 1.1, (k, cos, ratio)
+        cos_f = float(torch.nn.functional.cosine_similarity(gf[k].reshape(-1), gh[k].reshape(-1), dim=0))
+        assert cos_f >= 0.995, (k, cos_f)
+        checked += 1
+    assert checked >= 20
