@@ -527,6 +527,12 @@ def main():
             train_extra.update({"mfma_gflop_per_iteration": round(flop_it / 1e9, 1), "mfma_gflop_source": src,
                                 "tflops": round(tfs, 1), "path_frac_of_mfma_peak": round(tfs / FP32_MFMA_PEAK_TFLOPS, 4)})
 
+        # ... and the same step under torch.autocast (engine.py:304, SOLVER.AMP.ENABLED - BASELINE config 5's arithmetic):
+        # bf16-operand GEMMs, fp32 accumulation / statistics / SO(3); a bf16-class number, not the fp32 contract
+        adt = run_train(cfg_fn, dev, None, 0, "bf16", tsteps, 1)
+        train_extra["autocast_bf16"] = {"value": round(B_PER_GPU * K_ITER * tsteps / adt, 1),
+                                        "ms_per_iteration": round(adt / tsteps / K_ITER * 1e3, 3)}
+
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     comm = comm_info(dist, dev, world, rank, local_rank)
 

@@ -31,6 +31,8 @@ if want train; then
   python profiles/train_step.py 16 64 256 2>/dev/null | grep '^{' > $o/r04_train_step.jsonl
   PROF_TRACE="$PWD/$o/r04_train_trace.csv 1500" profiles/prof.sh $o/r04_train_kernel_stats.csv python $PWD/bench.py --mode train --steps 3 --warmup 1
   python profiles/gemm_probe.py 2>/dev/null | grep '^{' > $o/r04_gemm_probe.jsonl
+  profiles/prof.sh $o/r04_train_bf16_kernel_stats.csv python $PWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1
+  profiles/prof.sh $o/r04_train_split_kernel_stats.csv python $PWD/bench.py --mode train --dtype split --steps 3 --warmup 1
 fi
 if want pmctrain; then   # counters for config 3 (MFMA busy, FETCH / WRITE per training kernel)
   profiles/pmc.sh /tmp/pmc_r04t --mode train > /dev/null 2>&1
