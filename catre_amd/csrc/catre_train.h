@@ -2707,7 +2707,13 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ Wn, const void* __restrict__ A,
                                                        const u32x4* __restrict__ WpT, void* __restrict__ dA,
-                                                       float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
+                                                       float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw,
+                                                       unsigned long long* __restrict__ trace = nullptr) {
+#define L1L_STAMP(i)                                                                                       \
+  do {                                                                                                     \
+    if (CATRE_TRACE_ON && trace && (threadIdx.x & 63) == 0)                                                \
+      trace[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
   extern __shared__ __attribute__((aligned(16))) u32x4 ldsq[];
   u32x4* dys = ldsq;                // row-major, bf_off<32>(row, chunk)
   u32x4* dyt = ldsq + L1L_IMG;      // transposed, tn_slot(column, chunk of 8 rows)
@@ -2762,6 +2768,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
   if (t0 < t1) request_y(t0, 0);
   for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)obj * P + (size_t)t * TP;
+    L1L_STAMP(0);
     request_a(t, 0);
     request(t, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -2827,7 +2834,9 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
       if (bb < 2) request(t, bb + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    L1L_STAMP(1);
     __syncthreads();
+    L1L_STAMP(2);
     if (t + 1 < t1) request_y(t + 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     {  // dA tile = dY W: input-channel blocks 2 wave, 2 wave + 1, both 32-row halves; a lane owns one input channel and
@@ -2863,6 +2872,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
         }
       }
     }
+    L1L_STAMP(3);
     {  // dW += dY^T A: output-channel blocks 2 wave, 2 wave + 1 x all eight input-channel blocks; 16 rows per step.
        // tn_slot(32 kb + i, 2 ks + h) = 256 kb + (b0 ^ (2 (kb ^ ks) & 7)) with b0 = tn_slot(i, h): one per-lane base, the
        // block and the step only through compile-time (kb: wave-uniform) constants
@@ -2891,8 +2901,11 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    L1L_STAMP(4);
     __syncthreads();
+    L1L_STAMP(5);
   }
+#undef L1L_STAMP
   float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (256 * 256 + 256);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
