@@ -372,14 +372,23 @@ __global__ void k_op_pack_bf(const float* __restrict__ src, int ld, int J, int K
 }
 
 // IO bit 0: X holds bf16 rows (ldx in elements, already the operand format: staged with one 16-byte copy per chunk);
-// bit 1: Y holds bf16 rows (full tiles, no masks) - the all-bf16 activations of train_ops._RotHeadLP.
+// bit 1: Y holds bf16 rows (full tiles, no masks) - the all-bf16 activations of train_ops._RotHeadLP;
+// bit 2 (with bit 0, K = 256): X is the INPUT of a GroupNorm(32,256) + GELU whose output is this GEMM's operand - a chunk of 8
+// channels is one GroupNorm group: the staging thread widens it, applies k_gnp_gelu_fwd's arithmetic with (mean, rstd) of
+// its object from xf_stat [B][32][2], rounds to bf16 into LDS and stores the same 16 bytes to xf_out (bf16 rows: the
+// activation the backward needs) - the GroupNorm + GELU pass between the two linears of a RotHead without its own launch
+// and without re-reading what it wrote.
 template <int MB, int CP, bool MAXP, int IO = 0>
 __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ X, int ldx, const u32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ mask,
                                                       int ldm, float* __restrict__ Y, int ldy, int R, int J, int relu,
                                                       const float* __restrict__ xmask, int ldxm, CloudBias cb,
                                                       const int* __restrict__ Rdev = nullptr,
-                                                      const int* __restrict__ mrows = nullptr) {
+                                                      const int* __restrict__ mrows = nullptr,
+                                                      const float* __restrict__ xf_stat = nullptr,
+                                                      const float* __restrict__ xf_gamma = nullptr,
+                                                      const float* __restrict__ xf_beta = nullptr,
+                                                      unsigned short* __restrict__ xf_out = nullptr, int xf_P = 1) {
   constexpr int NKC = CP / 2;  // K = 8 * CP
   __shared__ u32x4 xs[TP * CP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -395,8 +404,25 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
     const int row = i / CP, ch = i % CP;
     const int gr = min(r0 + row, R - 1);
     if constexpr (IO & 1) {
-      xs[bf_off<CP>(row, ch)] = __builtin_nontemporal_load(
+      u32x4 v = __builtin_nontemporal_load(
           reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(X) + (size_t)gr * ldx) + ch);
+      if constexpr (IO & 4) {
+        static_assert(CP == 32, "the GroupNorm + GELU staging is for 256-channel rows");
+        const float* st2 = xf_stat + ((size_t)(gr / xf_P) * 32 + ch) * 2;
+        const float mean = st2[0], rstd = st2[1];
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(xf_gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(xf_gamma + ch * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(xf_beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(xf_beta + ch * 8 + 4);
+        const float y[8] = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1]), bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float sc = rstd * (q < 4 ? g0[q & 3] : g1[q & 3]);
+          a[q] = gelu_erf(fmaf(y[q], sc, (q < 4 ? b0[q & 3] : b1[q & 3]) - mean * sc));  // k_gnp_gelu_fwd's operation sequence
+        }
+        v = pack_bf8(a);
+        reinterpret_cast<u32x4*>(xf_out + (size_t)gr * 256)[ch] = v;
+      }
+      xs[bf_off<CP>(row, ch)] = v;
       continue;
     }
     const float* src = X + (size_t)gr * ldx + ch * 8;

@@ -169,6 +169,7 @@ _SIGS = {
     "catre_op_gemm_rows_gn_h": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "catre_op_gnp_gelu_fwd_pre_h": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_fwd_s_h": (_I, [_P] * 10 + [_I, _I, _P]),
+    "catre_op_gn_gelu_gemm_rows_h": (_I, [_P] * 10 + [_I, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_bwd_s": (_I, [_P] * 11 + [_SZ, _I, _I, _P]),
     "catre_op_pad_cols": (_I, [_P, ctypes.c_long, ctypes.c_long, _I, _I, _P, _I, _P]),
     "catre_op_rot_l1_bwd_ws_bytes": (_SZ, [_I, _I]),

@@ -1132,11 +1132,16 @@ class _RotHeadLP(torch.autograd.Function):
         pk0 = _pack_bf16(w0c, 256, 64, dev)
         hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 1, hip.ptr(y0), 256, 256, 64,
                                               B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
-        hip.check(lib.catre_op_gnp_gelu_fwd_pre_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
-                                                  hip.ptr(stat0), B, P, st), "catre_op_gnp_gelu_fwd_pre_h")
         pk1 = _pack_bf16(w1c, 256, 256, dev)
-        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(a0), 256, hip.ptr(pk1), hip.ptr(b1c), 0, hip.ptr(y1), 256, 256, 256,
-                                              B, N, M, hip.ptr(part1), 3, st), "catre_op_gemm_rows_gn_h")
+        if LP_ROT_FUSE_GN0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
+            hip.check(lib.catre_op_gn_gelu_gemm_rows_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
+                                                       hip.ptr(stat0), hip.ptr(pk1), hip.ptr(b1c), hip.ptr(y1), hip.ptr(part1),
+                                                       B, N, M, st), "catre_op_gn_gelu_gemm_rows_h")
+        else:
+            hip.check(lib.catre_op_gnp_gelu_fwd_pre_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
+                                                      hip.ptr(stat0), B, P, st), "catre_op_gnp_gelu_fwd_pre_h")
+            hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(a0), 256, hip.ptr(pk1), hip.ptr(b1c), 0, hip.ptr(y1), 256, 256, 256,
+                                                  B, N, M, hip.ptr(part1), 3, st), "catre_op_gemm_rows_gn_h")
         y3, spart = f(R, 3), f(R // 64, 3, 256)
         hip.check(lib.catre_op_gnp_gelu_neck_fwd_s_h(hip.ptr(y1), hip.ptr(part1), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
                                                      hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat1), hip.ptr(spart), B, P,
@@ -1183,6 +1188,8 @@ class _RotHeadLP(torch.autograd.Function):
                 dbn, dwp.view(sp), dbp, None, None, None)
 
 
+# CATRE_LP_ROT_GN0=separate: the head's GroupNorm-0 + GELU as its own pass (A/B measurements, tests/test_hip_rot_lp.py)
+LP_ROT_FUSE_GN0 = os.environ.get("CATRE_LP_ROT_GN0", "fused") != "separate"
 # CATRE_LP_ROT_ROWS=fp32: keep the autocast heads' [rows,256] activations in fp32 (_RotL0Block + _RotL1TailLP)
 LP_ROT_BF16_ROWS = os.environ.get("CATRE_LP_ROT_ROWS", "bf16") != "fp32"
 

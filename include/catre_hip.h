@@ -417,6 +417,12 @@ int catre_op_gemm_rows_gn_h(const void* X, int ldx, const void* Wp, const float*
                             int K, int B, int N, int M, float* gn_part, int io, void* stream);
 int catre_op_gnp_gelu_fwd_pre_h(const void* Y, const float* part64, const float* gamma, const float* beta, void* A,
                                 float* stat, int B, int P, void* stream);
+/* catre_op_gnp_gelu_fwd_pre_h followed by catre_op_gemm_rows_gn_h (K = 256, bf16 rows in and out) as one kernel behind the
+ * statistics merge: the GroupNorm + GELU is applied while the GEMM stages its operand tile; A (bf16 rows) is still written
+ * for the backward.  Same values as the two calls. */
+int catre_op_gn_gelu_gemm_rows_h(const void* Y0, const float* part64, const float* gamma, const float* beta, void* A,
+                                 float* stat, const void* Wp, const float* bias, void* Y1, float* gn_part, int B, int N, int M,
+                                 void* stream);
 int catre_op_gnp_gelu_neck_fwd_s_h(const void* Y, const float* part64, const float* gamma, const float* beta, const float* Wn,
                                    const float* bn, const float* wp, float* Y3, float* stat, float* Spart, int B, int P,
                                    void* stream);

@@ -210,3 +210,34 @@ def test_autocast_iteration_with_bf16_rows_tracks_the_fp32_iteration():
         assert cos_f >= 0.995, (k, cos_f)
         checked += 1
     assert checked >= 20
+
+
+def test_groupnorm0_inside_the_second_linears_staging_changes_nothing():
+    """catre_op_gn_gelu_gemm_rows_h (GroupNorm-0 + GELU applied while the 256 -> 256 GEMM stages its operand) against the
+    separate pass + GEMM: the head's output and every gradient bit for bit."""
+    from catre_amd import train_ops as T
+
+    B, N, M = 4, 256, 320
+    g = torch.Generator().manual_seed(77)
+    P = N + M
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    t = dict(x=r(B * P, 64), w0=r(256, 64, 1, sc=0.1), bias=r(2 * B, 256, sc=0.3), g0=1 + r(256, sc=0.1), be0=r(256, sc=0.1),
+             w1=r(256, 256, 1, sc=0.06), b1=r(256, sc=0.1), g1=1 + r(256, sc=0.1), be1=r(256, sc=0.1), wn=r(3, 256, sc=0.1),
+             bn=r(3, sc=0.1), wp=r(1, P, 1, sc=0.05), bp=r(1, sc=0.1))
+    for v in t.values():
+        v.requires_grad_(True)
+    t["dout"] = r(B, 3)
+    fn = lambda: T.rot_head_lp(t["x"], t["w0"], t["bias"], t["g0"], t["be0"], t["w1"], t["b1"], t["g1"], t["be1"], t["wn"],
+                               t["bn"], t["wp"], t["bp"], B, N, M)
+    res = []
+    with T.amp_mode("bf16"):
+        for fused in (True, False):
+            T.LP_ROT_FUSE_GN0 = fused
+            try:
+                res.append(_run(fn, t))
+            finally:
+                T.LP_ROT_FUSE_GN0 = True
+    (o1, g1), (o2, g2) = res
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
