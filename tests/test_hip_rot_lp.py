@@ -241,3 +241,33 @@ def test_groupnorm0_inside_the_second_linears_staging_changes_nothing():
     assert torch.equal(o1, o2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
+
+
+def test_autocast_iteration_off_the_64_point_grid_takes_the_layerwise_heads():
+    """N, M not multiples of 64: the one-node heads do not apply (rot_head_lp_ok), the autocast iteration runs on the
+    layer-wise ops and still tracks the fp32 iteration."""
+    from catre_amd import train_ops as T
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 5, 96, 40
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 35, 1)
+
+    def run(autocast):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            ld = _iteration(model, kw, sym)
+        return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l32, g32 = run(False)
+    lh, gh = run(True)
+    for k in l32:
+        assert abs(float(lh[k]) - float(l32[k])) <= 3e-2 * abs(float(l32[k])) + 1e-3, (k, float(lh[k]), float(l32[k]))
+    checked = 0
+    for k, g in g32.items():
+        assert torch.isfinite(gh[k]).all(), k
+        if g.numel() < 4096 or float(g.norm()) < 1e-8:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), gh[k].reshape(-1), dim=0))
+        assert cos >= 0.97, (k, cos)
+        checked += 1
+    assert checked >= 20
