@@ -7,6 +7,8 @@ matrices so that ``torch.autograd`` can chain the hand-written HIP backward kern
 feature becomes a per-cloud bias of rot-head layer 0; the ``[B,1088,N]`` tensors are never built), so the
 gradients equal the reference's up to fp32 re-association.
 """
+import os
+
 import torch
 
 from . import hip
@@ -135,6 +137,8 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 
 
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
+# CATRE_SPLIT_L0=layerwise: the split mode's first rot-head block on the layer-wise split backward (A/B measurements)
+SPLIT_L0_ONE_PASS = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"
 
 
 def _rot_heads_shapes_ok_p(p, N, M):
@@ -173,9 +177,16 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
     out = []
     for h, pre in enumerate(_ROT_PREFIX):
         w = lambda n: p[f"{pre}.{n}"]
-        y, _ = T.linear_cloudbias(pf_obj, W0s[h], b0s[h], B, N, M, with_gn_partials=True,
-                                  pre=(buf["y0"][h], None))
-        a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, None, pre=(buf["a0"][h], buf["stat0"][h]))
+        if SPLIT_L0_ONE_PASS:
+            # the first block as one node: its backward is the fp32 one-pass kernel (k_rot_l0_bwd: sums + one pass over
+            # (da, y0)) instead of the GroupNorm apply pass, a per-cloud bias reduction and a split dgrad and wgrad
+            a = T.rot_l0_block(pf_obj, W0s[h], b0s[h], w("layers.1.weight"), w("layers.1.bias"), B, N, M,
+                               pre=(buf["y0"][h], buf["a0"][h], buf["stat0"][h]))
+        else:
+            y, _ = T.linear_cloudbias(pf_obj, W0s[h], b0s[h], B, N, M, with_gn_partials=True,
+                                      pre=(buf["y0"][h], None))
+            a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, None,
+                                 pre=(buf["a0"][h], buf["stat0"][h]))
         y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
                                          pre=(buf["y1"][h], buf["part1"][h]))
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))

@@ -1228,10 +1228,15 @@ class _RotL0Block(torch.autograd.Function):
     materialising that [R,256] gradient and reading it three more times."""
 
     @staticmethod
-    def forward(ctx, x, w, bias2d, gamma, beta, B, N, M):
+    def forward(ctx, x, w, bias2d, gamma, beta, B, N, M, pre=None):
         lib = hip.load()
         xc, w2, bc = _c(x), _c(w.reshape(256, -1)), _c(bias2d)
         R, P = xc.shape[0], N + M
+        if pre is not None:   # (y, a, stat) from a fused forward (rot_heads_forward, split mode): only the graph node; its
+            y, a, stat = pre  # backward is the fp32 one-pass kernel - fp32-grade like the split GEMMs, in one pass
+            ctx.save_for_backward(xc, w2, y, stat, gamma, beta)
+            ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, 0
+            return a
         amp = 1 if _amp() == 1 else 0   # autocast: the forward linear on bf16 operands (what _RotLinear does there)
         if amp:
             wp = _pack_bf16(w2, 256, 64, x.device)
@@ -1266,7 +1271,7 @@ class _RotL0Block(torch.autograd.Function):
         hip.check(fn(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
                      x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
                      hip.ptr(dbe), 0, hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")
-        return dx, dw.view(ctx.wshape), db, dg, dbe, None, None, None
+        return dx, dw.view(ctx.wshape), db, dg, dbe, None, None, None, None
 
 
 def rot_l0_block_ok(x, w, N, M):
@@ -1275,10 +1280,10 @@ def rot_l0_block_ok(x, w, N, M):
             and N % 64 == 0 and M % 64 == 0 and N > 0)
 
 
-def rot_l0_block(x, w, bias2d, gamma, beta, B, N, M):
-    """gelu(GroupNorm(x w^T + bias2d[cloud])) for x [B*(N+M),64] object-major, w [256,64], bias2d [2B,256] (fp32 mode,
-    N and M multiples of 64: rot_l0_block_ok)."""
-    return _RotL0Block.apply(x, w, bias2d, gamma, beta, B, N, M)
+def rot_l0_block(x, w, bias2d, gamma, beta, B, N, M, pre=None):
+    """gelu(GroupNorm(x w^T + bias2d[cloud])) for x [B*(N+M),64] object-major, w [256,64], bias2d [2B,256] (fp32 mode or
+    autocast, N and M multiples of 64: rot_l0_block_ok).  pre: (y, a, stat) already computed by a fused forward."""
+    return _RotL0Block.apply(x, w, bias2d, gamma, beta, B, N, M, pre)
 
 
 class _RotL1Block(torch.autograd.Function):
