@@ -529,9 +529,11 @@ def main():
 
         # ... and the same step under torch.autocast (engine.py:304, SOLVER.AMP.ENABLED - BASELINE config 5's arithmetic):
         # bf16-operand GEMMs, fp32 accumulation / statistics / SO(3); a bf16-class number, not the fp32 contract
-        adt = run_train(cfg_fn, dev, None, 0, "bf16", tsteps, 1)
+        torch.cuda.empty_cache()  # the fp32 run's 8 GB of saved activations: start from a clean allocator
+        adt = run_train(cfg_fn, dev, None, 0, "bf16", tsteps, 2)
         train_extra["autocast_bf16"] = {"value": round(B_PER_GPU * K_ITER * tsteps / adt, 1),
-                                        "ms_per_iteration": round(adt / tsteps / K_ITER * 1e3, 3)}
+                                        "ms_per_iteration": round(adt / tsteps / K_ITER * 1e3, 3),
+                                        "steps": tsteps, "warmup": 2}
 
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     comm = comm_info(dist, dev, world, rank, local_rank)
