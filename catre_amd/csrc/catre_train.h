@@ -2950,6 +2950,231 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_rot_l1_bwd in split mode: the one-pass structure of k_rot_l1_bwd_bf with every MFMA operand as hi + lo bf16
+// and three products - fp32-grade dA and dW on the bf16 matrix pipe.  The hi and lo images of a 64-row tile would be
+// 192 KiB, so a tile is taken as two 32-row HALVES (row-major dY hi / lo for the dgrad, transposed dY and A hi / lo for the
+// wgrad: 6 x 16 KiB): stage half, dgrad (32 rows), wgrad (two 16-row steps), next half.  Transposed images of 4 chunks per
+// column: tn4_slot (conflict-free for the staging writes - columns 4 apart, one chunk - and the fragment reads - 32
+// consecutive columns, one chunk; found by search, profiles/ubench/tn4_swizzle.py).  Y, A, dA: fp32 rows.
+// WpT: catre_op_pack_split of W^T (hi pack, then lo pack 256 * 256 / 8 u32x4 further).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn4_slot(int c, int chunk) {
+  return (c >> 2) * 16 + (((c & 3) ^ ((c >> 4) & 3)) << 2) + ((chunk ^ (c >> 2)) & 3);
+}
+#define L1S_IMG (32 * 32)  // 16-byte slots of one 32 x 256 bf16 image
+__global__ __launch_bounds__(256) void k_rot_l1_bwd_sp(const float* __restrict__ dY3, const float* __restrict__ Y,
+                                                       const float* __restrict__ stat, const float* __restrict__ sums,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ Wn, const float* __restrict__ A,
+                                                       const u32x4* __restrict__ WpT, float* __restrict__ dA,
+                                                       float* __restrict__ part /*[wg][256*256 + 256]*/, int P, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 ldsq[];
+  u32x4* dysh = ldsq;                // row-major dY, hi / lo: bf_off<32>(row, chunk)
+  u32x4* dysl = ldsq + L1S_IMG;
+  u32x4* dyth = ldsq + 2 * L1S_IMG;  // transposed dY, hi / lo: tn4_slot(column, chunk of 8 rows)
+  u32x4* dytl = ldsq + 3 * L1S_IMG;
+  u32x4* asth = ldsq + 4 * L1S_IMG;  // transposed A tile, hi / lo
+  u32x4* astl = ldsq + 5 * L1S_IMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int obj = blockIdx.x, T = P / TP;
+  const int t0 = blockIdx.y * tpw, t1 = min(T, t0 + tpw);
+  const int grp = lane >> 1;
+  const float mean = stat[((size_t)obj * 32 + grp) * 2], rstd = stat[((size_t)obj * 32 + grp) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + grp) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + grp) * 2 + 1] * inv_m;
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  const f32x4 w0 = reinterpret_cast<const f32x4*>(Wn)[lane], w1 = reinterpret_cast<const f32x4*>(Wn)[64 + lane],
+              w2 = reinterpret_cast<const f32x4*>(Wn)[128 + lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 wacc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) wacc[a][kb] = zero16();
+  const int i = lane & 31, h = lane >> 5;
+  // batch bb (0..3) of a tile: rows (bb >> 1) * 32 + 8 wave + 4 (bb & 1) + u, u = 0..3 - half bb >> 1, the wave's 8-row chunk
+  auto row_of = [&](int bb, int u) { return (bb >> 1) * 32 + 8 * wave + 4 * (bb & 1) + u; };
+  f32x4 vy[2][4], va[2][4];
+  auto request_y = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      vy[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (rr + row_of(bb, u)) * 64 + lane);
+  };
+  auto request_a = [&](int tt, int bb) {
+    const size_t rr = (size_t)obj * P + (size_t)tt * TP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      va[bb & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A) + (rr + row_of(bb, u)) * 64 + lane);
+  };
+  auto request = [&](int tt, int bb) {
+    request_y(tt, bb);
+    request_a(tt, bb);
+  };
+  u32x2* dysh2 = reinterpret_cast<u32x2*>(dysh);
+  u32x2* dysl2 = reinterpret_cast<u32x2*>(dysl);
+  // hi / lo of a pair of fp32 values as packed bf16 pairs
+  auto split2 = [](float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack_bf2(a, b);
+    lo = pack_bf2(a - bf_lo(hi), b - bf_hi(hi));
+  };
+  if (t0 < t1) request_y(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const size_t r0 = (size_t)obj * P + (size_t)t * TP;
+    request_a(t, 0);
+    request(t, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      unsigned lane_o = lane;  // opaque per half: keeps the LDS addresses out of the loop preheaders (k_rot_l1_bwd_bf)
+      asm volatile("" : "+v"(lane_o));
+      unsigned hyh[4][2], hyl[4][2], hah[4][2], hal[4][2];  // rows 0..3 of the chunk until rows 4..7 arrive
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bb = 2 * hh + b2;
+        unsigned pyh[4][2], pyl[4][2];  // this batch's two row pairs per column, hi / lo
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {  // a pair of rows at a time
+          float d3v[2][3];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const float* d3 = dY3 + (r0 + row_of(bb, 2 * up + w)) * 3;
+            d3v[w][0] = d3[0];
+            d3v[w][1] = d3[1];
+            d3v[w][2] = d3[2];
+          }
+          f32x4 o[2];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const int u = 2 * up + w, row = 8 * wave + 4 * b2 + u;  // row inside the half
+            const float d0 = d3v[w][0], d1 = d3v[w][1], d2 = d3v[w][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float yv = vy[bb & 1][u][q];
+              const float xh = (yv - mean) * rstd;
+              const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
+              const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+              o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
+              cs[q] += o[w][q];
+            }
+            unsigned ph0, pl0, ph1, pl1;
+            split2(o[w][0], o[w][1], ph0, pl0);
+            split2(o[w][2], o[w][3], ph1, pl1);
+            const u32x2 ph = {ph0, ph1}, pl = {pl0, pl1};
+            const int off = (row * 32 + ((lane_o >> 1) ^ (row & 15))) * 2 + (lane_o & 1);
+            dysh2[off] = ph;
+            dysl2[off] = pl;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split2(o[0][q], o[1][q], pyh[q][up], pyl[q][up]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (b2 == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            hyh[q][0] = pyh[q][0];
+            hyh[q][1] = pyh[q][1];
+            hyl[q][0] = pyl[q][0];
+            hyl[q][1] = pyl[q][1];
+            split2(va[0][0][q], va[0][1][q], hah[q][0], hal[q][0]);
+            split2(va[0][2][q], va[0][3][q], hah[q][1], hal[q][1]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int slot = tn4_slot(4 * (int)lane_o + q, wave);
+            dyth[slot] = u32x4{hyh[q][0], hyh[q][1], pyh[q][0], pyh[q][1]};
+            dytl[slot] = u32x4{hyl[q][0], hyl[q][1], pyl[q][0], pyl[q][1]};
+            unsigned h2, l2, h3, l3;
+            split2(va[1][0][q], va[1][1][q], h2, l2);
+            split2(va[1][2][q], va[1][3][q], h3, l3);
+            asth[slot] = u32x4{hah[q][0], hah[q][1], h2, h3};
+            astl[slot] = u32x4{hal[q][0], hal[q][1], l2, l3};
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (bb < 2) request(t, bb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (hh == 1 && t + 1 < t1) request_y(t + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {  // dA half tile = dY W: input-channel blocks 2 wave, 2 wave + 1 x the half's 32 rows
+        f32x16 acc[2][1];
+        acc[0][0] = acc[1][0] = zero16();
+        GemmPipeS<2, 1, true, 32, 1> gp;  // (two K-steps of weight fragments ahead: 16 more registers, spills)
+        gp.prefetch(WpT + ((size_t)(2 * wave) * 16) * 64 + lane_o, 16 * 64, 256 * 256 / 8);
+        gp.run(acc, dysh, dysl, (int)lane_o);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          float* o = dA + (r0 + 32 * hh + 4 * h) * 256 + (2 * wave + mb) * 32 + i;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st_stream(o + ((r & 3) + 8 * (r >> 2)) * 256, acc[mb][0][r]);
+        }
+      }
+      {  // dW += dY^T A over the half's rows: 16 rows per step, three products per block
+        const unsigned io = lane_o & 31, ho = lane_o >> 5;
+        const unsigned b0 = (io >> 2) * 16 + (((io & 3) ^ (io >> 4)) << 2) + ((ho ^ (io >> 2)) & 3);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 fah[2], fal[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int jb = 2 * wave + a;
+            const unsigned sl = jb * 128 + (b0 ^ (((2 * jb) & 3) << 2) ^ (2 * ks));
+            fah[a] = dyth[sl];
+            fal[a] = dytl[sl];
+          }
+#pragma unroll
+          for (int kq = 0; kq < 2; ++kq) {  // four input-channel blocks at a time (all eight: 64 fragment registers, spills)
+            u32x4 fbh[4], fbl[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+              const int kb = 4 * kq + k4;
+              const unsigned sl = kb * 128 + (b0 ^ (((2 * kb) & 3) << 2) ^ (2 * ks));
+              fbh[k4] = asth[sl];
+              fbl[k4] = astl[sl];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+                wacc[a][4 * kq + k4] = mfma_bf(fal[a], fbh[k4], wacc[a][4 * kq + k4]);
+                wacc[a][4 * kq + k4] = mfma_bf(fah[a], fbl[k4], wacc[a][4 * kq + k4]);
+                wacc[a][4 * kq + k4] = mfma_bf(fah[a], fbh[k4], wacc[a][4 * kq + k4]);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (256 * 256 + 256);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = (2 * wave + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[(size_t)j * 256 + kb * 32 + i] = wacc[a][kb][reg];
+      }
+  float* red = reinterpret_cast<float*>(ldsq);
+  *reinterpret_cast<f32x4*>(red + wave * 256 + 4 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __syncthreads();
+  out[256 * 256 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_rot_l0_bwd on the bf16 matrix pipe (autocast), built like k_rot_l1_bwd_bf: dY goes to LDS row-major (dgrad: dX = dY W,
 // K = 256) and transposed next to the transposed X tile (wgrad: dW += dY^T X over the tile's rows); a thread stages the 8
 // rows of wave w's chunk x 4 columns in two batches of four rows, the batch registers are re-requested for the NEXT tile as

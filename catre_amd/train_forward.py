@@ -139,6 +139,7 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
 # CATRE_SPLIT_L0=layerwise: the split mode's first rot-head block on the layer-wise split backward (A/B measurements)
 SPLIT_L0_ONE_PASS = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"
+SPLIT_L1_ONE_PASS = os.environ.get("CATRE_SPLIT_L1", "onepass") != "layerwise"   # the same for the second block
 
 
 def _rot_heads_shapes_ok_p(p, N, M):
@@ -187,10 +188,16 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
                                       pre=(buf["y0"][h], None))
             a = T.gn_points_gelu(y, w("layers.1.weight"), w("layers.1.bias"), B, P, None,
                                  pre=(buf["a0"][h], buf["stat0"][h]))
-        y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
-                                         pre=(buf["y1"][h], buf["part1"][h]))
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         rd = w("neck.0.weight").shape[0]
+        if SPLIT_L1_ONE_PASS:
+            # the second block + tail as one node: backward = conv_p, then ONE pass with hi + lo operands (k_rot_l1_bwd_sp)
+            out.append(T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"),
+                                        wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, N, M,
+                                        pre=(buf["y1"][h], buf["part1"][h]))[:, :rd])
+            continue
+        y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
+                                         pre=(buf["y1"][h], buf["part1"][h]))
         out.append(T.neck_tail(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
                                p.get(f"{pre}.conv_p.bias"), B, P, part1)[:, :rd])
     return out

@@ -1061,18 +1061,23 @@ class _RotL1TailLP(torch.autograd.Function):
     instead of the apply pass + a dgrad and a wgrad launch that each re-read a [B*P,256] fp32 matrix."""
 
     @staticmethod
-    def forward(ctx, a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M):
+    def forward(ctx, a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M, pre=None):
         lib = hip.load()
         ac, w2, wn = _c(a), _c(w.reshape(256, -1)), _c(wn)
         bc, bnc = _c(b), (_c(bn) if bn is not None else None)
         wv = _c(wp.reshape(-1))
         dev = a.device
         R, P = ac.shape[0], N + M
-        pk = _pack_bf16(w2, 256, 256, dev)
-        y = torch.empty(R, 256, dtype=torch.float32, device=dev)
-        part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=dev)
-        hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(ac), ac.stride(0), hip.ptr(pk), hip.ptr(bc), 0, hip.ptr(y), 256, 256, 256,
-                                            B, N, M, hip.ptr(part), 1, _st(a)), "catre_op_gemm_rows_gn")
+        if pre is not None:   # split mode: (y, partials) from the fused forward (rot_heads_forward); the backward is the
+            y, part = pre     # one-pass kernel with hi + lo operands (k_rot_l1_bwd_sp)
+            ctx.lp = "split"
+        else:
+            ctx.lp = True
+            pk = _pack_bf16(w2, 256, 256, dev)
+            y = torch.empty(R, 256, dtype=torch.float32, device=dev)
+            part = torch.empty(R // 64, 32, 2, dtype=torch.float32, device=dev)
+            hip.check(lib.catre_op_gemm_rows_gn(hip.ptr(ac), ac.stride(0), hip.ptr(pk), hip.ptr(bc), 0, hip.ptr(y), 256, 256,
+                                                256, B, N, M, hip.ptr(part), 1, _st(a)), "catre_op_gemm_rows_gn")
         y3 = torch.empty(R, 3, dtype=torch.float32, device=dev)
         stat = torch.empty(B, 32, 2, dtype=torch.float32, device=dev)
         spart = torch.empty(R // 64, 3, 256, dtype=torch.float32, device=dev)
@@ -1099,9 +1104,10 @@ class _RotL1TailLP(torch.autograd.Function):
         ws = _ws(B * P * 4, dev)
         hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
                                         hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
-        da, dw, db, dpar = _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=dout, spart=spart, lp=True)
+        da, dw, db, dpar = _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=dout, spart=spart, lp=ctx.lp)
         dbn = _colsum(dy3) if ctx.has_bn else None
-        return (da, dw.view(ctx.wshape), db, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None)
+        return (da, dw.view(ctx.wshape), db, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None,
+                None)
 
 
 class _RotHeadLP(torch.autograd.Function):
@@ -1215,9 +1221,10 @@ def rot_l1_tail_lp_ok(a, w, b, N, M):
             and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
 
 
-def rot_l1_tail_lp(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M):
-    """conv_p(neck(gelu(GroupNorm(a w^T + b)))) -> [B,3] under autocast (rot_l1_tail_lp_ok); a [B*(N+M),256] object-major."""
-    return _RotL1TailLP.apply(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M)
+def rot_l1_tail_lp(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M, pre=None):
+    """conv_p(neck(gelu(GroupNorm(a w^T + b)))) -> [B,3] under autocast (rot_l1_tail_lp_ok); a [B*(N+M),256] object-major.
+    pre = (y, partials) from the split mode's fused forward: graph node only, split one-pass backward."""
+    return _RotL1TailLP.apply(a, w, b, gamma, beta, wn, bn, wp, bp, B, N, M, pre)
 
 
 class _RotL0Block(torch.autograd.Function):
@@ -1354,7 +1361,8 @@ def _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=None, spar
     dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
     ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
     if lp:
-        hip.check(lib.catre_op_rot_l1_bwd_lp(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
+        fn = lib.catre_op_rot_l1_bwd_sp if lp == "split" else lib.catre_op_rot_l1_bwd_lp
+        hip.check(fn(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
                                              hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(a), hip.ptr(w2), hip.ptr(da),
                                              hip.ptr(dwb), hip.ptr(dpar), hip.ptr(ws), ws.numel(), B, P, _st(dy3)),
                   "catre_op_rot_l1_bwd_lp")

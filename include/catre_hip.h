@@ -407,6 +407,11 @@ int catre_op_rot_l1_bwd_s(const float* dY3, const float* dout, const float* Spar
 int catre_op_rot_l1_bwd_lp(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
                            const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
                            float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* ... and in split mode: hi + lo bf16 operands, three products per block - fp32-grade dA and dW on the bf16 pipe
+ * (k_rot_l1_bwd_sp, 32-row half tiles). */
+int catre_op_rot_l1_bwd_sp(const float* dY3, const float* dout, const float* Spart, const float* Y, const float* stat,
+                           const float* gamma, const float* beta, const float* Wn, const float* A, const float* W, float* dA,
+                           float* dWb, float* dparams, void* ws, size_t ws_bytes, int B, int P, void* stream);
 /* The all-bf16-activation form of the autocast rotation heads: the [rows,256] tensors that travel between these kernels -
  * y0, a0, y1, dA - are bf16 rows (256 bf16 per row; `void*`), what torch.autocast's Conv1d outputs are (engine.py:304), so
  * every pass over them moves half the bytes; statistics, GroupNorm / GELU arithmetic, accumulation and every other output

@@ -271,3 +271,37 @@ def test_autocast_iteration_off_the_64_point_grid_takes_the_layerwise_heads():
         assert cos >= 0.97, (k, cos)
         checked += 1
     assert checked >= 20
+
+
+def test_split_iteration_with_one_pass_head_backward_matches_the_layerwise_split_backward():
+    """COMPUTE_DTYPE='split': the rot heads' blocks as one-pass nodes (k_rot_l0_bwd on the fp32 pipe, k_rot_l1_bwd_sp with
+    hi + lo operands) against the layer-wise split dgrad / wgrad GEMMs: identical losses (the forward is the same fused
+    kernel), every gradient within 2e-4 of its largest entry - both are fp32-grade - and within the split mode's bar (5e-2
+    relative L2) of the fp32 iteration."""
+    from catre_amd import train_forward as F
+    from catre_amd import train_ops as T
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 6, 256, 192
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 37, 1)
+
+    def run(mode, one_pass):
+        F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = one_pass
+        try:
+            opt.zero_grad(set_to_none=True)
+            with T.amp_mode(mode):
+                ld = _iteration(model, kw, sym)
+            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = True
+
+    l1, g1 = run("split", True)
+    l2, g2 = run("split", False)
+    l32, g32 = run("fp32", True)
+    for k in l2:
+        assert torch.equal(l1[k], l2[k]), k
+    for k in g2:
+        scale = float(g32[k].abs().max()) + 1e-30
+        assert float((g1[k] - g2[k]).abs().max()) / scale <= 2e-4, (k, float((g1[k] - g2[k]).abs().max()) / scale)
+        # (against the fp32 iteration: the bar of test_hip_train's split test, 5e-2 relative L2 - max-pool winners flip)
+        assert float((g1[k] - g32[k]).norm() / (g32[k].norm() + 1e-30)) <= 5e-2, k
