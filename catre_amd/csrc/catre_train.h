@@ -3333,6 +3333,183 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const void* __restrict__ 
   }
 }
 
+// k_rot_l0_bwd in split mode: k_rot_l0_bwd_bf's pass with every MFMA operand as hi + lo bf16 and three products
+// (fp32-grade dX and dW): hi and lo images of the row-major and the transposed dY tile and of the transposed X tile, 144 KiB
+// of LDS.  dA, Y: fp32 rows.  WpT: catre_op_pack_split of W^T (lo pack 64 * 256 / 8 u32x4 behind the hi pack).
+__global__ __launch_bounds__(512) void k_rot_l0_bwd_sp(const float* __restrict__ dA, const float* __restrict__ Y,
+                                                       const float* __restrict__ stat, const float* __restrict__ sums,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ X, int ldx, const u32x4* __restrict__ WpT,
+                                                       float* __restrict__ dX, int lddx, float* __restrict__ wpart,
+                                                       float* __restrict__ dbias, int B, int N, int M, int acc_dx) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 ldsq[];
+  u32x4* dys = ldsq;                  // row-major hi, bf_off<32>(row, chunk); lo image L0L_IMG slots further
+  u32x4* dyt = ldsq + 2 * L0L_IMG;    // transposed hi, tn_slot(column, chunk of 8 rows); lo L0L_IMG further
+  u32x4* xt = ldsq + 4 * L0L_IMG;     // transposed X tile hi: 64 columns x 8 chunks; lo 512 slots further
+  auto split2 = [](float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack_bf2(a, b);
+    lo = pack_bf2(a - bf_lo(hi), b - bf_hi(hi));
+  };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = N + M;
+  const int obj = blockIdx.x % B, prior = blockIdx.x / B;
+  const int ntile = (prior ? M : N) / TP;
+  const size_t row0 = (size_t)obj * P + (prior ? N : 0);
+  const size_t xrow0 = (acc_dx & 2) ? (prior ? (size_t)B * N + (size_t)obj * M : (size_t)obj * N) : row0;
+  const int grp = lane >> 1;
+  const float mean = stat[((size_t)obj * 32 + grp) * 2], rstd = stat[((size_t)obj * 32 + grp) * 2 + 1];
+  const float inv_m = 1.0f / (8.f * (float)P);
+  const float m1 = sums[((size_t)obj * 32 + grp) * 2] * inv_m, m2 = sums[((size_t)obj * 32 + grp) * 2 + 1] * inv_m;
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[lane], be = reinterpret_cast<const f32x4*>(beta)[lane];
+  f32x4 sc, sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = rstd * ga[q];
+    sh[q] = be[q] - mean * sc[q];
+  }
+  // batch bb of a tile: rows 8 wave + 4 bb + u, u = 0..3
+  f32x4 vd[2][4], vy[2][4], vx[2];
+  auto request = [&](int t, int bb) {
+    const size_t r = row0 + (size_t)t * TP + 8 * wave + 4 * bb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vd[bb][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dA) + (r + u) * 64 + lane);
+      vy[bb][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y) + (r + u) * 64 + lane);
+    }
+  };
+  const int xc4 = tid & 15, xrp = tid >> 4;  // X tile: column quad and row pair (rows 2 xrp, 2 xrp + 1) of this thread
+  auto request_x = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      vx[u] = *reinterpret_cast<const f32x4*>(X + (xrow0 + (size_t)t * TP + 2 * xrp + u) * ldx + 4 * xc4);
+  };
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 wacc[2];  // weight gradient: output-channel block `wave` x both input-channel blocks
+  wacc[0] = wacc[1] = zero16();
+  const int i = lane & 31, h = lane >> 5;
+  u32x2* dys2 = reinterpret_cast<u32x2*>(dys);
+  if (ntile > 0) {
+    request(0, 0);
+    request(0, 1);
+    request_x(0);
+  }
+  for (int t = 0; t < ntile; ++t) {
+    unsigned lane_o = lane;  // opaque per tile: keeps the tile's LDS addresses out of the loop preheader (k_rot_l1_bwd_bf)
+    asm volatile("" : "+v"(lane_o));
+    unsigned hy[4][4], hl[4][4];  // the chunk's four row pairs per column, hi / lo, packed as they are produced
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+      for (int up = 0; up < 2; ++up) {  // a pair of rows at a time (a row's temporaries do not overlap the next one's)
+        f32x4 o[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int u = 2 * up + w, row = 8 * wave + 4 * bb + u;
+          const f32x4 y4 = vy[bb][u], d4 = vd[bb][u];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float yv = y4[q];
+            const float xh = (yv - mean) * rstd;
+            const float dxh = d4[q] * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+            o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_bwd_apply
+            cs[q] += o[w][q];
+          }
+          unsigned ph0, pl0, ph1, pl1;
+          split2(o[w][0], o[w][1], ph0, pl0);
+          split2(o[w][2], o[w][3], ph1, pl1);
+          const int off = (row * 32 + ((lane_o >> 1) ^ (row & 15))) * 2 + (lane_o & 1);
+          dys2[off] = u32x2{ph0, ph1};
+          dys2[2 * L0L_IMG + off] = u32x2{pl0, pl1};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2(o[0][q], o[1][q], hy[q][2 * bb + up], hl[q][2 * bb + up]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ntile) request(t + 1, bb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = tn_slot(4 * (int)lane_o + q, wave);
+      dyt[slot] = u32x4{hy[q][0], hy[q][1], hy[q][2], hy[q][3]};
+      dyt[L0L_IMG + slot] = u32x4{hl[q][0], hl[q][1], hl[q][2], hl[q][3]};
+    }
+    {  // X tile transposed: rows 2 xrp, 2 xrp + 1 of column 4 xc4 + q are one dword of chunk xrp >> 2
+      unsigned* xt32 = reinterpret_cast<unsigned*>(xt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned xh, xl;
+        split2(vx[0][q], vx[1][q], xh, xl);
+        const int e = tn_slot(4 * xc4 + q, xrp >> 2) * 4 + (xrp & 3);
+        xt32[e] = xh;
+        xt32[512 * 4 + e] = xl;
+      }
+      if (t + 1 < ntile) request_x(t + 1);
+    }
+    __syncthreads();
+    if (wave < 4) {  // dX tile [64 x 64] = dY W: one 32 x 32 block per wave; a lane owns one row and 16 of the block's channels
+      const int mbk = wave & 1, nb = wave >> 1;
+      f32x16 acc[1][1];
+      acc[0][0] = zero16();
+      GemmPipeS<1, 1, false, 32, 2> gp;
+      gp.prefetch(WpT + ((size_t)mbk * 16) * 64 + lane_o, 0, 64 * 256 / 8);
+      gp.run(acc, dys + nb * 32 * 32, dys + L0L_IMG + nb * 32 * 32, (int)lane_o);
+      float* o = dX + (row0 + (size_t)t * TP + nb * 32 + i) * lddx + mbk * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
+        if (acc_dx & 1) v += *reinterpret_cast<const f32x4*>(o + 8 * g);  // second head of a pair: dX += (the heads share X)
+        *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+      }
+    }
+    {  // dW [256 x 64] += dY^T X: every wave its output-channel block x both input-channel blocks, 16 rows per step
+      const unsigned io = lane_o & 31, ho = lane_o >> 5;
+      const unsigned b0 = (io >> 1) * 16 + 8 * ((io ^ (io >> 2)) & 1) + ((ho ^ (io >> 1) ^ (io >> 4)) & 7);
+#pragma unroll
+      for (int ks = 0; ks < TP / 16; ++ks) {
+        const int sa = wave * 256 + (b0 ^ ((2 * (wave ^ ks)) & 7));
+        const u32x4 fa = dyt[sa], fal = dyt[L0L_IMG + sa];
+        u32x4 fb[2], fbl[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int sb = kb * 256 + (b0 ^ ((2 * (kb ^ ks)) & 7));
+          fb[kb] = xt[sb];
+          fbl[kb] = xt[512 + sb];
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          wacc[kb] = mfma_bf(fal, fb[kb], wacc[kb]);
+          wacc[kb] = mfma_bf(fa, fbl[kb], wacc[kb]);
+          wacc[kb] = mfma_bf(fa, fb[kb], wacc[kb]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  {
+    float* out = wpart + (size_t)blockIdx.x * (256 * 64);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[(size_t)j * 64 + kb * 32 + i] = wacc[kb][reg];
+      }
+  }
+  // bias gradient of the cloud (fp32 values, before the bf16 rounding): eight row slices of 256 column sums, in wave order
+  float* red = reinterpret_cast<float*>(ldsq);
+  *reinterpret_cast<f32x4*>(red + wave * 256 + 4 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __syncthreads();
+  if (tid < 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red[w * 256 + tid];
+    dbias[(size_t)blockIdx.x * 256 + tid] = sum;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32,256) + GELU on rows [R,256] (ts head): groups of 8 channels inside a row
 // ------------------------------------------------------------------------------------------------

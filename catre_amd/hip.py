@@ -161,6 +161,7 @@ _SIGS = {
     "catre_op_rot_l0_bwd_ws_bytes": (_SZ, [_I, _I, _I]),
     "catre_op_rot_l0_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _I, _P]),
     "catre_op_rot_l0_bwd_lp": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _I, _P]),
+    "catre_op_rot_l0_bwd_sp": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_fwd_s": (_I, [_P] * 10 + [_I, _I, _P]),
     "catre_op_rot_l1_bwd_s": (_I, [_P] * 14 + [_SZ, _I, _I, _P]),
     "catre_op_rot_l1_bwd_lp": (_I, [_P] * 14 + [_SZ, _I, _I, _P]),

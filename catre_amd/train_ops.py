@@ -1194,6 +1194,8 @@ class _RotHeadLP(torch.autograd.Function):
                 dbn, dwp.view(sp), dbp, None, None, None)
 
 
+# CATRE_SPLIT_L0_KERNEL=fp32: split mode's first block on fp32 k_rot_l0_bwd instead of k_rot_l0_bwd_sp (A/B measurements)
+SPLIT_L0_SP = os.environ.get("CATRE_SPLIT_L0_KERNEL", "split") != "fp32"
 # CATRE_LP_ROT_GN0=separate: the head's GroupNorm-0 + GELU as its own pass (A/B measurements, tests/test_hip_rot_lp.py)
 LP_ROT_FUSE_GN0 = os.environ.get("CATRE_LP_ROT_GN0", "fused") != "separate"
 # CATRE_LP_ROT_ROWS=fp32: keep the autocast heads' [rows,256] activations in fp32 (_RotL0Block + _RotL1TailLP)
@@ -1240,9 +1242,9 @@ class _RotL0Block(torch.autograd.Function):
         xc, w2, bc = _c(x), _c(w.reshape(256, -1)), _c(bias2d)
         R, P = xc.shape[0], N + M
         if pre is not None:   # (y, a, stat) from a fused forward (rot_heads_forward, split mode): only the graph node; its
-            y, a, stat = pre  # backward is the fp32 one-pass kernel - fp32-grade like the split GEMMs, in one pass
+            y, a, stat = pre  # backward is the one-pass kernel with hi + lo operands (k_rot_l0_bwd_sp): fp32-grade
             ctx.save_for_backward(xc, w2, y, stat, gamma, beta)
-            ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, 0
+            ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, (2 if SPLIT_L0_SP else 0)
             return a
         amp = 1 if _amp() == 1 else 0   # autocast: the forward linear on bf16 operands (what _RotLinear does there)
         if amp:
@@ -1274,7 +1276,8 @@ class _RotL0Block(torch.autograd.Function):
         db = torch.empty(2 * B if M > 0 else B, 256, dtype=torch.float32, device=dev)
         dg, dbe = torch.empty_like(gamma), torch.empty_like(beta)
         ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
-        fn = lib.catre_op_rot_l0_bwd_lp if ctx.amp else lib.catre_op_rot_l0_bwd   # autocast: both GEMMs on the bf16 pipe
+        # autocast: both GEMMs on the bf16 pipe; split: hi + lo operands
+        fn = (lib.catre_op_rot_l0_bwd_sp if ctx.amp == 2 else lib.catre_op_rot_l0_bwd_lp) if ctx.amp else lib.catre_op_rot_l0_bwd
         hip.check(fn(hip.ptr(da), hip.ptr(y), hip.ptr(stat), hip.ptr(gamma), hip.ptr(beta), hip.ptr(x),
                      x.stride(0), hip.ptr(w2), hip.ptr(dx), 64, hip.ptr(dw), hip.ptr(db), hip.ptr(dg),
                      hip.ptr(dbe), 0, hip.ptr(ws), ws.numel(), B, N, M, _st(da)), "catre_op_rot_l0_bwd")

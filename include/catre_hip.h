@@ -384,6 +384,11 @@ int catre_op_rot_l0_bwd_lp(const float* dA, const float* Y, const float* stat, c
                            const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
                            float* dgamma, float* dbeta, int accumulate_dx, void* ws, size_t ws_bytes, int B, int N, int M,
                            void* stream);
+/* ... and in split mode: hi + lo bf16 operands, three products - fp32-grade dX and dW (k_rot_l0_bwd_sp). */
+int catre_op_rot_l0_bwd_sp(const float* dA, const float* Y, const float* stat, const float* gamma, const float* beta,
+                           const float* X, int ldx, const float* W, float* dX, int lddx, float* dW, float* dbias2d,
+                           float* dgamma, float* dbeta, int accumulate_dx, void* ws, size_t ws_bytes, int B, int N, int M,
+                           void* stream);
 /* Backward of a RotHead's second block - Conv1d(256 -> 256), GroupNorm, GELU, neck (conv_out_per_rot_head.py:129-137) - from
  * dY3 [R,3]: the sums pass, then one pass over (Y, A) that keeps the linear's output gradient in LDS.  A [R,256] the block's
  * input, W [256][256]; dA [R,256], dWb [256*256 + 256] = dW then db, dparams [5][256] = dgamma, dbeta, dWn.  P % 64 == 0. */
