@@ -124,7 +124,7 @@ def test_l0_block_under_autocast_matches_the_layerwise_autocast_ops(B, N, M):
         assert float((gf[k] - g32[k]).abs().max()) / scale <= 3e-2, k
 
 
-@pytest.mark.parametrize("B,N,M", [(5, 256, 192), (2, 1024, 1024)])
+@pytest.mark.parametrize("B,N,M", [(5, 256, 192), (2, 1024, 1024), (40, 1024, 1024)])
 def test_head_with_bf16_rows_tracks_the_fp32_row_form(B, N, M):
     """train_ops._RotHeadLP (y0 / a0 / y1 / dA as bf16 rows) against the same head with fp32 rows (_RotL0Block + _RotL1TailLP,
     same bf16-operand GEMMs) and against the fp32 head: a0 is rounded to bf16 by the next GEMM in both forms, so only the
@@ -305,3 +305,36 @@ def test_split_iteration_with_one_pass_head_backward_matches_the_layerwise_split
         assert float((g1[k] - g2[k]).abs().max()) / scale <= 2e-4, (k, float((g1[k] - g2[k]).abs().max()) / scale)
         # (against the fp32 iteration: the bar of test_hip_train's split test, 5e-2 relative L2 - max-pool winners flip)
         assert float((g1[k] - g32[k]).norm() / (g32[k].norm() + 1e-30)) <= 5e-2, k
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+def test_one_pass_heads_at_a_batch_whose_workgroups_walk_several_tiles(mode):
+    """B = 40 objects of N = M = 1024 points: the one-pass backward kernels run 6 chunks of 6 tiles per object (the small
+    cases above give every workgroup one tile, the bench shape one workgroup per object) - against the layer-wise backward
+    of the same mode."""
+    from catre_amd import train_forward as F
+    from catre_amd import train_ops as T
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 40, 1024, 1024
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 39, 1)
+
+    def run(one_pass):
+        F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = T.FUSED_LP_ROT = one_pass
+        T.LP_ROT_BF16_ROWS = False   # fp32 rows: the layer-wise path's own tensors, so the comparison is tight
+        try:
+            opt.zero_grad(set_to_none=True)
+            with T.amp_mode(mode):
+                ld = _iteration(model, kw, sym)
+            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = T.FUSED_LP_ROT = T.LP_ROT_BF16_ROWS = True
+
+    l1, g1 = run(True)
+    l2, g2 = run(False)
+    for k in l2:
+        assert torch.equal(l1[k], l2[k]), k
+    for k in g2:
+        scale = float(g2[k].abs().max()) + 1e-30
+        err = float((g1[k] - g2[k]).abs().max()) / scale
+        assert err <= (2e-4 if mode == "split" else 2e-3), (k, err)
