@@ -237,8 +237,10 @@ struct TrainSave {
   int* pidx;                      // [tiles][1024]
 };
 
-template <int RS, bool SAVE = false>
-__global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* __restrict__ W1,
+// ONE (full grids, RS == 1): a single workgroup per CU with ONE wave per SIMD, the last layer as an MB8 x NB2 wave tile in
+// one pass (256 accumulators) - the power-limited sweep form of k_trunk4; same K order per output element: same bits.
+template <int RS, bool SAVE = false, bool ONE = false>
+__global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stn3d(catre_points P, const float* __restrict__ W1,
                                                const float* __restrict__ b1, const f32x4* __restrict__ wp2,
                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
                                                const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
@@ -267,13 +269,15 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
   if (SAVE) save_tile_rows<64, 256, false>(a1, LD64, sv.s1 + row0 * 64, tid);
   // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks (RS = 1); RS workgroups
   // per tile: 8/RS m-blocks per wave from mb0 in one pass (see k_trunk)
-  constexpr int MB3 = RS == 8 ? 1 : RS == 4 ? 2 : 4;
+  constexpr int MB3 = ONE ? 8 : RS == 8 ? 1 : RS == 4 ? 2 : 4;
+  static_assert(!ONE || RS == 1, "ONE is the full-grid form");
+  constexpr bool TWO = RS == 1 && !ONE;  // two passes of 4 m-blocks
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
   GemmPipe<MB3, 2, true, false, 16, RS == 8 ? 3 : 2, 1> g3a, g3b;
   float bl[2][MB3];
   g3a.prefetch(wp3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
   load_bias_lane<MB3>(bl[0], b3, mb0 * 32, lane);
-  if (RS == 1) load_bias_lane<MB3>(bl[1], b3, (mb0 + 4) * 32, lane);
+  if (TWO) load_bias_lane<MB3>(bl[1], b3, (mb0 + 4) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {  // conv2 64->128: wave -> m-block `wave`, both point blocks
     f32x16 acc[1][2] = {{zero16(), zero16()}};
@@ -288,14 +292,14 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, a2, LD128, lane);
-    if (RS == 1) g3b.prefetch(wp3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
+    if (TWO) g3b.prefetch(wp3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
     if (SAVE)
       argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl[0],
                                 (int)row0, lane);
     else
       max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
-  if (RS == 1) {
+  if (TWO) {
     f32x16 acc[MB3][2];
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d(catre_points P, const float* _
 // a3+a4: x' = x T3, relu(conv1), STNkd conv stack 64->64->128->1024 (+ReLU), per-tile max
 // (pointnet.py:98-103, 57-61).  256 threads, 2 workgroups per CU.
 // ------------------------------------------------------------------------------------------
-template <int RS, bool SAVE = false>
-__global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* __restrict__ trans3,
+template <int RS, bool SAVE = false, bool ONE = false>
+__global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stnkd(catre_points P, const float* __restrict__ trans3,
                                                const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
@@ -355,13 +359,15 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
   if (SAVE) save_tile_rows<64, 256, false>(f1, LD64, sv.s1 + row0 * 64, tid);
-  constexpr int MB3 = RS == 8 ? 1 : RS == 4 ? 2 : 4;
+  constexpr int MB3 = ONE ? 8 : RS == 8 ? 1 : RS == 4 ? 2 : 4;
+  static_assert(!ONE || RS == 1, "ONE is the full-grid form");
+  constexpr bool TWO = RS == 1 && !ONE;  // two passes of 4 m-blocks
   const int mb0 = part * (32 / RS) + wave * (8 / RS);
   GemmPipe<MB3, 2, true, false, 16, RS == 8 ? 3 : 2, 1> g3a, g3b;
   float bl[2][MB3];
   g3a.prefetch(wpf3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
   load_bias_lane<MB3>(bl[0], bf3, mb0 * 32, lane);
-  if (RS == 1) load_bias_lane<MB3>(bl[1], bf3, (mb0 + 4) * 32, lane);
+  if (TWO) load_bias_lane<MB3>(bl[1], bf3, (mb0 + 4) * 32, lane);
   __builtin_amdgcn_sched_barrier(0);
   {  // fstn.conv2 64->128
     f32x16 acc[1][2] = {{zero16(), zero16()}};
@@ -376,14 +382,14 @@ __global__ __launch_bounds__(256, 2) void k_stnkd(catre_points P, const float* _
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3a.run(acc, f2, LD128, lane);
-    if (RS == 1) g3b.prefetch(wpf3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
+    if (TWO) g3b.prefetch(wpf3 + ((size_t)(mb0 + 4) * 16) * 64 + lane, 16 * 64);
     if (SAVE)
       argmax_tile_store<MB3, 2>(acc, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl[0],
                                 (int)row0, lane);
     else
       max_tile_store_pre<MB3, 2>(acc, out, mb0 * 32, bl[0], true, lane);
   }
-  if (RS == 1) {
+  if (TWO) {
     f32x16 acc[MB3][2];
 #pragma unroll
     for (int mb = 0; mb < MB3; ++mb) acc[mb][0] = acc[mb][1] = zero16();
@@ -581,6 +587,175 @@ __global__ __launch_bounds__(512) void k_trunk(catre_points P, const float* __re
                               (int)trow0, lane);
   } else {
     max_tile_store_pre<MB4, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
+  }
+  TRUNK_STAMP(7);
+#undef TRUNK_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// The trunk for grids that fill the chip (one workgroup per tile): 256 threads = ONE wave per SIMD, so that a wave may
+// hold 512 registers and conv4 becomes an MB8 x NB2 wave tile (256 channels x 64 points = 256 accumulators): every LDS
+// fragment feeds 8 MFMAs instead of 4.  The sweep is power-limited, not issue-limited (profiles/ubench/power.hip: the
+// 8-wave MB4 x NB2 sweep saturates the matrix pipe and the chip answers with 2.0 GHz, 132-134 TFLOP/s; this form holds
+// 2.36 GHz at 147).  Same operands in the same K order as k_trunk for every output element: same bits.
+// ------------------------------------------------------------------------------------------
+#ifndef TRUNK4_PFD
+#define TRUNK4_PFD 2
+#endif
+#ifndef TRUNK4_PFB
+#define TRUNK4_PFB 1
+#endif
+template <bool SAVE = false>
+__global__ __launch_bounds__(256) void k_trunk4(catre_points P, const float* __restrict__ trans3,
+                                                const float* __restrict__ trans64, const float* __restrict__ Wc1,
+                                                const float* __restrict__ bc1, const f32x4* __restrict__ wp2,
+                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                                const float* __restrict__ b3, const f32x4* __restrict__ wp4,
+                                                const float* __restrict__ b4, float* __restrict__ pm,
+                                                float* __restrict__ pointfeat, int B, int N, int M,
+                                                unsigned long long* __restrict__ trace, TrainSave sv = TrainSave{}) {
+  __shared__ __attribute__((aligned(16))) float smem[TRUNK_SMEM];
+#define TRUNK_STAMP(i)                                                                     \
+  do {                                                                                     \
+    if (CATRE_TRACE_ON && trace && lane == 0) trace[((size_t)tile * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  float* h1 = smem;                      // [64][68]
+  float* t64 = smem + TP * LD64;         // [64][64]
+  float* pf = smem + TP * LD64 + 4096;   // [64][68]
+  float* a3 = smem;                      // [64][512] swizzled
+  float* a2 = smem + TP * 512;           // [64][128] swizzled
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const TileInfo ti = tile_info(tile, B, N, M);
+  const bool ft = trans64 != nullptr;
+  TRUNK_STAMP(0);
+
+  // conv2 64->128: wave -> m-block `wave`, both point blocks
+  GemmPipe<1, 2, false, false, 8, 3> g2;
+  g2.prefetch(wp2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  const size_t trow0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  {
+    float x, y, z;
+    load_point(P, ti, lane, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    if (SAVE && wave == 0) {
+      float* xr = sv.s1 + (trow0 + lane) * 8;
+      *reinterpret_cast<f32x4*>(xr) = f32x4{x, y, z, 0.f};
+      *reinterpret_cast<f32x4*>(xr + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    conv3_relu_row<16>(x, y, z, Wc1, bc1, wave * 16, h1 + lane * LD64);
+    if (ft) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(trans64 + (size_t)ti.cloud * 4096);
+      f32x4* dst = reinterpret_cast<f32x4*>(t64);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[tid + 256 * u] = src[tid + 256 * u];
+    }
+  }
+  __syncthreads();
+  TRUNK_STAMP(1);
+  if (SAVE) save_tile_rows<64, 256, false>(h1, LD64, sv.s2 + trow0 * 64, tid);
+  if (ft) {
+    {  // pointfeat[j][n] = sum_i T64[i][j] h1[i][n]  (pointnet.py:107-109): 2 m-blocks x 2 point blocks, one per wave
+      const int mblk = wave >> 1, nb = wave & 1;
+      const int n = lane & 31, h = lane >> 5;
+      f32x16 acc = zero16();
+      const float* xr = h1 + (nb * 32 + n) * LD64 + 4 * h;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(xr + kc * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float a = t64[(kc * 8 + 4 * h + s) * 64 + mblk * 32 + n];
+          acc = mfma32(a, bx[s], acc);
+        }
+      }
+      f32x16 accs[1][1] = {{acc}};
+      store_tile_lds<1, 1, false>(accs, pf + nb * 32 * LD64, LD64, mblk * 32, nullptr, lane);
+    }
+    __syncthreads();
+  } else {
+    pf = h1;
+  }
+  TRUNK_STAMP(2);
+  // conv3 128->512: 16 m-blocks, four per wave
+  GemmPipe<4, 2, false, true, 16, 2, 1> g3;
+  g3.prefetch(wp3 + (wave * 4 * 16) * 64 + lane, 16 * 64);
+  f32x4 bv3[4][4];
+  load_bias_quads<4>(bv3, b3, wave * 128, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 pf_out[4];
+  float pf_max = 0.f;
+  {
+    // pointfeat tile -> registers now, -> HBM after the last barrier (see k_trunk); 16-byte chunk tid + 256 u of the tile
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      pf_out[u] = *reinterpret_cast<const f32x4*>(pf + (i >> 4) * LD64 + (i & 15) * 4);
+    }
+    {  // max_n pointfeat: wave w reduces points [16w, 16w+16) for channel `lane`, 64 threads merge the 4 partials
+      float* scratch = smem + 2 * TP * LD64 + 4096;  // [4][64]
+      const float* col = pf + (wave * 16) * LD64 + lane;
+      float m = col[0];
+#pragma unroll
+      for (int p = 1; p < 16; ++p) m = fmaxf(m, col[p * LD64]);
+      scratch[wave * 64 + lane] = m;
+      __syncthreads();
+      if (tid < 64) {
+        m = scratch[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = fmaxf(m, scratch[w * 64 + tid]);
+        pf_max = m;
+      }
+    }
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, pf, LD64, lane);
+    store_tile_lds_pre<1, 2, true, true>(acc, a2, 128, wave * 32, bv2, lane);
+  }
+  __syncthreads();
+  TRUNK_STAMP(3);
+  if (SAVE) save_tile_rows<128, 256, true>(a2, 128, sv.s3 + trow0 * 128, tid);
+  // conv4 512->1024: wave owns 8 m-blocks (channels [wave*256, +256)); first weight chunks + bias requested now
+  const int mb0 = wave * 8;
+  GemmPipe<8, 2, true, true, 64, TRUNK4_PFD, TRUNK4_PFB> g4;
+  float bl4[8];
+  {
+    f32x16 acc3[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc3[mb][0] = acc3[mb][1] = zero16();
+    g3.run(acc3, a2, 128, lane);
+    // conv4's first weight chunks + bias are requested behind conv3's sweep: the L2 round trip hides behind the epilogue
+    // and the barrier, and the 64 registers they land in are not live during the sweep
+    g4.prefetch(wp4 + ((size_t)mb0 * 64) * 64 + lane, 64 * 64);
+    load_bias_lane<8>(bl4, b4, mb0 * 32, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile_lds_pre<4, 2, true, true>(acc3, a3, 512, wave * 128, bv3, lane);
+    TRUNK_STAMP(4);
+  }
+  __syncthreads();
+  TRUNK_STAMP(5);
+  {  // deferred stores of the pointfeat tile (point-major [cloud points][64]: the tile is 16 KiB contiguous) and its max
+    float* dstbase = pointfeat + trow0 * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      if ((i >> 4) < ti.valid) *reinterpret_cast<f32x4*>(dstbase + (size_t)i * 4) = pf_out[u];
+    }
+    if (tid < 64) pm[(size_t)tile * PMW + 1024 + tid] = pf_max;
+  }
+  if (SAVE) save_tile_rows<512, 256, true>(a3, 512, sv.s4 + trow0 * 512, tid);
+  f32x16 acc4[8][2];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) acc4[mb][0] = acc4[mb][1] = zero16();
+  g4.run(acc4, a3, 512, lane);
+  TRUNK_STAMP(6);
+  if constexpr (SAVE) {
+    argmax_tile_store<8, 2>(acc4, sv.pmax + (size_t)tile * 1024, sv.pidx + (size_t)tile * 1024, mb0 * 32, bl4, (int)trow0,
+                            lane);
+  } else {
+    max_tile_store_pre<8, 2>(acc4, pm + (size_t)tile * PMW, mb0 * 32, bl4, false, lane);
   }
   TRUNK_STAMP(7);
 #undef TRUNK_STAMP
@@ -1353,6 +1528,23 @@ static int bf_pair_min() {
   return v;
 }
 
+// A/B switch of the one-wave-per-SIMD trunk (k_trunk4), read once: CATRE_TRUNK4=0 keeps the 8-wave kernel on full grids
+static bool trunk4_on() {
+  static const bool v = [] {
+    const char* e = getenv("CATRE_TRUNK4");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
+static bool stn4_on() {
+  static const bool v = [] {
+    const char* e = getenv("CATRE_STN4");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
 // The measurement hooks are the library's only process-global mutable state.  They are fenced: compiled out entirely
 // with -DCATRE_NO_PROFILING (catre_profile_* then return CATRE_ERR_UNSUPPORTED), off unless catre_profile_enable was
 // called, and the record table is guarded by a mutex so that concurrent callers of the data path cannot corrupt it.
@@ -1395,6 +1587,10 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
                      pkb(packed, L.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
+  } else if (row_split8(tiles) == 1 && stn4_on()) {
+    hipLaunchKernelGGL((k_stn3d<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+                       prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3),
+                       prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
   } else {
 #define LAUNCH_(RS)                                                                                      \
   hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
@@ -1418,6 +1614,10 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
                      prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
+  } else if (row_split8(tiles) == 1 && stn4_on()) {
+    hipLaunchKernelGGL((k_stnkd<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],
+                       prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),
+                       prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
   } else {
 #define LAUNCH_(RS)                                                                                                     \
   hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],                \
@@ -1442,6 +1642,11 @@ void launch_trunk(const catre_points* pts, const float* trans3, const float* tra
                      ws + W.pm, pointfeat, B, N, M, g_trunk_trace)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
+  } else if (row_split8(tiles) == 1 && trunk4_on()) {
+    hipLaunchKernelGGL(k_trunk4<false>, dim3(tiles), dim3(256), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W],
+                       prm[CATRE_P_CONV1_B], pk4(packed, L.c2), prm[CATRE_P_CONV2_B], pk4(packed, L.c3),
+                       prm[CATRE_P_CONV3_B], pk4(packed, L.c4), prm[CATRE_P_CONV4_B], ws + W.pm, pointfeat, B, N, M,
+                       g_trunk_trace);
   } else {
 #define LAUNCH_(RS)                                                                                             \
   hipLaunchKernelGGL(k_trunk<RS>, dim3(tiles * RS), dim3(512), 0, st, *pts, trans3, trans64, prm[CATRE_P_CONV1_W], \
@@ -2094,6 +2299,17 @@ int catre_debug_knob(int id, int value) {
   (void)value;
   return CATRE_ERR_UNSUPPORTED;
 #endif
+}
+
+// Identity of the capture `stream` is recording into (0: not capturing).  HipRuntime keys "this capture already holds a
+// weight-pack node" on it: two captures on one stream are two graphs, each needs its own pack node.
+int catre_stream_capture_id(void* stream, unsigned long long* id_out) {
+  REQUIRE(id_out);
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id) != hipSuccess) return CATRE_ERR_LAUNCH;
+  *id_out = status == hipStreamCaptureStatusActive ? id : 0ull;
+  return CATRE_OK;
 }
 
 int catre_debug_trunk_trace(void* device_buffer) {

@@ -199,6 +199,7 @@ _SIGS = {
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),
     "catre_debug_knob": (_I, [_I, _I]),
+    "catre_stream_capture_id": (_I, [_P, _P]),
     "catre_status_string": (ctypes.c_char_p, [_I]),
     "catre_version": (ctypes.c_char_p, []),
 }
@@ -218,9 +219,17 @@ def bump_param_epoch():
 
     The packed weight images are rebuilt when a parameter's ``(data_ptr, _version)`` changes - what ``load_state_dict``,
     ``p.copy_()`` and the optimizers do.  Writes through ``p.data`` (EMA updates, some third-party optimizers) bump neither;
-    INFERENCE callers that do that call this once afterwards.  The training forward does not depend on it: it re-packs the
-    encoder image it reads on every call."""
+    INFERENCE callers that do that call this once afterwards.  The training forward does not depend on it: its first
+    kernel re-packs every image the forward reads on every call (``HipRuntime.train_stn3d``; with ``PCLNET.FREEZE`` the
+    frozen-encoder branch of ``train_forward.forward_train`` does the same before the inference encoder kernels)."""
     _param_epoch[0] += 1
+
+
+def capture_id(device):
+    """Identity of the capture the current stream of ``device`` is recording into (0: not capturing)."""
+    out = ctypes.c_ulonglong(0)
+    check(load().catre_stream_capture_id(stream_ptr(device), ctypes.byref(out)), "catre_stream_capture_id")
+    return int(out.value)
 
 
 def param_epoch():

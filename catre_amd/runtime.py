@@ -74,7 +74,7 @@ class HipRuntime:
         self._param_keep = None
         self._packed = None
         self._packed_sel = 0
-        self._capture_fp = None  # ((stream, fingerprint), sel) of the pack recorded by the capture in progress
+        self._capture_fp = None  # ((stream, capture id, fingerprint), sel) of the pack recorded by the capture in progress
         self._ws = None
 
     # ------------------------------------------------------------------ weights
@@ -105,9 +105,11 @@ class HipRuntime:
         tensors = self._live_params()
         fp = (hip.param_epoch(),) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
         capturing = torch.cuda.is_current_stream_capturing()
+        # keyed on the capture's identity, not only on (stream, weights): a second capture on the same stream with unchanged
+        # weights is another graph and needs its own pack node
+        cap_key = (torch.cuda.current_stream(device).cuda_stream, hip.capture_id(device), fp) if capturing else None
         if capturing and self._packed is not None and self._packed.device == device and self._capture_fp is not None \
-                and self._capture_fp[0] == (torch.cuda.current_stream(device).cuda_stream, fp) \
-                and not (sel & ~self._capture_fp[1]):
+                and self._capture_fp[0] == cap_key and not (sel & ~self._capture_fp[1]):
             # this capture has already recorded a pack of these weights holding every image asked for: the later
             # encoder / head entry points of the same captured forward reuse it (one pack node per replay, not one per call)
             return self._param_arr, self._packed
@@ -137,7 +139,7 @@ class HipRuntime:
             self._fingerprint = None if capturing else fp
             self._packed_sel = int(sel)
             if capturing:
-                self._capture_fp = ((torch.cuda.current_stream(device).cuda_stream, fp), int(sel))
+                self._capture_fp = (cap_key, int(sel))
         return self._param_arr, self._packed
 
     # ------------------------------------------------------------------ workspace

@@ -236,6 +236,9 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     if rt is not None and enc_frozen and T._amp() == 0 and N + M == rt.N + rt.M:
         # PCLNET.FREEZE (CATRE_disR_shared.py:301-304): nothing in front of the heads needs a gradient, so the encoder runs
         # on the INFERENCE kernels - no activation saves, no arg-max rows, no graph nodes (and no encoder backward)
+        # like train_stn3d: the first kernel of a training forward re-packs what it reads - the fingerprint cannot see writes
+        # through `p.data` (the reference's own Ranger, EMA), and the heads' backward reads the LIVE w0 / w1
+        rt._fingerprint = None
         st = rt.stage_pointnet(x, tfd_kps, feature_transform=bool(opts.feature_transform))
         g, pfmax, pf = st["gfeat"][:, :1024], st["gfeat"][:, 1024:], st["pointfeat"]
         hub = (pfmax, pf if fused_rot else T.object_major(pf, B, N, M))

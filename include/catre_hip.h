@@ -266,6 +266,11 @@ int catre_profile_collect(float* ms_out, int max_out, int* n_out);
  * boundaries into `device_buffer` ([tiles][8 waves][8]); NULL disables.  Process-global. */
 int catre_debug_trunk_trace(void* device_buffer);
 
+/* Identity of the stream capture `stream` is currently recording into (hipStreamGetCaptureInfo; 0 when the stream is not
+ * capturing).  The host mirror keys its "this capture already recorded a weight-pack node" shortcut on it
+ * (catre_amd/runtime.py; the reference has no counterpart: torch packs nothing). */
+int catre_stream_capture_id(void* stream, unsigned long long* id_out);
+
 const char* catre_status_string(int status);
 
 /* ---- training ops (forward with saved activations + backward), chained by torch.autograd ------------------

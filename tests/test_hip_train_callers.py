@@ -217,6 +217,38 @@ def test_frozen_pcl_net_takes_the_inference_encoder_kernels(monkeypatch):
     assert (out["pose_1"].detach() - want["pose_1"]).abs().max() <= 2e-5
 
 
+def test_frozen_pcl_net_forward_sees_out_of_band_head_writes():
+    """with ``PCLNET.FREEZE`` the training forward starts on the inference encoder kernels, not on
+    ``train_stn3d`` - it must still re-pack the images it reads: head weights rewritten through ``p.data`` (the reference's
+    own ``lib/torch_utils/solver/ranger.py`` does ``p.data.copy_``; EMA too) bump neither ``_version`` nor the parameter
+    epoch, and the heads' backward reads the live w0 / w1.  Losses and gradients must equal, bit for bit, a second model that
+    got the same weights through ``load_state_dict``."""
+    def mutate(cfg):
+        cfg.MODEL.CATRE.PCLNET.FREEZE = True
+
+    cfg, m_a, o_a, b, sym = _setup(4, 128, 64, mutate=mutate)
+    _, m_b, o_b, _, _ = _setup(4, 128, 64, mutate=mutate)
+    _, ld = _forward(m_a, b, sym)
+    sum(ld.values()).backward()
+    o_a.zero_grad(set_to_none=True)
+    new = {k: v.detach() * 1.01 for k, v in m_a.state_dict().items()}
+    for k, p in m_a.named_parameters():
+        p.data.copy_(new[k])
+    m_b.load_state_dict(new)
+    res = []
+    for m_ in (m_a, m_b):
+        _, ld = _forward(m_, b, sym)
+        sum(ld.values()).backward()
+        res.append({k: v.detach().clone() for k, v in ld.items()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    n = 0
+    for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None) and (pa.grad is None or torch.equal(pa.grad, pb.grad)), k
+        n += pa.grad is not None
+    assert n > 0
+
+
 # ------------------------------------------------------------------------------------------------ CLIP_GRADIENTS
 @pytest.mark.parametrize("clip_type", ["full_model", "norm", "value"])
 def test_clip_gradients_steps_the_fused_ranger_on_device_gradients(clip_type):
