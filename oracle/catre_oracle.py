@@ -34,8 +34,15 @@ _ROUND = {"mode": None}
 
 
 class operand_rounding:
+    """``"bf16"``: the inference rounding described above.  ``"bf16_train"``: the same forward AND what the autocast
+    TRAINING path (engine.py:304,333-347 on ``catre_amd/train_ops.py``) does on the way back, for ``torch.autograd`` through
+    these functions: the rounding of an operand is straight-through (the gradient passes unchanged - ``Tensor.to`` already
+    differentiates like that), every bf16 GEMM's incoming gradient is rounded to bf16 before it feeds the dgrad and wgrad
+    products (their operands are bf16: dY, W, X) while the bias gradient sums the unrounded one, and the rotation heads'
+    y0 / y1 rows are bf16 values normalised with the statistics of the unrounded ones (``_RotHeadLP``)."""
+
     def __init__(self, mode):
-        assert mode in (None, "bf16")
+        assert mode in (None, "bf16", "bf16_train")
         self.mode = mode
 
     def __enter__(self):
@@ -46,7 +53,56 @@ class operand_rounding:
 
 
 def _q(t):
-    return t.to(torch.bfloat16).to(t.dtype) if _ROUND["mode"] == "bf16" else t
+    return t.to(torch.bfloat16).to(t.dtype) if _ROUND["mode"] is not None else t
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity whose gradient is rounded to bf16 (the dY operand of a bf16 dgrad / wgrad GEMM)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _FcWgradRounded(torch.autograd.Function):
+    """``F.linear`` whose WEIGHT gradient is a bf16-operand product (dY and X rounded, fp32 accumulation) while the forward,
+    the data gradient and the bias gradient stay fp32: the small FC layers of the path under autocast training
+    (``train_ops._Linear``: ``catre_linear`` / ``catre_linear_t`` are fp32 kernels, the weight gradient goes through
+    ``k_gemm_tn_lp``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        q = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        return dy @ w, q(dy).t() @ q(x), (dy.sum(0) if ctx.has_b else None)
+
+
+def _fc(x, w, b=None):
+    """One FC layer of the path (STN tails, ts head, the global half of rot-head layer 0)."""
+    if _ROUND["mode"] == "bf16_train":
+        return _FcWgradRounded.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
+def _mm(fn, x, w, b=None):
+    """One per-point GEMM of the path (``fn``: ``F.conv1d`` with a k=1 weight) under the active rounding mode."""
+    mode = _ROUND["mode"]
+    if mode is None:
+        return fn(x, w, b)
+    if mode == "bf16":
+        return fn(_q(x), _q(w), b)
+    y = _RoundGrad.apply(fn(_q(x), _q(w)))
+    return y if b is None else y + b.reshape(1, -1, 1)
 
 
 # ----------------------------------------------------------------------------- a1
@@ -78,14 +134,14 @@ def stn(x, sd, prefix, k):
     if k == 3:  # 3 -> 64 runs on the VALU in fp32
         h = F.relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")))
     else:
-        h = F.relu(F.conv1d(_q(x), _q(w("conv1.weight")), w("conv1.bias")))
-    h = F.relu(F.conv1d(_q(h), _q(w("conv2.weight")), w("conv2.bias")))
-    h = F.relu(F.conv1d(_q(h), _q(w("conv3.weight")), w("conv3.bias")))
+        h = F.relu(_mm(F.conv1d, x, w("conv1.weight"), w("conv1.bias")))
+    h = F.relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")))
+    h = F.relu(_mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias")))
     h = torch.max(h, 2)[0]  # [B,1024]
     pooled = h
-    h = F.relu(F.linear(h, w("fc1.weight"), w("fc1.bias")))
-    h = F.relu(F.linear(h, w("fc2.weight"), w("fc2.bias")))
-    h = F.linear(h, w("fc3.weight"), w("fc3.bias"))
+    h = F.relu(_fc(h, w("fc1.weight"), w("fc1.bias")))
+    h = F.relu(_fc(h, w("fc2.weight"), w("fc2.bias")))
+    h = _fc(h, w("fc3.weight"), w("fc3.bias"))
     h = h + torch.eye(k, dtype=h.dtype).reshape(1, k * k)
     return h.reshape(-1, k, k), pooled
 
@@ -103,9 +159,9 @@ def pointnet_feat(x, sd, prefix="pcl_net", feature_transform=True, global_feat=F
         trans_feat, pool64 = stn(h, sd, f"{prefix}.fstn", 64)  # :106
         h = _q(torch.bmm(h.transpose(2, 1), _q(trans_feat)).transpose(2, 1))  # :107-109
     pointfeat = h  # :111
-    h = F.relu(F.conv1d(h, _q(w("conv2.weight")), w("conv2.bias")))
-    h = F.relu(F.conv1d(_q(h), _q(w("conv3.weight")), w("conv3.bias")))
-    h = F.conv1d(_q(h), _q(w("conv4.weight")), w("conv4.bias"))  # no ReLU, :114
+    h = F.relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")))  # (h is rounded already: _q is idempotent)
+    h = F.relu(_mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias")))
+    h = _mm(F.conv1d, h, w("conv4.weight"), w("conv4.bias"))  # no ReLU, :114
     g = torch.max(h, 2)[0]  # :115-116
     if global_feat:
         out = g
@@ -126,13 +182,13 @@ def gelu_exact(v):
 def ts_head(feat, sd, prefix="ts_head", num_gn_groups=32):
     """``FC_TransSizeHead.forward``, ``heads/fc_trans_size_head.py:61-70`` (layers built ``:33-45``)."""
     w = lambda n: sd[f"{prefix}.{n}"]
-    h = F.linear(feat, w("linears.0.weight"), w("linears.0.bias"))
+    h = _fc(feat, w("linears.0.weight"), w("linears.0.bias"))
     h = F.group_norm(h, num_gn_groups, w("linears.1.weight"), w("linears.1.bias"), 1e-5)
     h = gelu_exact(h)
-    h = F.linear(h, w("linears.3.weight"), w("linears.3.bias"))
+    h = _fc(h, w("linears.3.weight"), w("linears.3.bias"))
     h = F.group_norm(h, num_gn_groups, w("linears.4.weight"), w("linears.4.bias"), 1e-5)
     h = gelu_exact(h)
-    return F.linear(h, w("fc_t.weight"), w("fc_t.bias")), F.linear(h, w("fc_s.weight"), w("fc_s.bias"))
+    return _fc(h, w("fc_t.weight"), w("fc_t.bias")), _fc(h, w("fc_s.weight"), w("fc_s.bias"))
 
 
 # ----------------------------------------------------------------------------- a9
@@ -150,10 +206,28 @@ def rot_head_single(feat, sd, prefix, num_gn_groups=32):
         # rounded) through the bf16 GEMM; y1 is stored rounded but normalised with the statistics of the
         # unrounded values
         w0 = w("layers.0.weight")
-        h = F.conv1d(feat[:, :1024], w0[:, :1024], w("layers.0.bias")) + F.conv1d(_q(feat[:, 1024:]), _q(w0[:, 1024:]))
-        h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+        if _ROUND["mode"] == "bf16_train":
+            # the global half as the product computes it: ONE FC row per cloud (the feature is constant over a cloud's points;
+            # feat = cat(observed, prior) along the points), broadcast as a per-cloud bias
+            Pn = feat.shape[2]
+            diff = (feat[0, :1024] != feat[0, :1024, :1]).any(0)                # first point whose global feature differs
+            nobs = int(diff.to(torch.int8).argmax()) if bool(diff.any()) else Pn   # = points of the first (observed) cloud
+            gl = torch.stack([feat[:, :1024, 0], feat[:, :1024, Pn - 1]], 1)    # [B, 2, 1024]
+            bias = _fc(gl.reshape(-1, 1024), w0[:, :1024, 0], w("layers.0.bias")).reshape(-1, 2, w0.shape[0])
+            hg = torch.cat([bias[:, 0, :, None].expand(-1, -1, nobs), bias[:, 1, :, None].expand(-1, -1, Pn - nobs)], 2)
+            h = hg + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
+        else:
+            h = F.conv1d(feat[:, :1024], w0[:, :1024], w("layers.0.bias")) + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
+        if _ROUND["mode"] == "bf16_train":  # y0 rows are bf16 too, normalised with the statistics of the unrounded values
+            B, C, P = h.shape
+            hg = h.reshape(B, num_gn_groups, -1)
+            mean, var = hg.mean(-1, keepdim=True), hg.var(-1, unbiased=False, keepdim=True)
+            h = ((_q(h).reshape(B, num_gn_groups, -1) - mean) / torch.sqrt(var + 1e-5)).reshape(B, C, P)
+            h = h * w("layers.1.weight").reshape(1, C, 1) + w("layers.1.bias").reshape(1, C, 1)
+        else:
+            h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
         h = gelu_exact(h)
-        h = F.conv1d(_q(h), _q(w("layers.3.weight")), w("layers.3.bias"))
+        h = _mm(F.conv1d, h, w("layers.3.weight"), w("layers.3.bias"))
         B, C, P = h.shape
         hg = h.reshape(B, num_gn_groups, -1)
         mean, var = hg.mean(-1, keepdim=True), hg.var(-1, unbiased=False, keepdim=True)

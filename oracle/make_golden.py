@@ -150,6 +150,9 @@ CASES = {
 TRAIN_CASES = {
     # name: (B, N, M, seed, salt, symmetric object indices, #sym rotations)
     "train_b4": (4, 128, 96, 21, 0, (1, 3), 12),
+    # N and M multiples of 64: the shape class whose training forward takes the fused kernels (and, under autocast, the
+    # one-node bf16-row rotation heads)
+    "train_b4_t64": (4, 128, 64, 22, 0, (0, 2), 12),
 }
 
 
@@ -159,10 +162,20 @@ def train_sym_info(B, sym_idx, nsym):
     return [y_axis_symmetries(nsym) if i in sym_idx else None for i in range(B)]
 
 
-def run_reference_train(cfg, batch, sym_info, salt=0):
+def grad_sample_index(numel, n=512):
+    """The entries of a flattened gradient the AMP training fixture keeps: every one up to n, else n evenly spaced."""
+    if numel <= n:
+        return np.arange(numel, dtype=np.int64)
+    return np.unique(np.linspace(0, numel - 1, n).astype(np.int64))
+
+
+def run_reference_train(cfg, batch, sym_info, salt=0, amp_dtype=None, samples=False):
     """One training iteration of the reference (engine.py:293-349 without the optimizer): batch_updater_test
     pose-apply, model(..., do_loss=True), sum of the loss dict, backward.  Records the losses and, per parameter,
-    the gradient L2 norm and its first 64 entries."""
+    the gradient L2 norm and its first 64 entries.  With ``amp_dtype`` the forward runs inside
+    ``torch.autocast("cpu", dtype=amp_dtype)`` like engine.py:304's AMP branch (no GradScaler: bf16 needs none) and
+    every gradient additionally leaves ``gradsample__*``: its entries at ``grad_sample_index`` (``samples``: those for the
+    fp32 run as well)."""
     ref_shim.install()
     from core.catre.engine.batch_test import batch_updater_test
 
@@ -182,15 +195,25 @@ def run_reference_train(cfg, batch, sym_info, salt=0):
 
     saved = ref_mod.get_event_storage
     ref_mod.get_event_storage = lambda: _Storage()
+    import contextlib
+
+    # numpy has no bfloat16: the reference's logging / symmetry helpers call `.cpu().numpy()` on network outputs
+    # (model_utils.py:228, pose_utils.py get_closest_rot_batch), which raises for bf16 tensors on any device.  For the
+    # autocast run only, Tensor.numpy upcasts bf16 first (exact) - the reference source itself stays unmodified.
+    orig_numpy = torch.Tensor.numpy
+    if amp_dtype is torch.bfloat16:
+        torch.Tensor.numpy = lambda self, *a, **k: orig_numpy(self.float() if self.dtype == torch.bfloat16 else self, *a, **k)
     try:
-        out_dict, loss_dict = model(
-            b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
-            obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
-            obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1,
-        )
+        with (torch.autocast("cpu", dtype=amp_dtype) if amp_dtype is not None else contextlib.nullcontext()):
+            out_dict, loss_dict = model(
+                b["x"], b["tfd_kps"], init_pose=b["obj_pose_est"], init_scale=b["obj_scale_est"], K_zoom=b["K"],
+                obj_class=b["obj_cls"], gt_ego_rot=b["gt_rot"], gt_trans=b["gt_trans"], gt_scale=b["gt_scale"],
+                obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True, cur_iter=1,
+            )
+            losses = sum(loss_dict.values())
     finally:
         ref_mod.get_event_storage = saved
-    losses = sum(loss_dict.values())
+        torch.Tensor.numpy = orig_numpy
     losses.backward()
     out = {"pose_1": _np(out_dict["pose_1"]), "scale_1": _np(out_dict["scale_1"])}
     assert len(logged) == 14, sorted(logged)
@@ -204,6 +227,8 @@ def run_reference_train(cfg, batch, sym_info, salt=0):
         else:
             out[f"gradnorm__{k}"] = _np(p.grad.norm().reshape(1))
             out[f"gradhead__{k}"] = _np(p.grad.reshape(-1)[:64])
+            if amp_dtype is not None or samples:
+                out[f"gradsample__{k}"] = _np(p.grad.reshape(-1)[torch.from_numpy(grad_sample_index(p.grad.numel()))])
     return out
 
 
@@ -221,6 +246,30 @@ def make_train_golden(name):
     np.savez_compressed(path, **arrays)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
     print("   losses:", {k[6:]: float(v[0]) for k, v in out.items() if k.startswith("loss__")})
+
+
+def make_amp_train_golden(name="train_b4"):
+    """engine.py:304,333-347 on the REFERENCE: the ``train_b4`` iteration again, forward under bf16 autocast.  Stores the
+    losses, pose / scale, and per parameter the gradient norm, head and 512 sampled entries - plus the same samples of the
+    reference's fp32 gradients (so a test can ask "no further from fp32 than the reference's own autocast is")."""
+    B, N, M, seed, salt, sym_idx, nsym = TRAIN_CASES[name]
+    batch = synth.make_inputs(B, N, M, seed=seed)
+    cfg = reference_cfg(N, M, {})
+    sym = train_sym_info(B, sym_idx, nsym)
+    out = run_reference_train(cfg, batch, sym, salt, amp_dtype=torch.bfloat16)
+    ref32 = run_reference_train(cfg, batch, sym, salt, samples=True)
+    arrays = dict(out)
+    for k, v in ref32.items():
+        if k.startswith("gradsample__") or k.startswith("loss__"):
+            arrays["fp32__" + k] = v
+    arrays["meta"] = np.array([B, N, M, 1, seed, salt], dtype=np.int64)
+    arrays["meta_sym"] = np.array(list(sym_idx) + [nsym], dtype=np.int64)
+    arrays["meta_inputs"] = np.array(f"{name}.npz")
+    path = os.path.join(GOLDEN_DIR, f"amp_{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"amp_{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    print("   losses bf16:", {k[6:]: float(v[0]) for k, v in out.items() if k.startswith("loss__")})
+    print("   losses fp32:", {k[6:]: float(v[0]) for k, v in ref32.items() if k.startswith("loss__")})
 
 
 AMP_CASES = ("refine_b2_n1024", "refine_b1_n2048_k8")
@@ -495,10 +544,16 @@ def main(argv=None):
     if "amp" in names:
         make_amp_golden()
         names = [n for n in names if n != "amp"]
+    if "amp_train" in names:
+        for n in TRAIN_CASES:
+            make_amp_train_golden(n)
+        names = [n for n in names if n != "amp_train"]
     if not (argv or sys.argv[1:]):
         names = names + list(TRAIN_CASES)
         make_ranger_golden()
         make_amp_golden()
+        for n in TRAIN_CASES:
+            make_amp_train_golden(n)
         make_aug_golden()
         make_pcl_golden()
         make_rot_mats_golden()

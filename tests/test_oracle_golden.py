@@ -103,3 +103,71 @@ def test_oracle_training_losses_and_grads_match_reference():
         np.testing.assert_allclose(p.grad.reshape(-1)[:64].numpy(), ref[f"gradhead__{k}"], atol=2e-4 * nrm + 1e-9, rtol=0,
                                    err_msg=k)
     assert n_none == 6
+
+
+def _oracle_train_iteration(g, mode, dtype=torch.float32):
+    """One training iteration through the oracle under ``operand_rounding(mode)`` -> (losses, gradients)."""
+    cfg, b = g["cfg"], g["batch"]
+    sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in recipe_sd(cfg, g["salt"]).items()}
+    bb = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in b.items()}
+    with O.operand_rounding(mode):
+        x, tfd = O.pose_apply(bb["pcl"], bb["obj_kps"], bb["obj_pose_est"], bb["obj_scale_est"])
+        pose, scale = O.model_forward(x, tfd, bb["obj_pose_est"], bb["obj_scale_est"], sd, cfg, K_zoom=bb["K"],
+                                      mean_scales=bb["obj_mean_scales"])
+    ld = O.catre_loss(pose[:, :, :3], pose[:, :, 3], scale, bb["gt_rot"], bb["gt_trans"], bb["gt_scale"], bb["obj_kps"],
+                      g["sym_info"], cfg.MODEL.CATRE.LOSS_CFG)
+    sum(ld.values()).backward()
+    return {k: float(v.detach()) for k, v in ld.items()}, {k: p.grad for k, p in sd.items() if p.grad is not None}
+
+
+def amp_fixture(name="train_b4"):
+    """tests/golden/amp_<name>.npz: the REFERENCE's training iteration under ``torch.autocast("cpu", bfloat16)``
+    (engine.py:304,333-347) on the inputs of tests/golden/<name>.npz, and its fp32 gradients at the same sampled entries."""
+    import os
+
+    from tests.util import GOLDEN_DIR
+
+    return np.load(os.path.join(GOLDEN_DIR, f"amp_{name}.npz"), allow_pickle=False)
+
+
+def grad_sample_index(numel, n=512):
+    # the entries oracle/make_golden.py keeps of a flattened gradient (restated: the generator itself imports the reference)
+    if numel <= n:
+        return np.arange(numel, dtype=np.int64)
+    return np.unique(np.linspace(0, numel - 1, n).astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["train_b4", "train_b4_t64"])
+def test_oracle_autocast_training_emulation_is_pinned_to_the_reference_autocast_iteration(name):
+    """``operand_rounding("bf16_train")`` under autograd - what the HIP autocast training path is held to on the GPU - against
+    the reference's own autocast iteration:
+      * the fixture's fp32 samples are the fp32 oracle's, bit for bit (the fixture is the train_b4 iteration);
+      * every loss term of the emulation within 3e-2 relative (+1e-3) of fp32 - the reference's bf16 losses are not (its
+        loss arithmetic itself runs in bf16 on CPU autocast: ``loss_rot`` collapses to 0, ``loss_trans_z`` is 58 % off);
+      * per tensor, on the sampled entries, the emulation is no further from the fp32 reference than the reference's own
+        autocast run is (factor 1.2 + 5e-3 of the tensor's norm): rounding only GEMM operands and keeping GroupNorm, GELU,
+        the pose update and the loss in fp32 is the milder of the two reduced-precision iterations."""
+    from tests.util import load_train_golden
+
+    g = load_train_golden(name)
+    z = amp_fixture(name)
+    torch.set_num_threads(4)
+    l32, g32 = _oracle_train_iteration(g, None)
+    lq, gq = _oracle_train_iteration(g, "bf16_train")
+    assert len(gq) == 68 and set(gq) == set(g32)
+    for k in l32:
+        np.testing.assert_allclose(l32[k], float(z[f"fp32__loss__{k}"][0]), rtol=2e-5, atol=1e-7, err_msg=k)
+        assert abs(lq[k] - l32[k]) <= 3e-2 * abs(l32[k]) + 1e-3, (k, lq[k], l32[k])
+    if name == "train_b4":   # what the docstring says
+        assert float(z["loss__loss_rot"][0]) == 0.0 and float(z["fp32__loss__loss_rot"][0]) > 1e-3
+    worse = []
+    for k in g32:
+        idx = torch.from_numpy(grad_sample_index(g32[k].numel()))
+        r32, ramp = torch.from_numpy(z[f"fp32__gradsample__{k}"]), torch.from_numpy(z[f"gradsample__{k}"])
+        np.testing.assert_allclose(g32[k].reshape(-1)[idx].numpy(), r32.numpy(), rtol=0, atol=2e-4 * float(r32.norm()) + 1e-9,
+                                   err_msg=k)
+        n = float(r32.norm()) + 1e-30
+        d_emu, d_ref = float((gq[k].reshape(-1)[idx] - r32).norm()) / n, float((ramp - r32).norm()) / n
+        if d_emu > 1.2 * d_ref + 5e-3:
+            worse.append((k, d_emu, d_ref))
+    assert not worse, worse
