@@ -64,7 +64,9 @@ class CATRE_disR_shared(nn.Module):
         request maps to the same kernels)."""
         want = self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)
         if want is None:
-            return self._opts_bf16 if torch.is_autocast_enabled() else self._opts
+            from .train_ops import autocast_on
+
+            return self._opts_bf16 if autocast_on() else self._opts
         if want in ("bf16", "bfloat16"):
             return self._opts_bf16
         if want in ("fp32", "float32"):
@@ -124,11 +126,12 @@ class CATRE_disR_shared(nn.Module):
         # Like the reference, gradients flow to the parameters only: the caller detaches the fed-back pose
         # (engine.py:324-325) and x / tfd_kps come from the data batch.
         from .train_forward import forward_train
-        from .train_ops import amp_mode
+        from .train_ops import amp_mode, train_kernels
 
         # under torch.autocast (SOLVER.AMP.ENABLED in the reference's loop) the row GEMMs take bf16 operands;
-        # cfg.MODEL.CATRE.COMPUTE_DTYPE forces either precision
-        with amp_mode(self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)):
+        # cfg.MODEL.CATRE.COMPUTE_DTYPE forces either precision; cfg.MODEL.CATRE.TRAIN_KERNELS picks kernel forms (A/B)
+        with amp_mode(self.cfg.MODEL.CATRE.get("COMPUTE_DTYPE", None)), \
+                train_kernels(self.cfg.MODEL.CATRE.get("TRAIN_KERNELS", None)):
             pose, scale, aux = forward_train(dict(self.named_parameters()), self._opts, x, tfd_kps, init_pose, init_scale,
                                              K_zoom, mean_scales, rt=self._runtime())
         out_dict = {f"pose_{cur_iter}": pose, f"scale_{cur_iter}": scale}

@@ -1170,14 +1170,18 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         }
         if (abl & 8) continue;
         float s = 0.f, m2 = 0.f, q = 0.f;
-        if (rt.valid == TP) {  // full tile (wave-uniform): no predication; sum and sum of squares in ONE pass (VALU time
-                               // adds to MFMA time here): M2 = sum v^2 - n mean^2, fp32, 512 values of O(1)
+        // full tile: sum and sum of squares in ONE pass (VALU time adds to MFMA time here), taken around an
+        // anchor - one value of the group (its first lane's first point), so that M2 = sum d^2 - (sum d)^2 / n does not
+        // cancel when the group's mean is large against its spread (the layer's bias sits in the accumulators)
+        const float anchor = __shfl(acc[mb][0][0], n & ~7);
+        if (rt.valid == TP) {  // (wave-uniform: no predication)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              s += acc[mb][nb][r];
-              q = fmaf(acc[mb][nb][r], acc[mb][nb][r], q);
+              const float d = acc[mb][nb][r] - anchor;
+              s += d;
+              q = fmaf(d, d, q);
             }
         } else {  // ragged tile: see k_rot_l1
 #pragma unroll
@@ -1189,9 +1193,9 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 32);
-        const float mean = s * inv_cnt;
+        const float mean = rt.valid == TP ? fmaf(s, inv_cnt, anchor) : s * inv_cnt;
         if (rt.valid == TP) {
-          m2 = q;  // reduced over the group below like the ragged form's M2, then q_group - s_group * mean
+          m2 = q;  // reduced over the group below like the ragged form's M2, then q_group - s_group^2 / n
         } else {
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1_bf(const u32x4* __restrict__ 
         m2 += __shfl_xor(m2, 2);
         m2 += __shfl_xor(m2, 4);
         m2 += __shfl_xor(m2, 32);
-        if (rt.valid == TP) m2 = fmaxf(m2 - s * mean, 0.f);
+        if (rt.valid == TP) m2 = fmaxf(m2 - s * (s * inv_cnt), 0.f);
         if ((lane & 7) == 0 && h == 0) {
           float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
           out[0] = mean;

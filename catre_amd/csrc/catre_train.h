@@ -125,6 +125,9 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
         if (full || row < lim) {
           if (mo) t = mo[mrow * ldm] > 0.f ? t : 0.f;
           if constexpr (!YB) yo[(size_t)row * ldy] = t;
+          // bf16 rows: the GroupNorm partials below are those of the ROUNDED values - the tensor that is normalised and that
+          // the backward re-reads (torch.autocast's GroupNorm sees the Conv1d's bf16 output too)
+          if constexpr (YB) t = bf_lo(pack_bf2(t, 0.f));
           s += t;
         } else {
           t = 0.f;

@@ -7,8 +7,6 @@ matrices so that ``torch.autograd`` can chain the hand-written HIP backward kern
 feature becomes a per-cloud bias of rot-head layer 0; the ``[B,1088,N]`` tensors are never built), so the
 gradients equal the reference's up to fp32 re-association.
 """
-import os
-
 import torch
 
 from . import hip
@@ -137,9 +135,6 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
 
 
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
-# CATRE_SPLIT_L0=layerwise: the split mode's first rot-head block on the layer-wise split backward (A/B measurements)
-SPLIT_L0_ONE_PASS = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"
-SPLIT_L1_ONE_PASS = os.environ.get("CATRE_SPLIT_L1", "onepass") != "layerwise"   # the same for the second block
 
 
 def _rot_heads_shapes_ok_p(p, N, M):
@@ -178,7 +173,7 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
     out = []
     for h, pre in enumerate(_ROT_PREFIX):
         w = lambda n: p[f"{pre}.{n}"]
-        if SPLIT_L0_ONE_PASS:
+        if T.knobs().split_l0_one_pass:
             # the first block as one node: its backward is the fp32 one-pass kernel (k_rot_l0_bwd: sums + one pass over
             # (da, y0)) instead of the GroupNorm apply pass, a per-cloud bias reduction and a split dgrad and wgrad
             a = T.rot_l0_block(pf_obj, W0s[h], b0s[h], w("layers.1.weight"), w("layers.1.bias"), B, N, M,
@@ -190,7 +185,7 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
                                  pre=(buf["a0"][h], buf["stat0"][h]))
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         rd = w("neck.0.weight").shape[0]
-        if SPLIT_L1_ONE_PASS:
+        if T.knobs().split_l1_one_pass:
             # the second block + tail as one node: backward = conv_p, then ONE pass with hi + lo operands (k_rot_l1_bwd_sp)
             out.append(T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"),
                                         wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, N, M,

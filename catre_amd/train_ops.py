@@ -8,6 +8,8 @@ Row orders used below: "cloud-major" = B*N observed rows then B*M prior rows; "o
 import ctypes
 import logging
 import os
+import threading
+import typing
 
 import torch
 import torch.nn.functional as F
@@ -74,7 +76,7 @@ def _pad_cols(t, mult):
 # sums).  `amp_mode("fp32" | "bf16" | "split")` overrides the autocast state (cfg.MODEL.CATRE.COMPUTE_DTYPE); "split"
 # keeps fp32-grade results on the bf16 pipe (hi + lo bf16 operands, three products - DESIGN 5e).
 # The mode is the C ABI's compute_dtype: 0 = CATRE_DTYPE_F32, 1 = CATRE_DTYPE_BF16, 2 = CATRE_DTYPE_SPLIT.
-_AMP_OVERRIDE = [None]
+_TLS = threading.local()   # per-thread: the compute mode override and the kernel-selection knobs of the forward in progress
 _MODES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "split": 2}
 
 
@@ -84,14 +86,75 @@ class amp_mode:
         self.mode = None if mode is None else _MODES[mode]
 
     def __enter__(self):
-        self.prev, _AMP_OVERRIDE[0] = _AMP_OVERRIDE[0], self.mode if self.mode is not None else _AMP_OVERRIDE[0]
+        self.prev = getattr(_TLS, "amp", None)
+        _TLS.amp = self.mode if self.mode is not None else self.prev
 
     def __exit__(self, *a):
-        _AMP_OVERRIDE[0] = self.prev
+        _TLS.amp = self.prev
+
+
+_warned_fp16 = [False]
+
+
+def autocast_on():
+    """``torch.is_autocast_enabled()`` - and, once per process, a warning when the request is for fp16 (what the reference's
+    ``autocast(enabled=AMP_ON)`` asks for on "cuda", engine.py:304): the reduced-precision kernels of this library take
+    bf16 operands (8-bit significands, fp32 accumulation and outputs, no loss scaling needed), whatever dtype autocast names."""
+    if not torch.is_autocast_enabled():
+        return False
+    if not _warned_fp16[0]:
+        try:
+            dt = torch.get_autocast_dtype("cuda")
+        except Exception:  # older torch
+            dt = torch.get_autocast_gpu_dtype()
+        if dt == torch.float16:
+            _warned_fp16[0] = True
+            logger.warning("torch.autocast asks for float16: catre_amd's reduced-precision kernels use BFLOAT16 operands "
+                           "(fp32 accumulation / outputs) for any autocast dtype - 8-bit significands instead of 11.  "
+                           "MODEL.CATRE.COMPUTE_DTYPE='split' keeps fp32-grade results on the bf16 matrix pipe, 'fp32' "
+                           "ignores autocast.")
+    return True
 
 
 def _amp():
-    return int(torch.is_autocast_enabled()) if _AMP_OVERRIDE[0] is None else _AMP_OVERRIDE[0]
+    ov = getattr(_TLS, "amp", None)
+    return int(autocast_on()) if ov is None else ov
+
+
+class TrainKernels(typing.NamedTuple):
+    """Which kernels the training forward picks where more than one form exists (A/B measurements, tests).  Per MODEL:
+    ``cfg.MODEL.CATRE.TRAIN_KERNELS = dict(fused_lp_rot=False, ...)`` is applied around that model's forward; the
+    environment variables only set the process defaults."""
+    split_l0_sp: bool = os.environ.get("CATRE_SPLIT_L0_KERNEL", "split") != "fp32"      # split mode's first block on k_rot_l0_bwd_sp (else fp32 k_rot_l0_bwd)
+    lp_rot_fuse_gn0: bool = os.environ.get("CATRE_LP_ROT_GN0", "fused") != "separate"    # autocast head: GroupNorm-0 + GELU inside the second linear's staging
+    lp_rot_bf16_rows: bool = os.environ.get("CATRE_LP_ROT_ROWS", "bf16") != "fp32"       # autocast heads' [rows,256] activations as bf16 rows (_RotHeadLP)
+    fused_lp_rot: bool = os.environ.get("CATRE_LP_ROT_FUSED", "1") != "0"                # autocast rot heads as fused nodes (else layer-wise)
+    split_l0_one_pass: bool = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"  # split mode: first rot-head block as one node
+    split_l1_one_pass: bool = os.environ.get("CATRE_SPLIT_L1", "onepass") != "layerwise"  # split mode: second block + tail as one node
+
+
+_DEFAULT_KNOBS = TrainKernels()
+
+
+def knobs():
+    return getattr(_TLS, "knobs", None) or _DEFAULT_KNOBS
+
+
+class train_kernels:
+    """``with train_kernels(fused_lp_rot=False):`` - knob overrides for the training forwards issued inside (this thread)."""
+
+    def __init__(self, overrides=None, **kw):
+        self.ov = dict(overrides or {}, **kw)
+        unknown = set(self.ov) - set(TrainKernels._fields)
+        if unknown:
+            raise ValueError(f"MODEL.CATRE.TRAIN_KERNELS: unknown keys {sorted(unknown)} (known: {TrainKernels._fields})")
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "knobs", None)
+        _TLS.knobs = knobs()._replace(**{k: bool(v) for k, v in self.ov.items()})
+
+    def __exit__(self, *a):
+        _TLS.knobs = self.prev
 
 
 def _pack_bf16(w, J, K, dev, transpose=0):
@@ -1139,7 +1202,7 @@ class _RotHeadLP(torch.autograd.Function):
         hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 1, hip.ptr(y0), 256, 256, 64,
                                               B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
         pk1 = _pack_bf16(w1c, 256, 256, dev)
-        if LP_ROT_FUSE_GN0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
+        if knobs().lp_rot_fuse_gn0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
             hip.check(lib.catre_op_gn_gelu_gemm_rows_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
                                                        hip.ptr(stat0), hip.ptr(pk1), hip.ptr(b1c), hip.ptr(y1), hip.ptr(part1),
                                                        B, N, M, st), "catre_op_gn_gelu_gemm_rows_h")
@@ -1194,16 +1257,8 @@ class _RotHeadLP(torch.autograd.Function):
                 dbn, dwp.view(sp), dbp, None, None, None)
 
 
-# CATRE_SPLIT_L0_KERNEL=fp32: split mode's first block on fp32 k_rot_l0_bwd instead of k_rot_l0_bwd_sp (A/B measurements)
-SPLIT_L0_SP = os.environ.get("CATRE_SPLIT_L0_KERNEL", "split") != "fp32"
-# CATRE_LP_ROT_GN0=separate: the head's GroupNorm-0 + GELU as its own pass (A/B measurements, tests/test_hip_rot_lp.py)
-LP_ROT_FUSE_GN0 = os.environ.get("CATRE_LP_ROT_GN0", "fused") != "separate"
-# CATRE_LP_ROT_ROWS=fp32: keep the autocast heads' [rows,256] activations in fp32 (_RotL0Block + _RotL1TailLP)
-LP_ROT_BF16_ROWS = os.environ.get("CATRE_LP_ROT_ROWS", "bf16") != "fp32"
-
-
 def rot_head_lp_ok(x, w0, w1, b1, N, M):
-    return (FUSED_LP_ROT and LP_ROT_BF16_ROWS and _amp() == 1 and x.shape[1] == 64 and w0.shape[0] == 256
+    return (knobs().fused_lp_rot and knobs().lp_rot_bf16_rows and _amp() == 1 and x.shape[1] == 64 and w0.shape[0] == 256
             and w0.reshape(256, -1).shape[1] == 64 and w1.shape[0] == 256 and w1.reshape(256, -1).shape[1] == 256
             and b1 is not None and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
 
@@ -1214,12 +1269,8 @@ def rot_head_lp(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M
     return _RotHeadLP.apply(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M)
 
 
-# CATRE_LP_ROT_FUSED=0: the layer-wise autocast rot heads (A/B measurements, tests/test_hip_rot_lp.py)
-FUSED_LP_ROT = os.environ.get("CATRE_LP_ROT_FUSED", "1") != "0"
-
-
 def rot_l1_tail_lp_ok(a, w, b, N, M):
-    return (FUSED_LP_ROT and _amp() == 1 and a.shape[1] == 256 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 256 and b is not None
+    return (knobs().fused_lp_rot and _amp() == 1 and a.shape[1] == 256 and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 256 and b is not None
             and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
 
 
@@ -1244,7 +1295,7 @@ class _RotL0Block(torch.autograd.Function):
         if pre is not None:   # (y, a, stat) from a fused forward (rot_heads_forward, split mode): only the graph node; its
             y, a, stat = pre  # backward is the one-pass kernel with hi + lo operands (k_rot_l0_bwd_sp): fp32-grade
             ctx.save_for_backward(xc, w2, y, stat, gamma, beta)
-            ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, (2 if SPLIT_L0_SP else 0)
+            ctx.dims, ctx.wshape, ctx.amp = (B, N, M), w.shape, (2 if knobs().split_l0_sp else 0)
             return a
         amp = 1 if _amp() == 1 else 0   # autocast: the forward linear on bf16 operands (what _RotLinear does there)
         if amp:
@@ -1285,8 +1336,8 @@ class _RotL0Block(torch.autograd.Function):
 
 
 def rot_l0_block_ok(x, w, N, M):
-    # autocast takes the node too (FUSED_LP_ROT): bf16-operand forward, the one-pass backward
-    return ((_amp() == 0 or (_amp() == 1 and FUSED_LP_ROT)) and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 64 and x.shape[1] == 64
+    # autocast takes the node too (knob fused_lp_rot): bf16-operand forward, the one-pass backward
+    return ((_amp() == 0 or (_amp() == 1 and knobs().fused_lp_rot)) and w.shape[0] == 256 and w.reshape(256, -1).shape[1] == 64 and x.shape[1] == 64
             and N % 64 == 0 and M % 64 == 0 and N > 0)
 
 

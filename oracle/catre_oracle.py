@@ -39,7 +39,7 @@ class operand_rounding:
     these functions: the rounding of an operand is straight-through (the gradient passes unchanged - ``Tensor.to`` already
     differentiates like that), every bf16 GEMM's incoming gradient is rounded to bf16 before it feeds the dgrad and wgrad
     products (their operands are bf16: dY, W, X) while the bias gradient sums the unrounded one, and the rotation heads'
-    y0 / y1 rows are bf16 values normalised with the statistics of the unrounded ones (``_RotHeadLP``)."""
+    y0 / y1 rows are bf16 values whose GroupNorm statistics are those of the rounded values (``_RotHeadLP``)."""
 
     def __init__(self, mode):
         assert mode in (None, "bf16", "bf16_train")
@@ -218,16 +218,18 @@ def rot_head_single(feat, sd, prefix, num_gn_groups=32):
             h = hg + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
         else:
             h = F.conv1d(feat[:, :1024], w0[:, :1024], w("layers.0.bias")) + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
-        if _ROUND["mode"] == "bf16_train":  # y0 rows are bf16 too, normalised with the statistics of the unrounded values
-            B, C, P = h.shape
-            hg = h.reshape(B, num_gn_groups, -1)
-            mean, var = hg.mean(-1, keepdim=True), hg.var(-1, unbiased=False, keepdim=True)
-            h = ((_q(h).reshape(B, num_gn_groups, -1) - mean) / torch.sqrt(var + 1e-5)).reshape(B, C, P)
-            h = h * w("layers.1.weight").reshape(1, C, 1) + w("layers.1.bias").reshape(1, C, 1)
-        else:
-            h = F.group_norm(h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+        train = _ROUND["mode"] == "bf16_train"
+        # training (_RotHeadLP): y0 / y1 are bf16 rows and GroupNorm's statistics are those of the rounded values (what
+        # autocast's GroupNorm sees); inference (k_rot_l1_bf): y0 stays fp32 on chip, y1 is stored rounded but normalised
+        # with the statistics of the unrounded values
+        h = F.group_norm(_q(h) if train else h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
         h = gelu_exact(h)
         h = _mm(F.conv1d, h, w("layers.3.weight"), w("layers.3.bias"))
+        if train:
+            h = F.group_norm(_q(h), num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
+            h = gelu_exact(h)
+            h = F.conv1d(h, w("neck.0.weight"), w("neck.0.bias")).permute(0, 2, 1)
+            return F.conv1d(h, w("conv_p.weight"), sd.get(f"{prefix}.conv_p.bias")).squeeze(1).contiguous()
         B, C, P = h.shape
         hg = h.reshape(B, num_gn_groups, -1)
         mean, var = hg.mean(-1, keepdim=True), hg.var(-1, unbiased=False, keepdim=True)

@@ -167,6 +167,37 @@ def test_bf16_ragged_and_full_size_properties():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("offset", [4.0, -8.0])
+def test_bf16_rot_head_with_an_offset_second_layer_matches_the_rounding_oracle(offset):
+    """k_rot_l1_bf folds the layer-1 bias into its accumulators and takes the GroupNorm-1 partials of FULL tiles
+    in one pass (sum, sum of squares).  With a bias that puts the group means far from zero the plain `sum v^2 - s mean` form
+    cancels; the kernel takes both sums around an anchor value of the group instead.  Full tiles (N = M = 128) and ragged ones
+    (two-pass form) against the rounding oracle, one iteration, with `layers.3.bias` shifted by `offset` (|mean| / std of a
+    group ~ 15-30 with the recipe weights; larger offsets leave bf16's own resolution, not the statistics, as the limit)."""
+    from catre_amd import synth
+    from oracle import catre_oracle as O
+    from tests.test_hip_parity import build_model, to_dev
+
+    g = load_golden("refine_b3_ragged")
+    for (B, N, M) in [(3, 128, 128), (2, 100, 70)]:
+        cfg = g["cfg"].__deepcopy__({})
+        cfg.INPUT.NUM_PCL, cfg.INPUT.NUM_KPS = N, M
+        cfg.MODEL.CATRE.ROT_HEAD.INIT_CFG.num_points = N + M
+        model, sd = build_model(cfg, 2)
+        sd = {k: v.clone() for k, v in sd.items()}
+        for h in ("x", "y"):
+            sd[f"rot_head.rot_head_{h}.layers.3.bias"] += offset
+        model.load_state_dict({k: v.to("cuda:0") for k, v in sd.items()}, strict=True)
+        model.cfg.MODEL.CATRE.COMPUTE_DTYPE = "bf16"
+        b = synth.make_inputs(B, N, M, seed=60 + B)
+        out = model.refine(to_dev(b), n_iter=1)
+        with O.operand_rounding("bf16"):
+            emu = O.refine_k(b, sd, cfg, n_iter=1)
+        for key in ("pose_1", "scale_1"):
+            assert np.abs(out[key].cpu().numpy() - emu[key].numpy()).max() <= EMU_TOL, (offset, B, N, M, key)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,N,M", [(40, 1024, 1024), (130, 300, 100), (48, 1000, 500)])
 def test_bf16_pair_trunk_returns_the_bits_of_the_tile_trunk(B, N, M):
     """Grids of >= 512 tile PAIRS run the bf16 trunk on 128 points per workgroup (`k_trunk_bf2`: half the L2 weight stream per

@@ -71,14 +71,12 @@ def test_autocast_iteration_with_fused_lp_heads_tracks_the_layerwise_iteration()
     cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 31, 1)
     res = []
     for fused in (True, False):
-        T.FUSED_LP_ROT, T.LP_ROT_BF16_ROWS = fused, False   # the fp32-row form: the layer-wise path's own tensors
-        try:
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                ld = _iteration(model, kw, sym)
-            res.append((ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
-        finally:
-            T.FUSED_LP_ROT = T.LP_ROT_BF16_ROWS = True
+        # (per-model knobs: cfg.MODEL.CATRE.TRAIN_KERNELS) the fp32-row form: the layer-wise path's own tensors
+        model.cfg.MODEL.CATRE.TRAIN_KERNELS = dict(fused_lp_rot=fused, lp_rot_bf16_rows=False)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ld = _iteration(model, kw, sym)
+        res.append((ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
     (lf, gf), (ll, gl) = res
     for k in ll:
         assert torch.equal(lf[k], ll[k]), k
@@ -185,14 +183,11 @@ def test_autocast_iteration_with_bf16_rows_tracks_the_fp32_iteration():
     cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 33, 1)
 
     def run(autocast, rows):
-        T.LP_ROT_BF16_ROWS = rows
-        try:
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-                ld = _iteration(model, kw, sym)
-            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        finally:
-            T.LP_ROT_BF16_ROWS = True
+        model.cfg.MODEL.CATRE.TRAIN_KERNELS = dict(lp_rot_bf16_rows=rows)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            ld = _iteration(model, kw, sym)
+        return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
     l32, g32 = run(False, True)
     lh, gh = run(True, True)
@@ -232,11 +227,8 @@ def test_groupnorm0_inside_the_second_linears_staging_changes_nothing():
     res = []
     with T.amp_mode("bf16"):
         for fused in (True, False):
-            T.LP_ROT_FUSE_GN0 = fused
-            try:
+            with T.train_kernels(lp_rot_fuse_gn0=fused):
                 res.append(_run(fn, t))
-            finally:
-                T.LP_ROT_FUSE_GN0 = True
     (o1, g1), (o2, g2) = res
     assert torch.equal(o1, o2)
     for k in g1:
@@ -286,14 +278,11 @@ def test_split_iteration_with_one_pass_head_backward_matches_the_layerwise_split
     cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 37, 1)
 
     def run(mode, one_pass):
-        F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = one_pass
-        try:
-            opt.zero_grad(set_to_none=True)
-            with T.amp_mode(mode):
-                ld = _iteration(model, kw, sym)
-            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        finally:
-            F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = True
+        model.cfg.MODEL.CATRE.TRAIN_KERNELS = dict(split_l0_one_pass=one_pass, split_l1_one_pass=one_pass)
+        opt.zero_grad(set_to_none=True)
+        with T.amp_mode(mode):
+            ld = _iteration(model, kw, sym)
+        return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
     l1, g1 = run("split", True)
     l2, g2 = run("split", False)
@@ -320,15 +309,13 @@ def test_one_pass_heads_at_a_batch_whose_workgroups_walk_several_tiles(mode):
     cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 39, 1)
 
     def run(one_pass):
-        F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = T.FUSED_LP_ROT = one_pass
-        T.LP_ROT_BF16_ROWS = False   # fp32 rows: the layer-wise path's own tensors, so the comparison is tight
-        try:
-            opt.zero_grad(set_to_none=True)
-            with T.amp_mode(mode):
-                ld = _iteration(model, kw, sym)
-            return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        finally:
-            F.SPLIT_L0_ONE_PASS = F.SPLIT_L1_ONE_PASS = T.FUSED_LP_ROT = T.LP_ROT_BF16_ROWS = True
+        # fp32 rows: the layer-wise path's own tensors, so the comparison is tight
+        model.cfg.MODEL.CATRE.TRAIN_KERNELS = dict(split_l0_one_pass=one_pass, split_l1_one_pass=one_pass,
+                                                   fused_lp_rot=one_pass, lp_rot_bf16_rows=False)
+        opt.zero_grad(set_to_none=True)
+        with T.amp_mode(mode):
+            ld = _iteration(model, kw, sym)
+        return ld, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
     l1, g1 = run(True)
     l2, g2 = run(False)

@@ -390,3 +390,28 @@ def test_bench_train_flop_count_comes_from_the_committed_pmc_pass():
     assert src and src.startswith("profiles/r") and src.endswith("_train_pmc_summary.csv")
     # forward 1.10 TFLOP (4.315 GFLOP x 256) + rot-head backward 0.34 + row-sparse encoder backward < 0.1
     assert 1.45e12 < flop < 1.65e12, flop
+
+
+def test_training_kernel_knobs_are_scoped_per_call_not_module_globals():
+    """the A/B switches of the training forward are fields of ``cfg.MODEL.CATRE.TRAIN_KERNELS`` applied
+    around ONE model's forward (thread-local, restored on exit), not module attributes."""
+    import threading
+
+    from catre_amd import train_ops as T
+
+    base = T.knobs()
+    assert all(isinstance(v, bool) for v in base)
+    with T.train_kernels(dict(fused_lp_rot=False), lp_rot_bf16_rows=False):
+        assert T.knobs().fused_lp_rot is False and T.knobs().lp_rot_bf16_rows is False
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(T.knobs()))   # another thread keeps the defaults
+        t.start()
+        t.join()
+        assert seen[0] == base
+        with T.train_kernels(None):
+            assert T.knobs().fused_lp_rot is False
+    assert T.knobs() == base
+    with pytest.raises(ValueError):
+        T.train_kernels(dict(no_such_knob=True))
+    for name in ("FUSED_LP_ROT", "LP_ROT_BF16_ROWS", "LP_ROT_FUSE_GN0", "SPLIT_L0_SP"):
+        assert not hasattr(T, name)
