@@ -16,7 +16,7 @@ has no collective ("weak" scaling: 256 objects per GPU).  Timing: barrier + sync
 synchronize + barrier, MAX over ranks.
 
 The JSON line also carries
-  roofline     - the dominant kernel (k_trunk: feature transform + conv2..conv4 + max-pool, 57 % of the
+  roofline     - the dominant kernel (k_trunk4: feature transform + conv2..conv4 + max-pool, 57 % of the
                  FLOPs) measured live with HIP events recorded on its launch stream inside the timed
                  region, against the dense fp32 MFMA peak (157.3 TFLOP/s);
   cpu_baseline - the oracle (torch CPU port of the reference path) timed on this box's host cores on a
@@ -38,7 +38,7 @@ B_PER_GPU, N_PTS, M_PTS, K_ITER = 256, 1024, 1024, 4
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: BF16 dense (no sparsity)
 
-# algorithmic FLOPs: per point of one cloud through k_trunk
+# algorithmic FLOPs: per point of one cloud through k_trunk4 / k_trunk
 #   pointfeat = h1^T T64 (2*64*64) + conv2 (2*64*128) + conv3 (2*128*512) + conv4 (2*512*1024) + conv1/T3 (2*3*64 + 18)
 TRUNK_FLOPS_PER_POINT = 2 * (64 * 64 + 64 * 128 + 128 * 512 + 512 * 1024) + 2 * 3 * 64 + 18
 
@@ -165,7 +165,7 @@ def train_flops_per_iteration():
     mt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mt)
     pm = mt._raw_pmc(files[-1])
-    its = sum(r["n"] for r in pm if r["k"] == "k_trunk<1, true>")
+    its = sum(r["n"] for r in pm if r["k"] in ("k_trunk4<true>", "k_trunk<1, true>"))   # once per iteration, either form
     if not its:
         return None, None
     return sum(r["n"] * r["flop"] for r in pm) / its, os.path.relpath(files[-1], ROOT)
@@ -589,7 +589,7 @@ def main():
             "path_tflops": round(value * path_flops / 1e12, 2),
             "path_frac_of_mfma_peak": round(value * path_flops / 1e12 / (mfma_peak * world), 4),
             "roofline": {
-                "kernel": "k_trunk_bf2" if bf16 else ("k_trunk_split" if split else "k_trunk"),  # (B=256: the 128-point pair form)
+                "kernel": "k_trunk_bf2" if bf16 else ("k_trunk_split" if split else "k_trunk4"),  # (full grids: the forms that fill the chip)
                 "bound": "mfma",
                 "achieved": round(achieved, 2) if achieved else None,
                 "peak": mfma_peak,

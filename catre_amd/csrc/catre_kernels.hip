@@ -403,6 +403,171 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stnkd(catre_points P, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// The ONE form of the two STN kernels on PAIRS of tiles (128 points per workgroup): with one wave per SIMD nothing runs
+// under a barrier, a point load or the dependent MFMA chains of the thin layers, so the prologue is done once for two tiles
+// (four independent accumulators in conv2 instead of two, half the barriers and load round trips per tile) and the last
+// layer sweeps the two tiles one after the other on the same 256 accumulators.  Every output element sees the operands of
+// k_stn3d / k_stnkd in the same K order: same bits.  A cloud with an odd number of tiles ends in a pair of one tile: its
+// second half holds clamped duplicates and is not swept.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_info32(int bid, int B, int N, int M, TileInfo& ti, int& tile0) {
+  const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, PN = (TN + 1) / 2, PM_ = (TM + 1) / 2;
+  if (bid < B * PN) {
+    ti.obj = bid / PN;
+    ti.cloud = ti.obj;
+    ti.is_obs = 1;
+    const int pi = bid % PN;
+    ti.p0 = pi * 2 * TP;
+    ti.valid = min(2 * TP, N - ti.p0);
+    tile0 = ti.obj * TN + 2 * pi;
+  } else {
+    const int r = bid - B * PN;
+    ti.obj = r / PM_;
+    ti.cloud = B + ti.obj;
+    ti.is_obs = 0;
+    const int pi = r % PM_;
+    ti.p0 = pi * 2 * TP;
+    ti.valid = min(2 * TP, M - ti.p0);
+    tile0 = B * TN + ti.obj * TM + 2 * pi;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stn3d_pair(catre_points P, const float* __restrict__ W1,
+                                                    const float* __restrict__ b1, const f32x4* __restrict__ wp2,
+                                                    const float* __restrict__ b2, const f32x4* __restrict__ wp3,
+                                                    const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
+                                                    int M) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + 2 * TP * LD128];
+  float* a1 = smem;                   // [128][68]
+  float* a2 = smem + 2 * TP * LD64;   // [128][132]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TileInfo ti;
+  int tile0;
+  pair_info32(blockIdx.x, B, N, M, ti, tile0);
+  const bool has2 = ti.valid > TP;
+
+  GemmPipe<1, 4, false, false, 8, 3> g2;  // conv2 64->128: wave -> m-block `wave`, all four point blocks
+  g2.prefetch(wp2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  {  // conv1 3->64 on the VALU: thread = (point, 32-channel half)
+    const int p = (wave & 1) * TP + lane;
+    float x, y, z;
+    load_point(P, ti, p, x, y, z);
+    conv3_relu_row<32>(x, y, z, W1, b1, (wave >> 1) * 32, a1 + p * LD64);
+  }
+  __syncthreads();
+  const int mb0 = wave * 8;
+  float bl[8];
+  GemmPipe<8, 2, true, false, 16, 2, 1> g3;  // first sweep: its first weight chunks are requested in front of conv2
+  g3.prefetch(wp3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<8>(bl, b3, mb0 * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
+    g2.run(acc, a1, LD64, lane);
+    store_tile_lds_pre<1, 4, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
+  }
+  __syncthreads();
+  {  // the two tiles one after the other on the same accumulators.  (No weight ring carried across the epilogue - the 256
+     // maxima pass through the VGPRs there and 64 prefetched registers next to them spill; a runtime loop over the two
+     // sweeps spills as well.)
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3.run(acc, a2, LD128, lane);
+    max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
+  }
+  if (has2) {
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    // opaque: otherwise the second sweep shares the first one's 32 fragment base pointers, which then stay live across the
+    // epilogue in between - where the 256 maxima pass through the VGPRs - and spill
+    unsigned lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    gemm_core<8, 2, true, false, 16, 2, 1>(acc, wp3 + ((size_t)mb0 * 16) * 64 + lane_o, 16 * 64, a2 + TP * LD128, LD128, lane);
+    max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stnkd_pair(catre_points P, const float* __restrict__ trans3,
+                                                    const float* __restrict__ Wc1, const float* __restrict__ bc1,
+                                                    const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
+                                                    const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
+                                                    const f32x4* __restrict__ wpf3, const float* __restrict__ bf3,
+                                                    float* __restrict__ pm, int B, int N, int M) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * TP * LD64 + 2 * TP * LD128];
+  float* h1 = smem;                   // [128][68]
+  float* f1 = smem + 2 * TP * LD64;   // [128][68]
+  float* f2 = smem + 4 * TP * LD64;   // [128][132]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TileInfo ti;
+  int tile0;
+  pair_info32(blockIdx.x, B, N, M, ti, tile0);
+  const bool has2 = ti.valid > TP;
+
+  const int mblk1 = wave >> 1, half1 = wave & 1;
+  GemmPipe<1, 2, false, false, 8, 4> g1;  // fstn.conv1 64->64: wave -> (m-block, tile of the pair)
+  g1.prefetch(wpf1 + (mblk1 * 8) * 64 + lane, 0);
+  f32x4 bv1[1][4];
+  load_bias_quads<1>(bv1, bf1, mblk1 * 32, lane);
+  {
+    const int p = (wave & 1) * TP + lane;
+    float x, y, z;
+    load_point(P, ti, p, x, y, z);
+    apply_t3(trans3 + ti.cloud * 9, x, y, z);
+    conv3_relu_row<32>(x, y, z, Wc1, bc1, (wave >> 1) * 32, h1 + p * LD64);
+  }
+  __syncthreads();
+  GemmPipe<1, 4, false, false, 8, 3> g2;
+  g2.prefetch(wpf2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, bf2, wave * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g1.run(acc, h1 + half1 * TP * LD64, LD64, lane);
+    store_tile_lds_pre<1, 2, true, false>(acc, f1 + half1 * TP * LD64, LD64, mblk1 * 32, bv1, lane);
+  }
+  __syncthreads();
+  const int mb0 = wave * 8;
+  float bl[8];
+  GemmPipe<8, 2, true, false, 16, 2, 1> g3;  // first sweep: its first weight chunks are requested in front of conv2
+  g3.prefetch(wpf3 + ((size_t)mb0 * 16) * 64 + lane, 16 * 64);
+  load_bias_lane<8>(bl, bf3, mb0 * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc[1][4] = {{zero16(), zero16(), zero16(), zero16()}};
+    g2.run(acc, f1, LD64, lane);
+    store_tile_lds_pre<1, 4, true, false>(acc, f2, LD128, wave * 32, bv2, lane);
+  }
+  __syncthreads();
+  {  // the two tiles one after the other on the same accumulators.  (No weight ring carried across the epilogue - the 256
+     // maxima pass through the VGPRs there and 64 prefetched registers next to them spill; a runtime loop over the two
+     // sweeps spills as well.)
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    g3.run(acc, f2, LD128, lane);
+    max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
+  }
+  if (has2) {
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
+    // opaque: otherwise the second sweep shares the first one's 32 fragment base pointers, which then stay live across the
+    // epilogue in between - where the 256 maxima pass through the VGPRs - and spill
+    unsigned lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    gemm_core<8, 2, true, false, 16, 2, 1>(acc, wpf3 + ((size_t)mb0 * 16) * 64 + lane_o, 16 * 64, f2 + TP * LD128, LD128, lane);
+    max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // a3+a5: trunk.  x' = x T3 -> relu(conv1) -> pointfeat = h1^T T64 -> relu(conv2) -> relu(conv3)
 // -> conv4 -> max  (pointnet.py:98-116).  512 threads = 8 waves, 1 workgroup per CU.
 // The whole 64-point x 512-channel conv4 input lives in LDS (128 KiB, XOR-swizzled, no padding) next to
@@ -1537,6 +1702,13 @@ static bool trunk4_on() {
   return v;
 }
 
+static bool stn_pair_on() {  // CATRE_STN_PAIR=0: one tile per workgroup (A/B)
+  static const bool v = [] {
+    const char* e = getenv("CATRE_STN_PAIR");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
 static bool stn4_on() {
   static const bool v = [] {
     const char* e = getenv("CATRE_STN4");
@@ -1587,6 +1759,11 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
                      pkb(packed, L.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
+  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on()) {
+    const int pairs = B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2);
+    hipLaunchKernelGGL(k_stn3d_pair, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
+                       pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
+                       ws + W.pm, B, N, M);
   } else if (row_split8(tiles) == 1 && stn4_on()) {
     hipLaunchKernelGGL((k_stn3d<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
                        prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3),
@@ -1614,6 +1791,11 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
                      prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
+  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on()) {
+    const int pairs = B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2);
+    hipLaunchKernelGGL(k_stnkd_pair, dim3(pairs), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
+                       pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2), prm[CATRE_P_FSTN_CONV2_B],
+                       pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
   } else if (row_split8(tiles) == 1 && stn4_on()) {
     hipLaunchKernelGGL((k_stnkd<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],
                        prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),

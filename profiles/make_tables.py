@@ -33,6 +33,13 @@ ALGO = {
     "k_stn3d<1>": (STN3D, "a2 STN3d conv stack + max", FP32_PEAK),
     "k_stnkd<1>": (STNKD, "a4 STNkd conv stack + max", FP32_PEAK),
     "k_rot_l1<1>": (ROT_L1, "a9 rot heads: layer 0 (recomputed) + GN0 + GELU + layer 1", FP32_PEAK),
+    # round 5: full grids run the encoder with ONE wave per SIMD (256 accumulators per wave)
+    "k_trunk4": (TRUNK, "a3+a5 trunk, one wave per SIMD: conv4 as MB8 x NB2 + max", FP32_PEAK),
+    "k_stn3d_pair": (STN3D, "a2 STN3d conv stack + max, one wave per SIMD, 128-point pairs", FP32_PEAK),
+    "k_stnkd_pair": (STNKD, "a4 STNkd conv stack + max, one wave per SIMD, 128-point pairs", FP32_PEAK),
+    "k_stn3d<1, false, true>": (STN3D, "a2 STN3d, one wave per SIMD, 64-point tiles", FP32_PEAK),
+    "k_stnkd<1, false, true>": (STNKD, "a4 STNkd, one wave per SIMD, 64-point tiles", FP32_PEAK),
+    "k_trunk4<true>": (TRUNK, "training forward: trunk (one wave per SIMD) + activation saves", FP32_PEAK),
     "k_trunk_split<1>": (TRUNK, "trunk, conv3/conv4 as split-bf16 (3 products)", SPLIT_PEAK),
     "k_rot_l1_split": (ROT_L1, "rot heads, split-bf16", SPLIT_PEAK),
     "k_stn3d_split<1>": (STN3D, "STN3d, split-bf16", SPLIT_PEAK),
@@ -66,7 +73,10 @@ def canon(n):
     -> k_trunk_bf2.  `true` (training SAVE) instances keep theirs."""
     n = n.strip()
     n = re.sub(r",\s*false>$", ">", n)
-    return re.sub(r"<false>$", "", n)
+    n = re.sub(r"<false>$", "", n)
+    # k_stn*<1, false, false> (two workgroups per CU, the round-3/4 form) -> k_stn*<1>; <1, true, false> -> <1, true>
+    n = re.sub(r"^(k_stn[3k]d)<(\d+), (true|false), false>$", lambda m: f"{m.group(1)}<{m.group(2)}" + (", true>" if m.group(3) == "true" else ">"), n)
+    return n
 
 
 def short(name):
@@ -160,8 +170,9 @@ def budget(title, stats_file, pmc_file, ref, peak, only=None):
     kernels whose name matches (runs that also time another mode)."""
     st, pm = _raw_stats(os.path.join(HERE, stats_file)), _raw_pmc(os.path.join(HERE, pmc_file))
     keep = (lambda k: re.search(only, k) is not None) if only else (lambda k: True)
-    it_s = sum(c for k, c, _ in st if k == ref)
-    it_p = sum(r["n"] for r in pm if r["k"] == ref)
+    refs = (ref,) if isinstance(ref, str) else tuple(ref)   # the once-per-iteration kernel under any of its names
+    it_s = sum(c for k, c, _ in st if k in refs)
+    it_p = sum(r["n"] for r in pm if r["k"] in refs)
     if not it_s or not it_p:
         return f"| {title} | - | - | - | - | - | - | (`profiles/{stats_file}` / `profiles/{pmc_file}` not collected) |"
     flop = sum(r["n"] * r["flop"] for r in pm if keep(r["k"])) / it_p
@@ -183,14 +194,14 @@ def budgets(tag):
              "| mode | MFMA GFLOP / iteration (PMC) | HBM GB / iteration (PMC) | kernel ms / iteration | launches | non-MFMA tail | TFLOP/s | fraction of the dense peak |",
              "|---|---|---|---|---|---|---|---|"]
     no_other = r"^(?!.*(_split|_bf|k_colmax|distribution|reduce_kernel))"
-    lines.append(budget("fp32 inference", f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv", "k_trunk<1>", FP32_PEAK, only=no_other))
+    lines.append(budget("fp32 inference", f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv", ("k_trunk4", "k_trunk<1>"), FP32_PEAK, only=no_other))
     lines.append(budget("bf16 operands", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv", "k_trunk_bf2", BF16_PEAK,
                         only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
     lines.append(budget("split mode (issued bf16 products: three per fp32-grade product)", f"{tag}_split_kernel_stats.csv",
                         f"{tag}_split_pmc_summary.csv", "k_trunk_split<1>", BF16_PEAK,
                         only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
     lines.append(budget("fp32 training (forward + loss + backward + Ranger)", f"{tag}_train_kernel_stats.csv",
-                        f"{tag}_train_pmc_summary.csv", "k_trunk<1, true>", FP32_PEAK))
+                        f"{tag}_train_pmc_summary.csv", ("k_trunk4<true>", "k_trunk<1, true>"), FP32_PEAK))
     lines.append("")
     return lines
 
@@ -199,7 +210,8 @@ def render(tag="r03"):
     out = [f"<!-- BEGIN GENERATED by profiles/make_tables.py {tag} -->"]
     out += block(tag, "fp32 headline path, B=256, N=M=1024, one refine iteration per row",
                  f"{tag}_kernel_stats.csv", f"{tag}_pmc_summary.csv",
-                 ["k_trunk<1>", "k_stn3d<1>", "k_stnkd<1>", "k_rot_l1<1>"], "")
+                 ["k_trunk4", "k_trunk<1>", "k_stn3d_pair", "k_stn3d<1, false, true>", "k_stn3d<1>", "k_stnkd_pair",
+                  "k_stnkd<1, false, true>", "k_stnkd<1>", "k_rot_l1<1>"], "")
     out += block(tag, "split mode (opt-in)", f"{tag}_split_kernel_stats.csv",
                  f"{tag}_split_pmc_summary.csv" if os.path.exists(os.path.join(HERE, f"{tag}_split_pmc_summary.csv")) else f"{tag}_pmc_summary.csv",
                  ["k_trunk_split<1>", "k_stn3d_split<1>", "k_stnkd_split<1>", "k_rot_l1_split"],
@@ -207,7 +219,7 @@ def render(tag="r03"):
     out += block(tag, "bf16 operands (BASELINE config 5 arithmetic)", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv",
                  ["k_trunk_bf2", "k_trunk_bf", "k_stn3d_bf2", "k_stnkd_bf2", "k_stn3d_bf", "k_stnkd_bf", "k_rot_l1_bf"], "")
     out += block(tag, "training iteration (BASELINE config 3), fp32", f"{tag}_train_kernel_stats.csv", f"{tag}_train_pmc_summary.csv",
-                 ["k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
+                 ["k_trunk4<true>", "k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
                   "k_gemm_rows<1, 32>", "k_gemm_rows<1, 8>", "k_gemm_rows<1, 16>", "k_gemm_tn<2>",
                   "k_gemm_tn<1>"],
                  "; GFLOP = the op's dense GEMM work on B*(N+M) rows")

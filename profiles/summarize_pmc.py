@@ -31,12 +31,12 @@ def main(root, out, tag="r02"):
             n = max(len(v) for k, v in d.items() if not k.startswith("_"))
             w.writerow([name, n] + [round(sum(d[c]) / len(d[c]), 3) if d.get(c) else "" for c in counters]
                        + [round(sum(d["_dur_ns"]) / len(d["_dur_ns"]) / 1e3, 2)])
-    t = acc.get("k_trunk<1, false>") or acc.get("k_trunk<1>") or acc.get("k_trunk")
+    t = acc.get("k_trunk4<false>") or acc.get("k_trunk4") or acc.get("k_trunk<1, false>") or acc.get("k_trunk<1>") or acc.get("k_trunk")
     if t and t.get("FETCH_SIZE") and t.get("WRITE_SIZE"):
         fetch = sum(t["FETCH_SIZE"]) / len(t["FETCH_SIZE"]) * 1024
         write = sum(t["WRITE_SIZE"]) / len(t["WRITE_SIZE"]) * 1024
         js = {
-            "kernel": "k_trunk<1, false>", "collected_with": "profiles/pmc.sh (separate --pmc passes) on the build of this commit",
+            "kernel": "k_trunk4<false>" if (acc.get("k_trunk4<false>") or acc.get("k_trunk4")) else "k_trunk<1, false>", "collected_with": "profiles/pmc.sh (separate --pmc passes) on the build of this commit",
             "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes_raw": write,
             "hbm_bytes_per_launch": 2 * fetch + write,
             "note": "read side doubled per MI355X_MICROARCH.md gfx950 FETCH_SIZE correction; WRITE_SIZE uncalibrated",
