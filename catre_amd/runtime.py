@@ -371,8 +371,10 @@ def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
     obj_kps = hip.require_dev_f32(obj_kps.contiguous(), "obj_kps", (B, M, 3))
     pose = hip.require_dev_f32(pose.contiguous(), "pose", (B, 3, 4))
     scale = hip.require_dev_f32(scale.contiguous(), "scale", (B, 3))
-    xo = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
-    ko = torch.empty(B, M, 3, dtype=torch.float32, device=dev)
+    # one buffer, observed rows then prior rows: the training forward reads the two as ONE cloud-major [B*N + B*M, 3] matrix
+    # (train_forward._cloud_major_rows) without a cat
+    both = torch.empty(B * (N + M), 3, dtype=torch.float32, device=dev)
+    xo, ko = both[: B * N].view(B, N, 3), both[B * N:].view(B, M, 3)
     hip.check(lib.catre_pose_apply(hip.ptr(pcl), hip.ptr(obj_kps), hip.ptr(pose), hip.ptr(scale), hip.ptr(xo),
                                    hip.ptr(ko), B, N, M, int(zero_center), hip.stream_ptr(dev)), "catre_pose_apply")
     return xo.permute(0, 2, 1), ko.permute(0, 2, 1)

@@ -18,6 +18,17 @@ def _points_rows(x):
     return x.permute(0, 2, 1).reshape(-1, 3).contiguous()
 
 
+def _cloud_major_rows(x, tfd_kps):
+    """x [B,3,N], tfd_kps [B,3,M] -> [B*N + B*M, 3] cloud-major point rows.  ``runtime.pose_apply`` (``batch_updater_test``)
+    writes the two clouds back to back into one buffer: then the matrix is a view of it; anything else is concatenated."""
+    xr, kr = _points_rows(x), _points_rows(tfd_kps)
+    if (not xr.requires_grad and not kr.requires_grad and xr.dtype == kr.dtype == torch.float32 and xr.device == kr.device
+            and xr.untyped_storage().data_ptr() == kr.untyped_storage().data_ptr()
+            and kr.data_ptr() == xr.data_ptr() + xr.numel() * 4):
+        return torch.as_strided(xr, (xr.shape[0] + kr.shape[0], 3), (3, 1))
+    return torch.cat([xr, kr], 0)
+
+
 def _stn(rows, p, prefix, k, B, N, M, pre=None):
     """STN3d / STNkd on cloud-major rows [R, k] -> [C, k, k]  (pointnet.py:24-41 / 57-78).  ``pre``: (conv1 out, conv2
     out, pooled maxima, arg-max rows) already computed by the fused forward kernel - the nodes then only build the graph."""
@@ -239,12 +250,12 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
         hub = (pfmax, pf if fused_rot else T.object_major(pf, B, N, M))
     elif rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
-        pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)         # cloud-major rows
+        pts = _cloud_major_rows(x, tfd_kps)
         g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
                                          obj_copy=not fused_rot)
         fused_rot = fused_rot and hub is not None
     else:
-        pts = torch.cat([_points_rows(x), _points_rows(tfd_kps)], 0)
+        pts = _cloud_major_rows(x, tfd_kps)
         (g, pf), hub = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform)), None
         fused_rot = False
     # max_n pointfeat (flat_pcl_feat tail) and the rot heads' input in object-major order: [N observed | M prior] per object
