@@ -1702,6 +1702,7 @@ static bool trunk4_on() {
   return v;
 }
 
+inline int stn_pairs(int B, int N, int M) { return B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2); }
 static bool stn_pair_on() {  // CATRE_STN_PAIR=0: one tile per workgroup (A/B)
   static const bool v = [] {
     const char* e = getenv("CATRE_STN_PAIR");
@@ -1759,8 +1760,8 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
                      pkb(packed, L.sp_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
-  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on()) {
-    const int pairs = B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2);
+  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on() && stn_pairs(B, N, M) >= 256) {
+    const int pairs = stn_pairs(B, N, M);  // (fewer pairs than CUs: one tile per workgroup keeps the whole chip busy)
     hipLaunchKernelGGL(k_stn3d_pair, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
                        pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
                        ws + W.pm, B, N, M);
@@ -1791,8 +1792,8 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
                      prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
     RS_DISPATCH(row_split(tiles), LAUNCH_)
 #undef LAUNCH_
-  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on()) {
-    const int pairs = B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2);
+  } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on() && stn_pairs(B, N, M) >= 256) {
+    const int pairs = stn_pairs(B, N, M);
     hipLaunchKernelGGL(k_stnkd_pair, dim3(pairs), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
                        pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2), prm[CATRE_P_FSTN_CONV2_B],
                        pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
