@@ -374,7 +374,8 @@ def test_design_roofline_table_is_generated_from_the_committed_profiles():
     m = re.search(r"<!-- BEGIN GENERATED by profiles/make_tables.py (\w+) -->.*?<!-- END GENERATED -->", doc, flags=re.S)
     assert m, "DESIGN.md lost its GENERATED block"
     assert m.group(0) == mt.render(m.group(1)), "DESIGN.md table is stale: python profiles/make_tables.py <tag> --write"
-    for row in ("| `k_trunk<1>`", "| `k_rot_l1<1>`", "| `k_rot_l1<1, true>`", "| `k_rot_l1_bwd`", "| `k_trunk_bf2`", "| `k_trunk_split<1>`"):
+    for row in ("| `k_trunk4`", "| `k_stn3d_pair`", "| `k_rot_l1<1>`", "| `k_trunk4<true>`", "| `k_rot_l1<1, true>`", "| `k_rot_l1_bwd`", "| `k_trunk_bf2`",
+                "| `k_trunk_split<1>`"):
         assert row in m.group(0), f"roofline table lost its {row} row (kernel renamed? see make_tables.canon)"
 
 
