@@ -250,7 +250,10 @@ __device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const
 // linear + max-pool over points without materialising the [R, J] matrix (Y = float maxima [tiles][J], mask = the int
 // arg-max rows [tiles][J]).  Uses the "swapped" MFMA orientation so that a lane owns a channel and the reduction is
 // in-register; the first maximum wins, like torch.max.
-template <int MB, int NKC, bool MAXP = false>
+// KS = 2 (MB = 1, J <= 128: at most four m-blocks for eight waves): the waves that would only help staging take the second
+// half of every K chunk of the same m-blocks, and the two partial tiles meet in LDS behind the last chunk (fixed order:
+// first half + second half) - the conv3 dgrad of the row-sparse trunk chain (J = 128, K = 512) ran with four idle waves.
+template <int MB, int NKC, bool MAXP = false, int KS = 1>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    int ldm, float* __restrict__ Y, int ldy, int R, int J, int K,
@@ -277,7 +280,9 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
   f32x16 acc[MB][2];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = zero16();
-  const bool active = wave < nblk;  // waves beyond the channel count only help staging
+  static_assert(KS == 1 || (KS == 2 && MB == 1 && !MAXP && (NKC / KS) % 8 == 0), "K split: swizzled images shift by whole 8-chunk groups");
+  const int blk_w = KS > 1 ? wave % nblk : wave, ks = KS > 1 ? wave / nblk : 0;
+  const bool active = KS > 1 ? wave < KS * nblk : wave < nblk;  // waves beyond that only help staging
   for (int c = 0; c < nchunks; ++c) {
     if (c) __syncthreads();
     // stage X[r0..r0+64, c*KC .. +KC) : coalesced float4 along K, swizzled rows
@@ -336,11 +341,26 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float*
       // m-blocks of this wave: wave + 8*i; packed stride between them = 8 m-blocks
       // two weight chunks in flight, except the widest instance (4 m-blocks x K-chunk 256): 32 MFMAs per chunk cover
       // one chunk's L2 round trip, and the third ring slot would not fit 256 VGPRs (2 spills)
-      GemmPipe<MB, 2, MAXP, true, NKC, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;
+      GemmPipe<MB, 2, MAXP, true, NKC / KS, (NKC >= 4 && !(MB == 4 && NKC == 32) ? 2 : 1), 1> g;
       // the launcher guarantees J <= 256 (MB = 1, waves >= J/32 idle) or J % 256 == 0 (every wave owns MB blocks)
-      g.prefetch(Wp + ((size_t)wave * nkc_total + c * NKC) * 64 + lane, 8 * nkc_total * 64);
-      g.run(acc, xs, LDX, lane);
+      g.prefetch(Wp + ((size_t)blk_w * nkc_total + c * NKC + ks * (NKC / KS)) * 64 + lane, 8 * nkc_total * 64);
+      g.run(acc, xs + ks * (NKC / KS) * 8, LDX, lane);
     }
+  }
+  if constexpr (KS > 1) {
+    __syncthreads();  // the last chunk's image is free: [m-block][point block][register][lane] partials of the second halves
+    if (active && ks == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[((blk_w * 2 + nb) * 16 + r) * 64 + lane] = acc[0][nb][r];
+    }
+    __syncthreads();
+    if (!active || ks != 0) return;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][nb][r] += xs[((blk_w * 2 + nb) * 16 + r) * 64 + lane];
   }
   if (!active) return;
   // (store form: normal orientation - at the fp32 MFMA rate the L2 write requests of its 16-byte stores are hidden, and
