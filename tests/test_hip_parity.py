@@ -283,6 +283,33 @@ def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtyp
     assert torch.equal(out["pose_2"], ref["pose_2"][9:12]) and torch.equal(out["scale_2"], ref["scale_2"][9:12])
 
 
+@pytest.mark.parametrize("B,N,M", [(40, 960, 448), (130, 300, 100), (48, 1000, 500), (20, 1024, 1024)])
+def test_full_grid_kernel_forms_return_the_bits_of_the_small_grid_forms(B, N, M):
+    """Round 5: grids that fill the chip run the encoder with one wave per SIMD (`k_trunk4`, `k_stn3d<1,false,true>`) and,
+    from 256 pairs on, the STN kernels on 128-point PAIRS of tiles (`k_stn3d_pair` / `k_stnkd_pair`).  Clouds with an ODD
+    number of tiles (960 = 15, 448 = 7, 300 = 5 tiles) end in a pair of one tile whose second half is not swept; ragged last
+    tiles (300, 100, 1000, 500 points) clamp.  Whatever the form, an object's result must be the bits the same object gets in
+    a batch of 3 (small grids: the 8-wave kernels with their RS splits), and within 2e-5 of the oracle."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+    from oracle import catre_oracle as O
+
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=2)
+    model, sd = build_model(cfg, 4)
+    cpu = synth.make_inputs(B, N, M, seed=300 + B)
+    batch = to_dev(cpu)
+    big = model.refine(batch, n_iter=2)
+    for lo in (0, B - 3):
+        sub = {k: v[lo:lo + 3].contiguous() for k, v in batch.items()}
+        small = model.refine(sub, n_iter=2)
+        for key in ("pose_1", "pose_2", "scale_2"):
+            assert torch.equal(small[key], big[key][lo:lo + 3]), (B, N, M, lo, key)
+    with torch.no_grad():
+        ref = O.refine_k({k: v[:2] for k, v in cpu.items()}, sd, cfg, n_iter=2)
+    for key in ("pose_2", "scale_2"):
+        assert (big[key][:2].cpu() - ref[key]).abs().max() <= 2e-5, (B, N, M, key)
+
+
 def test_batches_past_2_to_the_31_elements_index_correctly():
     """B=2100 at N=M=1024: the rot-head activation buffer holds 2100 x 2 x 2048 x 256 = 2.2e9 floats (> 2^31), the
     workspace 11.7 GB - offsets must be 64-bit everywhere.  Objects of the big batch equal the same objects run alone,
