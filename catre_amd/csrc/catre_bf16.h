@@ -704,9 +704,12 @@ typedef GemmPipeB<2, 4, true, 16, 3, 1, true> StnConv3Pipe;
 __device__ __forceinline__ void stn_conv3_prefetch(StnConv3Pipe (&g)[2], const u32x4* __restrict__ wp3, int wave, int lane) {
   g[0].prefetch(wp3 + ((size_t)(wave * 8) * 8) * 64 + lane, 8 * 64);
 }
+template <bool SAVE = false>
 __device__ __forceinline__ void stn_conv3_pair_bf(StnConv3Pipe (&g)[2], const u32x4* __restrict__ wp3,
                                                   const float* __restrict__ b3, const u32x4* a2,
-                                                  float* __restrict__ out, float* __restrict__ out2, int wave, int lane) {
+                                                  float* __restrict__ out, float* __restrict__ out2, int wave, int lane,
+                                                  float* __restrict__ pmax = nullptr, int* __restrict__ pidx = nullptr,
+                                                  bool has2 = false, int row0 = 0) {
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     f32x16 acc[2][4];
@@ -717,15 +720,21 @@ __device__ __forceinline__ void stn_conv3_pair_bf(StnConv3Pipe (&g)[2], const u3
     g[ps & 1].run(acc, a2, lane);
     if (ps < 3) g[(ps + 1) & 1].prefetch(wp3 + ((size_t)(wave * 8 + (ps + 1) * 2) * 8) * 64 + lane, 8 * 64);
     __builtin_amdgcn_sched_barrier(0);
-    max_tile_store_pre2<2, 4, true>(acc, out, out2, (wave * 8 + ps * 2) * 32, b3, lane);
+    if constexpr (SAVE)  // training: (max, arg-max row) of the pre-ReLU values, the pooled ReLU is the graph's
+      argmax_pair_store<2, 4>(acc, pmax, pidx, has2, (wave * 8 + ps * 2) * 32, b3, row0, lane);
+    else
+      max_tile_store_pre2<2, 4, true>(acc, out, out2, (wave * 8 + ps * 2) * 32, b3, lane);
   }
 }
 
+// SAVE (training forward under autocast, N and M multiples of 64): like k_stn3d_bf<true> / k_stnkd_bf<true> - the conv1 / conv2
+// images as fp32 rows (bf16 values) and the per-tile (max, arg-max row) pairs, written to both tiles' rows of a pair.
+template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, const u32x4* __restrict__ wp2,
                                                       const float* __restrict__ b2, const u32x4* __restrict__ wp3,
                                                       const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
-                                                      int M) {
+                                                      int M, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(1024))) u32x4 smem[2 * TP * 16 + 2 * TP * 8];
   u32x4* a2 = smem;                // [128][128 ch] (first: its rows are the XOR-addressed ones)
   u32x4* a1 = smem + 2 * TP * 16;  // [128][64 ch]
@@ -747,6 +756,8 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
     conv3_relu_chunks(x, y, z, W1, b1, g0 + 1, a1 + p * 8, bf_key<8>(p));
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_bf<64, 256, 2 * TP>(a1, sv.s1 + row0 * 64, ti.valid, tid);
   StnConv3Pipe g3[2];
   stn_conv3_prefetch(g3, wp3, wave, lane);
   {
@@ -755,16 +766,23 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
     store_tile_bf<1, 4, true, 16>(acc, a2, wave, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows_bf<128, 256, 2 * TP>(a2, sv.s2 + row0 * 128, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
-  stn_conv3_pair_bf(g3, wp3, b3, a2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+  if constexpr (SAVE)
+    stn_conv3_pair_bf<true>(g3, wp3, b3, a2, out, nullptr, wave, lane, sv.pmax + (size_t)tile0 * 1024,
+                            sv.pidx + (size_t)tile0 * 1024, ti.valid > TP, (int)row0);
+  else
+    stn_conv3_pair_bf(g3, wp3, b3, a2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
 }
 
+template <bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const float* __restrict__ trans3,
                                                       const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                       const u32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                       const u32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                       const u32x4* __restrict__ wpf3, const float* __restrict__ bf3,
-                                                      float* __restrict__ pm, int B, int N, int M) {
+                                                      float* __restrict__ pm, int B, int N, int M,
+                                                      TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(1024))) u32x4 smem[2 * TP * 16 + 2 * 2 * TP * 8];
   u32x4* f2 = smem;                              // [128][128 ch]
   u32x4* h1 = smem + 2 * TP * 16;                // [128][64 ch]
@@ -800,6 +818,8 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
     store_tile_bf<1, 2, true, 8>(acc, f1 + half1 * TP * 8, mblk1, bv1, lane);
   }
   __syncthreads();
+  const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
+  if (SAVE) save_tile_rows_bf<64, 256, 2 * TP>(f1, sv.s1 + row0 * 64, ti.valid, tid);
   StnConv3Pipe g3[2];
   stn_conv3_prefetch(g3, wpf3, wave, lane);
   {
@@ -808,8 +828,13 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
     store_tile_bf<1, 4, true, 16>(acc, f2, wave, bv2, lane);
   }
   __syncthreads();
+  if (SAVE) save_tile_rows_bf<128, 256, 2 * TP>(f2, sv.s2 + row0 * 128, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
-  stn_conv3_pair_bf(g3, wpf3, bf3, f2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
+  if constexpr (SAVE)
+    stn_conv3_pair_bf<true>(g3, wpf3, bf3, f2, out, nullptr, wave, lane, sv.pmax + (size_t)tile0 * 1024,
+                            sv.pidx + (size_t)tile0 * 1024, ti.valid > TP, (int)row0);
+  else
+    stn_conv3_pair_bf(g3, wpf3, bf3, f2, out, ti.valid > TP ? out + PMW : nullptr, wave, lane);
 }
 
 #define TRUNKB2_SMEM (2 * TP * 64 + 2 * TP * 16)

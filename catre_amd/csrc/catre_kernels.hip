@@ -2170,7 +2170,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
   {
     ProfScope ps(CATRE_K_STN3D, st);
     if (paired)
-      hipLaunchKernelGGL(k_stn3d_bf2, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
+      hipLaunchKernelGGL(k_stn3d_bf2<false>, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
                          prm[CATRE_P_STN_CONV1_B], pkb(packed, L.bf_stn_c2), prm[CATRE_P_STN_CONV2_B],
                          pkb(packed, L.bf_stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
     else
@@ -2186,7 +2186,7 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
     {
       ProfScope ps(CATRE_K_STNKD, st);
       if (paired)
-        hipLaunchKernelGGL(k_stnkd_bf2, dim3(pairs), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
+        hipLaunchKernelGGL(k_stnkd_bf2<false>, dim3(pairs), dim3(256), 0, st, *pts, ws + W.trans3, prm[CATRE_P_CONV1_W],
                            prm[CATRE_P_CONV1_B], pkb(packed, L.bf_fstn_c1), prm[CATRE_P_FSTN_CONV1_B],
                            pkb(packed, L.bf_fstn_c2), prm[CATRE_P_FSTN_CONV2_B], pkb(packed, L.bf_fstn_c3),
                            prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
