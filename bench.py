@@ -254,11 +254,102 @@ def cpu_baseline(cfg_fn, sd):
     }
 
 
-def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup):
+def ddp_bucket_plan(named_params, bucket_cap_mb=25):
+    """The buckets `DistributedDataParallel(find_unused_parameters=True)` builds and keeps (torch/nn/parallel/distributed.py
+    `_ddp_init_helper`: sizes [1 MiB, bucket_cap] over the parameters in definition order, bucket list reversed; with
+    find_unused_parameters the reducer never rebuilds them) -> list of lists of parameter names, in the order the reducer
+    launches their all-reduces."""
+    import torch.distributed as tdist
+
+    named = [(k, p) for k, p in named_params if p.requires_grad]
+    idx, _ = tdist._compute_bucket_assignment_by_size([p for _, p in named],
+                                                      [tdist._DEFAULT_FIRST_BUCKET_BYTES, int(bucket_cap_mb * 1024 * 1024)])
+    return [[named[i][0] for i in b] for b in reversed(idx)]
+
+
+class GradOrderProbe:
+    """Records, for ONE backward, the order in which the parameters' gradients are accumulated and a device event behind each
+    (post-accumulate-grad hooks: the point where DDP's reducer marks a gradient ready).  `report` relates that order to a
+    bucket plan: a bucket's all-reduce can start once the LAST of its gradients is in."""
+
+    def __init__(self, named_params, use_events=True):
+        self.names, self.events, self.handles = [], [], []
+        self.use_events = use_events
+        for k, p in named_params:
+            if p.requires_grad:
+                self.handles.append(p.register_post_accumulate_grad_hook(self._hook(k)))
+        self.t_begin = self.t_end = None
+
+    def _hook(self, k):
+        def fn(_p):
+            self.names.append(k)
+            if self.use_events:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.events.append(e)
+        return fn
+
+    def begin(self):
+        self.names, self.events = [], []
+        if self.use_events:
+            self.t_begin = torch.cuda.Event(enable_timing=True)
+            self.t_begin.record()
+
+    def end(self):
+        if self.use_events:
+            self.t_end = torch.cuda.Event(enable_timing=True)
+            self.t_end.record()
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+    def report(self, plan):
+        pos = {k: i for i, k in enumerate(self.names)}
+        n = len(self.names)
+        total_ms = self.t_begin.elapsed_time(self.t_end) if self.use_events else None
+        out = []
+        for b, names in enumerate(plan):
+            used = [k for k in names if k in pos]
+            if not used:
+                out.append({"bucket": b, "tensors": len(names), "unused_only": True})
+                continue
+            last = max(used, key=lambda k: pos[k])
+            first = min(used, key=lambda k: pos[k])
+            row = {"bucket": b, "tensors": len(names), "tensors_with_grad": len(used),
+                   "first_grad": first, "closes_with": last, "closes_at_hook": pos[last] + 1, "of_hooks": n}
+            if self.use_events:
+                ms = self.t_begin.elapsed_time(self.events[pos[last]])
+                row["closes_ms_into_backward"] = round(ms, 3)
+                row["backward_ms"] = round(total_ms, 3)
+                row["backward_left_to_hide_allreduce_ms"] = round(total_ms - ms, 3)
+            out.append(row)
+        return out
+
+
+def init_world1_group(dev):
+    """A one-rank RCCL process group on 127.0.0.1 (free port): what `DistributedDataParallel` needs to run its reducer -
+    hooks, find_unused_parameters graph walk, bucket copies, one all-reduce launch per bucket - on a single GPU."""
+    import socket
+
+    import torch.distributed as tdist
+
+    if not tdist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        tdist.init_process_group(backend="nccl" if dev.type == "cuda" else "gloo", init_method=f"tcp://127.0.0.1:{port}",
+                                 rank=0, world_size=1, **({"device_id": dev} if dev.type == "cuda" else {}))
+    return tdist
+
+
+def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup, ddp_kwargs=None, probe=None):
     """BASELINE.json configs 3/4: one step = the reference's train loop body for one data batch
     (core/catre/engine/engine.py:293-355): K_ITER x (pose-apply, forward + loss, backward, optimizer step), the fed-back
     pose detached.  With N > 1 the model is wrapped in DistributedDataParallel exactly like
-    core/catre/main_catre.py:154-160 and gradients are all-reduced over RCCL (17.19 MB per backward).
+    core/catre/main_catre.py:154-160 and gradients are all-reduced over RCCL (17.19 MB per backward).  `ddp_kwargs` (a dict,
+    possibly empty) forces the same wrap on a single rank (`--ddp-world1`: the reducer's cost without the wire); `probe` (a
+    dict) receives the gradient order of one extra, untimed backward against the wrapper's bucket plan.
     -> seconds for `steps` steps on this rank (barrier + synchronize on both sides)."""
     from catre_amd import synth
     from catre_amd.batching import batch_updater_test
@@ -274,16 +365,19 @@ def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup):
     model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
     model.train()
     net = model
-    if dist is not None:
+    if dist is not None or ddp_kwargs is not None:
         from torch.nn.parallel import DistributedDataParallel
 
-        net = DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False, find_unused_parameters=True)
+        net = DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False, find_unused_parameters=True,
+                                      **(ddp_kwargs or {}))
     batch = {k: v.to(dev) for k, v in synth.make_inputs(B_PER_GPU, N_PTS, M_PTS, seed=2000 + rank).items()}
     ang = torch.arange(1, 314, dtype=torch.float32) * (2 * 3.141592653589793 / 314)
     sym = torch.zeros(313, 3, 3)
     sym[:, 0, 0], sym[:, 0, 2], sym[:, 1, 1], sym[:, 2, 0], sym[:, 2, 2] = ang.cos(), ang.sin(), 1.0, -ang.sin(), ang.cos()
     sym = sym.numpy()  # 313 y-axis symmetry rotations (MAX_SYM_DISC_STEP=0.01, lib/pysixd/misc.py:220-231)
     sym_info = [sym if (i % 6) in (0, 1, 3) else None for i in range(B_PER_GPU)]  # bottle / bowl / can (ref/nocs.py:138-158)
+
+    gprobe = [None]
 
     def one_step():
         b = dict(batch)
@@ -296,7 +390,11 @@ def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup):
                               obj_kps=b["obj_kps"], mean_scales=b["obj_mean_scales"], sym_info=sym_info, do_loss=True,
                               cur_iter=it)
             poses_est, scales_est = out[f"pose_{it}"].detach(), out[f"scale_{it}"].detach()
+            if gprobe[0] is not None and it == K_ITER:
+                gprobe[0].begin()
             sum(ld.values()).backward()
+            if gprobe[0] is not None and it == K_ITER:
+                gprobe[0].end()
             opt.step()
             opt.zero_grad(set_to_none=True)
         return poses_est
@@ -316,13 +414,69 @@ def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup):
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(last).all()
+    if probe is not None:  # one more step, untimed, with a hook behind every gradient accumulation
+        gprobe[0] = GradOrderProbe(list(model.named_parameters()))
+        one_step()
+        torch.cuda.synchronize(dev)
+        cap = (ddp_kwargs or {}).get("bucket_cap_mb", 25)
+        plan = ddp_bucket_plan(model.named_parameters(), cap)
+        probe["bucket_cap_mb"] = cap
+        probe["gradients_accumulated"] = len(gprobe[0].names)
+        probe["first_gradients"] = gprobe[0].names[:3]
+        probe["last_gradients"] = gprobe[0].names[-3:]
+        probe["buckets_in_launch_order"] = gprobe[0].report(plan)
+        gprobe[0].remove()
+        gprobe[0] = None
     return dt
+
+
+def ddp_world1_block(cfg_fn, dev, base_ms_it, steps=3, warmup=1):
+    """Scaling evidence a 1-GPU box can produce (BASELINE configs 4/5 wrap every rank's model like this): the reference's
+    `DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)`
+    (core/catre/main_catre.py:154-160) around the same B=256 training step on a one-rank RCCL group - everything a rank of an
+    8-GPU job pays besides the wire: the find_unused_parameters graph walk after every forward, 68 reducer hooks, the copies
+    of 17.19 MB of gradients into the buckets, one all-reduce launch per bucket, K times per batch."""
+    tdist = init_world1_group(dev)
+    out = {"what": "the train_fp32 step with the reference's DDP wrap on a one-rank RCCL group (main_catre.py:154-160); "
+                   "overhead = this minus the unwrapped step of the same run", "steps": steps, "warmup": warmup}
+    probe = {}
+    t = run_train(cfg_fn, dev, None, 0, "fp32", steps, warmup, ddp_kwargs={}, probe=probe)
+    ms = t / steps / K_ITER * 1e3
+    out["ms_per_iteration"] = round(ms, 3)
+    out["overhead_ms_per_iteration"] = round(ms - base_ms_it, 3)
+    out["gradient_order_vs_buckets"] = probe
+    torch.cuda.empty_cache()
+    t = run_train(cfg_fn, dev, None, 0, "fp32", steps, warmup, ddp_kwargs={"gradient_as_bucket_view": True})
+    ms_v = t / steps / K_ITER * 1e3
+    out["gradient_as_bucket_view"] = {"ms_per_iteration": round(ms_v, 3), "overhead_ms_per_iteration": round(ms_v - base_ms_it, 3)}
+    torch.cuda.empty_cache()
+    probe4 = {}
+    t = run_train(cfg_fn, dev, None, 0, "fp32", steps, warmup, ddp_kwargs={"bucket_cap_mb": 4, "gradient_as_bucket_view": True},
+                  probe=probe4)
+    ms_4 = t / steps / K_ITER * 1e3
+    out["bucket_cap_4MB_bucket_view"] = {"ms_per_iteration": round(ms_4, 3), "overhead_ms_per_iteration": round(ms_4 - base_ms_it, 3),
+                                         "gradient_order_vs_buckets": probe4}
+    # expected 8-GPU iteration (UNMEASURED: the pool has no multi-GPU box): the wrapped iteration + the part of the ring
+    # all-reduce that the rest of the backward cannot hide.  Ring time 2 (N-1)/N x bytes / per-link bandwidth (xGMI, 153 GB/s)
+    wire_ms = 2 * 7 / 8 * GRAD_ALLREDUCE_BYTES / 153e9 * 1e3
+    out["expected_8gpu"] = {"unmeasured": True, "ring_allreduce_ms": round(wire_ms, 3),
+                            "ms_per_iteration_if_fully_exposed": round(ms + wire_ms, 3),
+                            "note": "default 25 MiB buckets: the one big bucket closes with the LAST gradient of the backward "
+                                    "(see gradient_order_vs_buckets), so its all-reduce is exposed; 4 MiB buckets overlap all "
+                                    "but the last one"}
+    tdist.barrier()
+    return out
 
 
 def bench_train(args, world, rank, dev, dist, cfg_fn):
     amp = args.dtype == "bf16"
     split = args.dtype == "split"
-    dt = run_train(cfg_fn, dev, dist, rank, args.dtype, args.steps, args.warmup)
+    ddp1 = None
+    if args.ddp_world1 and world == 1:
+        init_world1_group(dev)
+        ddp1 = {"bucket_cap_mb": args.bucket_cap_mb, "gradient_as_bucket_view": bool(args.bucket_view)}
+    probe = {} if ddp1 is not None else None
+    dt = run_train(cfg_fn, dev, dist, rank, args.dtype, args.steps, args.warmup, ddp_kwargs=ddp1, probe=probe)
     dt, per_rank_ms, ranks_seen = rank_stats(dist, dev, dt)
     comm = comm_info(dist, dev, world, rank, dev.index)
     if rank == 0:
@@ -330,6 +484,8 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
         print(json.dumps({
             "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms, "comm": comm, "shared_gpu": SHARE_GPU,
             "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if world > 1 else 0,
+            "ddp_world1": dict(ddp1, gradient_order_vs_buckets=probe) if ddp1 is not None else None,
+            "ms_per_iteration": round(dt / args.steps / K_ITER * 1e3, 3),
             "metric": "pose-refine TRAIN iters/sec (B=256, N=1024, K=4)" + (" [bf16 autocast]" if amp else " [split-bf16 GEMMs]" if split else ""),
             "value": round(value, 1),
             "unit": "object-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,12 +496,16 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
                                    + ("forward / dgrad / wgrad GEMMs as split-bf16 (hi+lo, three products) MFMAs, fp32 results; " if split else "")
                                    +
                                    "half the objects y-symmetric with 313 candidate rotations; "
-                                   + ("DDP gradient all-reduce over RCCL" if world > 1 else "single rank"),
+                                   + ("DDP gradient all-reduce over RCCL" if world > 1 else
+                                      ("single rank inside DistributedDataParallel on a one-rank RCCL group" if ddp1 is not None
+                                       else "single rank, no DistributedDataParallel wrapper (main_catre.py:154 wraps only when world > 1)")),
                        "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER},
         }), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    elif ddp1 is not None:
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -365,6 +525,11 @@ def main():
                     help="headline: B=256, N=M=1024, K=4; config5: N=2048 observed, M=1024, K=8; config2: B=64 (BASELINE "
                          "configs[1] as written - the headline metric is quoted at B=256)")
     ap.add_argument("--no-split-extra", action="store_true", help="skip the split-mode measurement of the default line")
+    ap.add_argument("--no-ddp-extra", action="store_true", help="skip the DDP-world-1 measurement of the default line")
+    ap.add_argument("--ddp-world1", action="store_true",
+                    help="--mode train on ONE GPU inside the reference's DistributedDataParallel wrap (one-rank RCCL group)")
+    ap.add_argument("--bucket-cap-mb", type=float, default=25, help="--ddp-world1: DDP bucket_cap_mb (torch default 25)")
+    ap.add_argument("--bucket-view", action="store_true", help="--ddp-world1: gradient_as_bucket_view=True")
     args = ap.parse_args()
     global N_PTS, K_ITER, B_PER_GPU
     if args.shape == "config5":
@@ -517,7 +682,8 @@ def main():
         tdt = run_train(cfg_fn, dev, None, 0, "fp32", tsteps, 1)
         train_extra = {"what": "BASELINE config 3: K=4 x (pose-apply, forward + device-side loss, backward, fused Ranger step) of "
                                "the same B=256, N=M=1024 batch, fp32 kernels, half the objects y-symmetric (313 candidates), "
-                               "DDP world 1; 1 warm-up + 3 timed steps",
+                               "single rank WITHOUT the DistributedDataParallel wrapper (the reference wraps only when world > 1, "
+                               "main_catre.py:154; `ddp_world1` below is the same step inside the wrapper); 1 warm-up + 3 timed steps",
                        "value": round(B_PER_GPU * K_ITER * tsteps / tdt, 1), "unit": "training object-iterations/s (1 GPU)",
                        "ms_per_step": round(tdt / tsteps * 1e3, 3), "ms_per_iteration": round(tdt / tsteps / K_ITER * 1e3, 3)}
 
@@ -526,6 +692,10 @@ def main():
             tfs = flop_it / (tdt / tsteps / K_ITER) / 1e12
             train_extra.update({"mfma_gflop_per_iteration": round(flop_it / 1e9, 1), "mfma_gflop_source": src,
                                 "tflops": round(tfs, 1), "path_frac_of_mfma_peak": round(tfs / FP32_MFMA_PEAK_TFLOPS, 4)})
+
+        if not args.no_ddp_extra:
+            torch.cuda.empty_cache()
+            train_extra["ddp_world1"] = ddp_world1_block(cfg_fn, dev, train_extra["ms_per_iteration"])
 
         # ... and the same step under torch.autocast (engine.py:304, SOLVER.AMP.ENABLED - BASELINE config 5's arithmetic):
         # bf16-operand GEMMs, fp32 accumulation / statistics / SO(3); a bf16-class number, not the fp32 contract
@@ -615,6 +785,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    elif torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()  # the one-rank group of the ddp_world1 block
 
 
 if __name__ == "__main__":

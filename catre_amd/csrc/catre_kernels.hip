@@ -1381,7 +1381,15 @@ __device__ __forceinline__ void pose_update_obj(const float* rotp, const float* 
                                                 const float* __restrict__ dsr, const float* __restrict__ pose0,
                                                 const float* __restrict__ scale0, const float* __restrict__ mean_scales,
                                                 const float* __restrict__ Ks, const catre_opts& o,
-                                                float* __restrict__ pose_out, float* __restrict__ scale_out, int b) {
+                                                float* __restrict__ pose_out, float* __restrict__ scale_out, int b,
+                                                float* __restrict__ pose_echo = nullptr,
+                                                float* __restrict__ scale_echo = nullptr) {
+  if (pose_echo) {  // catre_refine_k_from: slot 0 of the K-loop's output = the caller's initial estimate, no copy launch
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pose_echo[b * 12 + i] = pose0[b * 12 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) scale_echo[b * 3 + i] = scale0[b * 3 + i];
+  }
   float dR[9];
   if (o.rot_input_is_matrix) {
 #pragma unroll
@@ -1457,11 +1465,12 @@ __global__ void k_pose_update(const float* __restrict__ rot6d, const float* __re
                               const float* __restrict__ dsr, const float* __restrict__ pose0,
                               const float* __restrict__ scale0, const float* __restrict__ mean_scales,
                               const float* __restrict__ Ks, catre_opts o, float* __restrict__ pose_out,
-                              float* __restrict__ scale_out, int B) {
+                              float* __restrict__ scale_out, int B, float* __restrict__ pose_echo = nullptr,
+                              float* __restrict__ scale_echo = nullptr) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   pose_update_obj(rot6d + (size_t)b * (o.rot_input_is_matrix ? 9 : catre_rot_dim(o.rot_type)), dtr, dsr, pose0, scale0,
-                  mean_scales, Ks, o, pose_out, scale_out, b);
+                  mean_scales, Ks, o, pose_out, scale_out, b, pose_echo, scale_echo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2141,16 +2150,25 @@ int catre_rot_head(const float* gfeat, const float* pointfeat, const float* cons
   return rot_head_impl(gfeat, pointfeat, prm, packed, rot6d, (float*)workspace, W, B, N, M, (hipStream_t)stream);
 }
 
-int catre_pose_update(const float* rot6d, const float* trans_deltas, const float* scale_deltas, const float* init_pose,
-                      const float* init_scale, const float* mean_scales, const float* Ks, const catre_opts* o,
-                      float* pose_out, float* scale_out, int B, void* stream) {
+static int pose_update_impl(const float* rot6d, const float* trans_deltas, const float* scale_deltas,
+                            const float* init_pose, const float* init_scale, const float* mean_scales, const float* Ks,
+                            const catre_opts* o, float* pose_out, float* scale_out, int B, void* stream,
+                            float* pose_echo, float* scale_echo) {
   REQUIRE(rot6d && trans_deltas && scale_deltas && init_pose && init_scale && o && pose_out && scale_out && B > 0);
   if (o->k_aware && !o->delta_t_space_3d && !Ks) return CATRE_ERR_BAD_ARG;
   if (o->scale_base_mean && !mean_scales) return CATRE_ERR_BAD_ARG;
   if (o->rot_type < CATRE_ROT_6D || o->rot_type > CATRE_ROT_LIE_VEC) return CATRE_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pose_update, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, trans_deltas,
-                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
+                     scale_deltas, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B, pose_echo,
+                     scale_echo);
   return check_launch();
+}
+
+int catre_pose_update(const float* rot6d, const float* trans_deltas, const float* scale_deltas, const float* init_pose,
+                      const float* init_scale, const float* mean_scales, const float* Ks, const catre_opts* o,
+                      float* pose_out, float* scale_out, int B, void* stream) {
+  return pose_update_impl(rot6d, trans_deltas, scale_deltas, init_pose, init_scale, mean_scales, Ks, o, pose_out, scale_out,
+                          B, stream, nullptr, nullptr);
 }
 
 // One refine iteration on the bf16-operand kernels (catre_bf16.h); same launch chain, same workspace (pointfeat and
@@ -2158,7 +2176,7 @@ int catre_pose_update(const float* rot6d, const float* trans_deltas, const float
 static int refine_iter_bf(const catre_points* pts, const float* init_pose, const float* init_scale,
                           const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
                           const catre_opts* o, float* pose_out, float* scale_out, float* ws, const WsLayout& W, int B,
-                          int N, int M, hipStream_t st) {
+                          int N, int M, hipStream_t st, float* pose_echo, float* scale_echo) {
   const PackLayout L = pack_layout(1);
   const int TN = (N + TP - 1) / TP, TM = (M + TP - 1) / TP, T = TN + TM, tiles = B * T;
   const int rd = catre_rot_dim(o->rot_type) / 2;
@@ -2259,14 +2277,14 @@ static int refine_iter_bf(const catre_points* pts, const float* init_pose, const
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B],
                      ws + W.rot6d, B, T, rd);
   if ((rc = check_launch())) return rc;
-  return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
-                           scale_out, B, (void*)st);
+  return pose_update_impl(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                          scale_out, B, (void*)st, pose_echo, scale_echo);
 }
 
-int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
-                      const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
-                      const catre_opts* o, float* pose_out, float* scale_out, void* workspace, size_t ws_bytes, int B,
-                      int N, int M, void* stream) {
+static int refine_iter_impl(const catre_points* pts, const float* init_pose, const float* init_scale,
+                            const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                            const catre_opts* o, float* pose_out, float* scale_out, void* workspace, size_t ws_bytes, int B,
+                            int N, int M, void* stream, float* pose_echo, float* scale_echo) {
   REQUIRE(pts && pts->obs && pts->kps && init_pose && init_scale && prm && packed && o && pose_out && scale_out &&
           workspace && dims_ok(B, N, M));
   const WsLayout W = ws_layout(B, N, M);
@@ -2278,7 +2296,7 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   if (o->rot_type != CATRE_ROT_6D && o->rot_type != CATRE_ROT_QUAT) return CATRE_ERR_UNSUPPORTED;
   if (o->compute_dtype == CATRE_DTYPE_BF16)
     return refine_iter_bf(pts, init_pose, init_scale, mean_scales, Ks, prm, packed, o, pose_out, scale_out, ws, W, B, N, M,
-                          st);
+                          st, pose_echo, scale_echo);
   if (o->compute_dtype != CATRE_DTYPE_F32 && o->compute_dtype != CATRE_DTYPE_SPLIT) return CATRE_ERR_UNSUPPORTED;
   const bool split = o->compute_dtype == CATRE_DTYPE_SPLIT;
   const int T = (N + TP - 1) / TP + (M + TP - 1) / TP, R = 2 * B;
@@ -2330,8 +2348,8 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
       return rc;
     if ((rc = rot_head_impl(ws + W.gfeat, ws + W.pointfeat, prm, packed, ws + W.rot6d, ws, W, B, N, M, st, split, rd)))
       return rc;
-    return catre_pose_update(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
-                             scale_out, B, stream);
+    return pose_update_impl(ws + W.rot6d, ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, o, pose_out,
+                            scale_out, B, stream, pose_echo, scale_echo);
   }
   // ---- latency path after the trunk: 5 launches (catre_small.h), 6 when the pooled feature is reduced by its own ----
   if (!fold) reduce_pm(ws + W.gfeat, PMW, PMW, rsh ? 2 : 1);
@@ -2421,14 +2439,27 @@ int catre_refine_iter(const catre_points* pts, const float* init_pose, const flo
   }
   hipLaunchKernelGGL(k_finish_update, dim3((B + 7) / 8), dim3(64), 0, st, ws + W.rpart, prm[CATRE_P_ROTX_NECK_B],
                      prm[CATRE_P_ROTY_NECK_B], packed + L.sumwp, prm[CATRE_P_ROTX_CONVP_B], prm[CATRE_P_ROTY_CONVP_B], T, rd,
-                     ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B);
+                     ws + W.dt, ws + W.ds, init_pose, init_scale, mean_scales, Ks, *o, pose_out, scale_out, B, pose_echo,
+                     scale_echo);
   return check_launch();
 }
 
-int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,
-                   const float* const* prm, const float* packed, const catre_opts* o, float* poses, float* scales,
-                   void* workspace, size_t ws_bytes, int B, int N, int M, int n_iter, void* stream) {
+int catre_refine_iter(const catre_points* pts, const float* init_pose, const float* init_scale,
+                      const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                      const catre_opts* o, float* pose_out, float* scale_out, void* workspace, size_t ws_bytes, int B,
+                      int N, int M, void* stream) {
+  return refine_iter_impl(pts, init_pose, init_scale, mean_scales, Ks, prm, packed, o, pose_out, scale_out, workspace,
+                          ws_bytes, B, N, M, stream, nullptr, nullptr);
+}
+
+// init_pose / init_scale == nullptr: slot 0 of poses / scales holds the initial estimate (catre_refine_k); otherwise the
+// first iteration reads the caller's buffers and its pose-update kernel copies them into slot 0 (catre_refine_k_from)
+static int refine_k_impl(const float* pcl, const float* kps, const float* init_pose, const float* init_scale,
+                         const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                         const catre_opts* o, float* poses, float* scales, void* workspace, size_t ws_bytes, int B, int N,
+                         int M, int n_iter, void* stream) {
   REQUIRE(pcl && kps && prm && packed && o && poses && scales && workspace && dims_ok(B, N, M) && n_iter >= 0);
+  REQUIRE((init_pose == nullptr) == (init_scale == nullptr));
   const WsLayout W = ws_layout(B, N, M);
   if (ws_bytes < W.total * sizeof(float)) return CATRE_ERR_WORKSPACE;
   float* ws = (float*)workspace;
@@ -2452,10 +2483,18 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
   pts.apply_pose = on_the_fly ? 1 : 0;
   pts.zero_center = o->zero_center;
   pts.pose = pts.scale = nullptr;
+  if (init_pose && n_iter == 0) {  // nothing to ride on: plain copies
+    if (hipMemcpyAsync(poses, init_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+            hipSuccess ||
+        hipMemcpyAsync(scales, init_scale, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+            hipSuccess)
+      return CATRE_ERR_LAUNCH;
+  }
   for (int i = 1; i <= n_iter; ++i) {
-    const float* pose_in = poses + (size_t)(i - 1) * B * 12;
+    const bool first = init_pose && i == 1;
+    const float* pose_in = first ? init_pose : poses + (size_t)(i - 1) * B * 12;
     // batch_test.py:74-75: the scale estimate is only fed back when REFINE_SCLAE
-    const float* scale_in = scales + (size_t)(o->refine_scale ? i - 1 : 0) * B * 3;
+    const float* scale_in = first ? init_scale : scales + (size_t)(o->refine_scale ? i - 1 : 0) * B * 3;
     if (on_the_fly) {
       pts.pose = pose_in;
       pts.scale = scale_in;
@@ -2464,11 +2503,28 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
           catre_pose_apply(pcl, kps, pose_in, scale_in, ws + W.xbuf, ws + W.kbuf, B, N, M, o->zero_center, stream);
       if (rc0) return rc0;
     }
-    const int rc = catre_refine_iter(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
-                                     scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream);
+    const int rc = refine_iter_impl(&pts, pose_in, scale_in, mean_scales, Ks, prm, packed, o, poses + (size_t)i * B * 12,
+                                    scales + (size_t)i * B * 3, workspace, ws_bytes, B, N, M, stream,
+                                    first ? poses : nullptr, first ? scales : nullptr);
     if (rc) return rc;
   }
   return CATRE_OK;
+}
+
+int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales, const float* Ks,
+                   const float* const* prm, const float* packed, const catre_opts* o, float* poses, float* scales,
+                   void* workspace, size_t ws_bytes, int B, int N, int M, int n_iter, void* stream) {
+  return refine_k_impl(pcl, kps, nullptr, nullptr, mean_scales, Ks, prm, packed, o, poses, scales, workspace, ws_bytes, B, N,
+                       M, n_iter, stream);
+}
+
+int catre_refine_k_from(const float* pcl, const float* kps, const float* init_pose, const float* init_scale,
+                        const float* mean_scales, const float* Ks, const float* const* prm, const float* packed,
+                        const catre_opts* o, float* poses, float* scales, void* workspace, size_t ws_bytes, int B, int N,
+                        int M, int n_iter, void* stream) {
+  REQUIRE(init_pose && init_scale);
+  return refine_k_impl(pcl, kps, init_pose, init_scale, mean_scales, Ks, prm, packed, o, poses, scales, workspace, ws_bytes,
+                       B, N, M, n_iter, stream);
 }
 
 

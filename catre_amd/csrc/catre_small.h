@@ -181,7 +181,9 @@ __global__ __launch_bounds__(64) void k_finish_update(const float* __restrict__ 
                                                       const float* __restrict__ scale0,
                                                       const float* __restrict__ mean_scales, const float* __restrict__ Ks,
                                                       catre_opts o, float* __restrict__ pose_out,
-                                                      float* __restrict__ scale_out, int B) {
+                                                      float* __restrict__ scale_out, int B,
+                                                      float* __restrict__ pose_echo = nullptr,
+                                                      float* __restrict__ scale_echo = nullptr) {
   __shared__ float rot[8][8];
   const int tid = threadIdx.x, nv = 2 * rd;
   if (tid < 8 * nv) {
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(64) void k_finish_update(const float* __restrict__ 
   }
   __syncthreads();
   const int b = blockIdx.x * 8 + tid;
-  if (tid < 8 && b < B) pose_update_obj(rot[tid], dtr, dsr, pose0, scale0, mean_scales, Ks, o, pose_out, scale_out, b);
+  if (tid < 8 && b < B)
+    pose_update_obj(rot[tid], dtr, dsr, pose0, scale0, mean_scales, Ks, o, pose_out, scale_out, b, pose_echo, scale_echo);
 }
 
 // ---- the trunk on HALF tiles ----------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@ _SIGS = {
     "catre_pose_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_refine_k_from": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_colmax": (_I, [_P, _P, _I, _I, _I, _P]),
     # training ops (include/catre_hip.h "training ops")
     "catre_op_pack": (_I, [_P, _I, _I, _I, _I, _P, _P]),

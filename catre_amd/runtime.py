@@ -214,13 +214,14 @@ class HipRuntime:
         ws = self.workspace(B, N, M, dev)
         poses = torch.empty(n_iter + 1, B, 3, 4, dtype=torch.float32, device=dev)
         scales = torch.empty(n_iter + 1, B, 3, dtype=torch.float32, device=dev)
-        poses[0].copy_(init_pose)
-        scales[0].copy_(init_scale)
+        # slot 0 (the reference's out_dict["pose_0"], catre_evaluator.py:292) is written by iteration 1's pose-update kernel:
+        # no copy launch inside a refine
+        init_pose, init_scale = init_pose.contiguous(), init_scale.contiguous()
         hip.check(
-            lib.catre_refine_k(hip.ptr(pcl), hip.ptr(obj_kps), hip.ptr(ms), hip.ptr(Ks), prm, hip.ptr(packed),
-                               ctypes.byref(opts), hip.ptr(poses), hip.ptr(scales), hip.ptr(ws), ws.numel(),
-                               B, N, M, n_iter, hip.stream_ptr(dev)),
-            "catre_refine_k",
+            lib.catre_refine_k_from(hip.ptr(pcl), hip.ptr(obj_kps), hip.ptr(init_pose), hip.ptr(init_scale), hip.ptr(ms),
+                                    hip.ptr(Ks), prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(poses), hip.ptr(scales),
+                                    hip.ptr(ws), ws.numel(), B, N, M, n_iter, hip.stream_ptr(dev)),
+            "catre_refine_k_from",
         )
         return poses, scales
 

@@ -236,6 +236,14 @@ int catre_refine_k(const float* pcl, const float* kps, const float* mean_scales,
                    float* poses, float* scales, void* workspace, size_t ws_bytes,
                    int B, int N, int M, int n_iter, void* stream);
 
+/* The same loop with slot 0 as an OUTPUT: iteration 1 reads the caller's init_pose [B,3,4] / init_scale [B,3]
+ * (`out_dict["pose_0"]`, catre_evaluator.py:292) and its pose-update kernel copies them into slot 0 - no copy launch
+ * in front of the loop (n_iter == 0: two device-to-device copies). */
+int catre_refine_k_from(const float* pcl, const float* kps, const float* init_pose, const float* init_scale,
+                        const float* mean_scales, const float* Ks, const float* const* params, const float* packed,
+                        const catre_opts* opts, float* poses, float* scales, void* workspace, size_t ws_bytes,
+                        int B, int N, int M, int n_iter, void* stream);
+
 /* ---- stand-alone memory-bound kernels (HBM roofline figures of SURVEY.md 8d) --------------- */
 
 /* torch.max(x, 2)[0] for x [B,C,N] contiguous -> out [B,C]  (pointnet.py:28,61,115). */

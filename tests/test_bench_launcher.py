@@ -45,3 +45,50 @@ def test_single_rank_does_not_spawn():
 def test_world_size_mismatch_is_an_error():
     r, _ = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "does not match" in r.stderr
+
+
+def test_ddp_bucket_plan_and_gradient_order_probe_on_a_toy_model():
+    """The `ddp_world1` block of the default line relates the order in which gradients are accumulated to the buckets
+    `DistributedDataParallel(find_unused_parameters=True)` builds (main_catre.py:154-160).  Here: the plan against the wrapper's
+    own reducer on a one-rank gloo group (CPU), and the probe's bookkeeping on a real backward."""
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+
+    import bench
+
+    torch.manual_seed(0)
+    # definition order big -> small -> unused: [1 MiB, cap] over that order, reversed
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.add_module("0", torch.nn.Linear(600, 600))
+            self.add_module("1", torch.nn.Linear(600, 64))
+            self.add_module("2", torch.nn.Linear(64, 8))
+            self.dead = torch.nn.Linear(4, 4)   # like the 6 unused `norm` tensors of the reference heads
+
+        def forward(self, x):
+            return getattr(self, "2")(getattr(self, "1")(getattr(self, "0")(x)))
+
+    model = Toy()
+    tdist = bench.init_world1_group(torch.device("cpu"))
+    try:
+        plan = bench.ddp_bucket_plan(model.named_parameters(), bucket_cap_mb=25)
+        assert sorted(k for b in plan for k in b) == sorted(k for k, _ in model.named_parameters())
+        # first bucket of the assignment is capped at 1 MiB: 0.weight (1.44 MB) closes it; it is launched LAST
+        assert plan[-1][0] == "0.weight" and "dead.weight" in plan[0]
+        ddp = DistributedDataParallel(model, broadcast_buffers=False, find_unused_parameters=True)
+        probe = bench.GradOrderProbe(list(model.named_parameters()), use_events=False)
+        probe.begin()
+        ddp(torch.randn(5, 600)).sum().backward()
+        probe.end()
+        assert len(probe.names) == 6 and probe.names[0].startswith("2.") and probe.names[-1].startswith("0.")
+        rep = probe.report(plan)
+        assert [r["bucket"] for r in rep] == list(range(len(plan)))
+        assert rep[-1]["closes_at_hook"] == 6 and rep[-1]["of_hooks"] == 6      # the first layer's gradients come last
+        assert rep[0]["tensors_with_grad"] == len(plan[0]) - 2                  # the dead layer never fires
+        probe.remove()
+        # the reducer's own bucket count agrees with the plan
+        assert len(ddp._get_ddp_logging_data()["bucket_sizes"].split(",")) == len(plan) if hasattr(ddp, "_get_ddp_logging_data") else True
+    finally:
+        tdist.destroy_process_group()

@@ -572,3 +572,40 @@ def test_concurrent_streams_reproduce_the_single_stream_result_in_every_mode(dty
         torch.cuda.synchronize()
         bad += sum(not torch.equal(o, w) for o, w in zip(outs, want))
     assert bad == 0, f"{bad} of {60 * len(Bs)} concurrent refines differ from their single-stream result"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "split"])
+@pytest.mark.parametrize("B,K", [(2, 3), (12, 2), (3, 0)])
+def test_refine_k_from_equals_refine_k_with_slot0_prefilled(B, K, dtype):
+    """`catre_refine_k_from` (slot 0 written by iteration 1's pose-update kernel: no copy launch inside a refine) against
+    `catre_refine_k` (slot 0 filled by the caller): every slot bit-identical - latency path (B = 2, 3), batch path (B = 12),
+    every compute mode, K = 0 (copies only), with and without the scale fed back."""
+    import ctypes
+
+    from catre_amd import hip, synth
+    from catre_amd.config import default_cfg
+
+    N, M = 256, 128
+    for refine_scale in (True, False):
+        cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=max(K, 1), device=DEV)
+        cfg.MODEL.REFINE_SCLAE = refine_scale
+        cfg.MODEL.CATRE.COMPUTE_DTYPE = dtype
+        model, _ = build_model(cfg, 3)
+        batch = to_dev(synth.make_inputs(B, N, M, seed=77))
+        out = model.refine(batch, n_iter=K)          # the _from entry point
+        rt, lib = model._runtime(), hip.load()
+        dev = batch["pcl"].device
+        opts = model._inference_opts()
+        prm, packed = rt.params(dev)
+        ws = rt.workspace(B, N, M, dev)
+        poses = torch.empty(K + 1, B, 3, 4, device=dev)
+        scales = torch.empty(K + 1, B, 3, device=dev)
+        poses[0].copy_(batch["obj_pose_est"])
+        scales[0].copy_(batch["obj_scale_est"])
+        hip.check(lib.catre_refine_k(hip.ptr(batch["pcl"]), hip.ptr(batch["obj_kps"]), hip.ptr(batch["obj_mean_scales"]),
+                                     hip.ptr(batch["K"]), prm, hip.ptr(packed), ctypes.byref(opts), hip.ptr(poses),
+                                     hip.ptr(scales), hip.ptr(ws), ws.numel(), B, N, M, K, hip.stream_ptr(dev)), "catre_refine_k")
+        torch.cuda.synchronize()
+        for i in range(K + 1):
+            assert torch.equal(out[f"pose_{i}"], poses[i]) and torch.equal(out[f"scale_{i}"], scales[i]), (i, refine_scale)
+        assert torch.equal(out["pose_0"], batch["obj_pose_est"]) and torch.equal(out["scale_0"], batch["obj_scale_est"])
