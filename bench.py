@@ -60,6 +60,25 @@ SHARE_GPU = os.environ.get("CATRE_BENCH_SHARE_GPU", "0") == "1"
 GRAD_ALLREDUCE_BYTES = 4297175 * 4  # trainable-and-used fp32 parameters: one all-reduce per backward
 
 
+_OUT = [None]
+
+
+def claim_stdout():
+    """The driver reads ONE JSON line from stdout.  Libraries write there too (RCCL prints a version banner under
+    NCCL_DEBUG=VERSION, which the GPU boxes export): keep the real stdout for the line and point fd 1 at stderr for everyone
+    else - this process's C libraries and its children."""
+    if _OUT[0] is None:
+        sys.stdout.flush()
+        _OUT[0] = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _OUT[0] or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def self_launch(n):
     """Re-run this script as `n` ranks under torch.distributed.run on 127.0.0.1 (free port) and return its exit code."""
     import socket
@@ -70,7 +89,8 @@ def self_launch(n):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd).returncode
+    sys.stdout.flush()
+    return subprocess.run(cmd).returncode   # (the ranks inherit the real stdout; rank 0 writes the line, everything else goes to stderr)
 
 
 def rank_stats(dist, dev, dt):
@@ -138,14 +158,14 @@ def bench_dryrun(args, world, rank):
     barrier()
     dt, per_rank, seen = rank_stats(dist, dev, time.perf_counter() - t0)
     if rank == 0:
-        print(json.dumps({
+        emit(({
             "metric": "DRYRUN (launcher / rendezvous plumbing only, no GPU work)", "value": None, "unit": "object-iterations/s",
             "n_gpus": world, "ranks_seen": seen, "per_rank_ms": per_rank, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "dryrun", "dryrun": True, "mode": args.mode,
             "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if (args.mode == "train" and world > 1) else 0,
             "config": {"workload": "dryrun", "backend": "gloo"},
-        }), flush=True)
+        }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -343,7 +363,7 @@ def init_world1_group(dev):
     return tdist
 
 
-def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup, ddp_kwargs=None, probe=None):
+def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup, ddp_kwargs=None, probe=None, freeze_dead=False):
     """BASELINE.json configs 3/4: one step = the reference's train loop body for one data batch
     (core/catre/engine/engine.py:293-355): K_ITER x (pose-apply, forward + loss, backward, optimizer step), the fed-back
     pose detached.  With N > 1 the model is wrapped in DistributedDataParallel exactly like
@@ -364,6 +384,14 @@ def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup, ddp_kwargs=None, pr
     sd = synth.recipe_state_dict(expected_state_shapes(cfg))
     model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
     model.train()
+    if freeze_dead:
+        # the six `norm.*` tensors no forward uses (conv_out_per_rot_head.py:92, fc_trans_size_head.py:28) taken out of the
+        # reducer: with them DDP's find_unused_parameters path waits for its used-parameter bitmap and copies it to the host
+        # at the end of every backward (reducer.cpp finalize_bucket_dense) - a device synchronisation per iteration
+        for k, prm_ in model.named_parameters():
+            if k.endswith(("head_x.norm.weight", "head_x.norm.bias", "head_y.norm.weight", "head_y.norm.bias",
+                           "ts_head.norm.weight", "ts_head.norm.bias")):
+                prm_.requires_grad_(False)
     net = model
     if dist is not None or ddp_kwargs is not None:
         from torch.nn.parallel import DistributedDataParallel
@@ -456,6 +484,14 @@ def ddp_world1_block(cfg_fn, dev, base_ms_it, steps=3, warmup=1):
     ms_4 = t / steps / K_ITER * 1e3
     out["bucket_cap_4MB_bucket_view"] = {"ms_per_iteration": round(ms_4, 3), "overhead_ms_per_iteration": round(ms_4 - base_ms_it, 3),
                                          "gradient_order_vs_buckets": probe4}
+    torch.cuda.empty_cache()
+    t = run_train(cfg_fn, dev, None, 0, "fp32", steps, warmup, ddp_kwargs={"gradient_as_bucket_view": True}, freeze_dead=True)
+    ms_f = t / steps / K_ITER * 1e3
+    out["bucket_view_dead_norms_frozen"] = {
+        "what": "same wrap, the six never-used `norm.*` tensors with requires_grad=False (they stay in the state_dict): every "
+                "reducer parameter is then used in every iteration and the find_unused_parameters path never synchronises "
+                "the device on its used-parameter bitmap",
+        "ms_per_iteration": round(ms_f, 3), "overhead_ms_per_iteration": round(ms_f - base_ms_it, 3)}
     # expected 8-GPU iteration (UNMEASURED: the pool has no multi-GPU box): the wrapped iteration + the part of the ring
     # all-reduce that the rest of the backward cannot hide.  Ring time 2 (N-1)/N x bytes / per-link bandwidth (xGMI, 153 GB/s)
     wire_ms = 2 * 7 / 8 * GRAD_ALLREDUCE_BYTES / 153e9 * 1e3
@@ -481,7 +517,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
     comm = comm_info(dist, dev, world, rank, dev.index)
     if rank == 0:
         value = world * B_PER_GPU * K_ITER * args.steps / dt
-        print(json.dumps({
+        emit(({
             "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms, "comm": comm, "shared_gpu": SHARE_GPU,
             "allreduce_bytes_per_step": GRAD_ALLREDUCE_BYTES * K_ITER if world > 1 else 0,
             "ddp_world1": dict(ddp1, gradient_order_vs_buckets=probe) if ddp1 is not None else None,
@@ -500,7 +536,7 @@ def bench_train(args, world, rank, dev, dist, cfg_fn):
                                       ("single rank inside DistributedDataParallel on a one-rank RCCL group" if ddp1 is not None
                                        else "single rank, no DistributedDataParallel wrapper (main_catre.py:154 wraps only when world > 1)")),
                        "objects_per_gpu": B_PER_GPU, "N": N_PTS, "M": M_PTS, "K": K_ITER},
-        }), flush=True)
+        }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -542,6 +578,8 @@ def main():
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else (BF16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not ("WORLD_SIZE" not in os.environ and args.gpus > 1):
+        claim_stdout()   # a rank (or the single process): from here on only `emit` reaches the real stdout
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, like main_catre.py:186-193's
         # detectron2 `launch`), forward the ranks' exit status
@@ -781,7 +819,7 @@ def main():
             line["train_fp32"] = train_extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg_fn, sd)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

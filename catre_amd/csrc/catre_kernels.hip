@@ -3,6 +3,7 @@
 // Reference citations (file:line) are relative to the CATRE tree; see include/catre_hip.h.
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 #include "catre_device.h"
@@ -1702,30 +1703,31 @@ static int bf_pair_min() {
   return v;
 }
 
-// A/B switch of the one-wave-per-SIMD trunk (k_trunk4), read once: CATRE_TRUNK4=0 keeps the 8-wave kernel on full grids
-static bool trunk4_on() {
-  static const bool v = [] {
-    const char* e = getenv("CATRE_TRUNK4");
-    return e ? atoi(e) != 0 : true;
-  }();
+// Which kernel FORM a full grid takes where more than one exists (all forms of a stage give the same bits; the switches
+// exist for A/B measurements and for tests that compare the forms in one process).  Defaults: the encoder forms on,
+// k_rot_l1w OFF (it measured 8 % slower than k_rot_l1<1>: profiles/r06_rotw_phases.txt); the environment
+// (CATRE_TRUNK4 / CATRE_STN4 / CATRE_STN_PAIR = 0, CATRE_ROTW = 1) sets the process default once, catre_form_switch
+// changes it at run time.
+enum { FORM_TRUNK4 = 1, FORM_STN4 = 2, FORM_STN_PAIR = 4, FORM_ROTW = 8 };
+static std::atomic<int> g_forms{-1};
+static int forms() {
+  int v = g_forms.load(std::memory_order_relaxed);
+  if (v < 0) {
+    auto on = [](const char* name, bool dflt = true) {
+      const char* e = getenv(name);
+      return e ? atoi(e) != 0 : dflt;
+    };
+    v = (on("CATRE_TRUNK4") ? FORM_TRUNK4 : 0) | (on("CATRE_STN4") ? FORM_STN4 : 0) |
+        (on("CATRE_STN_PAIR") ? FORM_STN_PAIR : 0) | (on("CATRE_ROTW", false) ? FORM_ROTW : 0);
+    g_forms.store(v, std::memory_order_relaxed);
+  }
   return v;
 }
-
+static bool trunk4_on() { return forms() & FORM_TRUNK4; }  // one-wave-per-SIMD trunk (k_trunk4); off: the 8-wave kernel
 inline int stn_pairs(int B, int N, int M) { return B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2); }
-static bool stn_pair_on() {  // CATRE_STN_PAIR=0: one tile per workgroup (A/B)
-  static const bool v = [] {
-    const char* e = getenv("CATRE_STN_PAIR");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
-}
-static bool stn4_on() {
-  static const bool v = [] {
-    const char* e = getenv("CATRE_STN4");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
-}
+static bool stn_pair_on() { return forms() & FORM_STN_PAIR; }  // off: one tile per workgroup
+static bool stn4_on() { return forms() & FORM_STN4; }
+static bool rotw_on() { return forms() & FORM_ROTW; }  // rotation heads, one wave per SIMD (k_rot_l1w); off (default): k_rot_l1<1>
 
 // The measurement hooks are the library's only process-global mutable state.  They are fenced: compiled out entirely
 // with -DCATRE_NO_PROFILING (catre_profile_* then return CATRE_ERR_UNSUPPORTED), off unless catre_profile_enable was
@@ -2095,7 +2097,13 @@ static int rot_head_impl(const float* gfeat, const float* pointfeat, const float
                          pkb(packed, L.sp_rot_l0[1]), ws + W.aff0, pkb(packed, L.sp_rot_l1[0]), pkb(packed, L.sp_rot_l1[1]),
                          prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
                          g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
-    else {
+    else if (B * T >= ROTW_MIN_TILES && rotw_on()) {
+      // grids that fill the chip: one wave per SIMD, a tile per wave (same bits as k_rot_l1)
+      hipLaunchKernelGGL(k_rot_l1w, dim3((B * T + 3) / 4), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),
+                         pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),
+                         prm[CATRE_P_ROTX_L1_B], prm[CATRE_P_ROTY_L1_B], ws + W.y1, ws + W.gn1, B, N, M,
+                         g_trunk_trace ? g_trunk_trace + ((size_t)1 << 24) : nullptr);
+    } else {
 #define LAUNCH_ROT_L1(RS)                                                                                               \
   hipLaunchKernelGGL(k_rot_l1<RS>, dim3(B * T * RS), dim3(256), 0, st, pointfeat, pk4(packed, L.rot_l0[0]),               \
                      pk4(packed, L.rot_l0[1]), ws + W.aff0, pk4(packed, L.rot_l1[0]), pk4(packed, L.rot_l1[1]),         \
@@ -2527,6 +2535,14 @@ int catre_refine_k_from(const float* pcl, const float* kps, const float* init_po
                        B, N, M, n_iter, stream);
 }
 
+
+int catre_form_switch(int id, int value) {
+  if (id < 0 || id > 3) return -1;
+  const int bit = 1 << id;
+  const int cur = forms();
+  if (value >= 0) g_forms.store(value ? (cur | bit) : (cur & ~bit), std::memory_order_relaxed);
+  return (cur & bit) ? 1 : 0;
+}
 
 int catre_debug_knob(int id, int value) {
 #ifdef CATRE_DEBUG_TRACE

@@ -258,6 +258,265 @@ __global__ __launch_bounds__(256, 2) void k_rot_l1(const float* __restrict__ poi
 #undef ROT_STAMP
 }
 
+// ------------------------------------------------------------------------------------------
+// k_rot_l1 for grids that fill the chip: ONE wave per SIMD (256 threads, one workgroup per CU), every wave carries its OWN
+// 64-point tile through both heads with an MB8 x NB2 layer-1 wave tile - all 256 output channels x 64 points = 256
+// accumulators.  Nothing is shared between waves (no barrier), and a0 never touches LDS: layer 0 runs in the "normal"
+// orientation, whose result registers - 4 consecutive channels of one point per quad - ARE the B fragments layer 1's
+// "swapped" MFMAs want (catre_device.h: lane (n, h) supplies channels 8 kc + 4 h + s of point n), so GroupNorm-0 + GELU turn
+// a quad of layer-0 accumulators straight into the operand of the next 64 layer-1 MFMAs.  Layer 0 is produced in quarters of
+// 64 channels (64 accumulators), each consumed by the matching K = 64 slice of layer 1's sweep.
+//   * K order of every output element as in k_rot_l1 (layer 0: chunks 0..7; layer 1: chunks 0..31 in order, accumulators
+//     starting at the bias): same bits.
+//   * the 256 layer-1 accumulators fill the AGPRs; hipcc selects the AGPR form for EVERY MFMA of a function that needs
+//     AGPRs, so layer 0's 64 accumulators (read by the VALU right away) would evict layer-1 blocks to scratch.  Its MFMAs
+//     are therefore inline asm with VGPR operands (accumulate-in-place chains four MFMAs apart; 20 wait states before the
+//     VALU reads the result, CDNA3 ISA 4.5: a 16-pass XDL write followed by a VALU read needs 18).
+//   * the GELU of step i + 1 is interleaved with the MFMAs of step i two VALU instructions per MFMA - the rate at which
+//     VALU issue is free next to fp32 MFMAs - instead of standing alone in an epilogue.
+// Why it was built: k_rot_l1 issues at 88 % but runs at ~2.13 GHz (two waves per SIMD, an LDS fragment per 2 MFMAs) - the
+// power signature k_trunk showed before k_trunk4.  What it measured (profiles/r06_rotw_phases.txt, r06_ab_rotw*.txt): the
+// clock does go up (2.34 GHz) and the results are the same bits, but the kernel is 8 % SLOWER (1523 vs 1409 us): with one
+// wave per SIMD nothing overlaps - 164 k cycles of MFMA issue per (tile, head) + 54 k of GELU / statistics VALU, weight
+// load issue and 256 dword stores per head, where k_rot_l1's second wave hides the store and load issue of the first
+// (187 k per tile pair).  fp32 MFMAs and VALU share the SIMD's issue whichever wave they come from, so the GELU cannot be
+// hidden either way; the trunk's win came from a sweep with no VALU in it.  Kept as an opt-in form (CATRE_ROTW=1,
+// catre_form_switch 3) with its bit-equality test; the default stays k_rot_l1<1>.
+// ------------------------------------------------------------------------------------------
+#ifndef ROTW_MIN_TILES
+#define ROTW_MIN_TILES 1024  // one full round: 4 tiles per workgroup x 256 CUs
+#endif
+#ifndef ROTW_VALU_PER_MFMA
+#define ROTW_VALU_PER_MFMA 2
+#endif
+#define ROTW_SMEM (4 * TP * 64)  // floats: four pointfeat tiles = 64 KiB
+__device__ __forceinline__ void mfma32_vg(f32x16& c, float a, float b) {  // VGPR form, accumulate in place
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_vg0(f32x16& c, float a, float b) {  // VGPR form, c = a b
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));  // (vDst must not overlap srcA / srcB)
+}
+__global__ __launch_bounds__(256) void k_rot_l1w(const float* __restrict__ pointfeat, const f32x4* __restrict__ wpl0x,
+                                                 const f32x4* __restrict__ wpl0y, const float* __restrict__ aff0,
+                                                 const f32x4* __restrict__ wpl1x, const f32x4* __restrict__ wpl1y,
+                                                 const float* __restrict__ b1x, const float* __restrict__ b1y,
+                                                 float* __restrict__ y1, float* __restrict__ gn1, int B, int N, int M,
+                                                 unsigned long long* __restrict__ trace) {
+  __shared__ __attribute__((aligned(16))) float smem[ROTW_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = (N + TP - 1) / TP + (M + TP - 1) / TP;
+  const int P = N + M;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= B * T) return;  // (wave-uniform; no barrier anywhere below)
+  int stamp_i = 0;
+#define ROTW_STAMP()                                                                                             \
+  do {                                                                                                           \
+    if (CATRE_TRACE_ON && trace && lane == 0) trace[((size_t)tile) * 32 + stamp_i] = __builtin_readcyclecounter(); \
+    ++stamp_i;                                                                                                   \
+  } while (0)
+  ROTW_STAMP();
+  const RotTile rt = rot_tile(tile, B, N, M);
+  float* pf = smem + wave * (TP * 64);  // [64][64] swizzled, this wave's tile
+  {  // the wave stages its own tile: row = lane, 16 chunks
+    const int srow = min(lane, rt.valid - 1);
+    const f32x4* s = reinterpret_cast<const f32x4*>(pointfeat + rt.pf_off + (size_t)srow * 64);
+    f32x4 v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = s[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) *reinterpret_cast<f32x4*>(pf + swz_off(lane, c, 64)) = v[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  ROTW_STAMP();
+  const int n = lane & 31, h = lane >> 5, sw = lane & 15;
+  // layer 0's B fragments: chunk 2 kc + h of rows n and 32 + n of the swizzled tile (GemmPipe::run's addressing)
+  const float* xlow[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xlow[j] = pf + n * 64 + (((2 * j + h) ^ sw) << 2);
+#pragma unroll 1
+  for (int hd = 0; hd < 2; ++hd) {
+    const f32x4* wp0 = (hd ? wpl0y : wpl0x) + lane;
+    const f32x4* wp1 = (hd ? wpl1y : wpl1x) + lane;
+    const float* afh = aff0 + ((((size_t)rt.obj * 2 + hd) * 2 + (rt.is_obs ? 0 : 1)) * 2) * 256 + 4 * h;
+    f32x16 acc1[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const float bb = (hd ? b1y : b1x)[mb * 32 + n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[mb][0][r] = acc1[mb][1][r] = bb;
+    }
+    f32x4 a1[2][8];   // layer-1 weight chunks, ring of two (chunk kc in slot kc & 1): one step in flight
+    f32x4 w0[3][2];   // layer-0 weight chunks, ring of three: two in flight
+    f32x4 x0[2][2];   // layer-0 B fragments (LDS), ring of two
+    f32x4 scr[3], shr[3];
+    auto issue_a1 = [&](int kc) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a1[kc & 1][m] = wp1[(m * 32 + kc) * 64];
+    };
+    auto issue_w0 = [&](int kq, int kc) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) w0[kc % 3][mb] = wp0[((kq * 2 + mb) * 8 + kc) * 64];
+    };
+    auto issue_x0 = [&](int kc) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) x0[kc & 1][nb] = *reinterpret_cast<const f32x4*>(xlow[kc] + nb * 32 * 64);
+    };
+    auto issue_aff = [&](int kq, int i) {  // step i = (mb, g): the sc / sh quads of channels 64 kq + 32 mb + 8 g + 4 h ..+3
+      const float* af = afh + kq * 64 + (i >> 2) * 32 + 8 * (i & 3);
+      scr[i % 3] = *reinterpret_cast<const f32x4*>(af);
+      shr[i % 3] = *reinterpret_cast<const f32x4*>(af + 256);
+    };
+    issue_w0(0, 0);
+    issue_w0(0, 1);
+    issue_a1(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      // ---- layer 0, out channels [64 kq, +64): acc0[mb][nb], VGPR-form MFMAs
+      issue_aff(kq, 0);
+      issue_aff(kq, 1);
+      issue_x0(0);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc0[2][2];
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        if (kc + 2 < 8) issue_w0(kq, kc + 2);
+        if (kc + 1 < 8) issue_x0(kc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              if (kc == 0 && s == 0)
+                mfma32_vg0(acc0[mb][nb], w0[kc % 3][mb][s], x0[kc & 1][nb][s]);
+              else
+                mfma32_vg(acc0[mb][nb], w0[kc % 3][mb][s], x0[kc & 1][nb][s]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next quarter's first layer-0 weight chunks: in flight under this quarter's layer-1 slice
+      if (kq < 3) {
+        issue_w0(kq + 1, 0);
+        issue_w0(kq + 1, 1);
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // XDL write -> VALU read of acc0
+      __builtin_amdgcn_sched_barrier(0);
+      ROTW_STAMP();
+      // ---- GroupNorm-0 + GELU on one register quad per point block = layer 1's B fragment of chunk 8 kq + i, then the
+      //      64 MFMAs of that chunk; the GELU of step i + 1 is issued between the MFMAs of step i
+      f32x4 bq[2][2];  // ring of two steps x two point blocks
+      auto make_b = [&](int i) {
+        const int mb = i >> 2, g = i & 3;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          float zz[4];
+          gelu_affine4(acc0[mb][nb][4 * g], acc0[mb][nb][4 * g + 1], acc0[mb][nb][4 * g + 2], acc0[mb][nb][4 * g + 3],
+                       scr[i % 3], shr[i % 3], zz);
+          bq[i & 1][nb] = f32x4{zz[0], zz[1], zz[2], zz[3]};
+        }
+      };
+      make_b(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kc = kq * 8 + i;
+        if (kc + 1 < 32) issue_a1(kc + 1);
+        if (i + 2 < 8) issue_aff(kq, i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < 8) make_b(i + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc1[m][nb] = mfma32(bq[i & 1][nb][s], a1[kc & 1][m][s], acc1[m][nb]);
+        if (i + 1 < 8) {
+          // one MFMA, then two VALU instructions, ... : the next step's GELU rides in the MFMAs' free issue slots
+#pragma unroll
+          for (int u = 0; u < 64; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, ROTW_VALU_PER_MFMA, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ROTW_STAMP();
+    }
+    // ---- y1 + GroupNorm-1 partials: k_rot_l1's epilogue for all eight m-blocks
+    const float inv_cnt = 1.0f / (8.f * (float)rt.valid);
+    int valid_h = rt.valid - 4 * h;
+    asm volatile("" : "+v"(valid_h));
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      // one m-block at a time: left alone the scheduler reads all 256 accumulators out of the AGPRs up front
+      __builtin_amdgcn_sched_barrier(0);
+      const int ch = mb * 32 + n;
+      float* dst = y1 + (((size_t)rt.obj * 2 + hd) * P + rt.gp0) * 256 + ch;
+      float* dh = dst + (size_t)(4 * h) * 256;
+      float s = 0.f;
+      if (rt.valid == TP) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc1[mb][nb][r];
+            st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
+            s += v;
+          }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc1[mb][nb][r];
+            if (nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h) {
+              st_stream(dh + (nb * 32 + (r & 3) + 8 * (r >> 2)) * 256, v);
+              s += v;
+            }
+          }
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_cnt;
+      float m2 = 0.f;
+      if (rt.valid == TP) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc1[mb][nb][r] - mean;
+            m2 = fmaf(d, d, m2);
+          }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc1[mb][nb][r] - mean;
+            m2 += nb * 32 + (r & 3) + 8 * (r >> 2) < valid_h ? d * d : 0.f;
+          }
+      }
+      m2 += __shfl_xor(m2, 1);
+      m2 += __shfl_xor(m2, 2);
+      m2 += __shfl_xor(m2, 4);
+      m2 += __shfl_xor(m2, 32);
+      if ((lane & 7) == 0 && h == 0) {
+        float* out = gn1 + (((size_t)rt.obj * 2 + hd) * T + rt.t) * 64 + (ch >> 3) * 2;
+        out[0] = mean;
+        out[1] = m2;
+      }
+    }
+    ROTW_STAMP();
+  }
+#undef ROTW_STAMP
+}
+
 // GN1 -> GELU -> neck (256->3) -> conv_p weighted sum over the tile's points; HBM-bound read of y1.
 // Body for tile bx, head hd.  stat_oh: the 32 (mean, rstd) pairs of this (object, head) - k_gn_finalize's output or an
 // LDS copy (k_heads_d, catre_small.h).

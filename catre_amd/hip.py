@@ -119,6 +119,7 @@ _SIGS = {
     "catre_pose_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "catre_refine_iter": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "catre_refine_k": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "catre_form_switch": (_I, [_I, _I]),
     "catre_refine_k_from": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "catre_colmax": (_I, [_P, _P, _I, _I, _I, _P]),
     # training ops (include/catre_hip.h "training ops")
@@ -224,6 +225,18 @@ def bump_param_epoch():
     kernel re-packs every image the forward reads on every call (``HipRuntime.train_stn3d``; with ``PCLNET.FREEZE`` the
     frozen-encoder branch of ``train_forward.forward_train`` does the same before the inference encoder kernels)."""
     _param_epoch[0] += 1
+
+
+FORM_IDS = {"trunk4": 0, "stn4": 1, "stn_pair": 2, "rotw": 3}
+
+
+def form_switch(name, value=None):
+    """Kernel-form switch `name` (``FORM_IDS``) of the loaded library: set it (True / False) or just query (None);
+    returns the previous setting.  All forms of a stage give the same bits - for A/B measurements and form-vs-form tests."""
+    r = load().catre_form_switch(FORM_IDS[name], -1 if value is None else int(bool(value)))
+    if r < 0:
+        raise CatreHipError(f"unknown kernel-form switch {name!r}")
+    return bool(r)
 
 
 def capture_id(device):

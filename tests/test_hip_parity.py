@@ -283,7 +283,7 @@ def test_small_batches_split_tiles_over_workgroups_without_changing_results(dtyp
     assert torch.equal(out["pose_2"], ref["pose_2"][9:12]) and torch.equal(out["scale_2"], ref["scale_2"][9:12])
 
 
-@pytest.mark.parametrize("B,N,M", [(40, 960, 448), (130, 300, 100), (48, 1000, 500), (20, 1024, 1024)])
+@pytest.mark.parametrize("B,N,M", [(40, 960, 448), (130, 300, 100), (48, 1000, 500), (20, 1024, 1024), (47, 960, 448)])
 def test_full_grid_kernel_forms_return_the_bits_of_the_small_grid_forms(B, N, M):
     """Round 5: grids that fill the chip run the encoder with one wave per SIMD (`k_trunk4`, `k_stn3d<1,false,true>`) and,
     from 256 pairs on, the STN kernels on 128-point PAIRS of tiles (`k_stn3d_pair` / `k_stnkd_pair`).  Clouds with an ODD
@@ -308,6 +308,31 @@ def test_full_grid_kernel_forms_return_the_bits_of_the_small_grid_forms(B, N, M)
         ref = O.refine_k({k: v[:2] for k, v in cpu.items()}, sd, cfg, n_iter=2)
     for key in ("pose_2", "scale_2"):
         assert (big[key][:2].cpu() - ref[key]).abs().max() <= 2e-5, (B, N, M, key)
+
+
+@pytest.mark.parametrize("name", ["trunk4", "stn4", "stn_pair", "rotw"])
+def test_kernel_form_switches_flip_in_process_and_change_no_bit(name):
+    """`catre_form_switch`: every full-grid kernel form can be switched off in process; the refine of a batch that
+    takes the full-grid forms (64 objects, ragged tiles, a tile count that is not a multiple of 4) returns the same bits either
+    way - `rotw`: k_rot_l1w (one wave per SIMD, layer 1's B fragments straight from layer 0's registers) vs k_rot_l1<1>."""
+    from catre_amd import hip, synth
+    from catre_amd.config import default_cfg
+
+    N, M = 1000, 360      # T = 16 + 6 = 22 tiles, 22 x 49 = 1078 tiles = 269 workgroups of four + 2
+    cfg = default_cfg(num_pcl=N, num_kps=M, n_iter=2)
+    model, _ = build_model(cfg, 6)
+    batch = to_dev(synth.make_inputs(49, N, M, seed=41))
+    prev = hip.form_switch(name)
+    try:
+        hip.form_switch(name, True)
+        on = model.refine(batch, n_iter=2)
+        assert hip.form_switch(name, False) is True
+        off = model.refine(batch, n_iter=2)
+        assert hip.form_switch(name) is False
+    finally:
+        hip.form_switch(name, prev)
+    for key in ("pose_1", "pose_2", "scale_2"):
+        assert torch.equal(on[key], off[key]), (name, key)
 
 
 def test_batches_past_2_to_the_31_elements_index_correctly():

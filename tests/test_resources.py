@@ -56,8 +56,8 @@ def test_headline_kernels_keep_their_occupancy_shape():
 
 def test_committed_table_lists_every_kernel_of_the_build():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r05_resource_usage.txt")
+    path = os.path.join(root, "profiles", "r06_resource_usage.txt")
     text = open(path).read()
     names = {ln[:72].strip() for ln in text.splitlines()[1:]}
     missing = [r["kernel"][:72] for r in _rows() if r["kernel"][:72].strip() not in names]
-    assert not missing, f"profiles/r05_resource_usage.txt is stale (python -m catre_amd.resusage --out ...): {missing[:5]}"
+    assert not missing, f"profiles/r06_resource_usage.txt is stale (python -m catre_amd.resusage --out ...): {missing[:5]}"
