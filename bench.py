@@ -380,18 +380,15 @@ def run_train(cfg_fn, dev, dist, rank, dtype, steps, warmup, ddp_kwargs=None, pr
     if dtype == "split":
         cfg.MODEL.CATRE.COMPUTE_DTYPE = "split"  # hi + lo bf16 operands, three products: fp32-grade GEMMs on the bf16 pipe
     cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=1e-5, weight_decay=0, clean_grads=True)  # shipped optimiser, fused HIP step
-    model, opt = build_model_optimizer(cfg, is_test=False)
-    sd = synth.recipe_state_dict(expected_state_shapes(cfg))
-    model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
-    model.train()
     if freeze_dead:
         # the six `norm.*` tensors no forward uses (conv_out_per_rot_head.py:92, fc_trans_size_head.py:28) taken out of the
         # reducer: with them DDP's find_unused_parameters path waits for its used-parameter bitmap and copies it to the host
         # at the end of every backward (reducer.cpp finalize_bucket_dense) - a device synchronisation per iteration
-        for k, prm_ in model.named_parameters():
-            if k.endswith(("head_x.norm.weight", "head_x.norm.bias", "head_y.norm.weight", "head_y.norm.bias",
-                           "ts_head.norm.weight", "ts_head.norm.bias")):
-                prm_.requires_grad_(False)
+        cfg.MODEL.CATRE.FREEZE_UNUSED_NORM = True
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    sd = synth.recipe_state_dict(expected_state_shapes(cfg))
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    model.train()
     net = model
     if dist is not None or ddp_kwargs is not None:
         from torch.nn.parallel import DistributedDataParallel
@@ -488,7 +485,7 @@ def ddp_world1_block(cfg_fn, dev, base_ms_it, steps=3, warmup=1):
     t = run_train(cfg_fn, dev, None, 0, "fp32", steps, warmup, ddp_kwargs={"gradient_as_bucket_view": True}, freeze_dead=True)
     ms_f = t / steps / K_ITER * 1e3
     out["bucket_view_dead_norms_frozen"] = {
-        "what": "same wrap, the six never-used `norm.*` tensors with requires_grad=False (they stay in the state_dict): every "
+        "what": "same wrap, cfg.MODEL.CATRE.FREEZE_UNUSED_NORM=True: the six never-used `norm.*` tensors with requires_grad=False (they stay in the state_dict): every "
                 "reducer parameter is then used in every iteration and the find_unused_parameters path never synchronises "
                 "the device on its used-parameter bitmap",
         "ms_per_iteration": round(ms_f, 3), "overhead_ms_per_iteration": round(ms_f - base_ms_it, 3)}

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stn3d(catre_points P, cons
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows<64, 256, false>(a1, LD64, sv.s1 + row0 * 64, tid);
+  if (SAVE && sv.s1) save_tile_rows<64, 256, false>(a1, LD64, sv.s1 + row0 * 64, tid);  // (no rows: the backward recomputes them, k_stn_recompute)
   // conv3 128->1024 + max: wave owns channels [wave*256, +256) in two passes of 4 m-blocks (RS = 1); RS workgroups
   // per tile: 8/RS m-blocks per wave from mb0 in one pass (see k_trunk)
   constexpr int MB3 = ONE ? 8 : RS == 8 ? 1 : RS == 4 ? 2 : 4;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stn3d(catre_points P, cons
     store_tile_lds_pre<1, 2, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows<128, 256, false>(a2, LD128, sv.s2 + row0 * 128, tid);
+  if (SAVE && sv.s2) save_tile_rows<128, 256, false>(a2, LD128, sv.s2 + row0 * 128, tid);
   float* out = pm + (size_t)tile * PMW;
   {
     f32x16 acc[MB3][2];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stnkd(catre_points P, cons
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows<64, 256, false>(f1, LD64, sv.s1 + row0 * 64, tid);
+  if (SAVE && sv.s1) save_tile_rows<64, 256, false>(f1, LD64, sv.s1 + row0 * 64, tid);
   constexpr int MB3 = ONE ? 8 : RS == 8 ? 1 : RS == 4 ? 2 : 4;
   static_assert(!ONE || RS == 1, "ONE is the full-grid form");
   constexpr bool TWO = RS == 1 && !ONE;  // two passes of 4 m-blocks
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stnkd(catre_points P, cons
     store_tile_lds_pre<1, 2, true, false>(acc, f2, LD128, wave * 32, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows<128, 256, false>(f2, LD128, sv.s2 + row0 * 128, tid);
+  if (SAVE && sv.s2) save_tile_rows<128, 256, false>(f2, LD128, sv.s2 + row0 * 128, tid);
   float* out = pm + (size_t)tile * PMW;
   {  // fstn.conv3 128->1024 + max, two passes of 4 m-blocks (RS = 1) or one pass of 8/RS
     f32x16 acc[MB3][2];
@@ -433,11 +433,19 @@ __device__ __forceinline__ void pair_info32(int bid, int B, int N, int M, TileIn
   }
 }
 
+// ARGMAX (training forward without activation saves: the row-sparse backward rebuilds the two thin layers on its live rows,
+// k_stn_recompute): per tile the (max + bias, arg-max row) pairs of the pooled layer instead of the tile maxima.
+// cloud-major row (B*N observed rows, then B*M prior rows) of the first point of a pair
+__device__ __forceinline__ int pair_row0(const TileInfo& ti, int B, int N, int M) {
+  return (ti.is_obs ? ti.obj * N : B * N + ti.obj * M) + ti.p0;
+}
+
+template <bool ARGMAX = false>
 __global__ __launch_bounds__(256) void k_stn3d_pair(catre_points P, const float* __restrict__ W1,
                                                     const float* __restrict__ b1, const f32x4* __restrict__ wp2,
                                                     const float* __restrict__ b2, const f32x4* __restrict__ wp3,
                                                     const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
-                                                    int M) {
+                                                    int M, TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + 2 * TP * LD128];
   float* a1 = smem;                   // [128][68]
   float* a2 = smem + 2 * TP * LD64;   // [128][132]
@@ -478,7 +486,11 @@ __global__ __launch_bounds__(256) void k_stn3d_pair(catre_points P, const float*
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3.run(acc, a2, LD128, lane);
-    max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
+    if constexpr (ARGMAX)
+      argmax_tile_store<8, 2>(acc, sv.pmax + (size_t)tile0 * 1024, sv.pidx + (size_t)tile0 * 1024, mb0 * 32, bl,
+                              pair_row0(ti, B, N, M), lane);
+    else
+      max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
   }
   if (has2) {
     f32x16 acc[8][2];
@@ -489,16 +501,22 @@ __global__ __launch_bounds__(256) void k_stn3d_pair(catre_points P, const float*
     unsigned lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     gemm_core<8, 2, true, false, 16, 2, 1>(acc, wp3 + ((size_t)mb0 * 16) * 64 + lane_o, 16 * 64, a2 + TP * LD128, LD128, lane);
-    max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
+    if constexpr (ARGMAX)
+      argmax_tile_store<8, 2>(acc, sv.pmax + (size_t)(tile0 + 1) * 1024, sv.pidx + (size_t)(tile0 + 1) * 1024, mb0 * 32, bl,
+                              pair_row0(ti, B, N, M) + TP, lane);
+    else
+      max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
   }
 }
 
+template <bool ARGMAX = false>
 __global__ __launch_bounds__(256) void k_stnkd_pair(catre_points P, const float* __restrict__ trans3,
                                                     const float* __restrict__ Wc1, const float* __restrict__ bc1,
                                                     const f32x4* __restrict__ wpf1, const float* __restrict__ bf1,
                                                     const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                     const f32x4* __restrict__ wpf3, const float* __restrict__ bf3,
-                                                    float* __restrict__ pm, int B, int N, int M) {
+                                                    float* __restrict__ pm, int B, int N, int M,
+                                                    TrainSave sv = TrainSave{}) {
   __shared__ __attribute__((aligned(16))) float smem[4 * TP * LD64 + 2 * TP * LD128];
   float* h1 = smem;                   // [128][68]
   float* f1 = smem + 2 * TP * LD64;   // [128][68]
@@ -553,7 +571,11 @@ __global__ __launch_bounds__(256) void k_stnkd_pair(catre_points P, const float*
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[mb][0] = acc[mb][1] = zero16();
     g3.run(acc, f2, LD128, lane);
-    max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
+    if constexpr (ARGMAX)
+      argmax_tile_store<8, 2>(acc, sv.pmax + (size_t)tile0 * 1024, sv.pidx + (size_t)tile0 * 1024, mb0 * 32, bl,
+                              pair_row0(ti, B, N, M), lane);
+    else
+      max_tile_store_pre<8, 2>(acc, pm + (size_t)tile0 * PMW, mb0 * 32, bl, true, lane);
   }
   if (has2) {
     f32x16 acc[8][2];
@@ -564,7 +586,11 @@ __global__ __launch_bounds__(256) void k_stnkd_pair(catre_points P, const float*
     unsigned lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     gemm_core<8, 2, true, false, 16, 2, 1>(acc, wpf3 + ((size_t)mb0 * 16) * 64 + lane_o, 16 * 64, f2 + TP * LD128, LD128, lane);
-    max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
+    if constexpr (ARGMAX)
+      argmax_tile_store<8, 2>(acc, sv.pmax + (size_t)(tile0 + 1) * 1024, sv.pidx + (size_t)(tile0 + 1) * 1024, mb0 * 32, bl,
+                              pair_row0(ti, B, N, M) + TP, lane);
+    else
+      max_tile_store_pre<8, 2>(acc, pm + (size_t)(tile0 + 1) * PMW, mb0 * 32, bl, true, lane);
   }
 }
 
@@ -1773,7 +1799,7 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
 #undef LAUNCH_
   } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on() && stn_pairs(B, N, M) >= 256) {
     const int pairs = stn_pairs(B, N, M);  // (fewer pairs than CUs: one tile per workgroup keeps the whole chip busy)
-    hipLaunchKernelGGL(k_stn3d_pair, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
+    hipLaunchKernelGGL(k_stn3d_pair<false>, dim3(pairs), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W], prm[CATRE_P_STN_CONV1_B],
                        pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B],
                        ws + W.pm, B, N, M);
   } else if (row_split8(tiles) == 1 && stn4_on()) {
@@ -1805,7 +1831,7 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
 #undef LAUNCH_
   } else if (row_split8(tiles) == 1 && stn4_on() && stn_pair_on() && stn_pairs(B, N, M) >= 256) {
     const int pairs = stn_pairs(B, N, M);
-    hipLaunchKernelGGL(k_stnkd_pair, dim3(pairs), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
+    hipLaunchKernelGGL(k_stnkd_pair<false>, dim3(pairs), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W], prm[CATRE_P_CONV1_B],
                        pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2), prm[CATRE_P_FSTN_CONV2_B],
                        pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
   } else if (row_split8(tiles) == 1 && stn4_on()) {

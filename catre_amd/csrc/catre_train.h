@@ -1305,9 +1305,12 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
 // clouds l, l + CL, ... with eight of them in flight, a thread owns one float4 column of its lane's rows, and the lanes'
 // partial sums are merged through LDS in lane order (deterministic).  The walk above is one chain of C / 8 steps of two
 // dependent global round trips whatever K is (150 us for K = 128 as for K = 512); here it is C / (8 CL) steps.
+// rowpos != nullptr: X holds COMPACT rows (the live rows of a row-sparse chain, recomputed by k_stn_recompute) - dense row r
+// sits at rowpos[r]; an arg-max row with dg == 0 is not live (rowpos < 0) and is read as row 0 (its product is an exact zero).
 __global__ __launch_bounds__(256) void k_maxlin_bwd_w4(const float* __restrict__ dg, const int* __restrict__ idx,
                                                        const float* __restrict__ X, int ldx, float* __restrict__ dW,
-                                                       float* __restrict__ db, int C, int J, int K) {
+                                                       float* __restrict__ db, int C, int J, int K,
+                                                       const int* __restrict__ rowpos = nullptr) {
   __shared__ f32x4 red[256];
   __shared__ float reds[256];
   const int j = blockIdx.x, Q = K >> 2, CL = 256 / Q, q = threadIdx.x % Q, cl = threadIdx.x / Q;
@@ -1322,6 +1325,10 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w4(const float* __restrict__
         const int c = c0 + u * CL, cc = min(c, C - 1);
         g[u] = c < C ? dg[(size_t)cc * J + j] : 0.f;
         row[u] = idx[(size_t)cc * J + j];
+      }
+      if (rowpos) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[u] = max(rowpos[row[u]], 0);
       }
       f32x4 xv[8];
 #pragma unroll
@@ -1365,7 +1372,8 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
                                                            const float* __restrict__ W, int ldw, float* __restrict__ dX,
                                                            int ldx, int J, int K, int B, int N, int M,
                                                            const int* __restrict__ rowpos = nullptr,
-                                                           const float* __restrict__ ymask = nullptr, int ldym = 0) {
+                                                           const float* __restrict__ ymask = nullptr, int ldym = 0,
+                                                           int ymask_compact = 0 /*ymask holds the compact rows*/) {
   __shared__ int start[MLX_MAXN + 1];
   __shared__ int fill[MLX_MAXN];
   __shared__ int lst[1024];
@@ -1475,7 +1483,7 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
       }
     }
     if (ymask) {
-      const float* mr = ymask + (size_t)(r0 + r) * ldym;
+      const float* mr = ymask + (size_t)(ymask_compact ? rowpos[r0 + r] : r0 + r) * ldym;
       if (q0 < nf4) {
         const f32x4 m = *reinterpret_cast<const f32x4*>(mr + q0 * 4);
 #pragma unroll
@@ -1643,6 +1651,66 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_x(const float* __restrict__ 
     for (int k = threadIdx.x; k < K; k += 256) xr[k] = fmaf(g, wr[k], xr[k]);
     __syncthreads();  // the next channel may hit the same row
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Recompute instead of save (STN stacks): the row-sparse backward of a pooled chain reads the two thin layers'
+// activations - y1 = relu(conv1 x), y2 = relu(conv2 y1) - on the LIVE rows only (~30 % at N = M = 1024), so the training
+// forward stores neither (470 MB per launch, which kept it off the one-wave pair kernels) and this kernel rebuilds them for
+// the n = count[0] live rows as COMPACT rows, 64 per workgroup, with the forward kernels' own device code (k_stn3d /
+// k_stnkd: same operands, same K order - same bits, so every ReLU mask agrees with the forward's).
+//   KIND 0 (STN3d): X = the point rows [R][>= 3]; conv1 3 -> 64 on the VALU (conv3_relu_row)
+//   KIND 1 (STNkd): X = h1 rows [R][64] (saved by the trunk kernel); conv1 64 -> 64 as an MFMA layer
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k_stn_recompute(const float* __restrict__ X, int ldx, const int* __restrict__ rows,
+                                                          const int* __restrict__ count, const float* __restrict__ W1,
+                                                          const f32x4* __restrict__ wp1, const float* __restrict__ b1,
+                                                          const f32x4* __restrict__ wp2, const float* __restrict__ b2,
+                                                          float* __restrict__ y1c, float* __restrict__ y2c) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + TP * LD128];
+  float* h1 = smem;                    // KIND 1: gathered input rows
+  float* a1 = smem + TP * LD64;        // y1 tile [64][68]
+  float* a2 = smem + 2 * TP * LD64;    // y2 tile [64][132]
+  const int n = count[0], t0 = blockIdx.x * TP;
+  if (t0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GemmPipe<1, 2, false, false, 8, 3> g2;
+  g2.prefetch(wp2 + (wave * 8) * 64 + lane, 0);
+  f32x4 bv2[1][4];
+  load_bias_quads<1>(bv2, b2, wave * 32, lane);
+  if constexpr (KIND == 0) {
+    const float* xr = X + (size_t)rows[min(t0 + lane, n - 1)] * ldx;
+    conv3_relu_row<16>(xr[0], xr[1], xr[2], W1, b1, wave * 16, a1 + lane * LD64);
+    __syncthreads();
+  } else {
+    const int mblk1 = wave >> 1, nb1 = wave & 1;
+    GemmPipe<1, 1, false, false, 8, 4> g1;
+    g1.prefetch(wp1 + (mblk1 * 8) * 64 + lane, 0);
+    f32x4 bv1[1][4];
+    load_bias_quads<1>(bv1, b1, mblk1 * 32, lane);
+    {  // gather: thread -> row tid / 4, float4 columns tid % 4 + 4 u
+      const int r = tid >> 2, c0 = tid & 3;
+      const f32x4* src = reinterpret_cast<const f32x4*>(X + (size_t)rows[min(t0 + r, n - 1)] * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(h1 + r * LD64 + (c0 + 4 * u) * 4) = src[c0 + 4 * u];
+    }
+    __syncthreads();
+    f32x16 acc[1][1] = {{zero16()}};
+    g1.run(acc, h1 + nb1 * 32 * LD64, LD64, lane);
+    store_tile_lds_pre<1, 1, true, false>(acc, a1 + nb1 * 32 * LD64, LD64, mblk1 * 32, bv1, lane);
+    __syncthreads();
+  }
+  {
+    f32x16 acc[1][2] = {{zero16(), zero16()}};
+    g2.run(acc, a1, LD64, lane);
+    store_tile_lds_pre<1, 2, true, false>(acc, a2, LD128, wave * 32, bv2, lane);
+  }
+  __syncthreads();
+  // (rows past count[0] of the last tile hold duplicates of the last live row: inside the buffers' capacity, never read)
+  save_tile_rows<64, 256, false>(a1, LD64, y1c + (size_t)t0 * 64, tid);
+  save_tile_rows<128, 256, false>(a2, LD128, y2c + (size_t)t0 * 128, tid);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -95,6 +95,9 @@ _SIGS = {
     "catre_pack_weights_sel": (_I, [_P, _I, _I, _I, _P, _SZ, _I, _P]),
     "catre_op_rows_compact": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "catre_op_maxlin_bwd_x_compact": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_x_compact_cm": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_w_c": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "catre_op_stn_recompute": (_I, [_I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "catre_op_gather_rows": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "catre_op_scatter_rows": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "catre_op_scatter_rows_merge": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

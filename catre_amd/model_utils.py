@@ -60,6 +60,17 @@ def _build_head(cfg, head_cfg, num_classes):
     init_cfg.update(num_classes=num_classes)
     head = HEADS[head_type](**init_cfg)
     params_lr_list = []
+    if cfg.MODEL.CATRE.get("FREEZE_UNUSED_NORM", False):
+        # opt-in (not a reference flag): the `norm` GroupNorm no forward uses (conv_out_per_rot_head.py:92,
+        # fc_trans_size_head.py:28) stops being a trainable parameter - it stays in the state_dict.  Under the reference's
+        # DistributedDataParallel(find_unused_parameters=True) wrap (main_catre.py:154-160) every never-used trainable tensor
+        # makes the reducer wait for its used-parameter bitmap and copy it to the host at the end of EVERY backward
+        # (a device synchronisation: +1.1 ms per B=256 iteration, bench.py `ddp_world1`).  What changes for a caller: these
+        # six tensors are no longer in the optimizer's param groups (the reference lists them; they never receive a
+        # gradient there either), so an optimizer state_dict saved by the reference does not load into this optimizer.
+        for n, p in head.named_parameters():
+            if n.split(".")[-2:-1] == ["norm"]:
+                p.requires_grad = False
     if head_cfg.get("FREEZE", False):
         for p in head.parameters():
             p.requires_grad = False

@@ -233,13 +233,17 @@ class HipRuntime:
             )
 
     # ------------------------------------------------------------------ training forward on the fused encoder kernels
-    def train_encoder_buffers(self, B, N, M, device):
+    def train_encoder_buffers(self, B, N, M, device, stn_rows=True):
+        """stn_rows=False (fp32): the STN stacks' activation rows are not stored - their backward recomputes them on its
+        live rows (train_ops._PooledChain, catre_op_stn_recompute): 0.94 GB less at B = 256."""
         R, C = B * (N + M), 2 * B
         e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=device)
-        return dict(
-            a1=e(R, 64), a2=e(R, 128), g_stn=e(C, 1024), i_stn=e(C, 1024, dt=torch.int32),
-            f1=e(R, 64), f2=e(R, 128), g_fstn=e(C, 1024), i_fstn=e(C, 1024, dt=torch.int32),
+        buf = dict(
+            g_stn=e(C, 1024), i_stn=e(C, 1024, dt=torch.int32), g_fstn=e(C, 1024), i_fstn=e(C, 1024, dt=torch.int32),
             x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128), c3=e(R, 512), g=e(C, 1024), i=e(C, 1024, dt=torch.int32))
+        for k, w in (("a1", 64), ("a2", 128), ("f1", 64), ("f2", 128)):
+            buf[k] = e(R, w) if stn_rows else None
+        return buf
 
     def _train_packs(self, device, mode):
         """(params, packed) for the fused training forward in `mode` (0 = fp32 kernels: encoder AND head images, the rotation

@@ -58,7 +58,9 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0, obj
     backward make of their operands anyway."""
     w = lambda n: p[f"{prefix}.{n}"]
     dev = pts.device
-    buf = rt.train_encoder_buffers(B, N, M, dev)
+    # fp32: the STN stacks store no activation rows (their row-sparse backward rebuilds them on its live rows)
+    buf = rt.train_encoder_buffers(B, N, M, dev,
+                                   stn_rows=not (mode == 0 and T.knobs().stn_recompute and not pts.requires_grad))
     rt.train_stn3d(desc, buf, B, N, M, dev, mode)
     trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M, pre=(buf["a1"], buf["a2"], buf["g_stn"], buf["i_stn"]))
     trans3 = trans.detach().reshape(-1, 9).contiguous()

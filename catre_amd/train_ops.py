@@ -131,6 +131,7 @@ class TrainKernels(typing.NamedTuple):
     fused_lp_rot: bool = os.environ.get("CATRE_LP_ROT_FUSED", "1") != "0"                # autocast rot heads as fused nodes (else layer-wise)
     split_l0_one_pass: bool = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"  # split mode: first rot-head block as one node
     split_l1_one_pass: bool = os.environ.get("CATRE_SPLIT_L1", "onepass") != "layerwise"  # split mode: second block + tail as one node
+    stn_recompute: bool = os.environ.get("CATRE_STN_RECOMPUTE", "1") != "0"              # fp32: STN stacks recompute their activation rows in the backward instead of saving them
 
 
 _DEFAULT_KNOBS = TrainKernels()
@@ -605,7 +606,9 @@ class _PooledChain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, relu_pool, B, N, M, y1, y2, g, idx):
         gout = _Relu.forward_only(g) if relu_pool else g
-        ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, gout if relu_pool else None)
+        # y1 is y2 is None: the forward kernel stored no activation rows - the backward recomputes them on its live rows
+        ctx.save_for_backward(x, w1, w2, w3, y1, y2, idx, gout if relu_pool else None, b1 if y1 is None else None,
+                              b2 if y1 is None else None)
         ctx.dims, ctx.relu_pool, ctx.amp = (B, N, M), relu_pool, _amp()
         ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
         return gout
@@ -620,6 +623,8 @@ def _pooled_chain_backward(ctx, dg, merge):
     from the rotation heads (object-major rows) and from max over points - added while dx is scattered to dense rows.
     -> (dx, dw1, db1, dw2, db2, dw3, db3)."""
     x, w1, w2, w3, y1, y2, idx, gout = ctx.saved_tensors[:8]
+    if y1 is None:
+        return _pooled_chain_backward_recompute(ctx, dg)
     B, N, M = ctx.dims
     lib = hip.load()
     dg = _c(dg)
@@ -671,6 +676,77 @@ def _pooled_chain_backward(ctx, dg, merge):
     hb = ctx.has_b
     return (dx, _c(dw1).reshape(w1.shape), _c(db1) if hb[0] else None, _c(dw2).reshape(w2.shape),
             _c(db2) if hb[1] else None, dw3.reshape(w3.shape), db3 if hb[2] else None)
+
+
+def _pooled_chain_backward_recompute(ctx, dg):
+    """:func:`_pooled_chain_backward` for a chain whose forward stored no activation rows (the STN stacks, fp32): the live
+    rows' y1 / y2 are rebuilt as COMPACT rows by the forward kernels' own device code (`catre_op_stn_recompute`: same bits),
+    and every consumer below reads compact operands - no row indirection except into the chain's input."""
+    x, w1, w2, w3, _, _, idx, gout, b1, b2 = ctx.saved_tensors[:10]
+    B, N, M = ctx.dims
+    lib = hip.load()
+    dev = dg.device
+    dg = _c(dg)
+    if ctx.relu_pool:
+        t = torch.empty_like(dg)
+        hip.check(lib.catre_op_relu_bwd(hip.ptr(dg), hip.ptr(gout), hip.ptr(t), dg.numel(), _st(dg)), "catre_op_relu_bwd")
+        dg = t
+    C, J3 = dg.shape
+    w1m, w2m, w3m = (_c(w.reshape(w.shape[0], -1)) for w in (w1, w2, w3))
+    K3 = w3m.shape[1]
+    rows, rowpos, count = _rows_compact(dg, idx, B, N, M)
+    cap = rows.shape[0]
+    xc = _c(x)
+    kind = 0 if w1m.shape[1] <= 4 else 1
+    wp2 = torch.empty(w2m.numel(), dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_pack(hip.ptr(w2m), w2m.stride(0), w2m.shape[0], w2m.shape[1], 0, hip.ptr(wp2), _st(dg)), "catre_op_pack")
+    wp1 = None
+    if kind == 1:
+        wp1 = torch.empty(w1m.numel(), dtype=torch.float32, device=dev)
+        hip.check(lib.catre_op_pack(hip.ptr(w1m), w1m.stride(0), w1m.shape[0], w1m.shape[1], 0, hip.ptr(wp1), _st(dg)),
+                  "catre_op_pack")
+    y1c = torch.empty(cap, w1m.shape[0], dtype=torch.float32, device=dev)
+    y2c = torch.empty(cap, w2m.shape[0], dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_stn_recompute(kind, hip.ptr(xc), xc.stride(0), hip.ptr(rows), hip.ptr(count),
+                                         hip.ptr(w1m) if kind == 0 else None, hip.ptr(wp1), hip.ptr(b1), hip.ptr(wp2),
+                                         hip.ptr(b2), hip.ptr(y1c), hip.ptr(y2c), cap, _st(dg)), "catre_op_stn_recompute")
+    # pooled layer: weight / bias gradient from the arg-max rows of y2 (compact)
+    dw3 = torch.empty(J3, K3, dtype=torch.float32, device=dev)
+    db3 = torch.empty(J3, dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_maxlin_bwd_w_c(hip.ptr(dg), hip.ptr(idx), hip.ptr(rowpos), hip.ptr(y2c), y2c.stride(0), hip.ptr(dw3),
+                                          hip.ptr(db3), C, J3, K3, _st(dg)), "catre_op_maxlin_bwd_w_c")
+    dy2 = torch.empty(cap, K3, dtype=torch.float32, device=dev)
+    hip.check(lib.catre_op_maxlin_bwd_x_compact_cm(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2c),
+                                                   y2c.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
+              "catre_op_maxlin_bwd_x_compact_cm")
+    amp = ctx.amp
+    xk = _c(_pad_cols(x, 4))
+    dw2, db2 = _wgrad_n(dy2, y1c, None, count, amp)
+    dy1 = _dgrad_n_masked(dy2, w2m, count, y1c)                              # [cap, K2], y1's ReLU applied
+    dw1, db1 = _wgrad_n(dy1, xk, None, count, amp, x_rows=rows)
+    dw1 = dw1[:, : w1m.shape[1]]
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dxc = _dgrad_n(dy1, w1m, None, count, amp)
+        dx = _scatter_rows(dxc, rowpos, dxc.shape[1])
+        if dx.shape[1] != x.shape[1]:
+            dx = _c(dx[:, : x.shape[1]])
+    hb = ctx.has_b
+    return (dx, _c(dw1).reshape(w1.shape), _c(db1) if hb[0] else None, _c(dw2).reshape(w2.shape),
+            _c(db2) if hb[1] else None, dw3.reshape(w3.shape), db3 if hb[2] else None)
+
+
+def _dgrad_n_masked(dy, w2, count, mask_c):
+    """dx[:n] = dy[:n] W, zeroed where the COMPACT mask rows are <= 0 (fp32 pipe)."""
+    lib = hip.load()
+    cap, J = dy.shape
+    K = w2.shape[1]
+    wp = torch.empty(J * K, dtype=torch.float32, device=dy.device)
+    hip.check(lib.catre_op_pack(hip.ptr(w2), w2.stride(0), K, J, 1, hip.ptr(wp), _st(dy)), "catre_op_pack")
+    dx = torch.empty(cap, K, dtype=torch.float32, device=dy.device)
+    hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), None, 0, hip.ptr(wp), None, hip.ptr(mask_c), mask_c.stride(0),
+                                       hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), 0, _st(dy)), "catre_op_gemm_rows_n")
+    return dx
 
 
 class _PointfeatHub(torch.autograd.Function):

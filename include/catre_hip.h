@@ -499,6 +499,21 @@ int catre_op_rows_compact(const float* dg, const int32_t* idx, int J, int B, int
 int catre_op_maxlin_bwd_x_compact(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
                                   const float* ymask, int ldym, float* dXc, int ldx, int J, int K, int B, int N, int M,
                                   void* stream);
+/* Recompute instead of save (the STN stacks' row-sparse backward, fp32): catre_op_stn_recompute rebuilds
+ * y1 = relu(conv1 x) [cap,64] and y2 = relu(conv2 y1) [cap,128] for the count[0] live rows as COMPACT rows with the forward
+ * kernels' own device code (same bits), so catre_train_stn3d_fwd / _stnkd_fwd may be called without row buffers.
+ * kind 0: STN3d (pointnet.py:24-26) - X point rows [R][ldx >= 3], w1 = conv1.weight [64,3], wp1 NULL; kind 1: STNkd
+ * (:57-59) - X = relu(conv1) rows [R][64] as the trunk kernel saves them, wp1 = catre_op_pack of fstn.conv1.weight, w1 NULL.
+ * wp2 = catre_op_pack of conv2.weight [128,64].  catre_op_maxlin_bwd_w_c / catre_op_maxlin_bwd_x_compact_cm are
+ * catre_op_maxlin_bwd_w / catre_op_maxlin_bwd_x_compact reading those compact rows (dense row r at rowpos[r]). */
+int catre_op_stn_recompute(int kind, const float* X, int ldx, const int32_t* rows, const int32_t* count, const float* w1,
+                           const float* wp1, const float* b1, const float* wp2, const float* b2, float* y1c, float* y2c,
+                           int cap, void* stream);
+int catre_op_maxlin_bwd_w_c(const float* dg, const int32_t* idx, const int32_t* rowpos, const float* Xc, int ldx, float* dW,
+                            float* db, int C, int J, int K, void* stream);
+int catre_op_maxlin_bwd_x_compact_cm(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
+                                     const float* ymask_c, int ldym, float* dXc, int ldx, int J, int K, int B, int N, int M,
+                                     void* stream);
 int catre_op_gather_rows(const float* src, int lds, const int32_t* rows, const int32_t* count, float* dst, int ldd, int cols,
                          int cap, void* stream);
 int catre_op_scatter_rows(const float* srcc, int lds, const int32_t* rowpos, float* dst, int ldd, int cols, int R,
@@ -537,7 +552,10 @@ int catre_op_gemm_tn_bias_nr(const float* dY, int ldy, const float* ymask, int l
  * kernels, CATRE_PACK_BF16 packs; the saved rows then hold the bf16-rounded activations as fp32 - the reduced-precision
  * dgrad / wgrad ops round their operands the same way when they stage them; trans64 required) or CATRE_DTYPE_SPLIT (the
  * split-bf16 kernels, CATRE_PACK_SPLIT | CATRE_PACK_F32_ENCODER packs - conv2 of the trunk stays an fp32 MFMA layer; the saved rows
- * hold hi + lo; trans64 required). */
+ * hold hi + lo; trans64 required).
+ * catre_train_stn3d_fwd / _stnkd_fwd, CATRE_DTYPE_F32 only: a1 = a2 = NULL (f1 = f2 = NULL) stores no activation rows - the
+ * backward recomputes them on its live rows (catre_op_stn_recompute) - and full grids then run on the one-wave pair kernels
+ * of the inference path with an arg-max epilogue. */
 int catre_train_stn3d_fwd(const catre_points* pts, const float* const* params, const float* packed, float* a1, float* a2,
                           float* g, int32_t* idx, void* workspace, size_t ws_bytes, int B, int N, int M, int compute_dtype,
                           void* stream);

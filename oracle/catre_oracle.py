@@ -39,10 +39,21 @@ class operand_rounding:
     these functions: the rounding of an operand is straight-through (the gradient passes unchanged - ``Tensor.to`` already
     differentiates like that), every bf16 GEMM's incoming gradient is rounded to bf16 before it feeds the dgrad and wgrad
     products (their operands are bf16: dY, W, X) while the bias gradient sums the unrounded one, and the rotation heads'
-    y0 / y1 rows are bf16 values whose GroupNorm statistics are those of the rounded values (``_RotHeadLP``)."""
+    y0 / y1 rows are bf16 values whose GroupNorm statistics are those of the rounded values (``_RotHeadLP``).
+    ``"bf16_train_layerwise"``: the rounding points of the LAYER-WISE autocast ops (shapes off the 64-point grid,
+    ``train_forward.pointnet_rows`` / ``_rot_head``) on matrices the tiled bf16 row GEMM takes (>= 2048 rows): every row
+    GEMM still rounds its operands and its incoming gradient, but the rows BETWEEN the GEMMs are fp32 - relu(conv1) and the
+    feature transform (``k_cloud_matmul64``: an fp32 kernel on the unrounded h1 and T64) are not rounded, max over the
+    points of pointfeat sees the unrounded values, and the rotation heads' GroupNorms normalise the unrounded fp32 rows y0 /
+    y1 with their own statistics.
+    ``"bf16_train_wgrad"``: the same layer-wise ops BELOW 2048 rows (``train_ops._tiled_gemm_ok``; the ``train_b4`` fixture:
+    896 rows): forward and data gradients of every layer run on the fp32 small-matrix kernels (``catre_linear`` /
+    ``catre_linear_t``) and ONLY the weight gradients are bf16-operand products (``k_gemm_tn_lp``: dY and X rounded, fp32
+    accumulation) - except the pooled layers' (``catre_op_maxlin_bwd_w``) and the 3 -> 64 conv1s' (``k_skinny_bwd``), which
+    are fp32 kernels in every mode."""
 
     def __init__(self, mode):
-        assert mode in (None, "bf16", "bf16_train")
+        assert mode in (None, "bf16", "bf16_train", "bf16_train_layerwise", "bf16_train_wgrad")
         self.mode = mode
 
     def __enter__(self):
@@ -53,7 +64,57 @@ class operand_rounding:
 
 
 def _q(t):
-    return t.to(torch.bfloat16).to(t.dtype) if _ROUND["mode"] is not None else t
+    return t.to(torch.bfloat16).to(t.dtype) if _ROUND["mode"] not in (None, "bf16_train_wgrad") else t
+
+
+# Teacher forcing (tests that compare GRADIENTS at sizes where a rounding emulation is chaotic): the discrete decisions of a
+# forward - which units a ReLU lets through, which point wins a max-pool - taken from a recorded run instead of from this
+# restatement's own values.  ``with teacher_forcing({key: tensor}):`` keys "<tag><prefix>.<layer>" -> a {0,1} mask shaped like
+# the activation [B,C,n], or "<...>.pool" -> the winning point index [B,C] (int64) (+ ".poolrelu": mask [B,C] of the pooled
+# ReLU); tags "x." (observed cloud) / "k." (prior).  Autograd then differentiates along the recorded activation pattern.
+# ``teacher_forcing(d, record=True)`` fills ``d`` with this run's own decisions instead.
+_FORCE = {"d": None, "rec": None}
+
+
+class teacher_forcing:
+    def __init__(self, d, record=False):
+        self.d, self.record = d, record
+
+    def __enter__(self):
+        self.prev = dict(_FORCE)
+        _FORCE["d"], _FORCE["rec"] = (None, self.d) if self.record else (self.d, None)
+
+    def __exit__(self, *a):
+        _FORCE.update(self.prev)
+
+
+def _relu(h, key=None):
+    d = _FORCE["d"]
+    if d is not None and key in d:
+        return h * d[key].to(h.dtype)
+    if _FORCE["rec"] is not None and key is not None:
+        _FORCE["rec"][key] = (h.detach() > 0)
+    return F.relu(h)
+
+
+def _maxpool(h, key=None):
+    """max over the points (dim 2) -> [B,C]"""
+    d = _FORCE["d"]
+    if d is not None and key in d:
+        return torch.gather(h, 2, d[key].unsqueeze(-1)).squeeze(-1)
+    m, i = torch.max(h, 2)
+    if _FORCE["rec"] is not None and key is not None:
+        _FORCE["rec"][key] = i.detach()
+    return m
+
+
+def _train_mode():
+    return _ROUND["mode"] in ("bf16_train", "bf16_train_layerwise", "bf16_train_wgrad")
+
+
+def _q_rows(t):
+    """rounding of an activation that the FUSED kernels hold as a bf16 image / bf16 rows; the layer-wise ops keep it fp32"""
+    return t if _ROUND["mode"] in ("bf16_train_layerwise", "bf16_train_wgrad") else _q(t)
 
 
 class _RoundGrad(torch.autograd.Function):
@@ -89,16 +150,37 @@ class _FcWgradRounded(torch.autograd.Function):
 
 def _fc(x, w, b=None):
     """One FC layer of the path (STN tails, ts head, the global half of rot-head layer 0)."""
-    if _ROUND["mode"] == "bf16_train":
+    if _train_mode():
         return _FcWgradRounded.apply(x, w, b)
     return F.linear(x, w, b)
 
 
-def _mm(fn, x, w, b=None):
-    """One per-point GEMM of the path (``fn``: ``F.conv1d`` with a k=1 weight) under the active rounding mode."""
+class _ConvWgradRounded(torch.autograd.Function):
+    """k = 1 ``F.conv1d`` whose WEIGHT gradient alone is a bf16-operand product (:class:`_FcWgradRounded` on [B,C,n] rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return F.conv1d(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        q = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        dx = torch.einsum("bjn,jc->bcn", dy, w[:, :, 0])
+        dw = torch.einsum("bjn,bcn->jc", q(dy), q(x)).unsqueeze(-1)
+        return dx, dw, (dy.sum((0, 2)) if ctx.has_b else None)
+
+
+def _mm(fn, x, w, b=None, pooled=False):
+    """One per-point GEMM of the path (``fn``: ``F.conv1d`` with a k=1 weight) under the active rounding mode.  pooled: the
+    layer in front of a max-pool (its weight gradient is an fp32 gather kernel in every mode)."""
     mode = _ROUND["mode"]
     if mode is None:
         return fn(x, w, b)
+    if mode == "bf16_train_wgrad":
+        return fn(x, w, b) if pooled else _ConvWgradRounded.apply(x, w, b)
     if mode == "bf16":
         return fn(_q(x), _q(w), b)
     y = _RoundGrad.apply(fn(_q(x), _q(w)))
@@ -128,16 +210,20 @@ def pose_apply(pcl, obj_kps, pose, scale, zero_center=True):
 
 
 # ----------------------------------------------------------------------------- a2 / a4
-def stn(x, sd, prefix, k):
+def stn(x, sd, prefix, k, tag=""):
     """``STN3d.forward`` / ``STNkd.forward``, ``core/catre/models/pointnets/pointnet.py:24-41,57-78``."""
     w = lambda n: sd[f"{prefix}.{n}"]
+    key = f"{tag}{prefix}"
     if k == 3:  # 3 -> 64 runs on the VALU in fp32
-        h = F.relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")))
+        h = _relu(F.conv1d(x, w("conv1.weight"), w("conv1.bias")), f"{key}.conv1")
     else:
-        h = F.relu(_mm(F.conv1d, x, w("conv1.weight"), w("conv1.bias")))
-    h = F.relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")))
-    h = F.relu(_mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias")))
-    h = torch.max(h, 2)[0]  # [B,1024]
+        h = _relu(_mm(F.conv1d, x, w("conv1.weight"), w("conv1.bias")), f"{key}.conv1")
+    h = _relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")), f"{key}.conv2")
+    h = _mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias"), pooled=True)
+    if (_FORCE["d"] is not None and f"{key}.pool" in _FORCE["d"]) or _FORCE["rec"] is not None:
+        h = _relu(_maxpool(h, f"{key}.pool"), f"{key}.poolrelu")  # max_n relu(y) = relu(max_n y): the (recorded) winner, then the ReLU
+    else:
+        h = torch.max(F.relu(h), 2)[0]  # [B,1024]
     pooled = h
     h = F.relu(_fc(h, w("fc1.weight"), w("fc1.bias")))
     h = F.relu(_fc(h, w("fc2.weight"), w("fc2.bias")))
@@ -147,22 +233,22 @@ def stn(x, sd, prefix, k):
 
 
 # ----------------------------------------------------------------------------- a3 / a5 / a6
-def pointnet_feat(x, sd, prefix="pcl_net", feature_transform=True, global_feat=False, detail=False):
+def pointnet_feat(x, sd, prefix="pcl_net", feature_transform=True, global_feat=False, detail=False, tag=""):
     """``PointNetfeat.forward``, ``pointnet.py:97-121``.  x [B,3,n] -> [B,1088,n]."""
     w = lambda n: sd[f"{prefix}.{n}"]
     n_pts = x.shape[2]
-    trans, pool3 = stn(x, sd, f"{prefix}.stn", 3)
+    trans, pool3 = stn(x, sd, f"{prefix}.stn", 3, tag)
     h = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)  # :100-102
-    h = _q(F.relu(F.conv1d(h, w("conv1.weight"), w("conv1.bias"))))  # :103
+    h = _q_rows(_relu(F.conv1d(h, w("conv1.weight"), w("conv1.bias")), f"{tag}{prefix}.conv1"))  # :103
     trans_feat, pool64 = None, None
     if feature_transform:
-        trans_feat, pool64 = stn(h, sd, f"{prefix}.fstn", 64)  # :106
-        h = _q(torch.bmm(h.transpose(2, 1), _q(trans_feat)).transpose(2, 1))  # :107-109
+        trans_feat, pool64 = stn(h, sd, f"{prefix}.fstn", 64, tag)  # :106
+        h = _q_rows(torch.bmm(h.transpose(2, 1), _q_rows(trans_feat)).transpose(2, 1))  # :107-109
     pointfeat = h  # :111
-    h = F.relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")))  # (h is rounded already: _q is idempotent)
-    h = F.relu(_mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias")))
-    h = _mm(F.conv1d, h, w("conv4.weight"), w("conv4.bias"))  # no ReLU, :114
-    g = torch.max(h, 2)[0]  # :115-116
+    h = _relu(_mm(F.conv1d, h, w("conv2.weight"), w("conv2.bias")), f"{tag}{prefix}.conv2")  # (h is rounded already: _q is idempotent)
+    h = _relu(_mm(F.conv1d, h, w("conv3.weight"), w("conv3.bias")), f"{tag}{prefix}.conv3")
+    h = _mm(F.conv1d, h, w("conv4.weight"), w("conv4.bias"), pooled=True)  # no ReLU, :114
+    g = _maxpool(h, f"{tag}{prefix}.pool")  # :115-116
     if global_feat:
         out = g
     else:
@@ -206,7 +292,7 @@ def rot_head_single(feat, sd, prefix, num_gn_groups=32):
         # rounded) through the bf16 GEMM; y1 is stored rounded but normalised with the statistics of the
         # unrounded values
         w0 = w("layers.0.weight")
-        if _ROUND["mode"] == "bf16_train":
+        if _train_mode():
             # the global half as the product computes it: ONE FC row per cloud (the feature is constant over a cloud's points;
             # feat = cat(observed, prior) along the points), broadcast as a per-cloud bias
             Pn = feat.shape[2]
@@ -218,17 +304,20 @@ def rot_head_single(feat, sd, prefix, num_gn_groups=32):
             h = hg + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
         else:
             h = F.conv1d(feat[:, :1024], w0[:, :1024], w("layers.0.bias")) + _mm(F.conv1d, feat[:, 1024:], w0[:, 1024:])
-        train = _ROUND["mode"] == "bf16_train"
+        train = _train_mode()
         # training (_RotHeadLP): y0 / y1 are bf16 rows and GroupNorm's statistics are those of the rounded values (what
-        # autocast's GroupNorm sees); inference (k_rot_l1_bf): y0 stays fp32 on chip, y1 is stored rounded but normalised
-        # with the statistics of the unrounded values
-        h = F.group_norm(_q(h) if train else h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
+        # autocast's GroupNorm sees; the layer-wise ops keep fp32 rows: _q_rows); inference (k_rot_l1_bf): y0 stays fp32 on
+        # chip, y1 is stored rounded but normalised with the statistics of the unrounded values
+        h = F.group_norm(_q_rows(h) if train else h, num_gn_groups, w("layers.1.weight"), w("layers.1.bias"), 1e-5)
         h = gelu_exact(h)
         h = _mm(F.conv1d, h, w("layers.3.weight"), w("layers.3.bias"))
         if train:
-            h = F.group_norm(_q(h), num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
+            h = F.group_norm(_q_rows(h), num_gn_groups, w("layers.4.weight"), w("layers.4.bias"), 1e-5)
             h = gelu_exact(h)
-            h = F.conv1d(h, w("neck.0.weight"), w("neck.0.bias")).permute(0, 2, 1)
+            if _ROUND["mode"] == "bf16_train_wgrad":   # the neck as a layer-wise linear (heads.neck_rows): bf16 weight gradient
+                h = _ConvWgradRounded.apply(h, w("neck.0.weight"), w("neck.0.bias")).permute(0, 2, 1)
+            else:
+                h = F.conv1d(h, w("neck.0.weight"), w("neck.0.bias")).permute(0, 2, 1)
             return F.conv1d(h, w("conv_p.weight"), sd.get(f"{prefix}.conv_p.bias")).squeeze(1).contiguous()
         B, C, P = h.shape
         hg = h.reshape(B, num_gn_groups, -1)
@@ -400,11 +489,11 @@ def model_forward(x, tfd_kps, init_pose, init_scale, sd, cfg, K_zoom=None, mean_
     rh, th = net_cfg.ROT_HEAD, net_cfg.TS_HEAD
     pn = net_cfg.PCLNET.INIT_CFG
     ft = pn.get("feature_transform", False)
-    pcl_feat, dx = pointnet_feat(x, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True)  # :66
-    kps_feat, dk = pointnet_feat(tfd_kps, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True)  # :67
-    flat_pcl_feat = torch.max(pcl_feat, 2)[0]  # :69
+    pcl_feat, dx = pointnet_feat(x, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True, tag="x.")  # :66
+    kps_feat, dk = pointnet_feat(tfd_kps, sd, "pcl_net", ft, pn.get("global_feat", True), detail=True, tag="k.")  # :67
+    flat_pcl_feat = _maxpool(pcl_feat, "x.flat")  # :69
     if th.WITH_KPS_FEATURE:
-        ts_feat = torch.cat((flat_pcl_feat, torch.max(kps_feat, 2)[0]), dim=1)  # :71-73
+        ts_feat = torch.cat((flat_pcl_feat, _maxpool(kps_feat, "k.flat")), dim=1)  # :71-73
     else:
         ts_feat = flat_pcl_feat
     if th.WITH_INIT_SCALE:

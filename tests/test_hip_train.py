@@ -718,3 +718,43 @@ def test_training_forward_sees_out_of_band_weight_writes():
         assert torch.equal(la[k], lb[k]), k
     for (k, pa), (_, pb) in zip(m_a.named_parameters(), m_b.named_parameters()):
         assert (pa.grad is None) == (pb.grad is None) and (pa.grad is None or torch.equal(pa.grad, pb.grad)), k
+
+
+@pytest.mark.parametrize("B", [2, 16])
+def test_stn_stacks_recompute_their_rows_in_the_backward_bit_for_bit(B):
+    """fp32 training: the STN stacks store no activation rows (forward on the inference kernels with an arg-max epilogue - the
+    one-wave pair kernels from 256 pairs on, B = 16); their row-sparse backward rebuilds y1 / y2 on its live rows with the
+    forward kernels' own device code (`catre_op_stn_recompute`).  Against the form that saves the rows
+    (`TRAIN_KERNELS.stn_recompute=False`): outputs and every one of the 68 gradients identical BIT FOR BIT - same operands, same
+    K order, same summation order in every consumer."""
+    from catre_amd import synth
+    from catre_amd import train_ops as T
+    from catre_amd.batching import batch_updater_test
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+    from catre_amd.config import default_cfg
+    from catre_amd.train_forward import forward_train
+
+    N = M = 1024
+    cfg = default_cfg(num_pcl=N, num_kps=M, device=DEV)
+    model, _ = build_model_optimizer(cfg, is_test=False)
+    sd = synth.recipe_state_dict(expected_state_shapes(cfg), 2)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    model.train()
+    batch = {k: v.to(DEV) for k, v in synth.make_inputs(B, N, M, seed=17).items()}
+    batch_updater_test(cfg, batch)
+    gen = torch.Generator().manual_seed(5)
+    Gp, Gs = torch.randn(B, 3, 4, generator=gen).to(DEV), torch.randn(B, 3, generator=gen).to(DEV)
+    p = dict(model.named_parameters())
+    res = {}
+    for rec in (False, True):
+        model.zero_grad(set_to_none=True)
+        with T.train_kernels(stn_recompute=rec):
+            pose, scale, _ = forward_train(p, model._opts, batch["x"], batch["tfd_kps"], batch["obj_pose_est"],
+                                           batch["obj_scale_est"], batch["K"], batch["obj_mean_scales"], rt=model._runtime())
+            ((pose * Gp).sum() + (scale * Gs).sum()).backward()
+        res[rec] = (pose.detach().clone(), scale.detach().clone(),
+                    {k: v.grad.detach().clone() for k, v in p.items() if v.grad is not None})
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert len(res[True][2]) == 68 and sorted(res[True][2]) == sorted(res[False][2])
+    for k, g in res[True][2].items():
+        assert torch.equal(g, res[False][2][k]), k

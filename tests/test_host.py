@@ -306,6 +306,26 @@ def test_optimizer_factory_follows_the_reference_builder():
     assert abs(float(total) - 0.5) < 1e-4
 
 
+def test_freeze_unused_norm_knob_takes_the_six_dead_tensors_out_of_the_trainable_set():
+    """MODEL.CATRE.FREEZE_UNUSED_NORM (opt-in, bench.py `ddp_world1`): the six `norm.*` tensors no forward uses stay in the
+    state_dict but leave the trainable set and the optimizer's groups - DDP's find_unused_parameters path then has nothing
+    to wait for.  Default: the reference's surface, 74 trainable tensors."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
+
+    cfg = default_cfg(device="cpu")
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="SGD", lr=1e-3)
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    assert sum(p.requires_grad for p in model.parameters()) == 74
+    assert sum(len(g["params"]) for g in opt.param_groups) == 74
+    cfg.MODEL.CATRE.FREEZE_UNUSED_NORM = True
+    model, opt = build_model_optimizer(cfg, is_test=False)
+    frozen = sorted(k for k, p in model.named_parameters() if not p.requires_grad)
+    assert frozen == sorted(f"{h}.norm.{w}" for h in ("rot_head.rot_head_x", "rot_head.rot_head_y", "ts_head")
+                            for w in ("weight", "bias"))
+    assert sum(len(g["params"]) for g in opt.param_groups) == 68
+    assert set(model.state_dict()) == set(expected_state_shapes(cfg))      # still 74 keys: strict loading keeps working
+
+
 def test_pretrained_pcl_net_checkpoint_is_loaded(tmp_path):
     from catre_amd.CATRE_disR_shared import build_model_optimizer
 

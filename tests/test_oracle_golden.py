@@ -137,10 +137,13 @@ def grad_sample_index(numel, n=512):
     return np.unique(np.linspace(0, numel - 1, n).astype(np.int64))
 
 
-@pytest.mark.parametrize("name", ["train_b4", "train_b4_t64"])
-def test_oracle_autocast_training_emulation_is_pinned_to_the_reference_autocast_iteration(name):
-    """``operand_rounding("bf16_train")`` under autograd - what the HIP autocast training path is held to on the GPU - against
-    the reference's own autocast iteration:
+@pytest.mark.parametrize("name,mode", [("train_b4", "bf16_train"), ("train_b4_t64", "bf16_train"),
+                                       ("train_b4", "bf16_train_layerwise"), ("train_b4", "bf16_train_wgrad")])
+def test_oracle_autocast_training_emulation_is_pinned_to_the_reference_autocast_iteration(name, mode):
+    """``operand_rounding("bf16_train")`` (the fused kernels' rounding points), ``"bf16_train_layerwise"`` (those of the
+    layer-wise autocast ops off the 64-point grid: fp32 rows between the GEMMs, fp32 feature transform) and
+    ``"bf16_train_wgrad"`` (the same ops below 2048 rows - what ``train_b4``'s 896 rows take on the GPU: only the weight
+    gradients are bf16-operand products) under autograd - what the HIP autocast training path is held to on the GPU - against the reference's own autocast iteration:
       * the fixture's fp32 samples are the fp32 oracle's, bit for bit (the fixture is the train_b4 iteration);
       * every loss term of the emulation within 3e-2 relative (+1e-3) of fp32 - the reference's bf16 losses are not (its
         loss arithmetic itself runs in bf16 on CPU autocast: ``loss_rot`` collapses to 0, ``loss_trans_z`` is 58 % off);
@@ -153,8 +156,11 @@ def test_oracle_autocast_training_emulation_is_pinned_to_the_reference_autocast_
     z = amp_fixture(name)
     torch.set_num_threads(4)
     l32, g32 = _oracle_train_iteration(g, None)
-    lq, gq = _oracle_train_iteration(g, "bf16_train")
+    lq, gq = _oracle_train_iteration(g, mode)
     assert len(gq) == 68 and set(gq) == set(g32)
+    if mode != "bf16_train":   # it IS a different emulation: the two sets of rounding points do not coincide
+        lf, gf = _oracle_train_iteration(g, "bf16_train")
+        assert any(float((gq[k] - gf[k]).norm()) > 1e-4 * float(gf[k].norm()) for k in gq)
     for k in l32:
         np.testing.assert_allclose(l32[k], float(z[f"fp32__loss__{k}"][0]), rtol=2e-5, atol=1e-7, err_msg=k)
         assert abs(lq[k] - l32[k]) <= 3e-2 * abs(l32[k]) + 1e-3, (k, lq[k], l32[k])
@@ -171,3 +177,37 @@ def test_oracle_autocast_training_emulation_is_pinned_to_the_reference_autocast_
         if d_emu > 1.2 * d_ref + 5e-3:
             worse.append((k, d_emu, d_ref))
     assert not worse, worse
+
+
+def test_teacher_forcing_with_the_runs_own_decisions_changes_nothing():
+    """``oracle.teacher_forcing``: ReLU masks and max-pool winners taken from a recorded run.  Forced with the decisions of the
+    very same run, the restatement returns the same outputs and the same gradients (the hooks sit where the decisions are
+    taken and nowhere else); forced with the decisions of ANOTHER arithmetic (the bf16 emulation's), an fp32 run follows that
+    activation pattern - its gradients move."""
+    from tests.util import load_train_golden
+
+    g = load_train_golden("train_b4_t64")
+    cfg, b = g["cfg"], g["batch"]
+    Gp = torch.randn(g["B"], 3, 4, generator=torch.Generator().manual_seed(1))
+
+    def run(mode, force=None, record=None):
+        sd = {k: v.clone().requires_grad_(True) for k, v in recipe_sd(cfg, g["salt"]).items()}
+        ctx = O.teacher_forcing(record, record=True) if record is not None else O.teacher_forcing(force)
+        with O.operand_rounding(mode), ctx:
+            x, tfd = O.pose_apply(b["pcl"], b["obj_kps"], b["obj_pose_est"], b["obj_scale_est"])
+            pose, scale = O.model_forward(x, tfd, b["obj_pose_est"], b["obj_scale_est"], sd, cfg, K_zoom=b["K"],
+                                          mean_scales=b["obj_mean_scales"])
+        ((pose * Gp).sum() + scale.sum()).backward()
+        return pose.detach(), {k: p.grad for k, p in sd.items() if p.grad is not None}
+
+    rec = {}
+    p0, g0 = run(None, record=rec)
+    assert {"x.pcl_net.stn.conv1", "k.pcl_net.fstn.pool", "x.pcl_net.pool", "x.flat", "k.pcl_net.conv3",
+            "x.pcl_net.stn.poolrelu"} <= set(rec)
+    p1, g1 = run(None, force=rec)
+    assert torch.equal(p0, p1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    recq = {}
+    run("bf16_train", record=recq)
+    assert any(not torch.equal(rec[k], recq[k]) for k in rec)          # the two arithmetics do decide differently somewhere
+    p2, g2 = run(None, force=recq)
+    assert any(not torch.equal(g0[k], g2[k]) for k in g0)
