@@ -228,6 +228,7 @@ __device__ __forceinline__ void debug_dephase(int) {}
 #define LD64 68
 #define LD128 132
 #define LD256 260
+#define FCT_BAR_WORDS 4  // arrival counters of k_fc_tail's device-wide barriers (zeroed by the encoder kernel in front of it)
 
 // SAVE (training forward, RS == 1, N and M multiples of 64): additionally writes what the layer-wise backward reads -
 // the activation images as point rows (cloud-major: B*N observed rows, then B*M prior rows) and, instead of the tile
@@ -245,11 +246,12 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stn3d(catre_points P, cons
                                                const float* __restrict__ b1, const f32x4* __restrict__ wp2,
                                                const float* __restrict__ b2, const f32x4* __restrict__ wp3,
                                                const float* __restrict__ b3, float* __restrict__ pm, int B, int N,
-                                               int M, TrainSave sv = TrainSave{}) {
+                                               int M, TrainSave sv = TrainSave{}, unsigned* __restrict__ zero_bar = nullptr) {
   __shared__ __attribute__((aligned(16))) float smem[TP * LD64 + TP * LD128];
   float* a1 = smem;
   float* a2 = smem + TP * LD64;
   const int tid = threadIdx.x, lane = tid & 63;
+  if (zero_bar && blockIdx.x == 0 && tid < FCT_BAR_WORDS) zero_bar[tid] = 0u;  // the fused FC tail behind this launch (k_fc_tail) counts arrivals here
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
   const TileInfo ti = tile_info(tile, B, N, M);
@@ -324,12 +326,13 @@ __global__ __launch_bounds__(256, ONE ? 1 : 2) void k_stnkd(catre_points P, cons
                                                const f32x4* __restrict__ wpf2, const float* __restrict__ bf2,
                                                const f32x4* __restrict__ wpf3, const float* __restrict__ bf3,
                                                float* __restrict__ pm, int B, int N, int M,
-                                               TrainSave sv = TrainSave{}) {
+                                               TrainSave sv = TrainSave{}, unsigned* __restrict__ zero_bar = nullptr) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TP * LD64 + TP * LD128];
   float* h1 = smem;
   float* f1 = smem + TP * LD64;
   float* f2 = smem + 2 * TP * LD64;
   const int tid = threadIdx.x, lane = tid & 63;
+  if (zero_bar && blockIdx.x == 0 && tid < FCT_BAR_WORDS) zero_bar[tid] = 0u;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x / RS, part = blockIdx.x % RS;
   const TileInfo ti = tile_info(tile, B, N, M);
@@ -1605,7 +1608,7 @@ PackLayout pack_layout(int ts_in) {
 
 struct WsLayout {
   size_t tspart, xbuf, kbuf, pm, pool, h1, h2, trans3, trans64, gfeat, pointfeat, dt, ds, rot6d, bias0, gn0, gn1, aff0, gn1stat, y1, rpart,
-      total;  // offsets in floats
+      bar, total;  // offsets in floats
 };
 
 WsLayout ws_layout(int B, int N, int M) {
@@ -1643,6 +1646,7 @@ WsLayout ws_layout(int B, int N, int M) {
     L.y1 = take(std::max(std::max(y1n, mom), y1t));
   }
   L.rpart = take(b * 2 * T * 4);
+  L.bar = take(64);  // k_fc_tail's barrier counters
   L.total = o;
   return L;
 }
@@ -1693,8 +1697,15 @@ inline TsHeadArgs ts_head_args(const float* l0part, const float* const* prm, con
 }
 
 int stn_fc_tail(const float* pooled, const float* const* prm, int base /*CATRE_P_*_FC1_W*/, float* h1, float* h2,
-                float* out, int k, int R, hipStream_t st, const float* pm = nullptr, int B = 0, int N = 0, int M = 0) {
+                float* out, int k, int R, hipStream_t st, const float* pm = nullptr, int B = 0, int N = 0, int M = 0,
+                unsigned* bar = nullptr) {
   // relu(fc1) -> relu(fc2) -> fc3 + I_k   (pointnet.py:31-40 / 64-77)
+  if (bar) {  // small batches: the three layers in ONE launch (k_fc_tail, catre_small.h)
+    const int nb3 = (k * k + 31) / 32, grid = nb3 > 16 ? nb3 : 16;
+    hipLaunchKernelGGL(k_fc_tail, dim3(grid), dim3(64 * LIN_WAVES), 0, st, pooled, pm, B, N, M, prm[base], prm[base + 1],
+                       prm[base + 2], prm[base + 3], prm[base + 4], prm[base + 5], h1, h2, out, k, R, bar);
+    return check_launch();
+  }
   if (pm)  // small batches (catre_small.h): fc1 pools the tile partials itself, no k_reduce_pm launch in front
     hipLaunchKernelGGL(k_linear_pm, dim3(1, 512 / 32), dim3(64 * LIN_WAVES), 0, st, pm, B, N, M, prm[base], 1024,
                        prm[base + 1], h1, 512, R, 512, 1, nullptr, nullptr, nullptr);
@@ -1731,10 +1742,10 @@ static int bf_pair_min() {
 
 // Which kernel FORM a full grid takes where more than one exists (all forms of a stage give the same bits; the switches
 // exist for A/B measurements and for tests that compare the forms in one process).  Defaults: the encoder forms on,
-// k_rot_l1w OFF (it measured 8 % slower than k_rot_l1<1>: profiles/r06_rotw_phases.txt); the environment
-// (CATRE_TRUNK4 / CATRE_STN4 / CATRE_STN_PAIR = 0, CATRE_ROTW = 1) sets the process default once, catre_form_switch
-// changes it at run time.
-enum { FORM_TRUNK4 = 1, FORM_STN4 = 2, FORM_STN_PAIR = 4, FORM_ROTW = 8 };
+// k_rot_l1w OFF (it measured 8 % slower than k_rot_l1<1>: profiles/r06_rotw_phases.txt), k_fc_tail OFF (one object:
+// 0.643 vs 0.620 ms per K = 4 refine, profiles/r06_fc_tail_ab.jsonl); the environment (CATRE_TRUNK4 / CATRE_STN4 /
+// CATRE_STN_PAIR = 0, CATRE_ROTW / CATRE_FC_TAIL = 1) sets the process default once, catre_form_switch changes it at run time.
+enum { FORM_TRUNK4 = 1, FORM_STN4 = 2, FORM_STN_PAIR = 4, FORM_ROTW = 8, FORM_FC_TAIL = 16 };
 static std::atomic<int> g_forms{-1};
 static int forms() {
   int v = g_forms.load(std::memory_order_relaxed);
@@ -1744,7 +1755,8 @@ static int forms() {
       return e ? atoi(e) != 0 : dflt;
     };
     v = (on("CATRE_TRUNK4") ? FORM_TRUNK4 : 0) | (on("CATRE_STN4") ? FORM_STN4 : 0) |
-        (on("CATRE_STN_PAIR") ? FORM_STN_PAIR : 0) | (on("CATRE_ROTW", false) ? FORM_ROTW : 0);
+        (on("CATRE_STN_PAIR") ? FORM_STN_PAIR : 0) | (on("CATRE_ROTW", false) ? FORM_ROTW : 0) |
+        (on("CATRE_FC_TAIL", false) ? FORM_FC_TAIL : 0);
     g_forms.store(v, std::memory_order_relaxed);
   }
   return v;
@@ -1753,6 +1765,7 @@ static bool trunk4_on() { return forms() & FORM_TRUNK4; }  // one-wave-per-SIMD 
 inline int stn_pairs(int B, int N, int M) { return B * (((N + TP - 1) / TP + 1) / 2 + ((M + TP - 1) / TP + 1) / 2); }
 static bool stn_pair_on() { return forms() & FORM_STN_PAIR; }  // off: one tile per workgroup
 static bool stn4_on() { return forms() & FORM_STN4; }
+static bool fc_tail_on() { return forms() & FORM_FC_TAIL; }  // B <= 8: an FC tail as one launch (k_fc_tail); off (default: the fused form measured SLOWER, profiles/r06_fc_tail_ab.jsonl): three k_linear launches
 static bool rotw_on() { return forms() & FORM_ROTW; }  // rotation heads, one wave per SIMD (k_rot_l1w); off (default): k_rot_l1<1>
 
 // The measurement hooks are the library's only process-global mutable state.  They are fenced: compiled out entirely
@@ -1786,7 +1799,7 @@ struct ProfScope {
 
 // The three encoder kernels of one iteration (fp32 or split compute), tile partial maxima -> ws + W.pm
 void launch_stn3d(const catre_points* pts, const float* const* prm, const float* packed, float* ws, const WsLayout& W,
-                  int B, int N, int M, bool split, hipStream_t st) {
+                  int B, int N, int M, bool split, hipStream_t st, unsigned* zero_bar = nullptr) {
   const PackLayout L = pack_layout(1);  // conv offsets do not depend on ts_in
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   ProfScope ps(CATRE_K_STN3D, st);
@@ -1805,19 +1818,19 @@ void launch_stn3d(const catre_points* pts, const float* const* prm, const float*
   } else if (row_split8(tiles) == 1 && stn4_on()) {
     hipLaunchKernelGGL((k_stn3d<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],
                        prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B], pk4(packed, L.stn_c3),
-                       prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M);
+                       prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M, TrainSave{}, zero_bar);
   } else {
 #define LAUNCH_(RS)                                                                                      \
   hipLaunchKernelGGL(k_stn3d<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, prm[CATRE_P_STN_CONV1_W],     \
                      prm[CATRE_P_STN_CONV1_B], pk4(packed, L.stn_c2), prm[CATRE_P_STN_CONV2_B],           \
-                     pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M)
+                     pk4(packed, L.stn_c3), prm[CATRE_P_STN_CONV3_B], ws + W.pm, B, N, M, TrainSave{}, zero_bar)
     RS_DISPATCH8(row_split8(tiles), LAUNCH_)
 #undef LAUNCH_
   }
 }
 
 void launch_stnkd(const catre_points* pts, const float* trans3, const float* const* prm, const float* packed, float* ws,
-                  const WsLayout& W, int B, int N, int M, bool split, hipStream_t st) {
+                  const WsLayout& W, int B, int N, int M, bool split, hipStream_t st, unsigned* zero_bar = nullptr) {
   const PackLayout L = pack_layout(1);
   const int tiles = B * ((N + TP - 1) / TP + (M + TP - 1) / TP);
   ProfScope ps(CATRE_K_STNKD, st);
@@ -1837,12 +1850,14 @@ void launch_stnkd(const catre_points* pts, const float* trans3, const float* con
   } else if (row_split8(tiles) == 1 && stn4_on()) {
     hipLaunchKernelGGL((k_stnkd<1, false, true>), dim3(tiles), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],
                        prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),
-                       prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M);
+                       prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M,
+                       TrainSave{}, zero_bar);
   } else {
 #define LAUNCH_(RS)                                                                                                     \
   hipLaunchKernelGGL(k_stnkd<RS>, dim3(tiles * RS), dim3(256), 0, st, *pts, trans3, prm[CATRE_P_CONV1_W],                \
                      prm[CATRE_P_CONV1_B], pk4(packed, L.fstn_c1), prm[CATRE_P_FSTN_CONV1_B], pk4(packed, L.fstn_c2),    \
-                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M)
+                     prm[CATRE_P_FSTN_CONV2_B], pk4(packed, L.fstn_c3), prm[CATRE_P_FSTN_CONV3_B], ws + W.pm, B, N, M,   \
+                     TrainSave{}, zero_bar)
     RS_DISPATCH8(row_split8(tiles), LAUNCH_)
 #undef LAUNCH_
   }
@@ -2346,16 +2361,19 @@ static int refine_iter_impl(const catre_points* pts, const float* init_pose, con
     hipLaunchKernelGGL(k_reduce_pm, dim3(R, (C + 255) / 256), dim3(256), 0, st, ws + W.pm, out, ldo, C, B, N, M, rpt);
   };
   // STN3d (pointnet.py:98) on both clouds
-  launch_stn3d(pts, prm, packed, ws, W, B, N, M, split, st);
+  // small fp32 batches: each FC tail as ONE launch (k_fc_tail); its barrier counters are zeroed by the encoder kernel in front
+  unsigned* bar = small && !split && fc_tail_on() ? reinterpret_cast<unsigned*>(ws + W.bar) : nullptr;
+  launch_stn3d(pts, prm, packed, ws, W, B, N, M, split, st, bar);
   if (!fold) reduce_pm(ws + W.pool, 1024, 1024);
-  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, R, st, pm, B, N, M)))
+  if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_STN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans3, 3, R, st, pm, B, N, M,
+                        bar)))
     return rc;
   const float* t64 = nullptr;
   if (o->feature_transform) {  // STNkd (pointnet.py:105-106)
-    launch_stnkd(pts, ws + W.trans3, prm, packed, ws, W, B, N, M, split, st);
+    launch_stnkd(pts, ws + W.trans3, prm, packed, ws, W, B, N, M, split, st, bar);
     if (!fold) reduce_pm(ws + W.pool, 1024, 1024);
     if ((rc = stn_fc_tail(ws + W.pool, prm, CATRE_P_FSTN_FC1_W, ws + W.h1, ws + W.h2, ws + W.trans64, 64, R, st, pm, B, N,
-                          M)))
+                          M, bar)))
       return rc;
     t64 = ws + W.trans64;
   }
@@ -2563,7 +2581,7 @@ int catre_refine_k_from(const float* pcl, const float* kps, const float* init_po
 
 
 int catre_form_switch(int id, int value) {
-  if (id < 0 || id > 3) return -1;
+  if (id < 0 || id > 4) return -1;
   const int bit = 1 << id;
   const int cur = forms();
   if (value >= 0) g_forms.store(value ? (cur | bit) : (cur & ~bit), std::memory_order_relaxed);

@@ -85,6 +85,64 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void k_linear_pm(const float* __res
               });
 }
 
+// ---- one launch per FC tail (B <= 8) ------------------------------------------------------------------------------------
+// relu(fc1 1024 -> 512) -> relu(fc2 512 -> 256) -> fc3 256 -> k*k (+ I_k) of an STN (pointnet.py:31-40 / 64-77) for R <=
+// SMALL_ROWS clouds as ONE launch instead of three dependent ones (3 x ~7 us of launch + drain at B = 1, a quarter of an
+// iteration's kernel time): every workgroup runs k_linear's own body (same fragments, same MFMA sequence, same LDS
+// reduction: same bits) on its share of a layer's 32-column blocks, and a device-wide barrier separates the layers.
+// The barrier: arrival counters in the workspace, zeroed by the encoder kernel launched in front of this one (k_stn3d /
+// k_stnkd, `zero_bar`); the grid - 16 workgroups for STN3d, 128 for STNkd's 4096 outputs - is far below the chip's
+// resident-workgroup capacity, so every workgroup arrives whatever else is running.
+// MEASURED SLOWER than the three launches it replaces (one object, K = 4: 0.643 vs 0.620 ms; B = 8: 1.521 vs 1.479 ms,
+// profiles/r06_fc_tail_ab.jsonl): a device-wide barrier on this chip is an agent-scope release + acquire across eight
+// XCDs with private L2s (write-back, then invalidate), and two of them cost more than the two launch boundaries they stand
+// in for.  Kept as an opt-in form (CATRE_FC_TAIL=1 / catre_form_switch 4) with its bit-equality test; default: off.
+__device__ __forceinline__ void fct_grid_barrier(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's stores of the layer's outputs
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * LIN_WAVES) void k_fc_tail(const float* __restrict__ pooled, const float* __restrict__ pm,
+                                                             int B, int N, int M, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, const float* __restrict__ W2,
+                                                             const float* __restrict__ b2, const float* __restrict__ W3,
+                                                             const float* __restrict__ b3, float* __restrict__ h1,
+                                                             float* __restrict__ h2, float* __restrict__ out, int k, int R,
+                                                             unsigned* __restrict__ bar) {
+  __shared__ __attribute__((aligned(16))) float smem[LINPM_SMEM];
+  float(*part)[16][64] = reinterpret_cast<float(*)[16][64]>(smem);
+  float* xs = smem + LIN_WAVES * 16 * 64;
+  const int G = gridDim.x;
+  // fc1: 16 column blocks; with pm the workgroup pools the tile partials itself (k_linear_pm), else X = the pooled feature
+  for (int by = blockIdx.x; by < 16; by += G) {
+    if (pm)
+      linear_body(xs, XS_LD, W1, 1024, b1, h1, 512, R, 512, 1024, 1, 0, 0, by, part, [&] {
+        stage_cloud_max(pm, xs, R, B, N, M, 64 * LIN_WAVES);
+        __syncthreads();
+      });
+    else
+      linear_body(pooled, 1024, W1, 1024, b1, h1, 512, R, 512, 1024, 1, 0, 0, by, part, [] {});
+    __syncthreads();
+  }
+  fct_grid_barrier(bar, G);
+  for (int by = blockIdx.x; by < 8; by += G) {
+    linear_body(h1, 512, W2, 512, b2, h2, 256, R, 256, 512, 1, 0, 0, by, part, [] {});
+    __syncthreads();
+  }
+  fct_grid_barrier(bar + 1, G);
+  const int nb3 = (k * k + 31) / 32;
+  for (int by = blockIdx.x; by < nb3; by += G) {
+    linear_body(h2, 256, W3, 256, b3, out, k * k, R, k * k, 256, 0, k, 0, by, part, [] {});
+    __syncthreads();
+  }
+}
+
 // ---- after the trunk, launch 1 of 5 ----------------------------------------------------------------------------------
 struct HeadsAArgs {
   // pointfeat moments (k_pf_moments)

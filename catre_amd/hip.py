@@ -230,7 +230,7 @@ def bump_param_epoch():
     _param_epoch[0] += 1
 
 
-FORM_IDS = {"trunk4": 0, "stn4": 1, "stn_pair": 2, "rotw": 3}
+FORM_IDS = {"trunk4": 0, "stn4": 1, "stn_pair": 2, "rotw": 3, "fc_tail": 4}
 
 
 def form_switch(name, value=None):

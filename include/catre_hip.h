@@ -266,9 +266,9 @@ typedef enum catre_kernel_id {
 int catre_profile_enable(int kernel_id, int max_records);
 /* Kernel-form switches (A/B measurements, tests): where a stage has more than one kernel form for full grids - all forms
  * give the same bits - `id` selects the switch (0: one-wave-per-SIMD trunk k_trunk4, 1: one-wave STN kernels, 2: STN kernels
- * on pairs of tiles, 3: one-wave rotation-head kernel k_rot_l1w), `value` 1 / 0 sets it, value < 0 only queries.  Returns
- * the PREVIOUS setting (1 / 0), -1 for an unknown id.  Process-wide (an atomic word; defaults: 0-2 on, 3 off - it measured
- * slower - or what the environment says: CATRE_TRUNK4 / CATRE_STN4 / CATRE_STN_PAIR = 0, CATRE_ROTW = 1); calls in flight keep the form they were
+ * on pairs of tiles, 3: one-wave rotation-head kernel k_rot_l1w, 4: one-launch FC tails of small batches k_fc_tail), `value` 1 / 0 sets it, value < 0 only queries.  Returns
+ * the PREVIOUS setting (1 / 0), -1 for an unknown id.  Process-wide (an atomic word; defaults: 0-2 on, 3 and 4 off - they
+ * measured slower - or what the environment says: CATRE_TRUNK4 / CATRE_STN4 / CATRE_STN_PAIR = 0, CATRE_ROTW / CATRE_FC_TAIL = 1); calls in flight keep the form they were
  * launched with. */
 int catre_form_switch(int id, int value);
 /* Experiment knobs of the instrumented library (id 0: start offset in cycles between the co-resident workgroups of the

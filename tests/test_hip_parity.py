@@ -310,6 +310,31 @@ def test_full_grid_kernel_forms_return_the_bits_of_the_small_grid_forms(B, N, M)
         assert (big[key][:2].cpu() - ref[key]).abs().max() <= 2e-5, (B, N, M, key)
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8])
+def test_one_launch_fc_tails_of_small_batches_return_the_bits_of_the_three_launch_form(B):
+    """B <= 8: each STN's FC tail is ONE launch (`k_fc_tail`: k_linear's own body per layer, a device-wide barrier in between)
+    - against the three k_linear launches (form switch `fc_tail` off): every slot of a K = 3 refine bit-identical, with (B <= 2)
+    and without the pooled feature folded into fc1, on the RS = 8 / 4 / 2 / 1 encoder forms that zero the barrier counters;
+    repeated, so that a stale counter would show."""
+    from catre_amd import hip, synth
+    from catre_amd.config import default_cfg
+
+    cfg = default_cfg(n_iter=3)
+    model, _ = build_model(cfg, 1)
+    batch = to_dev(synth.make_inputs(B, 1024, 1024, seed=90 + B))
+    prev = hip.form_switch("fc_tail")
+    try:
+        hip.form_switch("fc_tail", False)
+        ref = model.refine(batch, n_iter=3)
+        hip.form_switch("fc_tail", True)
+        for _ in range(3):
+            out = model.refine(batch, n_iter=3)
+            for i in range(4):
+                assert torch.equal(out[f"pose_{i}"], ref[f"pose_{i}"]) and torch.equal(out[f"scale_{i}"], ref[f"scale_{i}"]), (B, i)
+    finally:
+        hip.form_switch("fc_tail", prev)
+
+
 @pytest.mark.parametrize("name", ["trunk4", "stn4", "stn_pair", "rotw"])
 def test_kernel_form_switches_flip_in_process_and_change_no_bit(name):
     """`catre_form_switch`: every full-grid kernel form can be switched off in process; the refine of a batch that
