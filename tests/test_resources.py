@@ -49,7 +49,8 @@ def test_headline_kernels_keep_their_occupancy_shape():
         assert by[k]["lds"] <= 80 * 1024 and by[k]["vgpr"] <= 256, k  # two 256-thread workgroups per CU
     # round 5, full grids: ONE 256-thread workgroup per CU, one wave per SIMD with the whole register file - 256 accumulators
     # (AGPRs) next to <= 256 VGPRs, nothing spilled (the scratch / spill lint above covers them too)
-    for k in ("k_trunk4<false>", "k_trunk4<true>", "k_stn3d_pair", "k_stnkd_pair", "k_stn3d<1, false, true>", "k_stnkd<1, false, true>"):
+    for k in ("k_trunk4<false>", "k_trunk4<true>", "k_stn3d_pair<false>", "k_stnkd_pair<false>", "k_stn3d_pair<true>",
+              "k_stnkd_pair<true>", "k_stn3d<1, false, true>", "k_stnkd<1, false, true>", "k_rot_l1w"):
         assert by[k]["vgpr"] <= 256 and by[k]["lds"] <= 160 * 1024, k
     assert by["k_trunk4<false>"]["lds"] == 160 * 1024
 
