@@ -252,7 +252,9 @@ __device__ __forceinline__ void gemm_rows_epilogue_n(f32x16 (&acc)[MB][2], const
 // in-register; the first maximum wins, like torch.max.
 // KS = 2 (MB = 1, J <= 128: at most four m-blocks for eight waves): the waves that would only help staging take the second
 // half of every K chunk of the same m-blocks, and the two partial tiles meet in LDS behind the last chunk (fixed order:
-// first half + second half) - the conv3 dgrad of the row-sparse trunk chain (J = 128, K = 512) ran with four idle waves.
+// first half + second half).  The launcher instantiates it for K = 128, J <= 128 only - the conv2-class dgrads of the
+// row-sparse chains (53 -> 43 us each); for the conv3 dgrad (J = 128, K = 512) the split measured slower and is not used.
+// Those K = 128 dgrads are therefore RE-ASSOCIATED against the single-pass form: (first half of every chunk) + (second half).
 template <int MB, int NKC, bool MAXP = false, int KS = 1>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void k_gemm_rows(const float* __restrict__ X, int ldx, const f32x4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
