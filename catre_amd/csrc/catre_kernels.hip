@@ -1533,6 +1533,28 @@ __global__ __launch_bounds__(256) void k_colmax(const float* __restrict__ x, flo
 
 #include "catre_bf16.h"
 #include "catre_split.h"
+
+// every bf16 (or hi + lo split) fragment pack of a weight image in ONE launch (k_pack_frag_multi's job table; the
+// per-element arithmetic is k_pack_frag_bf's / k_pack_frag_split's): a training step re-packs the image after every
+// optimizer step, and twelve 3-us launches sat on the critical path of each autocast / split iteration
+template <bool SPLIT>
+__global__ void k_pack_frag_lp_multi(PackJobs J) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= J.end[J.n - 1]) return;
+  int j = 0;
+  while (gi >= J.end[j]) ++j;
+  const int base = j ? J.end[j - 1] : 0, idx = gi - base, total = J.end[j] - base;  // total = rows * K
+  const int K = J.K[j];
+  const int e = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9;
+  const int nkc = K / 16;
+  const int kc = rest % nkc, mb = rest / nkc;
+  const int row = mb * 32 + (lane & 31), col = kc * 16 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+  const float w = J.src[j][(size_t)row * J.ld[j] + J.coloff[j] + col];
+  unsigned short* dst = reinterpret_cast<unsigned short*>(J.dst[j]);
+  const __bf16 h = (__bf16)w;
+  dst[idx] = __builtin_bit_cast(unsigned short, h);
+  if constexpr (SPLIT) dst[(size_t)total + idx] = __builtin_bit_cast(unsigned short, (__bf16)(w - (float)h));
+}
 #include "catre_gram.h"
 #include "catre_small.h"
 #include "catre_train.h"
@@ -1951,11 +1973,31 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
     jobs.K[j] = K;
     jobs.end[j] = (j ? jobs.end[j - 1] : 0) + rows * K;
   };
-  auto frag_bf = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
+  PackJobs lpjobs;   // the bf16 / split packs: queued like the fp32 ones, one launch per kind
+  lpjobs.n = 0;
+  auto flush_lp = [&](bool split_kind) {
+    if (lpjobs.n) {
+      const dim3 grid((lpjobs.end[lpjobs.n - 1] + 255) / 256);
+      if (split_kind)
+        hipLaunchKernelGGL(k_pack_frag_lp_multi<true>, grid, dim3(256), 0, st, lpjobs);
+      else
+        hipLaunchKernelGGL(k_pack_frag_lp_multi<false>, grid, dim3(256), 0, st, lpjobs);
+    }
+    lpjobs.n = 0;
+  };
+  auto frag_lp = [&](bool split_kind, const float* src, int ld, int coloff, int rows, int K, size_t off) {
     if (!src) return;
-    const int n = rows * K;
-    hipLaunchKernelGGL(k_pack_frag_bf, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
-                       reinterpret_cast<unsigned short*>(packed + off));
+    if (lpjobs.n == PACK_MAX_JOBS) flush_lp(split_kind);
+    const int j = lpjobs.n++;
+    lpjobs.src[j] = src;
+    lpjobs.dst[j] = packed + off;
+    lpjobs.ld[j] = ld;
+    lpjobs.coloff[j] = coloff;
+    lpjobs.K[j] = K;
+    lpjobs.end[j] = (j ? lpjobs.end[j - 1] : 0) + rows * K;
+  };
+  auto frag_bf = [&](const float* src, int ld, int coloff, int rows, int K, size_t off) {
+    frag_lp(false, src, ld, coloff, rows, K, off);
   };
   if (bf) {
   frag_bf(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.bf_stn_c2);
@@ -1971,12 +2013,10 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
     frag_bf(prm[base], PMW, 1024, 256, 64, L.bf_rot_l0[h]);
     frag_bf(prm[base + 4], 256, 0, 256, 256, L.bf_rot_l1[h]);
   }
+  flush_lp(false);
   }
   auto frag_sp = [&](const float* src, int ld, int rows, int K, size_t off, int coloff = 0) {
-    if (!src) return;
-    const int n = rows * K;
-    hipLaunchKernelGGL(k_pack_frag_split, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, coloff, rows, K,
-                       reinterpret_cast<unsigned short*>(packed + off));
+    frag_lp(true, src, ld, coloff, rows, K, off);
   };
   if (sp) {
   frag_sp(prm[CATRE_P_STN_CONV2_W], 64, 128, 64, L.sp_stn_c2);
@@ -1990,6 +2030,7 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
   frag_sp(prm[CATRE_P_ROTY_L0_W], PMW, 256, 64, L.sp_rot_l0[1], 1024);
   frag_sp(prm[CATRE_P_ROTX_L0_W + 4], 256, 256, 256, L.sp_rot_l1[0]);
   frag_sp(prm[CATRE_P_ROTY_L0_W + 4], 256, 256, 256, L.sp_rot_l1[1]);
+  flush_lp(true);
   }
   if (enc32) {
   frag(prm[CATRE_P_STN_CONV2_W], 64, 0, 128, 64, L.stn_c2);

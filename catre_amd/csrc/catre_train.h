@@ -38,7 +38,14 @@ __global__ void k_op_pack(const float* __restrict__ src, int ld, int J, int K, i
 struct CloudBias {
   int B, N, M;
   float* gn_part;  // optional: per-tile GroupNorm partials of the output [tiles][32][2] (J == 256, no ReLU / mask)
+  int xcm;         // the rows of X are CLOUD-major (B*N observed rows, then B*M prior rows) while the output rows stay
+                   // object-major: the autocast rotation heads read pointfeat where the trunk wrote it, no re-ordered copy
 };
+// object-major row r ([N observed | M prior] per object) -> the cloud-major row of the same point
+__device__ __forceinline__ int cloud_major_row(int r, const CloudBias& cb) {
+  const int P = cb.N + cb.M, obj = r / P, w = r - obj * P;
+  return w < cb.N ? obj * cb.N + w : cb.B * cb.N + obj * cb.M + (w - cb.N);
+}
 __device__ __forceinline__ const float* cloud_bias(const float* bias, CloudBias cb, int r0, int J) {
   if (cb.B <= 0 || !bias) return bias;
   const int P = cb.N + cb.M, obj = r0 / P, within = r0 - obj * P;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
       xs[bf_off<CP>(row, ch)] = v;
       continue;
     }
-    const float* src = X + (size_t)gr * ldx + ch * 8;
+    const float* src = X + (size_t)(cb.xcm ? cloud_major_row(gr, cb) : gr) * ldx + ch * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     if (xmask) {

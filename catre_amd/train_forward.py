@@ -102,8 +102,9 @@ def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
     return g, pf
 
 
-def _rot_head(g, pf_obj, p, prefix, B, N, M):
-    """RotHead.forward (heads/conv_out_per_rot_head.py:126-140) on the never-materialised cat(pcl_feat,kps_feat)."""
+def _rot_head(g, pf_obj, p, prefix, B, N, M, x_cm=False):
+    """RotHead.forward (heads/conv_out_per_rot_head.py:126-140) on the never-materialised cat(pcl_feat,kps_feat).  x_cm: pf_obj
+    is pointfeat in CLOUD-major row order (only the autocast one-node head takes that: forward_train decided so)."""
     w = lambda n: p[f"{prefix}.{n}"]
     P = N + M
     W0g, W0b = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)   # global half (a view) | point half
@@ -114,7 +115,8 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M):
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         return T.rot_head_lp(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
                              w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
-                             p.get(f"{prefix}.conv_p.bias"), B, N, M)[:, :w("neck.0.weight").shape[0]]
+                             p.get(f"{prefix}.conv_p.bias"), B, N, M, x_cm)[:, :w("neck.0.weight").shape[0]]
+    assert not x_cm, "only the autocast one-node rotation head reads cloud-major rows"
     # [B*P,256]; the per-cloud bias and the GroupNorm tile partials are epilogue work of the GEMMs
     if T.rot_l0_block_ok(pf_obj, W0b, N, M):
         a = T.rot_l0_block(pf_obj, W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), B, N, M)
@@ -239,6 +241,9 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     # object-major copy is made for them
     fused_rot = (rt is not None and T._amp() == 0 and bool(opts.feature_transform) and N + M == rt.N + rt.M
                  and _rot_heads_shapes_ok_p(p, N, M))
+    # autocast: each head is one node (train_ops._RotHeadLP) that reads pointfeat cloud-major as well - no object-major copy
+    lp_cm = (rt is not None and T._amp() == 1 and T.knobs().fused_lp_rot and T.knobs().lp_rot_bf16_rows
+             and bool(opts.feature_transform) and N + M == rt.N + rt.M and _rot_heads_shapes_ok_p(p, N, M))
     enc_frozen = (not x.requires_grad and not tfd_kps.requires_grad
                   and not any(v.requires_grad for k, v in p.items() if k.startswith("pcl_net.")))
     if rt is not None and enc_frozen and T._amp() == 0 and N + M == rt.N + rt.M:
@@ -254,12 +259,13 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
             and N + M == rt.N + rt.M:
         pts = _cloud_major_rows(x, tfd_kps)
         g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
-                                         obj_copy=not fused_rot)
+                                         obj_copy=not (fused_rot or lp_cm))
         fused_rot = fused_rot and hub is not None
+        lp_cm = lp_cm and hub is not None
     else:
         pts = _cloud_major_rows(x, tfd_kps)
         (g, pf), hub = pointnet_rows(pts, p, B, N, M, bool(opts.feature_transform)), None
-        fused_rot = False
+        fused_rot = lp_cm = False
     # max_n pointfeat (flat_pcl_feat tail) and the rot heads' input in object-major order: [N observed | M prior] per object
     # (CATRE_disR_shared.py:69, :86)
     pfmax, pf_obj = hub if hub is not None else (T.maxpool_points(pf, B, N, M), T.object_major(pf, B, N, M))
@@ -284,8 +290,8 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):
         rx, ry = _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M)
     else:
-        rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M)
-        ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M)
+        rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M, lp_cm)
+        ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M, lp_cm)
     rot6d = torch.cat([rx, ry], 1)
 
     pose, scale = T.pose_update_autograd(rot6d, dt, ds, init_pose, init_scale, mean_scales, K_zoom, opts)

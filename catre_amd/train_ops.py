@@ -1260,7 +1260,7 @@ class _RotHeadLP(torch.autograd.Function):
     k_rot_l0_bwd_bf (include/catre_hip.h: the catre_op_*_h entry points)."""
 
     @staticmethod
-    def forward(ctx, x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M):
+    def forward(ctx, x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm=False):
         lib = hip.load()
         dev = x.device
         xc, bc = _c(x), _c(bias2d)
@@ -1275,8 +1275,10 @@ class _RotHeadLP(torch.autograd.Function):
         part0, part1 = f(R // 64, 32, 2), f(R // 64, 32, 2)
         stat0, stat1 = f(B, 32, 2), f(B, 32, 2)
         pk0 = _pack_bf16(w0c, 256, 64, dev)
-        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 1, hip.ptr(y0), 256, 256, 64,
-                                              B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
+        # x_cm: x is pointfeat in the trunk kernel's cloud-major row order (no object-major copy was made); y0 and every
+        # tensor behind it are object-major, and so is the gradient this node returns for x (train_ops._PointfeatHub)
+        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 2 if x_cm else 1, hip.ptr(y0),
+                                              256, 256, 64, B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
         pk1 = _pack_bf16(w1c, 256, 256, dev)
         if knobs().lp_rot_fuse_gn0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
             hip.check(lib.catre_op_gn_gelu_gemm_rows_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
@@ -1295,6 +1297,7 @@ class _RotHeadLP(torch.autograd.Function):
         hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, st), "catre_op_wsum_fwd")
         ctx.save_for_backward(xc, w0c, y0, stat0, g0, be0, a0, w1c, y1, stat1, g1, be1, wn, spart, y3, wv)
         ctx.dims = (B, N, M)
+        ctx.x_cm = bool(x_cm)
         ctx.shapes = (w0.shape, w1.shape, wp.shape)
         ctx.has_bn, ctx.has_bp = bn is not None, bp is not None
         return out
@@ -1326,11 +1329,12 @@ class _RotHeadLP(torch.autograd.Function):
         ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
         hip.check(lib.catre_op_rot_l0_bwd_h(hip.ptr(da0), hip.ptr(y0), hip.ptr(stat0), hip.ptr(g0), hip.ptr(be0), hip.ptr(x),
                                             x.stride(0), hip.ptr(w0), hip.ptr(dx), 64, hip.ptr(dw0), hip.ptr(db0), hip.ptr(dg0),
-                                            hip.ptr(dbe0), 0, hip.ptr(ws), ws.numel(), B, N, M, st), "catre_op_rot_l0_bwd_h")
+                                            hip.ptr(dbe0), 2 if ctx.x_cm else 0, hip.ptr(ws), ws.numel(), B, N, M, st),
+                  "catre_op_rot_l0_bwd_h")
         dbn = _colsum(dy3) if ctx.has_bn else None
         s0, s1, sp = ctx.shapes
         return (dx, dw0.view(s0), db0, dg0, dbe0, dwb1[: 256 * 256].view(s1), dwb1[256 * 256:], dpar1[0], dpar1[1], dpar1[2:5],
-                dbn, dwp.view(sp), dbp, None, None, None)
+                dbn, dwp.view(sp), dbp, None, None, None, None)
 
 
 def rot_head_lp_ok(x, w0, w1, b1, N, M):
@@ -1339,10 +1343,11 @@ def rot_head_lp_ok(x, w0, w1, b1, N, M):
             and b1 is not None and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0)
 
 
-def rot_head_lp(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M):
+def rot_head_lp(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm=False):
     """The RotHead behind its per-cloud layer-0 bias under autocast -> [B,3] (rot_head_lp_ok); x [B*(N+M),64] object-major,
-    w0 [256,64] the point half of layers.0, bias2d [2B,256] its global half + bias, wn [3,256], bn [3] or None."""
-    return _RotHeadLP.apply(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M)
+    w0 [256,64] the point half of layers.0, bias2d [2B,256] its global half + bias, wn [3,256], bn [3] or None.  x_cm: the rows
+    of x are cloud-major (pointfeat as the trunk kernel wrote it); the gradient returned for x stays object-major."""
+    return _RotHeadLP.apply(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm)
 
 
 def rot_l1_tail_lp_ok(a, w, b, N, M):

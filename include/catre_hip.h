@@ -441,7 +441,8 @@ int catre_op_rot_l1_bwd_sp(const float* dY3, const float* dout, const float* Spa
  * y0, a0, y1, dA - are bf16 rows (256 bf16 per row; `void*`), what torch.autocast's Conv1d outputs are (engine.py:304), so
  * every pass over them moves half the bytes; statistics, GroupNorm / GELU arithmetic, accumulation and every other output
  * stay fp32.  catre_op_gemm_rows_gn_h: catre_op_gemm_rows_gn on bf16 operands (Wp: catre_op_pack_bf16) with io bit 0: X is
- * bf16 rows, bit 1: Y is bf16 rows (ldx / ldy in elements); J = 256, K in {64, 256}.  The others: the op of the same name
+ * bf16 rows, bit 1: Y is bf16 rows (ldx / ldy in elements); J = 256, K in {64, 256}; per_cloud == 2 (fp32 X only): per-cloud bias
+ * and X rows in CLOUD-major order (pointfeat where the trunk kernel wrote it: no object-major copy), Y object-major.  The others: the op of the same name
  * without _h / with _lp, with the named tensors as bf16 rows (catre_op_rot_l1_bwd_h: Y, A, dA; catre_op_rot_l0_bwd_h: dA, Y). */
 int catre_op_gemm_rows_gn_h(const void* X, int ldx, const void* Wp, const float* bias, int per_cloud, void* Y, int ldy, int J,
                             int K, int B, int N, int M, float* gn_part, int io, void* stream);

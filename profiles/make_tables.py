@@ -40,6 +40,14 @@ ALGO = {
     "k_stn3d<1, false, true>": (STN3D, "a2 STN3d, one wave per SIMD, 64-point tiles", FP32_PEAK),
     "k_stnkd<1, false, true>": (STNKD, "a4 STNkd, one wave per SIMD, 64-point tiles", FP32_PEAK),
     "k_trunk4<true>": (TRUNK, "training forward: trunk (one wave per SIMD) + activation saves", FP32_PEAK),
+    # round 6: the fp32 STN stacks store no activation rows (the backward recomputes them): pair kernels + arg-max epilogue
+    "k_stn3d_pair<true>": (STN3D, "training forward: STN3d on 128-point pairs, arg-max epilogue, no row saves", FP32_PEAK),
+    "k_stnkd_pair<true>": (STNKD, "training forward: STNkd on 128-point pairs, arg-max epilogue, no row saves", FP32_PEAK),
+    "k_trunk_bf2<true>": (TRUNK, "autocast training forward: trunk, bf16 operands, saves", BF16_PEAK),
+    "k_stn3d_bf2<true>": (STN3D, "autocast training forward: STN3d + saves", BF16_PEAK),
+    "k_stnkd_bf2<true>": (STNKD, "autocast training forward: STNkd + saves", BF16_PEAK),
+    "k_rot_l1_bwd_bf<true>": (2 * 2 * 256 * 256, "autocast: rot head layer-1 backward, one head, bf16 rows", BF16_PEAK),
+    "k_rot_l0_bwd_bf<true>": (2 * 2 * 64 * 256, "autocast: rot head layer-0 backward, one head, bf16 rows", BF16_PEAK),
     "k_trunk_split<1>": (TRUNK, "trunk, conv3/conv4 as split-bf16 (3 products)", SPLIT_PEAK),
     "k_rot_l1_split": (ROT_L1, "rot heads, split-bf16", SPLIT_PEAK),
     "k_stn3d_split<1>": (STN3D, "STN3d, split-bf16", SPLIT_PEAK),
@@ -202,6 +210,8 @@ def budgets(tag):
                         only=r"^(?!.*(k_colmax|distribution|reduce_kernel))"))
     lines.append(budget("fp32 training (forward + loss + backward + Ranger)", f"{tag}_train_kernel_stats.csv",
                         f"{tag}_train_pmc_summary.csv", ("k_trunk4<true>", "k_trunk<1, true>"), FP32_PEAK))
+    lines.append(budget("autocast training (bf16 operands)", f"{tag}_train_bf16_kernel_stats.csv",
+                        f"{tag}_train_bf16_pmc_summary.csv", "k_trunk_bf2<true>", BF16_PEAK))
     lines.append("")
     return lines
 
@@ -219,10 +229,13 @@ def render(tag="r03"):
     out += block(tag, "bf16 operands (BASELINE config 5 arithmetic)", f"{tag}_bf16_kernel_stats.csv", f"{tag}_bf16_pmc_summary.csv",
                  ["k_trunk_bf2", "k_trunk_bf", "k_stn3d_bf2", "k_stnkd_bf2", "k_stn3d_bf", "k_stnkd_bf", "k_rot_l1_bf"], "")
     out += block(tag, "training iteration (BASELINE config 3), fp32", f"{tag}_train_kernel_stats.csv", f"{tag}_train_pmc_summary.csv",
-                 ["k_trunk4<true>", "k_trunk<1, true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
+                 ["k_trunk4<true>", "k_trunk<1, true>", "k_stn3d_pair<true>", "k_stnkd_pair<true>", "k_stn3d<1, true>", "k_stnkd<1, true>", "k_rot_l1<1, true>", "k_rot_l1_bwd", "k_rot_l0_bwd",
                   "k_gemm_rows<1, 32>", "k_gemm_rows<1, 8>", "k_gemm_rows<1, 16>", "k_gemm_tn<2>",
                   "k_gemm_tn<1>"],
                  "; GFLOP = the op's dense GEMM work on B*(N+M) rows")
+    out += block(tag, "training iteration under torch.autocast (bf16 operands)", f"{tag}_train_bf16_kernel_stats.csv",
+                 f"{tag}_train_bf16_pmc_summary.csv",
+                 ["k_trunk_bf2<true>", "k_stn3d_bf2<true>", "k_stnkd_bf2<true>", "k_rot_l1_bwd_bf<true>", "k_rot_l0_bwd_bf<true>"], "")
     out += budgets(tag)
     out.append("<!-- END GENERATED -->")
     return "\n".join(out)
