@@ -1626,8 +1626,15 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ 
                                                       float* __restrict__ dst, int ldd, int cols, int R,
                                                       const float* __restrict__ objsrc = nullptr, int ldo = 0, int B = 0,
                                                       int N = 0, int M = 0) {
+  // a wave carries RPW rows at a time: 64 / (cols / 4) of them when a row is narrower than 64 float4 (the 64-column rows of
+  // pointfeat / h1: four rows per wave - one row per wave left 48 of 64 lanes idle and the kernel at 1.7 TB/s of pure writes)
   const int lane = threadIdx.x & 63, q = cols >> 2;
-  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+  const int rpw = q >= 64 ? 1 : 64 / q, sub = q >= 64 ? 0 : lane / q, c0 = q >= 64 ? lane : lane % q;
+  const bool live = q >= 64 || sub < rpw;  // (q not a divisor of 64: the last lanes sit out)
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw; r0 < R; r0 += gridDim.x * 4 * rpw) {
+    const int r = r0 + sub;
+    if (!live || r >= R) continue;
     const int p = rowpos[r];
     float* d = dst + (size_t)r * ldd;
     const float* o = nullptr;
@@ -1635,8 +1642,7 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ 
       const int ro = r < B * N ? (r / N) * (N + M) + r % N : ((r - B * N) / M) * (N + M) + N + (r - B * N) % M;
       o = objsrc + (size_t)ro * ldo;
     }
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int c4 = lane; c4 < q; c4 += 64) {
+    for (int c4 = c0; c4 < q; c4 += 64) {
       f32x4 v = p >= 0 ? reinterpret_cast<const f32x4*>(srcc + (size_t)p * lds_)[c4] : z;
       if (o) {
         const f32x4 a = reinterpret_cast<const f32x4*>(o)[c4];
@@ -1965,14 +1971,26 @@ __global__ __launch_bounds__(256) void k_gnp_stats_chunk(const float* __restrict
   }
 }
 
+#define GNP_FINAL_MAXCH 128  // chunks of an object staged in LDS (P / 64 <= 128: clouds of up to 8192 points in total)
 __global__ __launch_bounds__(64) void k_gnp_stats_final(const float* __restrict__ part, float* __restrict__ stat, int P,
                                                         int nch, int rows_per_chunk) {
+  // the object's partials are staged in LDS with coalesced loads, all in flight at once; the merge itself is a serial chain
+  // per group and was a chain of nch dependent L2 round trips from global memory (16 us for 32 chunks; k_gn_finalize does
+  // the same for the inference path).  Same operations in the same order: same bits.
+  __shared__ float sp[GNP_FINAL_MAXCH * 64];
   const int obj = blockIdx.x, g = threadIdx.x;
+  const bool staged = nch <= GNP_FINAL_MAXCH;
+  const float* src = part + (size_t)obj * nch * 64;
+  if (staged) {
+    for (int i = g; i < nch * 64; i += 64) sp[i] = src[i];
+    __syncthreads();
+  }
   if (g >= 32) return;
+  const float* base = staged ? sp : src;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int c = 0; c < nch; ++c) {
     const float nb = 8.f * (float)(min(P, (c + 1) * rows_per_chunk) - c * rows_per_chunk);
-    const float* o = part + (((size_t)obj * nch + c) * 32 + g) * 2;
+    const float* o = base + ((size_t)c * 32 + g) * 2;
     const float nn = n + nb, delta = o[0] - mean;
     mean += delta * (nb / nn);
     m2 += o[1] + delta * delta * (n * nb / nn);

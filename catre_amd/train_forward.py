@@ -152,6 +152,23 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M, x_cm=False):
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
 
 
+def _rot_heads_lp(g, pf, p, B, N, M, x_cm):
+    """Both RotHeads under autocast as ONE node (train_ops._RotHeadPairLP): per head the kernels of `_RotHeadLP`, and the two
+    data gradients pointfeat receives from them are summed by the second head's backward kernel instead of by autograd."""
+    from .heads import neck_weight3
+
+    heads = []
+    for pre in _ROT_PREFIX:
+        w = lambda n: p[f"{pre}.{n}"]
+        W0g, W0b = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)
+        bias0 = T.linear(g, W0g, w("layers.0.bias"))
+        wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
+        heads.append((W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"), w("layers.3.bias"),
+                      w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias")))
+    outs = T.rot_head_pair_lp(pf, heads[0], heads[1], B, N, M, x_cm)
+    return [o[:, :p[f"{pre}.neck.0.weight"].shape[0]] for pre, o in zip(_ROT_PREFIX, outs)]
+
+
 def _rot_heads_shapes_ok_p(p, N, M):
     """:func:`_rot_heads_shapes_ok` before pointfeat exists (its width is pcl_net.conv1's: 64)."""
     return (tuple(p["pcl_net.conv1.weight"].shape[:1]) == (64,) and N % 64 == 0 and M % 64 == 0 and N > 0 and M > 0
@@ -289,6 +306,8 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
         rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
     elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):
         rx, ry = _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M)
+    elif lp_cm:
+        rx, ry = _rot_heads_lp(g, pf_obj, p, B, N, M, True)
     else:
         rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M, lp_cm)
         ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M, lp_cm)

@@ -1261,80 +1261,125 @@ class _RotHeadLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm=False):
-        lib = hip.load()
-        dev = x.device
-        xc, bc = _c(x), _c(bias2d)
-        w0c, w1c, wn = _c(w0.reshape(256, -1)), _c(w1.reshape(256, -1)), _c(wn)
-        b1c, bnc = _c(b1), (_c(bn) if bn is not None else None)
-        wv = _c(wp.reshape(-1))
-        R, P = xc.shape[0], N + M
-        st = _st(x)
-        h = lambda: torch.empty(R, 256, dtype=torch.bfloat16, device=dev)
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        y0, a0, y1 = h(), h(), h()
-        part0, part1 = f(R // 64, 32, 2), f(R // 64, 32, 2)
-        stat0, stat1 = f(B, 32, 2), f(B, 32, 2)
-        pk0 = _pack_bf16(w0c, 256, 64, dev)
-        # x_cm: x is pointfeat in the trunk kernel's cloud-major row order (no object-major copy was made); y0 and every
-        # tensor behind it are object-major, and so is the gradient this node returns for x (train_ops._PointfeatHub)
-        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 2 if x_cm else 1, hip.ptr(y0),
-                                              256, 256, 64, B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
-        pk1 = _pack_bf16(w1c, 256, 256, dev)
-        if knobs().lp_rot_fuse_gn0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
-            hip.check(lib.catre_op_gn_gelu_gemm_rows_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
-                                                       hip.ptr(stat0), hip.ptr(pk1), hip.ptr(b1c), hip.ptr(y1), hip.ptr(part1),
-                                                       B, N, M, st), "catre_op_gn_gelu_gemm_rows_h")
-        else:
-            hip.check(lib.catre_op_gnp_gelu_fwd_pre_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
-                                                      hip.ptr(stat0), B, P, st), "catre_op_gnp_gelu_fwd_pre_h")
-            hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(a0), 256, hip.ptr(pk1), hip.ptr(b1c), 0, hip.ptr(y1), 256, 256, 256,
-                                                  B, N, M, hip.ptr(part1), 3, st), "catre_op_gemm_rows_gn_h")
-        y3, spart = f(R, 3), f(R // 64, 3, 256)
-        hip.check(lib.catre_op_gnp_gelu_neck_fwd_s_h(hip.ptr(y1), hip.ptr(part1), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
-                                                     hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat1), hip.ptr(spart), B, P,
-                                                     st), "catre_op_gnp_gelu_neck_fwd_s_h")
-        out = f(B, 3)
-        hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, st), "catre_op_wsum_fwd")
-        ctx.save_for_backward(xc, w0c, y0, stat0, g0, be0, a0, w1c, y1, stat1, g1, be1, wn, spart, y3, wv)
-        ctx.dims = (B, N, M)
-        ctx.x_cm = bool(x_cm)
-        ctx.shapes = (w0.shape, w1.shape, wp.shape)
-        ctx.has_bn, ctx.has_bp = bn is not None, bp is not None
+        out, saved, meta = _lp_head_forward(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm)
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, w0, y0, stat0, g0, be0, a0, w1, y1, stat1, g1, be1, wn, spart, y3, wv = ctx.saved_tensors
-        B, N, M = ctx.dims
-        P = N + M
-        lib = hip.load()
-        dev = x.device
-        dout = _c(dout)
-        st = _st(dout)
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        dy3, dwp = f(B * P, 3), f(P)
-        dbp = f(1) if ctx.has_bp else None
-        ws = _ws(B * P * 4, dev)
-        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
-                                        hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd")
-        da0 = torch.empty(B * P, 256, dtype=torch.bfloat16, device=dev)
-        dwb1, dpar1 = f(256 * 256 + 256), f(5, 256)
-        ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
-        hip.check(lib.catre_op_rot_l1_bwd_h(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y1), hip.ptr(stat1), hip.ptr(g1),
-                                            hip.ptr(be1), hip.ptr(wn), hip.ptr(a0), hip.ptr(w1), hip.ptr(da0), hip.ptr(dwb1),
-                                            hip.ptr(dpar1), hip.ptr(ws), ws.numel(), B, P, st), "catre_op_rot_l1_bwd_h")
-        dx, dw0 = f(x.shape[0], 64), f(256, 64)
-        db0 = f(2 * B if M > 0 else B, 256)
-        dg0, dbe0 = torch.empty_like(g0), torch.empty_like(be0)
-        ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
-        hip.check(lib.catre_op_rot_l0_bwd_h(hip.ptr(da0), hip.ptr(y0), hip.ptr(stat0), hip.ptr(g0), hip.ptr(be0), hip.ptr(x),
-                                            x.stride(0), hip.ptr(w0), hip.ptr(dx), 64, hip.ptr(dw0), hip.ptr(db0), hip.ptr(dg0),
-                                            hip.ptr(dbe0), 2 if ctx.x_cm else 0, hip.ptr(ws), ws.numel(), B, N, M, st),
-                  "catre_op_rot_l0_bwd_h")
-        dbn = _colsum(dy3) if ctx.has_bn else None
-        s0, s1, sp = ctx.shapes
-        return (dx, dw0.view(s0), db0, dg0, dbe0, dwb1[: 256 * 256].view(s1), dwb1[256 * 256:], dpar1[0], dpar1[1], dpar1[2:5],
-                dbn, dwp.view(sp), dbp, None, None, None, None)
+        return _lp_head_backward(ctx.saved_tensors, ctx.meta, dout, None) + (None, None, None, None)
+
+
+def _lp_head_forward(x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp, B, N, M, x_cm):
+    """Forward of one autocast RotHead (:class:`_RotHeadLP`) -> (out [B,3], tensors to save, meta)."""
+    lib = hip.load()
+    dev = x.device
+    xc, bc = _c(x), _c(bias2d)
+    w0c, w1c, wn = _c(w0.reshape(256, -1)), _c(w1.reshape(256, -1)), _c(wn)
+    b1c, bnc = _c(b1), (_c(bn) if bn is not None else None)
+    wv = _c(wp.reshape(-1))
+    R, P = xc.shape[0], N + M
+    st = _st(x)
+    h = lambda: torch.empty(R, 256, dtype=torch.bfloat16, device=dev)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    y0, a0, y1 = h(), h(), h()
+    part0, part1 = f(R // 64, 32, 2), f(R // 64, 32, 2)
+    stat0, stat1 = f(B, 32, 2), f(B, 32, 2)
+    pk0 = _pack_bf16(w0c, 256, 64, dev)
+    # x_cm: x is pointfeat in the trunk kernel's cloud-major row order (no object-major copy was made); y0 and every
+    # tensor behind it are object-major, and so is the gradient this node returns for x (train_ops._PointfeatHub)
+    hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(xc), xc.stride(0), hip.ptr(pk0), hip.ptr(bc), 2 if x_cm else 1, hip.ptr(y0),
+                                          256, 256, 64, B, N, M, hip.ptr(part0), 2, st), "catre_op_gemm_rows_gn_h")
+    pk1 = _pack_bf16(w1c, 256, 256, dev)
+    if knobs().lp_rot_fuse_gn0:   # GroupNorm-0 + GELU inside the second linear's operand staging (same values, one launch less)
+        hip.check(lib.catre_op_gn_gelu_gemm_rows_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
+                                                   hip.ptr(stat0), hip.ptr(pk1), hip.ptr(b1c), hip.ptr(y1), hip.ptr(part1),
+                                                   B, N, M, st), "catre_op_gn_gelu_gemm_rows_h")
+    else:
+        hip.check(lib.catre_op_gnp_gelu_fwd_pre_h(hip.ptr(y0), hip.ptr(part0), hip.ptr(g0), hip.ptr(be0), hip.ptr(a0),
+                                                  hip.ptr(stat0), B, P, st), "catre_op_gnp_gelu_fwd_pre_h")
+        hip.check(lib.catre_op_gemm_rows_gn_h(hip.ptr(a0), 256, hip.ptr(pk1), hip.ptr(b1c), 0, hip.ptr(y1), 256, 256, 256,
+                                              B, N, M, hip.ptr(part1), 3, st), "catre_op_gemm_rows_gn_h")
+    y3, spart = f(R, 3), f(R // 64, 3, 256)
+    hip.check(lib.catre_op_gnp_gelu_neck_fwd_s_h(hip.ptr(y1), hip.ptr(part1), hip.ptr(g1), hip.ptr(be1), hip.ptr(wn),
+                                                 hip.ptr(bnc), hip.ptr(wv), hip.ptr(y3), hip.ptr(stat1), hip.ptr(spart), B, P,
+                                                 st), "catre_op_gnp_gelu_neck_fwd_s_h")
+    out = f(B, 3)
+    hip.check(lib.catre_op_wsum_fwd(hip.ptr(y3), hip.ptr(wv), hip.ptr(bp), hip.ptr(out), B, P, st), "catre_op_wsum_fwd")
+    saved = (xc, w0c, y0, stat0, g0, be0, a0, w1c, y1, stat1, g1, be1, wn, spart, y3, wv)
+    meta = dict(dims=(B, N, M), x_cm=bool(x_cm), shapes=(w0.shape, w1.shape, wp.shape), has_bn=bn is not None,
+                has_bp=bp is not None)
+    return out, saved, meta
+
+
+def _lp_head_backward(saved, meta, dout, dx_acc):
+    """Backward of one autocast RotHead -> gradients of (x, w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp).  dx_acc: a
+    [R,64] tensor the data gradient is ADDED to (the other head's: the pair node sums the two without a pass of its own)."""
+    x, w0, y0, stat0, g0, be0, a0, w1, y1, stat1, g1, be1, wn, spart, y3, wv = saved
+    B, N, M = meta["dims"]
+    P = N + M
+    lib = hip.load()
+    dev = x.device
+    dout = _c(dout)
+    st = _st(dout)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    dy3, dwp = f(B * P, 3), f(P)
+    dbp = f(1) if meta["has_bp"] else None
+    ws = _ws(B * P * 4, dev)
+    hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
+                                    hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd")
+    da0 = torch.empty(B * P, 256, dtype=torch.bfloat16, device=dev)
+    dwb1, dpar1 = f(256 * 256 + 256), f(5, 256)
+    ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
+    hip.check(lib.catre_op_rot_l1_bwd_h(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y1), hip.ptr(stat1), hip.ptr(g1),
+                                        hip.ptr(be1), hip.ptr(wn), hip.ptr(a0), hip.ptr(w1), hip.ptr(da0), hip.ptr(dwb1),
+                                        hip.ptr(dpar1), hip.ptr(ws), ws.numel(), B, P, st), "catre_op_rot_l1_bwd_h")
+    dx = dx_acc if dx_acc is not None else f(x.shape[0], 64)
+    dw0 = f(256, 64)
+    db0 = f(2 * B if M > 0 else B, 256)
+    dg0, dbe0 = torch.empty_like(g0), torch.empty_like(be0)
+    ws = _ws(lib.catre_op_rot_l0_bwd_ws_bytes(B, N, M), dev)
+    hip.check(lib.catre_op_rot_l0_bwd_h(hip.ptr(da0), hip.ptr(y0), hip.ptr(stat0), hip.ptr(g0), hip.ptr(be0), hip.ptr(x),
+                                        x.stride(0), hip.ptr(w0), hip.ptr(dx), 64, hip.ptr(dw0), hip.ptr(db0), hip.ptr(dg0),
+                                        hip.ptr(dbe0), (1 if dx_acc is not None else 0) | (2 if meta["x_cm"] else 0),
+                                        hip.ptr(ws), ws.numel(), B, N, M, st), "catre_op_rot_l0_bwd_h")
+    dbn = _colsum(dy3) if meta["has_bn"] else None
+    s0, s1, sp = meta["shapes"]
+    return (dx, dw0.view(s0), db0, dg0, dbe0, dwb1[: 256 * 256].view(s1), dwb1[256 * 256:], dpar1[0], dpar1[1], dpar1[2:5],
+            dbn, dwp.view(sp), dbp)
+
+
+class _RotHeadPairLP(torch.autograd.Function):
+    """Both autocast RotHeads (:class:`_RotHeadLP` twice) as ONE node: the same kernels in the same order, but the second
+    head's layer-0 backward ADDS its data gradient to the first one's (`catre_op_rot_l0_bwd_h`, accumulate flag) instead of
+    autograd summing two [B*(N+M),64] tensors in a pass of its own (134 MB read twice and written once per iteration).
+    Inputs: x, then the 12 per-head tensors of head x, then those of head y, B, N, M, x_cm -> (out_x [B,3], out_y [B,3])."""
+
+    @staticmethod
+    def forward(ctx, x, *a):
+        hx, hy, (B, N, M, x_cm) = a[:12], a[12:24], a[24:]
+        ox, sx, mx = _lp_head_forward(x, *hx, B, N, M, x_cm)
+        oy, sy, my = _lp_head_forward(x, *hy, B, N, M, x_cm)
+        ctx.save_for_backward(*sx, *sy)
+        ctx.meta = (mx, my, len(sx))
+        return ox, oy
+
+    @staticmethod
+    def backward(ctx, dox, doy):
+        mx, my, n = ctx.meta
+        sx, sy = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        if dox is None or doy is None:
+            z = torch.zeros_like(dox if dox is not None else doy)
+            dox, doy = (dox if dox is not None else z), (doy if doy is not None else z)
+        gx = _lp_head_backward(sx, mx, dox, None)
+        gy = _lp_head_backward(sy, my, doy, gx[0])           # dx: the two heads' sum, accumulated by the second kernel
+        return (gy[0],) + gx[1:] + gy[1:] + (None, None, None, None)
+
+
+def rot_head_pair_lp(x, head_x, head_y, B, N, M, x_cm=False):
+    """head_x / head_y: (w0, bias2d, g0, be0, w1, b1, g1, be1, wn, bn, wp, bp) of the two RotHeads -> (out_x, out_y)."""
+    return _RotHeadPairLP.apply(x, *head_x, *head_y, B, N, M, x_cm)
 
 
 def rot_head_lp_ok(x, w0, w1, b1, N, M):
