@@ -145,8 +145,8 @@ __device__ __forceinline__ void gelu_affine4(float v0, float v1, float v2, float
 // instead of 10, GELU max abs error 1.7e-5 (fitted and evaluated on the goldens by tests/emulate_gelu.py: 3.3e-5 on
 // (R, t, s), an order of magnitude inside what rounding the operands to bf16 costs; NOT used by the fp32 / split kernels,
 // whose 2e-5 bar it would eat).  The bf16 rotation-head kernels are VALU-bound on this function.
-__device__ __forceinline__ float gelu_erf_lp(float v) {
-  // v * Phi(v) with the scalings folded into the coefficients like gelu_cdf: 15 issue slots instead of 18
+__device__ __forceinline__ float gelu_cdf_lp(float v) {
+  // Phi(v) with the scalings folded into the coefficients like gelu_cdf
   const float c = __builtin_amdgcn_fmed3f(v, -5.091169f, 5.091169f);
   const float t = c * c;
   float p = fmaf(t, 2.9459565e-05f, 3.7487173e-03f);
@@ -155,7 +155,11 @@ __device__ __forceinline__ float gelu_erf_lp(float v) {
   float q = fmaf(t, 1.0829841e-03f, 2.4883246e-02f);
   q = fmaf(t, q, 2.4130477e-01f);
   q = fmaf(t, q, 1.0f);
-  return v * fmaf(c * p, __builtin_amdgcn_rcpf(q), 0.5f);
+  return fmaf(c * p, __builtin_amdgcn_rcpf(q), 0.5f);
+}
+__device__ __forceinline__ float gelu_erf_lp(float v) {
+  // v * Phi(v): 15 issue slots instead of 18
+  return v * gelu_cdf_lp(v);
 }
 __device__ __forceinline__ void gelu_affine4_lp(float v0, float v1, float v2, float v3, const f32x4& sc, const f32x4& sh,
                                                 float (&z)[4]) {

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float sc = rstd * (q < 4 ? g0[q & 3] : g1[q & 3]);
-          a[q] = gelu_erf(fmaf(y[q], sc, (q < 4 ? b0[q & 3] : b1[q & 3]) - mean * sc));  // k_gnp_gelu_fwd's operation sequence
+          a[q] = gelu_erf_lp(fmaf(y[q], sc, (q < 4 ? b0[q & 3] : b1[q & 3]) - mean * sc));  // k_gnp_gelu_fwd<true>'s operation sequence
         }
         v = pack_bf8(a);
         reinterpret_cast<u32x4*>(xf_out + (size_t)gr * 256)[ch] = v;
@@ -1922,6 +1922,18 @@ __device__ __forceinline__ float gelu_grad(float v) {
   // d/dv [0.5 v (1 + erf(v/sqrt2))] = 0.5 (1 + erf(v/sqrt2)) + v * exp(-v^2/2) / sqrt(2 pi)
   return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), gelu_cdf(v));
 }
+// LP = the autocast kernels on bf16 rows (HB instances): Phi from the P3 / Q3 rational of the bf16-operand inference path
+// (catre_device.h gelu_erf_lp: max error 1.7e-5, against the 2e-3 relative of rounding the result to bf16) - four FMAs less
+// per evaluation in kernels that are VALU-bound on exactly this (r04_rot_l1_bwd_bf_phases.txt).  The fp32-row instances keep
+// the fp32-accurate rational.
+template <bool LP>
+__device__ __forceinline__ float gelu_fwd_t(float v) {
+  return LP ? gelu_erf_lp(v) : gelu_erf(v);
+}
+template <bool LP>
+__device__ __forceinline__ float gelu_grad_t(float v) {
+  return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), LP ? gelu_cdf_lp(v) : gelu_cdf(v));
+}
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32, 256) + GELU over the P points of an object (rows object-major, 256 channels)
@@ -2042,7 +2054,7 @@ __global__ void k_gnp_gelu_fwd(const void* __restrict__ Y, const float* __restri
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float sc = rstd * ga[q];
-    a[q] = gelu_erf(fmaf(y[q], sc, be[q] - mean * sc));
+    a[q] = gelu_fwd_t<HB>(fmaf(y[q], sc, be[q] - mean * sc));
   }
   st_row4<HB>(A, i, a);
 }
@@ -2086,7 +2098,7 @@ __global__ __launch_bounds__(256) void k_gnp_bwd_sums(const void* __restrict__ d
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float xh = (yv[u][q] - mean) * rstd;
-        const float dyh = dv[u][q] * gelu_grad(fmaf(yv[u][q], sc[q], sh[q]));
+        const float dyh = dv[u][q] * gelu_grad_t<HB>(fmaf(yv[u][q], sc[q], sh[q]));
         dga[q] = fmaf(dyh, xh, dga[q]);
         dbe[q] += dyh;
         const float dxh = dyh * ga[q];
@@ -2161,8 +2173,9 @@ __global__ void k_gnp_bwd_apply(const float* __restrict__ dA, const float* __res
 // is rebuilt from the three floats of its row wherever it is needed.  Per head that removes a 0.5 GiB store + three
 // 0.5 GiB loads forward and backward, and the two padded GEMMs (a 3 x 256 weight gradient on 128 x 128 MFMA tiles).
 // ------------------------------------------------------------------------------------------------
+template <bool LP = false>
 __device__ __forceinline__ void gelu_both(float v, float& g, float& dg) {
-  const float cdf = gelu_cdf(v);
+  const float cdf = LP ? gelu_cdf_lp(v) : gelu_cdf(v);
   g = v * cdf;  // the operation sequences of gelu_erf / gelu_grad on one evaluation of Phi
   dg = fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
 }
@@ -2281,7 +2294,7 @@ __global__ __launch_bounds__(256) void k_gnp_gelu_neck_fwd_s(const void* __restr
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float dg;
-        gelu_both(fmaf(v[u][q], sc[q], sh[q]), z[q], dg);
+        gelu_both<HB>(fmaf(v[u][q], sc[q], sh[q]), z[q], dg);
         const float wd = wv[u] * dg;
         s1[q] += wd;
         s2[q] = fmaf(wd, (v[u][q] - mean) * rstd, s2[q]);
@@ -2945,7 +2958,7 @@ __global__ __launch_bounds__(256) void k_rot_l1_bwd_bf(const float* __restrict__
             const float yv = y4[q];
             const float xh = (yv - mean) * rstd;
             const float da = fmaf(w2[q], d2, fmaf(w1[q], d1, w0[q] * d0));
-            const float dxh = da * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+            const float dxh = da * gelu_grad_t<HB>(fmaf(yv, sc[q], sh[q])) * ga[q];
             o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_neck_bwd_apply
             cs[q] += o[w][q];
           }
@@ -3375,7 +3388,7 @@ __global__ __launch_bounds__(512) void k_rot_l0_bwd_bf(const void* __restrict__ 
           for (int q = 0; q < 4; ++q) {
             const float yv = y4[q];
             const float xh = (yv - mean) * rstd;
-            const float dxh = d4[q] * gelu_grad(fmaf(yv, sc[q], sh[q])) * ga[q];
+            const float dxh = d4[q] * gelu_grad_t<HB>(fmaf(yv, sc[q], sh[q])) * ga[q];
             o[w][q] = rstd * (dxh - m1 - xh * m2);  // the operation sequence of k_gnp_bwd_apply
             cs[q] += o[w][q];
           }
