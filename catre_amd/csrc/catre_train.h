@@ -1055,6 +1055,187 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole backward of a linear layer on FEW rows (R < 2048: the STNs' FC tails, the ts head, the rotation heads' global
+// halves - rows are clouds or objects) as ONE launch, in the latency form of k_linear (catre_kernels.hip): a workgroup per
+// 32 x 32 output block, its 8 waves split the contraction in interleaved 8-wide chunks with up to 8 chunks in flight per
+// wave, operands straight from L2, partial blocks summed through LDS in wave order (deterministic, no split buffers, no
+// merge launch).  dv = dY .* (YM > 0):
+//   workgroups [0, ndx)        : dX[R, Kx]  = dv W[J, Kw]                 (columns >= Kw zero)
+//   workgroups [ndx, ndx + ndw): dW[J, Kw]  = dv^T X[R, Kx]               (columns >= Kx zero);  k-block 0 also db = colsum dv
+// No alignment demands: every load is guarded, so J = 3 / 9 and K = 1091 need no padded copies.  LP: the weight gradient's
+// operands rounded to bf16 (the backward of a layer that ran under autocast; db from the unrounded dv, dX in fp32 like
+// k_linear_t before it).  It replaced, per layer: k_relu_bwd or masked loads, k_linear_t, k_pad_cols x 1-3,
+// k_gemm_tn + k_reduce_splits (+ k_colsum) - 4 to 7 launches of 4-19 us on a dependent chain.
+// ------------------------------------------------------------------------------------------------
+struct FcBwdArgs {
+  const float* dY;  // [R, J], ld = ldy
+  const float* YM;  // layer output (ReLU mask), same layout as dY, or null
+  const float* X;   // [R, Kx], ld = ldx
+  const float* W;   // [J, Kw], ld = ldw
+  float* dX;        // [R, Kx] contiguous or null
+  float* dW;        // [J, Kw] contiguous or null
+  float* db;        // [J] or null (needs dW's workgroups: dW may be null only when db is)
+  int ldy, ldx, ldw, R, J, Kx, Kw;
+  int ndx, dx_rb;  // dX workgroups, row blocks among them
+  int dw_jb;       // j blocks of the dW part
+};
+#define FCB_WAVES 8
+template <bool LP>
+__global__ __launch_bounds__(64 * FCB_WAVES) void k_fc_bwd(const FcBwdArgs A) {
+  __shared__ float part[FCB_WAVES][16][64];
+  __shared__ float colp[FCB_WAVES][64];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool dx_role = (int)blockIdx.x < A.ndx;
+  f32x16 acc = zero16();
+  float cs = 0.f;
+  int row0, col0, nrow, ncol, ldo;  // output block origin, output extents, leading dimension
+  float* out;
+  bool do_col = false;
+  // (addresses are 32-bit element offsets from wave-uniform bases: R * ld < 2^23 here, and one register per load in
+  // flight instead of two.  Every load of a trip is unconditional - clamped indices, validity applied afterwards - so that
+  // the whole trip is ONE round trip: a guarded load whose select sits in the same block waits for itself.)
+  if (dx_role) {
+    const int rb = blockIdx.x % A.dx_rb, kb = blockIdx.x / A.dx_rb;
+    row0 = rb * 32, col0 = kb * 32, nrow = A.R, ncol = A.Kx, ldo = A.Kx, out = A.dX;
+    const unsigned r = min(row0 + i, A.R - 1), k = min(col0 + i, A.Kw - 1);
+    const bool kok = col0 + i < A.Kw;
+    const float* __restrict__ Y = A.dY;
+    const float* __restrict__ M = A.YM;
+    const float* __restrict__ W = A.W;
+    const unsigned yo = r * (unsigned)A.ldy;
+    const int nkc = (A.J + 7) / 8;
+    auto trips = [&](auto vec_c, auto mask_c) {
+      constexpr bool VEC = decltype(vec_c)::value, MASK = decltype(mask_c)::value;
+      constexpr int U = MASK ? 4 : 8;  // chunks in flight per wave (three operands with the mask: 128 registers hold 4)
+#pragma unroll 1
+      for (int kc = wave; kc < nkc; kc += U * FCB_WAVES) {
+        f32x4 a[U], m[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = min(kc + FCB_WAVES * u, nkc - 1);
+          const int j = 8 * c + 4 * h;
+          if constexpr (VEC) {
+            a[u] = *reinterpret_cast<const f32x4*>(Y + (yo + j));
+            if constexpr (MASK) m[u] = *reinterpret_cast<const f32x4*>(M + (yo + j));
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const unsigned jj = min(j + s, A.J - 1);
+              a[u][s] = Y[yo + jj];
+              if constexpr (MASK) m[u][s] = M[yo + jj];
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[u][s] = W[(unsigned)min(j + s, A.J - 1) * (unsigned)A.ldw + k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = kc + FCB_WAVES * u;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bool ok = c < nkc && (VEC || 8 * c + 4 * h + s < A.J);
+            if constexpr (MASK) ok = ok && m[u][s] > 0.f;
+            a[u][s] = ok ? a[u][s] : 0.f;
+            b[u][s] = kok ? b[u][s] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);  // D[row r][col k]
+      }
+    };
+    // 16-byte loads along the contraction when every chunk is whole and aligned
+    const bool vec = (A.ldy & 3) == 0 && (A.J & 7) == 0;
+    if (vec) {
+      if (M) trips(std::true_type{}, std::true_type{});
+      else trips(std::true_type{}, std::false_type{});
+    } else {
+      if (M) trips(std::false_type{}, std::true_type{});
+      else trips(std::false_type{}, std::false_type{});
+    }
+  } else {
+    const int bw = blockIdx.x - A.ndx;
+    const int jb = bw % A.dw_jb, kb = bw / A.dw_jb;
+    row0 = jb * 32, col0 = kb * 32, nrow = A.J, ncol = A.Kw, ldo = A.Kw, out = A.dW;
+    do_col = A.db != nullptr && kb == 0;
+    const bool jok = row0 + i < A.J, kok = col0 + i < A.Kx;
+    const unsigned j = min(row0 + i, A.J - 1), k = min(col0 + i, A.Kx - 1);
+    const float* __restrict__ Y = A.dY;
+    const float* __restrict__ M = A.YM;
+    const float* __restrict__ X = A.X;
+    const int nkc = (A.R + 7) / 8;
+    auto trips = [&](auto mask_c) {
+      constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll 1
+      for (int kc = wave; kc < nkc; kc += 4 * FCB_WAVES) {
+        f32x4 a[4], m[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = min(kc + FCB_WAVES * u, nkc - 1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const unsigned r = min(8 * c + 4 * h + s, A.R - 1);
+            a[u][s] = Y[r * (unsigned)A.ldy + j];
+            if constexpr (MASK) m[u][s] = M[r * (unsigned)A.ldy + j];
+            b[u][s] = X[r * (unsigned)A.ldx + k];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = kc + FCB_WAVES * u;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bool ok = jok && c < nkc && 8 * c + 4 * h + s < A.R;
+            if constexpr (MASK) ok = ok && m[u][s] > 0.f;
+            a[u][s] = ok ? a[u][s] : 0.f;
+            b[u][s] = kok ? b[u][s] : 0.f;
+          }
+        }
+        if (do_col) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cs += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float av = LP ? bf_lo(pack_bf2(a[u][s], 0.f)) : a[u][s];
+            const float bv = LP ? bf_lo(pack_bf2(b[u][s], 0.f)) : b[u][s];
+            acc = mfma32(av, bv, acc);  // D[row j][col k]
+          }
+      }
+    };
+    if (M) trips(std::true_type{});
+    else trips(std::false_type{});
+    if (do_col) colp[wave][lane] = cs;
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) part[wave][reg][lane] = acc[reg];
+  __syncthreads();
+  if (do_col && tid < 32 && row0 + tid < A.J) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < FCB_WAVES; ++w) v += colp[w][tid] + colp[w][tid + 32];
+    A.db[row0 + tid] = v;
+  }
+  const int col = col0 + i;
+  if (col >= ncol) return;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {  // wave w finishes registers 2w, 2w+1 -> rows (reg&3) + 8(reg>>2) + 4h
+    const int reg = wave * 2 + q;
+    const int row = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (row < nrow) {
+      float v = part[0][reg][lane];
+#pragma unroll
+      for (int w = 1; w < FCB_WAVES; ++w) v += part[w][reg][lane];
+      out[(size_t)row * ldo + col] = v;
+    }
+  }
+}
+
 // out[i] = sum_s part[s][i]  (fixed order: deterministic)
 __global__ void k_reduce_splits(const float* __restrict__ part, float* __restrict__ out, int n, int splits,
                                 int accumulate) {

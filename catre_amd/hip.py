@@ -145,6 +145,7 @@ _SIGS = {
     "catre_op_gemm_tn_bias_m": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_gemm_tn_bias_lp": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _SZ, _I, _P]),
     "catre_op_gemm_tn_bias_ws_bytes": (_SZ, [_I, _I, _I]),
+    "catre_op_fc_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "catre_op_skinny_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_gemm_tn_bias": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "catre_op_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P, _SZ, _P]),

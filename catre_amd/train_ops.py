@@ -132,6 +132,7 @@ class TrainKernels(typing.NamedTuple):
     split_l0_one_pass: bool = os.environ.get("CATRE_SPLIT_L0", "onepass") != "layerwise"  # split mode: first rot-head block as one node
     split_l1_one_pass: bool = os.environ.get("CATRE_SPLIT_L1", "onepass") != "layerwise"  # split mode: second block + tail as one node
     stn_recompute: bool = os.environ.get("CATRE_STN_RECOMPUTE", "1") != "0"              # fp32: STN stacks recompute their activation rows in the backward instead of saving them
+    fc_bwd_one_launch: bool = os.environ.get("CATRE_FC_BWD", "1") != "0"                 # linear layers on < 2048 rows: dgrad + wgrad + bias gradient in one launch (catre_op_fc_bwd)
 
 
 _DEFAULT_KNOBS = TrainKernels()
@@ -282,6 +283,7 @@ class _Linear(torch.autograd.Function):
             y = _gemm_nt(xk, wk, b, relu, identity_k=identity_k, amp=amp)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.K, ctx.has_b, ctx.amp = relu, K, b is not None, amp
+        ctx.fc1 = knobs().fc_bwd_one_launch
         return y
 
     @staticmethod
@@ -311,6 +313,34 @@ def _skinny_backward(dy, dy2, ymask, x, w2, need_dx):
     return dx, _c(buf[:256].view(64, 4)[:, :Kw]), buf[256:]
 
 
+def _fc_backward(ctx, dy, x, w, w2, y):
+    """The layer's whole backward in one launch (rows are clouds or objects: the FC tails, the ts head, the rot heads'
+    global halves): ReLU mask, dgrad, wgrad and bias gradient, any widths - no padded or transposed copies."""
+    R, J = dy.shape
+    Kx, Kw = x.shape[1], w2.shape[1]
+    dev = dy.device
+    need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    need_db = ctx.has_b and ctx.needs_input_grad[2]
+    ym = None
+    if ctx.relu:
+        ym = y if (y.stride(1) == 1 and y.stride(0) == dy.stride(0)) else None
+        if ym is None:
+            ym, dy = _c(y), _c(dy)
+    if x.stride(1) != 1:
+        x = _c(x)
+    if w2.stride(1) != 1:
+        w2 = _c(w2)
+    dx = torch.empty(R, Kx, dtype=torch.float32, device=dev) if need_dx else None
+    # (the bias gradient comes out of the weight gradient's workgroups: a frozen weight still runs them)
+    buf = torch.empty(J * Kw + J, dtype=torch.float32, device=dev) if (need_dw or need_db) else None
+    dw = buf[: J * Kw].view(J, Kw) if buf is not None else None
+    db = buf[J * Kw:] if need_db else None
+    hip.check(hip.load().catre_op_fc_bwd(hip.ptr(dy), dy.stride(0), hip.ptr(ym), hip.ptr(x), x.stride(0), hip.ptr(w2),
+                                         w2.stride(0), hip.ptr(dx), hip.ptr(dw), hip.ptr(db), R, J, Kx, Kw, int(ctx.amp),
+                                         _st(dy)), "catre_op_fc_bwd")
+    return dx, dw.reshape(w.shape) if need_dw else None, db, None, None, None
+
+
 def _linear_backward(ctx, dy, dy2=None):
     x, w, y = ctx.saved_tensors
     lib = hip.load()
@@ -326,6 +356,9 @@ def _linear_backward(ctx, dy, dy2=None):
                 db if ctx.has_b and ctx.needs_input_grad[2] else None, None, None, None)
     if dy2 is not None:
         dy = dy + dy2
+    if getattr(ctx, "fc1", False) and 0 < dy.shape[0] < 2048 and x.dim() == 2 and x.shape[0] == dy.shape[0] \
+            and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        return _fc_backward(ctx, dy, x, w, w2, y)
     ymask = None
     if ctx.relu:
         # ReLU backward: folded into the operand loads of the two GEMMs below when both take the tiled kernels,

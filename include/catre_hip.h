@@ -353,6 +353,14 @@ int catre_op_gemm_tn_bias_lp(const float* dY, int ldy, const float* ymask, int l
 int catre_op_skinny_bwd(const float* dY, int ldy, const float* dY2, int ldy2, const float* ymask, int ldym, const float* X,
                         int ldx, const float* W, int ldw, int Kw, float* dW, float* db, float* dX, int lddx, int dxcols,
                         int R, void* ws, size_t ws_bytes, void* stream);
+/* whole backward of a linear layer on few rows (R < 2048: the reference's autograd of the F.linear / nn.Linear layers whose
+ * rows are clouds or objects - pointnet.py:31-33,64-66 fc1-fc3, fc_trans_size_head.py:61-70, the global half of
+ * conv_out_per_rot_head.py:126) in ONE launch: dv = dY .* (YM > 0) (YM: the layer's output behind a ReLU, laid out like dY,
+ * or NULL); dX[R,Kx] = dv W[J,Kw] (columns >= Kw zero), dW[J,Kw] = dv^T X[R,Kx] (columns >= Kx zero), db[J] = column sums
+ * of dv.  dX, dW, db optional (db needs dW) and contiguous; any J, Kx, Kw, leading dimensions.  compute_dtype as
+ * catre_op_gemm_tn_bias_lp for dW (dX in fp32).  Deterministic, no workspace. */
+int catre_op_fc_bwd(const float* dY, int ldy, const float* YM, const float* X, int ldx, const float* W, int ldw, float* dX,
+                    float* dW, float* db, int R, int J, int Kx, int Kw, int compute_dtype, void* stream);
 int catre_op_colsum(const float* dY, int ld, int R, int J, float* out, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 int catre_op_reduce_splits(const float* part, float* out, int n, int splits, int accumulate, void* stream);

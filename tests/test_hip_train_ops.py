@@ -143,6 +143,52 @@ def test_weight_gradient_on_the_bf16_pipe(mode, R, K, J, masked):
     assert torch.equal(dw, dw2), "deterministic"
 
 
+@pytest.mark.parametrize("R,J,Kx,Kw,masked", [(512, 512, 1024, 1024, True), (512, 9, 256, 256, False), (256, 3, 1091, 1091, False),
+                                              (33, 40, 77, 77, True), (7, 3, 5, 5, True), (100, 64, 8, 3, True),
+                                              (65, 36, 3, 8, False), (2047, 256, 64, 64, True), (512, 4096, 256, 256, False)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_small_linear_backward_in_one_launch(R, J, Kx, Kw, masked, mode):
+    """catre_op_fc_bwd: dX, dW and db of a linear layer on < 2048 rows from one launch, any widths and leading dimensions
+    (x wider or narrower than the weight: the missing columns count as zeros), ReLU mask on load.  'bf16': dW is the
+    product of the bf16-ROUNDED operands, dX and db stay fp32."""
+    from catre_amd import hip
+    from catre_amd import train_ops as T
+
+    g = _gen(R + J + Kx + Kw)
+    ldy, ldx, ldw = J + 3, Kx + 1, Kw + 5           # odd leading dimensions: nothing is aligned
+    dyb, ymb = torch.randn(R, ldy, generator=g), torch.randn(R, ldy, generator=g)
+    xb, wb = torch.randn(R, ldx, generator=g), torch.randn(J, ldw, generator=g) / Kw ** 0.5
+    dy, ym, x, w = dyb[:, :J], ymb[:, :J], xb[:, :Kx], wb[:, :Kw]
+    dv = (dy * (ym > 0) if masked else dy).double()
+    kk = min(Kx, Kw)
+    want_dx = torch.zeros(R, Kx, dtype=torch.float64)
+    want_dx[:, :kk] = dv @ w.double()[:, :kk]
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if mode == "bf16" else (lambda t: t.double())
+    want_dw = torch.zeros(J, Kw, dtype=torch.float64)
+    want_dw[:, :kk] = rnd(dv.float()).t() @ rnd(x)[:, :kk]
+    dyd, ymd, xd, wd = dyb.to(DEV), ymb.to(DEV), xb.to(DEV), wb.to(DEV)
+    dx = torch.full((R, Kx), 7.0, device=DEV)
+    dw = torch.full((J, Kw), 7.0, device=DEV)
+    db = torch.full((J,), 7.0, device=DEV)
+    lib = hip.load()
+
+    def run(dx, dw, db):
+        hip.check(lib.catre_op_fc_bwd(hip.ptr(dyd), ldy, hip.ptr(ymd) if masked else None, hip.ptr(xd), ldx, hip.ptr(wd), ldw,
+                                      hip.ptr(dx), hip.ptr(dw), hip.ptr(db), R, J, Kx, Kw, T._MODES[mode],
+                                      hip.stream_ptr(torch.device(DEV))), "catre_op_fc_bwd")
+    run(dx, dw, db)
+    _cmp(dx, want_dx, "dx", atol=2e-5 * max(1.0, float(want_dx.abs().max())), rtol=0)
+    _cmp(dw, want_dw, "dw", atol=2e-5 * max(1.0, float(want_dw.abs().max())), rtol=0)
+    _cmp(db, dv.sum(0), "db", atol=2e-4, rtol=2e-5)
+    # each output alone gives the same bits (the roles are separate workgroups), twice gives the same bits
+    dx2, dw2, db2 = torch.empty_like(dx), torch.empty_like(dw), torch.empty_like(db)
+    run(dx2, None, None)
+    run(None, dw2, db2)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert lib.catre_op_fc_bwd(hip.ptr(dyd), ldy, None, hip.ptr(xd), ldx, hip.ptr(wd), ldw, None, None, hip.ptr(db), R, J, Kx,
+                               Kw, 0, hip.stream_ptr(torch.device(DEV))) != 0, "db alone is refused"
+
+
 def test_linear_identity_tail():
     from catre_amd import train_ops as T
 
