@@ -2814,7 +2814,7 @@ int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, c
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, st, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid,
                      is_sym, *cfg, best, part_ws, B, M, S1);
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(64), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M,
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(512), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M,
                      pose, gt_trans, trans_deltas);
   return check_launch();
 }

@@ -194,32 +194,35 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
 // losses[6 .. 6+14) = the reference's vis/ scalars in its own order: error_R [deg], error_t [cm], |t_pred - t_gt| of
 // object 0 [cm] x3, t_pred x3, trans_deltas x3 (0 when no deltas are passed), t_gt x3 - all of object 0 like the
 // reference (`pred_trans[0, 0]` ...)
-// sum_b col[b * LOSS_NP] in object order (the order is part of the result), sixteen loads requested together: left as a
-// plain loop the adds wait for one L2 round trip per object (50 us for B = 256 on a single wave)
-__device__ __forceinline__ float loss_column_sum(const float* __restrict__ col, int B) {
-  float s = 0.f;
-  int b = 0;
-  for (; b + 16 <= B; b += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(b + u) * LOSS_NP];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += v[u];
+// column sums of part [B][LOSS_NP] and the symmetric-object count: wave w of the 8 adds column w (lane l: objects l, l + 64,
+// ... in order, then the butterfly over lanes - a fixed order), wave 0 also counts is_sym.  (A single wave walking the
+// objects in order was 2 x 16 dependent L2 round trips: 13.5 us.)
+__global__ __launch_bounds__(512) void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
+                                                     float* __restrict__ losses, int* __restrict__ counts, int B, int M,
+                                                     const float* __restrict__ pose, const float* __restrict__ gt_trans,
+                                                     const float* __restrict__ trans_deltas) {
+  static_assert(LOSS_NP == 8, "one wave per column of the partials");
+  __shared__ float colsum[LOSS_NP];
+  __shared__ int nsym_s;
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s = 0.f, c = 0.f;
+    for (int b = lane; b < B; b += 64) {
+      s += part[(size_t)b * LOSS_NP + w];
+      if (w == 0) c += is_sym[b] != 0 ? 1.f : 0.f;
+    }
+    s = wave_sum(s);
+    if (w == 0) c = wave_sum(c);
+    if (lane == 0) colsum[w] = s;
+    if (lane == 0 && w == 0) nsym_s = (int)c;
   }
-  for (; b < B; ++b) s += col[(size_t)b * LOSS_NP];
-  return s;
-}
-
-__global__ void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
-                              float* __restrict__ losses, int* __restrict__ counts, int B, int M,
-                              const float* __restrict__ pose, const float* __restrict__ gt_trans,
-                              const float* __restrict__ trans_deltas) {
+  __syncthreads();
   const int i = threadIdx.x;
   if (i >= 6 && i < 6 + LOSS_NVIS) {
     const int k = i - 6;
     float v;
     if (k < 2) {
-      const float s = loss_column_sum(part + 6 + k, B);
+      const float s = colsum[6 + k];
       v = s / (float)B * (k == 1 ? 100.f : 1.f);
     } else {
       const int c = (k - 2) % 3, what = (k - 2) / 3;
@@ -230,24 +233,13 @@ __global__ void k_loss_reduce(const float* __restrict__ part, const int* __restr
     return;
   }
   if (i >= 6) return;
-  int n_sym = 0;
-  {
-    int b = 0;
-    for (; b + 16 <= B; b += 16) {
-      int f[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) f[u] = is_sym[b + u];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) n_sym += f[u] != 0;
-    }
-    for (; b < B; ++b) n_sym += is_sym[b] != 0;
-  }
+  const int n_sym = nsym_s;
   const int n_nonsym = B - n_sym;
   if (i == 0) {
     counts[0] = n_sym;
     counts[1] = n_nonsym;
   }
-  const float s = loss_column_sum(part + i, B);
+  const float s = colsum[i];
   float v = 0.f;
   switch (i) {
     case 0: v = 3.f * (s / ((float)B * M * 3.f)) * cfg.pm_lw; break;

@@ -1247,6 +1247,37 @@ __global__ void k_reduce_splits(const float* __restrict__ part, float* __restric
   out[i] = s;
 }
 
+// the same sum for FEW outputs and MANY partials (a bias / affine gradient over 256 objects: k_reduce_splits would walk the
+// partials in one dependent chain per thread on a handful of workgroups): 64 outputs x 16 partial groups per workgroup, group
+// g adds partials g, g + 16, ... in order, the 16 group sums are added in order.  Outputs [0, n_a) go to out_a, the rest to
+// out_b (the dgamma | dbeta pairs of the GroupNorm backward kernels).  Deterministic.
+__global__ __launch_bounds__(1024) void k_reduce_splits_wide(const float* __restrict__ part, float* __restrict__ out_a,
+                                                             float* __restrict__ out_b, int n, int n_a, int splits,
+                                                             int accumulate, size_t pitch) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (i < n) {
+    int k = g;
+    for (; k + 48 < splits; k += 64) {  // four partials of this group requested together
+      const float v0 = part[(size_t)k * pitch + i], v1 = part[(size_t)(k + 16) * pitch + i];
+      const float v2 = part[(size_t)(k + 32) * pitch + i], v3 = part[(size_t)(k + 48) * pitch + i];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < splits; k += 16) s += part[(size_t)k * pitch + i];
+  }
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float* o = i < n_a ? out_a + i : out_b + (i - n_a);
+    float t = accumulate ? *o : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][c];
+    *o = t;
+  }
+}
+
 // column sums: part[split][J] = sum over rows of the split of dY[r][j]
 // same with an explicit row pitch of the partial buffer
 __global__ void k_reduce_splits_p(const float* __restrict__ part, float* __restrict__ out, int n, int splits,
@@ -1269,15 +1300,14 @@ __global__ void k_pad_cols(const float* __restrict__ src, long sr, long sc, int 
   dst[i] = c < cols ? src[(size_t)r * sr + (size_t)c * sc] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
-                                                int J, int rows_per_split) {
+__device__ __forceinline__ void colsum_body(const float* __restrict__ dY, int ld, float* __restrict__ part, int R, int J,
+                                            int rows_per_split, int bx, int by, float* red /*[256]*/) {
   // a block covers JB = min(J, 256) columns with 256/JB row lanes, so narrow matrices still use every thread
-  __shared__ float red[256];
   const int JB = J < 256 ? J : 256;
   const int RL = 256 / JB;  // row lanes (>= 1); threads beyond RL*JB idle
   const int col = threadIdx.x % JB, rl = threadIdx.x / JB;
-  const int j = blockIdx.x * 256 + col;
-  const int lo = blockIdx.y * rows_per_split, hi = min(R, lo + rows_per_split);
+  const int j = bx * 256 + col;
+  const int lo = by * rows_per_split, hi = min(R, lo + rows_per_split);
   float s = 0.f;
   if (rl < RL && j < J) {
     // eight rows requested before the first add (same order of additions): as a plain loop every load was waited for
@@ -1296,8 +1326,64 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, in
   __syncthreads();
   if (rl == 0 && j < J) {
     for (int k = 1; k < RL; ++k) s += red[k * JB + col];
-    part[(size_t)blockIdx.y * J + j] = s;
+    part[(size_t)by * J + j] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, float* __restrict__ part, int R,
+                                                int J, int rows_per_split) {
+  __shared__ float red[256];
+  colsum_body(dY, ld, part, R, J, rows_per_split, blockIdx.x, blockIdx.y, red);
+}
+
+// Several two-stage column reductions behind one kernel (the partial buffers a backward kernel leaves: weight gradient,
+// affine gradients, bias gradient) as TWO launches instead of two per buffer: k_colsum_multi = k_colsum's body per job
+// (64-row column sums into the job's stage), k_reduce_multi = the fixed-order merge of the stage rows into out_a[0, n_a) |
+// out_b[0, J - n_a).  Same operations in the same order as the single-job kernels: same bits.
+#define RED_MAX_JOBS 4
+struct RedJob {
+  const float* src;  // [R][ld]
+  float* stage;      // [nsp][J]
+  float* out_a;
+  float* out_b;      // outputs n_a .. J-1 (or null when n_a == J)
+  int ld, R, J, n_a, nsp, rps, accumulate;
+  int sb0, fb0;      // first workgroup of the job in the stage / final launch
+};
+struct RedJobs {
+  RedJob j[RED_MAX_JOBS];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_colsum_multi(const RedJobs A) {
+  __shared__ float red[256];
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < RED_MAX_JOBS; ++t)
+    if (t < A.n && (int)blockIdx.x >= A.j[t].sb0) q = t;
+  const RedJob& J = A.j[q];
+  const int gx = (J.J + 255) / 256, local = blockIdx.x - J.sb0;
+  colsum_body(J.src, J.ld, J.stage, J.R, J.J, J.rps, local % gx, local / gx, red);
+}
+__global__ __launch_bounds__(256) void k_reduce_multi(const RedJobs A) {
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < RED_MAX_JOBS; ++t)
+    if (t < A.n && (int)blockIdx.x >= A.j[t].fb0) q = t;
+  const RedJob& J = A.j[q];
+  const int i = (blockIdx.x - J.fb0) * 256 + threadIdx.x;
+  if (i >= J.J) return;
+  float* o = i < J.n_a ? J.out_a + i : J.out_b + (i - J.n_a);
+  float s = J.accumulate ? *o : 0.f;
+  int k = 0;
+  for (; k + 8 <= J.nsp; k += 8) {  // eight stage rows requested together, added in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = J.stage[(size_t)(k + u) * J.J + i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < J.nsp; ++k) s += J.stage[(size_t)k * J.J + i];
+  *o = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2165,8 +2251,8 @@ __global__ __launch_bounds__(256) void k_gnp_stats_chunk(const float* __restrict
 }
 
 #define GNP_FINAL_MAXCH 128  // chunks of an object staged in LDS (P / 64 <= 128: clouds of up to 8192 points in total)
-__global__ __launch_bounds__(64) void k_gnp_stats_final(const float* __restrict__ part, float* __restrict__ stat, int P,
-                                                        int nch, int rows_per_chunk) {
+__global__ __launch_bounds__(256) void k_gnp_stats_final(const float* __restrict__ part, float* __restrict__ stat, int P,
+                                                         int nch, int rows_per_chunk) {
   // the object's partials are staged in LDS with coalesced loads, all in flight at once; the merge itself is a serial chain
   // per group and was a chain of nch dependent L2 round trips from global memory (16 us for 32 chunks; k_gn_finalize does
   // the same for the inference path).  Same operations in the same order: same bits.
@@ -2175,7 +2261,22 @@ __global__ __launch_bounds__(64) void k_gnp_stats_final(const float* __restrict_
   const bool staged = nch <= GNP_FINAL_MAXCH;
   const float* src = part + (size_t)obj * nch * 64;
   if (staged) {
-    for (int i = g; i < nch * 64; i += 64) sp[i] = src[i];
+    // 256 threads, eight loads each requested before the first LDS store (64 threads in a plain loop were 32 dependent
+    // round trips: 15-19 us of a kernel whose arithmetic is 1 us)
+    const int n = nch * 64;
+    for (int i0 = 0; i0 < n; i0 += 2048) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256 + g;
+        v[u] = i < n ? src[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256 + g;
+        if (i < n) sp[i] = v[u];
+      }
+    }
     __syncthreads();
   }
   if (g >= 32) return;
@@ -3900,6 +4001,37 @@ __global__ void k_wsum_bwd(const float* __restrict__ dout, const float* __restri
   dY[(size_t)i * 3 + 1] = wp * d[1];
   dY[(size_t)i * 3 + 2] = wp * d[2];
   dw_part[i] = d[0] * y[0] + d[1] * y[1] + d[2] * y[2];
+}
+
+// the two bias gradients behind catre_op_wsum_bwd in one workgroup: dbias = sum(dout) (k_sum_acc's operations), and the
+// neck's bias gradient dbn[c] = sum_{b,p} dY[b*P+p][c] = (sum_p w[p]) (sum_b dout[b][c]) - the sum over 3 B P products
+// factors, so no pass over dY (a 256-split column sum + its merge before)
+__global__ __launch_bounds__(256) void k_wsum_bias(const float* __restrict__ dout, const float* __restrict__ w, int B, int P,
+                                                   float* __restrict__ dbias, float* __restrict__ dbn, int accumulate) {
+  __shared__ float red[4][5];
+  const int tid = threadIdx.x;
+  float s = 0.f, ws = 0.f, d[3] = {0.f, 0.f, 0.f};
+  for (int i = tid; i < B * 3; i += 256) s += dout[i];
+  if (dbn) {
+    for (int p = tid; p < P; p += 256) ws += w[p];
+    for (int b = tid; b < B; b += 256) {
+      d[0] += dout[b * 3], d[1] += dout[b * 3 + 1], d[2] += dout[b * 3 + 2];
+    }
+  }
+  s = wave_sum(s), ws = wave_sum(ws);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d[c] = wave_sum(d[c]);
+  if ((tid & 63) == 0) {
+    float* r = red[tid >> 6];
+    r[0] = s, r[1] = ws, r[2] = d[0], r[3] = d[1], r[4] = d[2];
+  }
+  __syncthreads();
+  if (tid == 0 && dbias) dbias[0] = (accumulate ? dbias[0] : 0.f) + ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+  if (tid < 3 && dbn) {
+    const float W = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const float D = (red[0][2 + tid] + red[1][2 + tid]) + (red[2][2 + tid] + red[3][2 + tid]);
+    dbn[tid] = (accumulate ? dbn[tid] : 0.f) + W * D;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

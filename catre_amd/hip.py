@@ -187,6 +187,7 @@ _SIGS = {
     "catre_op_gnr_gelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _P]),
     "catre_op_wsum_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "catre_op_wsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _P]),
+    "catre_op_wsum_bwd_n": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _I, _I, _P]),
     "catre_op_pose_update_bwd": (_I, [_P] * 13 + [_I, _P]),
     "catre_train_rot_fwd_ws_bytes": (_SZ, [_I]),
     "catre_train_rot_fwd": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _I, _P]),

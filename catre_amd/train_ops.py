@@ -252,6 +252,20 @@ def _gemm_tn(dy, x, with_bias=False, ymask=None, amp=0):
     return dw[:J, :K]
 
 
+def _wsum_backward(dout, y3, wv, B, P, has_bp, has_bn):
+    """conv_p backward behind the 256 -> 3 neck: dy3[b,p,:] = wp[p] dout[b,:], dwp, and the two bias gradients (conv_p's
+    and - has_bn - the neck's, the column sums of dy3) -> (dy3, dwp, dbp, dbn)."""
+    dev = dout.device
+    dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
+    dwp = torch.empty(P, dtype=torch.float32, device=dev)
+    dbp = torch.empty(1, dtype=torch.float32, device=dev) if has_bp else None
+    dbn = torch.empty(3, dtype=torch.float32, device=dev) if has_bn else None
+    ws = _ws(B * P * 4, dev)
+    hip.check(hip.load().catre_op_wsum_bwd_n(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp),
+                                             hip.ptr(dbn), 0, hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd_n")
+    return dy3, dwp, dbp, dbn
+
+
 def _colsum(dy):
     lib = hip.load()
     R, J = dy.shape
@@ -1202,19 +1216,13 @@ class _NeckTail(torch.autograd.Function):
         lib = hip.load()
         dev = y.device
         dout = _c(dout)
-        dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
-        dwp = torch.empty(P, dtype=torch.float32, device=dev)
-        dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp else None
-        ws = _ws(B * P * 4, dev)
-        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
-                                        hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+        dy3, dwp, dbp, dbn = _wsum_backward(dout, y3, wv, B, P, ctx.has_bp, ctx.has_bn)
         dy = torch.empty_like(y)
         dpar = torch.empty(5, 256, dtype=torch.float32, device=dev)
         ws = _ws(lib.catre_op_gnp_gelu_neck_bwd_ws_bytes(B, P), dev)
         hip.check(lib.catre_op_gnp_gelu_neck_bwd_s(hip.ptr(dy3), hip.ptr(dout), hip.ptr(spart), hip.ptr(y), hip.ptr(stat),
                                                    hip.ptr(gamma), hip.ptr(beta), hip.ptr(wn), hip.ptr(dy), hip.ptr(dpar),
                                                    hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_gnp_gelu_neck_bwd_s")
-        dbn = _colsum(dy3) if ctx.has_bn else None
         return dy, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None
 
 
@@ -1270,14 +1278,8 @@ class _RotL1TailLP(torch.autograd.Function):
         lib = hip.load()
         dev = a.device
         dout = _c(dout)
-        dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
-        dwp = torch.empty(P, dtype=torch.float32, device=dev)
-        dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp else None
-        ws = _ws(B * P * 4, dev)
-        hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
-                                        hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+        dy3, dwp, dbp, dbn = _wsum_backward(dout, y3, wv, B, P, ctx.has_bp, ctx.has_bn)
         da, dw, db, dpar = _rot_l1_backward(dy3, a, w2, y, stat, gamma, beta, wn, B, P, dout=dout, spart=spart, lp=ctx.lp)
-        dbn = _colsum(dy3) if ctx.has_bn else None
         return (da, dw.view(ctx.wshape), db, dpar[0], dpar[1], dpar[2:5], dbn, dwp.view(ctx.wp_shape), dbp, None, None, None,
                 None)
 
@@ -1357,11 +1359,7 @@ def _lp_head_backward(saved, meta, dout, dx_acc):
     dout = _c(dout)
     st = _st(dout)
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    dy3, dwp = f(B * P, 3), f(P)
-    dbp = f(1) if meta["has_bp"] else None
-    ws = _ws(B * P * 4, dev)
-    hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp), 0,
-                                    hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd")
+    dy3, dwp, dbp, dbn = _wsum_backward(dout, y3, wv, B, P, meta["has_bp"], meta["has_bn"])
     da0 = torch.empty(B * P, 256, dtype=torch.bfloat16, device=dev)
     dwb1, dpar1 = f(256 * 256 + 256), f(5, 256)
     ws = _ws(lib.catre_op_rot_l1_bwd_ws_bytes(B, P), dev)
@@ -1377,7 +1375,6 @@ def _lp_head_backward(saved, meta, dout, dx_acc):
                                         x.stride(0), hip.ptr(w0), hip.ptr(dx), 64, hip.ptr(dw0), hip.ptr(db0), hip.ptr(dg0),
                                         hip.ptr(dbe0), (1 if dx_acc is not None else 0) | (2 if meta["x_cm"] else 0),
                                         hip.ptr(ws), ws.numel(), B, N, M, st), "catre_op_rot_l0_bwd_h")
-    dbn = _colsum(dy3) if meta["has_bn"] else None
     s0, s1, sp = meta["shapes"]
     return (dx, dw0.view(s0), db0, dg0, dbe0, dwb1[: 256 * 256].view(s1), dwb1[256 * 256:], dpar1[0], dpar1[1], dpar1[2:5],
             dbn, dwp.view(sp), dbp)
@@ -1683,12 +1680,7 @@ class _RotHeads(torch.autograd.Function):
             w0, g0, be0, w1, g1, be1, wn, wv = keep[8 * h: 8 * h + 8]
             dout = _c(dout)
             # conv_p backward: dy3[b,p,:] = wp[p] dout[b,:], dwp, dbias (train_ops._WSum)
-            dy3 = torch.empty(B * P, 3, dtype=torch.float32, device=dev)
-            dwp = torch.empty(P, dtype=torch.float32, device=dev)
-            dbp = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bp[h] else None
-            ws = _ws(B * P * 4, dev)
-            hip.check(lib.catre_op_wsum_bwd(hip.ptr(dout), hip.ptr(y3[h]), hip.ptr(wv), hip.ptr(dy3), hip.ptr(dwp), hip.ptr(dbp),
-                                            0, hip.ptr(ws), ws.numel(), B, P, _st(dout)), "catre_op_wsum_bwd")
+            dy3, dwp, dbp, dbn = _wsum_backward(dout, y3[h], wv, B, P, ctx.has_bp[h], ctx.has_bn[h])
             da, dw1, db1, dpar = _rot_l1_backward(dy3, a0[h], w1, y1[h], stat1[h], g1, be1, wn, B, P, dout=dout,
                                                   spart=spart[h])
             dx, dw0, dbias0, dg0, dbe0 = _rot_l0_backward(da, pf_obj, w0, y0[h], stat0[h], g0, be0, B, N, M,
@@ -1696,7 +1688,6 @@ class _RotHeads(torch.autograd.Function):
                                                           x_cloud_major=ctx.x_cm)
             del da
             dxs.append(dx)
-            dbn = _colsum(dy3) if ctx.has_bn[h] else None
             grads += [dbias0, dw0.view(ctx.wshapes[2 * h]), dg0, dbe0, dw1.view(ctx.wshapes[2 * h + 1]), db1, dpar[0], dpar[1],
                       dpar[2:5], dbn, dwp.view(ctx.wshapes[4 + h]), dbp]
         return (None, dxs[0], None, None, None, None, None) + tuple(grads)

@@ -488,6 +488,10 @@ int catre_op_gnr_gelu_bwd(const float* dA, const float* Y, const float* gamma, c
 int catre_op_wsum_fwd(const float* Y, const float* w, const float* bias, float* out, int B, int P, void* stream);
 int catre_op_wsum_bwd(const float* dout, const float* Y, const float* w, float* dY, float* dw, float* dbias,
                       int accumulate, void* ws, size_t ws_bytes, int B, int P, void* stream);
+/* ... plus dbn[3] = column sums of dY - the bias gradient of the 256 -> 3 neck whose output gradient dY is
+ * (conv_out_per_rot_head.py:131-140: neck, then conv_p) - as (sum_p w[p]) (sum_b dout[b][:]), in the launch that sums dbias */
+int catre_op_wsum_bwd_n(const float* dout, const float* Y, const float* w, float* dY, float* dw, float* dbias, float* dbn,
+                        int accumulate, void* ws, size_t ws_bytes, int B, int P, void* stream);
 int catre_op_pose_update_bwd(const float* d_pose, const float* d_scale, const float* rot6d, const float* trans_deltas,
                              const float* scale_deltas, const float* init_pose, const float* init_scale,
                              const float* mean_scales, const float* Ks, const catre_opts* opts, float* d_rot6d,
