@@ -2808,14 +2808,31 @@ int catre_loss_fwd(const float* pose, const float* scale, const float* gt_rot, c
                    const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
                    const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
                    float* losses, const float* trans_deltas, int B, int M, int S1, void* stream) {
+  return catre_loss_fwd_sums(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, cfg, best, counts, part_ws,
+                             losses, trans_deltas, nullptr, 0, nullptr, B, M, S1, stream);
+}
+
+// ... plus prefix[k] = ((0 + losses[terms[0]]) + losses[terms[1]]) + ... + losses[terms[k]], k < n_terms <= 6 (terms: host
+// array of loss indices in the order the caller's loss dict holds them): every intermediate of `sum(loss_dict.values())`
+int catre_loss_fwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                        const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
+                        const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
+                        float* losses, const float* trans_deltas, const int32_t* terms, int n_terms, float* prefix, int B,
+                        int M, int S1, void* stream) {
   REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && part_ws && losses && B > 0 &&
           S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && valid && M > 0));
+  REQUIRE(n_terms >= 0 && n_terms <= 6 && (n_terms == 0 || (terms && prefix)));
+  unsigned order = 0;
+  for (int k = 0; k < n_terms; ++k) {
+    REQUIRE(terms[k] >= 0 && terms[k] < 6);
+    order |= (unsigned)terms[k] << (4 * k);
+  }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, st, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid,
                      is_sym, *cfg, best, part_ws, B, M, S1);
   hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(512), 0, st, (const float*)part_ws, is_sym, *cfg, losses, counts, B, M,
-                     pose, gt_trans, trans_deltas);
+                     pose, gt_trans, trans_deltas, order, n_terms, prefix);
   return check_launch();
 }
 
@@ -2823,11 +2840,29 @@ int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, c
                    const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
                    const int32_t* best, const int32_t* counts, const float* upstream, const catre_loss_cfg* cfg,
                    float* dpose, float* dscale, int B, int M, int S1, void* stream) {
-  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && upstream && dpose &&
-          dscale && B > 0 && S1 > 0);
+  REQUIRE(upstream);
+  return catre_loss_bwd_sums(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts, upstream, nullptr,
+                             nullptr, 0, cfg, dpose, dscale, B, M, S1, stream);
+}
+
+// ... with the upstream gradients of the prefix sums of catre_loss_fwd_sums (up_prefix [n_terms]) added to those of the six
+// losses (upstream [6]); either may be NULL (= zeros)
+int catre_loss_bwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                        const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
+                        const int32_t* best, const int32_t* counts, const float* upstream, const float* up_prefix,
+                        const int32_t* terms, int n_terms, const catre_loss_cfg* cfg, float* dpose, float* dscale, int B,
+                        int M, int S1, void* stream) {
+  REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && (upstream || up_prefix) &&
+          dpose && dscale && B > 0 && S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && M > 0));
+  REQUIRE(n_terms >= 0 && n_terms <= 6 && (!up_prefix || (terms && n_terms > 0)));
+  unsigned order = 0;
+  for (int k = 0; k < n_terms; ++k) {
+    REQUIRE(terms[k] >= 0 && terms[k] < 6);
+    order |= (unsigned)terms[k] << (4 * k);
+  }
   hipLaunchKernelGGL(k_loss_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, pose, scale, gt_rot, gt_trans, gt_scale, kps,
-                     cands, is_sym, best, upstream, *cfg, counts, dpose, dscale, B, M, S1);
+                     cands, is_sym, best, upstream, *cfg, counts, dpose, dscale, B, M, S1, up_prefix, order, n_terms);
   return check_launch();
 }
 

@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ pose
 __global__ __launch_bounds__(512) void k_loss_reduce(const float* __restrict__ part, const int* __restrict__ is_sym, LossCfg cfg,
                                                      float* __restrict__ losses, int* __restrict__ counts, int B, int M,
                                                      const float* __restrict__ pose, const float* __restrict__ gt_trans,
-                                                     const float* __restrict__ trans_deltas) {
+                                                     const float* __restrict__ trans_deltas, unsigned term_order = 0,
+                                                     int n_terms = 0, float* __restrict__ prefix = nullptr) {
   static_assert(LOSS_NP == 8, "one wave per column of the partials");
   __shared__ float colsum[LOSS_NP];
+  __shared__ float lossv[6];
   __shared__ int nsym_s;
   {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -230,9 +232,10 @@ __global__ __launch_bounds__(512) void k_loss_reduce(const float* __restrict__ p
       v = what == 0 ? fabsf(tp - tg) * 100.f : what == 1 ? tp : what == 2 ? (trans_deltas ? trans_deltas[c] : 0.f) : tg;
     }
     losses[i] = v;
-    return;
   }
-  if (i >= 6) return;
+  // prefix[k] = ((0 + l[t0]) + l[t1]) + ... + l[tk] over the terms the caller's loss dict holds, in its order: what python's
+  // `sum(loss_dict.values())` (engine.py:318) builds one add kernel at a time - same operations, same bits
+  if (i < 6) {
   const int n_sym = nsym_s;
   const int n_nonsym = B - n_sym;
   if (i == 0) {
@@ -250,6 +253,17 @@ __global__ __launch_bounds__(512) void k_loss_reduce(const float* __restrict__ p
     case 5: v = s / ((float)B * (cfg.scale_mse == 2 ? 1.f : 3.f)) * cfg.scale_lw; break;
   }
   losses[i] = v;
+  lossv[i] = v;
+  }
+  if (n_terms <= 0 || !prefix) return;
+  __syncthreads();
+  if (i == 0) {
+    float acc = 0.f;
+    for (int k = 0; k < n_terms; ++k) {
+      acc += lossv[(term_order >> (4 * k)) & 15u];
+      prefix[k] = acc;
+    }
+  }
 }
 
 // d(sum_i up[i] * losses[i]) / d(pose, scale);  up = the six upstream gradients (device)
@@ -257,10 +271,29 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
                                                   const float* __restrict__ gt_rot, const float* __restrict__ gt_trans,
                                                   const float* __restrict__ gt_scale, const float* __restrict__ kps,
                                                   const float* __restrict__ cands, const int* __restrict__ is_sym,
-                                                  const int* __restrict__ best, const float* __restrict__ up, LossCfg cfg,
+                                                  const int* __restrict__ best, const float* __restrict__ up_, LossCfg cfg,
                                                   const int* __restrict__ counts, float* __restrict__ dpose /*[B,3,4]*/,
-                                                  float* __restrict__ dscale, int B, int M, int S1) {
+                                                  float* __restrict__ dscale, int B, int M, int S1,
+                                                  const float* __restrict__ up_prefix = nullptr, unsigned term_order = 0,
+                                                  int n_terms = 0) {
   __shared__ float red[4];
+  // effective upstream of loss i: its own (up_in, optional) plus that of every prefix sum it is part of (k >= its position)
+  float up[6];
+  {
+    const float* up_in = up_;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) up[i] = up_in ? up_in[i] : 0.f;
+    if (up_prefix) {
+      float tail = 0.f;
+      for (int k = n_terms - 1; k >= 0; --k) {
+        tail += up_prefix[k];
+        const int t = (term_order >> (4 * k)) & 15u;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (i == t) up[i] += tail;
+      }
+    }
+  }
   const int n_sym = counts[0], n_nonsym = counts[1];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* Pp = pose + b * 12;

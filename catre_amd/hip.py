@@ -160,6 +160,7 @@ _SIGS = {
     "catre_op_cloud_matmul": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_cloud_matmul_bwd_t": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "catre_op_relu_bwd": (_I, [_P, _P, _P, _SZ, _P]),
+    "catre_op_sum_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "catre_op_gnp_gelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_bwd_ws_bytes": (_SZ, [_I, _I]),
@@ -202,6 +203,8 @@ _SIGS = {
     "catre_pcl_fps": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P, _I, _P, _P]),
     "catre_loss_fwd": (_I, [_P] * 15 + [_I, _I, _I, _P]),
     "catre_loss_bwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
+    "catre_loss_fwd_sums": (_I, [_P] * 16 + [_I, _P, _I, _I, _I, _P]),
+    "catre_loss_bwd_sums": (_I, [_P] * 13 + [_I, _P, _P, _P, _I, _I, _I, _P]),
     "catre_profile_enable": (_I, [_I, _I]),
     "catre_profile_collect": (_I, [_P, _I, _P]),
     "catre_debug_trunk_trace": (_I, [_P]),

@@ -81,37 +81,88 @@ def _loss_cfg_struct(cfg):
 
 
 class _FusedLoss(torch.autograd.Function):
+    """-> (losses [6], vis [N_VIS], prefix [len(terms)]): the six loss terms, the logging scalars, and the running sums
+    ((0 + l[t0]) + l[t1]) + ... of the terms the loss dict will hold, in its order (see :class:`_LossTerm`)."""
+
     @staticmethod
-    def forward(ctx, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, lcfg, trans_deltas):
+    def forward(ctx, pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, valid, is_sym, lcfg, trans_deltas, terms):
         lib = hip.load()
         B, M, S1 = pose.shape[0], (kps.shape[1] if kps is not None else 0), cands.shape[1]
         dev = pose.device
         best = torch.empty(B, dtype=torch.int32, device=dev)
         counts = torch.empty(2, dtype=torch.int32, device=dev)
         part = torch.empty(B * 8, dtype=torch.float32, device=dev)
-        buf = torch.empty(6 + N_VIS, dtype=torch.float32, device=dev)
-        hip.check(lib.catre_loss_fwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
-                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(valid), hip.ptr(is_sym), ctypes.byref(lcfg),
-                                     hip.ptr(best), hip.ptr(counts), hip.ptr(part), hip.ptr(buf), hip.ptr(trans_deltas),
-                                     B, M, S1, hip.stream_ptr(dev)), "catre_loss_fwd")
+        n = len(terms)
+        buf = torch.empty(6 + N_VIS + n, dtype=torch.float32, device=dev)
+        tarr = (ctypes.c_int32 * max(n, 1))(*terms)
+        hip.check(lib.catre_loss_fwd_sums(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
+                                          hip.ptr(kps), hip.ptr(cands), hip.ptr(valid), hip.ptr(is_sym), ctypes.byref(lcfg),
+                                          hip.ptr(best), hip.ptr(counts), hip.ptr(part), hip.ptr(buf), hip.ptr(trans_deltas),
+                                          tarr, n, hip.ptr(buf[6 + N_VIS:]) if n else None, B, M, S1, hip.stream_ptr(dev)),
+                  "catre_loss_fwd_sums")
         ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts)
-        ctx.lcfg, ctx.dims = lcfg, (B, M, S1)
-        losses, vis = buf[:6], buf[6:]
+        ctx.lcfg, ctx.dims, ctx.terms = lcfg, (B, M, S1), tuple(terms)
+        ctx.set_materialize_grads(False)
+        losses, vis, prefix = buf[:6], buf[6:6 + N_VIS], buf[6 + N_VIS:]
         ctx.mark_non_differentiable(vis)
-        return losses, vis
+        return losses, vis, prefix
 
     @staticmethod
-    def backward(ctx, up, _up_vis):
+    def backward(ctx, up, _up_vis, up_prefix):
+        if up is None and up_prefix is None:
+            return (None,) * 12
         pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts = ctx.saved_tensors
         B, M, S1 = ctx.dims
         lib = hip.load()
-        up = up.contiguous()
+        up = up.contiguous() if up is not None else None
+        up_prefix = up_prefix.contiguous() if up_prefix is not None else None
+        n = len(ctx.terms)
+        tarr = (ctypes.c_int32 * max(n, 1))(*ctx.terms)
         dpose, dscale = torch.empty_like(pose), torch.empty_like(scale)
-        hip.check(lib.catre_loss_bwd(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
-                                     hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(counts), hip.ptr(up),
-                                     ctypes.byref(ctx.lcfg), hip.ptr(dpose), hip.ptr(dscale), B, M, S1,
-                                     hip.stream_ptr(pose.device)), "catre_loss_bwd")
-        return dpose, dscale, None, None, None, None, None, None, None, None, None
+        hip.check(lib.catre_loss_bwd_sums(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
+                                          hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(counts),
+                                          hip.ptr(up), hip.ptr(up_prefix), tarr, n, ctypes.byref(ctx.lcfg), hip.ptr(dpose),
+                                          hip.ptr(dscale), B, M, S1, hip.stream_ptr(pose.device)), "catre_loss_bwd_sums")
+        return (dpose, dscale) + (None,) * 10
+
+
+_ADDS = (torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.add)
+
+
+class _LossTerm(torch.Tensor):
+    """A value of the loss dict (or a running sum of its first values).  The reference's train loop adds the dict up with
+    python's ``sum(loss_dict.values())`` (engine.py:318): ``0 + v0``, then ``+ v1`` ...  - one device add per term, and
+    autograd's per-term bookkeeping on the way back (ten small launches per iteration).  The loss kernels already hold every
+    intermediate of that chain (``prefix[k]``, the same additions in the same order: same bits), so an add that continues
+    the chain - ``0 + v0``, ``prefix[k] + v(k+1)``, either operand order - returns the precomputed tensor, attached to the
+    same autograd node.  Every other use of these tensors is plain torch."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in _ADDS and len(args) == 2 and not kwargs:
+            hit = _chain_next(args[0], args[1])
+            if hit is None:
+                hit = _chain_next(args[1], args[0])
+            if hit is not None:
+                return hit
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def _chain_next(acc, term):
+    """acc + term when that is the next step of the dict's sum chain, else None.  (A term holds the running sum it completes
+    and the chain's token; a running sum holds the token and its position - no reference cycles.)"""
+    if not isinstance(term, _LossTerm):
+        return None
+    nxt, pos = getattr(term, "_next_sum", None), getattr(term, "_term_pos", None)
+    if nxt is None or pos is None:
+        return None
+    if pos == 0:
+        ok = isinstance(acc, (int, float)) and not isinstance(acc, bool) and acc == 0
+    else:
+        ok = (isinstance(acc, _LossTerm) and getattr(acc, "_chain_tok", None) is term._chain_tok
+              and getattr(acc, "_sum_pos", None) == pos - 1)
+    return nxt if ok else None
 
 
 class SymTensors:
@@ -186,22 +237,29 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
     f32 = lambda t: hip.require_dev_f32(t.contiguous(), "loss input") if t is not None else None
     gs = f32(gt_scale) if gt_scale is not None else torch.zeros(B, 3, dtype=torch.float32, device=dev)
     td = f32(trans_deltas.detach()) if trans_deltas is not None else None
-    losses, vis = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
-                                   f32(obj_kps), cands, valid, is_sym, lcfg, td)
-    losses = losses.unbind(0)  # six 0-dim views; their backward is one stack instead of six zero-fill + index + add chains
-    ld = {}
+    # the dict's keys -> loss indices, in the reference's insertion order (CATRE_disR_shared.py:168-288)
+    keys = []
     if lcfg.pm_on:
-        ld["loss_PM_R"] = losses[0]
+        keys.append(("loss_PM_R", 0))
     if lcfg.rot_on:
         if n_nonsym > 0:
-            ld["loss_rot"] = losses[1]
+            keys.append(("loss_rot", 1))
         if n_sym > 0:
-            ld["loss_yaxis_rot"] = losses[2]
+            keys.append(("loss_yaxis_rot", 2))
     if lcfg.trans_on:
-        if lcfg.trans_split:
-            ld["loss_trans_xy"], ld["loss_trans_z"] = losses[3], losses[4]
-        else:
-            ld["loss_trans_LPnP"] = losses[3]
+        keys += [("loss_trans_xy", 3), ("loss_trans_z", 4)] if lcfg.trans_split else [("loss_trans_LPnP", 3)]
     if lcfg.scale_on:
-        ld["loss_scale"] = losses[5]
+        keys.append(("loss_scale", 5))
+    losses, vis, prefix = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
+                                           f32(obj_kps), cands, valid, is_sym, lcfg, td, [i for _, i in keys])
+    losses = losses.unbind(0)  # six 0-dim views; their backward is one stack instead of six zero-fill + index + add chains
+    tok = object()
+    sums = [t.as_subclass(_LossTerm) for t in prefix.unbind(0)] if keys else []
+    for k, t in enumerate(sums):
+        t._chain_tok, t._sum_pos = tok, k
+    ld = {}
+    for k, (name, i) in enumerate(keys):
+        t = losses[i].as_subclass(_LossTerm)
+        t._chain_tok, t._term_pos, t._next_sum = tok, k, sums[k]
+        ld[name] = t
     return (ld, vis) if return_vis else ld

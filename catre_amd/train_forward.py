@@ -158,10 +158,10 @@ def _rot_heads_lp(g, pf, p, B, N, M, x_cm):
     from .heads import neck_weight3
 
     heads = []
-    for pre in _ROT_PREFIX:
+    for h, pre in enumerate(_ROT_PREFIX):
         w = lambda n: p[f"{pre}.{n}"]
         W0g, W0b = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)
-        bias0 = T.linear(g, W0g, w("layers.0.bias"))
+        bias0 = T.linear(g[h], W0g, w("layers.0.bias"))
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         heads.append((W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"), w("layers.3.bias"),
                       w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias")))
@@ -196,10 +196,10 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
 
     P = N + M
     W0s, b0s = [], []
-    for pre in _ROT_PREFIX:
+    for h, pre in enumerate(_ROT_PREFIX):
         W0g, W0l = T.split_cols(p[f"{pre}.layers.0.weight"].reshape(256, 1088), 1024)
         W0s.append(W0l)
-        b0s.append(T.linear(g, W0g, p[f"{pre}.layers.0.bias"]))   # [2B,256]
+        b0s.append(T.linear(g[h], W0g, p[f"{pre}.layers.0.bias"]))   # [2B,256]
     prm, packed = rt._train_packs(pf.device, 2)
     buf = T.rot_heads_forward(pf.detach(), b0s[0], b0s[1], prm, packed, B, N, M, 2)
     out = []
@@ -235,10 +235,10 @@ def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
     from .heads import neck_weight3
 
     heads = []
-    for pre in _ROT_PREFIX:
+    for h, pre in enumerate(_ROT_PREFIX):
         w = lambda n: p[f"{pre}.{n}"]
         W0g, W0l = T.split_cols(w("layers.0.weight").reshape(256, 1088), 1024)   # global half | point half
-        bias0 = T.linear(g, W0g, w("layers.0.bias"))                              # [2B,256]: global half + conv bias
+        bias0 = T.linear(g[h], W0g, w("layers.0.bias"))                           # [2B,256]: global half + conv bias
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         heads.append((bias0, W0l, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"),
                       w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
@@ -287,9 +287,15 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     # (CATRE_disR_shared.py:69, :86)
     pfmax, pf_obj = hub if hub is not None else (T.maxpool_points(pf, B, N, M), T.object_major(pf, B, N, M))
 
-    feats = [g[:B], pfmax[:B]]
-    if opts.with_kps_feature:
-        feats += [g[B:], pfmax[B:]]
+    # g (pooled feature, [2B,1024]) has three consumers - its first B rows go to the ts head, all of it to each rotation
+    # head - and pfmax one that reads its first B rows: their gradients are summed by one launch each (train_ops._Hub)
+    if opts.with_kps_feature or g.shape[0] == B:
+        feats = [g[:B], pfmax[:B]] + ([g[B:], pfmax[B:]] if opts.with_kps_feature else [])
+        gs = (g, g)
+    else:
+        g_ts, gx, gy = T.hub(g, B)
+        feats = [g_ts, T.hub(pfmax, B)[0]]
+        gs = (gx, gy)
     if opts.with_init_scale:
         feats.append(init_scale)
     if opts.with_init_trans:
@@ -303,14 +309,14 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     ds = T.linear(h, p["ts_head.fc_s.weight"], p["ts_head.fc_s.bias"])
 
     if fused_rot:
-        rx, ry = _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M)
+        rx, ry = _rot_heads_fused(gs, pf, pf_obj, p, rt, B, N, M)
     elif hub is not None and T._amp() == 2 and _rot_heads_shapes_ok(p, pf_obj, N, M):
-        rx, ry = _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M)
+        rx, ry = _rot_heads_split(gs, pf, pf_obj, p, rt, B, N, M)
     elif lp_cm:
-        rx, ry = _rot_heads_lp(g, pf_obj, p, B, N, M, True)
+        rx, ry = _rot_heads_lp(gs, pf_obj, p, B, N, M, True)
     else:
-        rx = _rot_head(g, pf_obj, p, "rot_head.rot_head_x", B, N, M, lp_cm)
-        ry = _rot_head(g, pf_obj, p, "rot_head.rot_head_y", B, N, M, lp_cm)
+        rx = _rot_head(gs[0], pf_obj, p, "rot_head.rot_head_x", B, N, M, lp_cm)
+        ry = _rot_head(gs[1], pf_obj, p, "rot_head.rot_head_y", B, N, M, lp_cm)
     rot6d = torch.cat([rx, ry], 1)
 
     pose, scale = T.pose_update_autograd(rot6d, dt, ds, init_pose, init_scale, mean_scales, K_zoom, opts)

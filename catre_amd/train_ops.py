@@ -470,6 +470,35 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat([da, db], 1), None
 
 
+class _Hub(torch.autograd.Function):
+    """t [R,K] -> (t[:rc], t, t): the consumers of a tensor one of which reads only its first rc rows (the pooled feature:
+    `[:B]` of it to the ts head, all of it to both rotation heads, CATRE_disR_shared.py:69,86).  Backward: ONE launch sums
+    what arrived (catre_op_sum_rows) - autograd's route is a zero-fill + copy for the slice and an add per further consumer."""
+
+    @staticmethod
+    def forward(ctx, t, rc):
+        ctx.set_materialize_grads(False)
+        ctx.shape, ctx.rc = tuple(t.shape), rc
+        return t[:rc], t.view_as(t), t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, dc, da, db):
+        if dc is None and da is None and db is None:
+            return None, None
+        ref = next(d for d in (da, db, dc) if d is not None)
+        R, K = ctx.shape
+        out = torch.empty(R, K, dtype=torch.float32, device=ref.device)
+        da, db, dc = (_c(d) if d is not None else None for d in (da, db, dc))
+        hip.check(hip.load().catre_op_sum_rows(hip.ptr(da), hip.ptr(db), hip.ptr(dc), hip.ptr(out), R, ctx.rc, K, _st(ref)),
+                  "catre_op_sum_rows")
+        return out, None
+
+
+def hub(t, rc):
+    """-> (t[:rc], t, t) whose gradients are summed by one launch (see :class:`_Hub`)."""
+    return _Hub.apply(t, rc)
+
+
 def split_cols(w, k0):
     return _SplitCols.apply(w, k0)
 

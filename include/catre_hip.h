@@ -380,6 +380,11 @@ int catre_op_cloud_matmul(const float* X, int ldx, const float* T, float* Y, int
                           int transpose, void* stream);
 int catre_op_cloud_matmul_bwd_t(const float* X, int ldx, const float* dY, int ldy, float* dT, int kd, int B, int N,
                                 int M, void* stream);
+/* out[R,K] = a + b + (c on its first Rc rows): a, b [R,K], c [Rc,K] contiguous, each optional (NULL = zeros) - the
+ * gradient of a tensor whose consumers include a row slice (the pooled feature: CATRE_disR_shared.py:69 feeds `[:B]` of it
+ * to the ts head and all of it to both rotation heads), which autograd assembles from a zero-fill, a copy and an add per
+ * further consumer */
+int catre_op_sum_rows(const float* a, const float* b, const float* c, float* out, int R, int Rc, int K, void* stream);
 int catre_op_relu_bwd(const float* dY, const float* Y, float* dX, size_t n, void* stream);
 int catre_op_gnp_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, float* stat, int B, int P,
                           void* stream);
@@ -694,6 +699,23 @@ int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, c
                    const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
                    const int32_t* best, const int32_t* counts, const float* upstream, const catre_loss_cfg* cfg,
                    float* dpose, float* dscale, int B, int M, int S1, void* stream);
+/* The reference's train loop adds the loss dict up with python's sum() (core/catre/engine/engine.py:318
+ * `losses = sum(loss_dict.values())`): one add kernel per term, and autograd's per-term bookkeeping on the way back.
+ * catre_loss_fwd_sums also writes prefix[k] = ((0 + losses[terms[0]]) + losses[terms[1]]) + ... + losses[terms[k]] for
+ * k < n_terms <= 6 (terms: HOST array of loss indices in the dict's order) - every intermediate that sum() builds, same
+ * operations, same bits - and catre_loss_bwd_sums takes the upstream gradients of those prefix sums (up_prefix
+ * [n_terms], device) next to the six per-loss ones; either may be NULL (= zeros).  catre_amd/losses.py hands the dict's
+ * values out as tensors that answer `a + b` along that chain with the precomputed prefix. */
+int catre_loss_fwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                        const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
+                        const int32_t* is_sym, const catre_loss_cfg* cfg, int32_t* best, int32_t* counts, float* part_ws,
+                        float* losses, const float* trans_deltas, const int32_t* terms, int n_terms, float* prefix, int B,
+                        int M, int S1, void* stream);
+int catre_loss_bwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
+                        const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
+                        const int32_t* best, const int32_t* counts, const float* upstream, const float* up_prefix,
+                        const int32_t* terms, int n_terms, const catre_loss_cfg* cfg, float* dpose, float* dscale, int B,
+                        int M, int S1, void* stream);
 
 #ifdef __cplusplus
 }

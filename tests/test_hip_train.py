@@ -443,6 +443,61 @@ def test_fused_loss_matches_oracle_values_and_gradients(variant):
         assert err <= 2e-5, (name, err)
 
 
+@pytest.mark.parametrize("variant", [{}, {"TRANS_LOSS_DISENTANGLE": False}, {"PM_LW": 0.0}])
+def test_summing_the_loss_dict_takes_the_precomputed_chain(variant):
+    """`sum(loss_dict.values())` (engine.py:318) answers every step of its chain with the running sum the loss kernel wrote:
+    the total and the gradients are BIT-equal to the same chain run as plain torch adds; anything off the chain (another
+    order, a weighted sum, a sum of two of the terms) is plain torch on plain tensors."""
+    from catre_amd import synth
+    from catre_amd.config import default_cfg
+    from catre_amd.losses import _LossTerm, catre_loss
+    from oracle import catre_oracle as O
+
+    B, M = 9, 96
+    cfg = default_cfg(num_pcl=64, num_kps=M, device=DEV)
+    for k, v in variant.items():
+        cfg.MODEL.CATRE.LOSS_CFG[k] = v
+    inp = synth.make_inputs(B, 64, M, seed=31)
+    g = torch.Generator().manual_seed(5)
+    sym = [O.y_axis_symmetries(12) if i in (0, 3) else None for i in range(B)]
+    from oracle.aug_oracle import euler2mat
+    out_rot = (euler2mat(torch.randn(B, 3, generator=g) * 0.2) @ inp["gt_rot"]).contiguous()
+    out_trans = inp["gt_trans"] + 0.05 * torch.randn(B, 3, generator=g)
+    out_scale = inp["gt_scale"] + 0.02 * torch.randn(B, 3, generator=g)
+    dv = lambda x: x.to(DEV)
+
+    def run(total_of):
+        r, t, s = (x.clone().to(DEV).requires_grad_(True) for x in (out_rot, out_trans, out_scale))
+        ld = catre_loss(cfg, r, t, s, dv(inp["gt_rot"]), dv(inp["gt_trans"]), dv(inp["gt_scale"]), dv(inp["obj_kps"]), sym)
+        tot = total_of(ld)
+        tot.backward()
+        return ld, tot, [x.grad.clone() if x.grad is not None else None for x in (r, t, s)]
+
+    def plain_chain(ld):
+        acc = 0
+        for v in ld.values():
+            acc = acc + v.as_subclass(torch.Tensor)
+        return acc
+
+    ld, tot, grads = run(lambda ld: sum(ld.values()))
+    ld2, tot2, grads2 = run(plain_chain)
+    assert isinstance(tot, _LossTerm) and type(tot2) is torch.Tensor
+    assert tot.grad_fn is not None and "Add" not in type(tot.grad_fn).__name__      # no add kernel ran
+    assert torch.equal(tot.detach().as_subclass(torch.Tensor), tot2.detach())
+    for a, b in zip(grads, grads2):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    # off the chain: plain torch
+    vals = list(ld.values())
+    assert type(vals[0] + vals[-1]) is torch.Tensor and type(vals[0] * 2.0) is torch.Tensor
+    assert type(sum(reversed(vals))) is torch.Tensor if len(vals) > 2 else True
+    st = torch.stack(vals)
+    assert type(st) is torch.Tensor and torch.equal(st.sum(), st.sum())
+    np.testing.assert_allclose(float(st.double().sum()), float(tot), rtol=1e-6)
+    # a partial chain is a real tensor too: the first two terms
+    part = 0 + vals[0] + vals[1]
+    assert torch.equal(part.detach().as_subclass(torch.Tensor), (vals[0].as_subclass(torch.Tensor) + vals[1].as_subclass(torch.Tensor)).detach())
+
+
 @pytest.mark.parametrize("amp", [False, True])
 def test_graphed_train_step_replays_the_eager_iteration(amp):
     """GraphedTrainStep (forward + loss + backward + fused Ranger step in one HIP graph) against the eager loop on
