@@ -2845,24 +2845,26 @@ int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, c
                              nullptr, 0, cfg, dpose, dscale, B, M, S1, stream);
 }
 
-// ... with the upstream gradients of the prefix sums of catre_loss_fwd_sums (up_prefix [n_terms]) added to those of the six
-// losses (upstream [6]); either may be NULL (= zeros)
+// ... with the upstream gradients of the prefix sums of catre_loss_fwd_sums added to those of the six losses (upstream [6]):
+// up_prefix = HOST array of n_terms device pointers to one float each (NULL entries = zero); either argument may be NULL
 int catre_loss_bwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                         const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
-                        const int32_t* best, const int32_t* counts, const float* upstream, const float* up_prefix,
-                        const int32_t* terms, int n_terms, const catre_loss_cfg* cfg, float* dpose, float* dscale, int B,
-                        int M, int S1, void* stream) {
+                        const int32_t* best, const int32_t* counts, const float* upstream,
+                        const float* const* up_prefix, const int32_t* terms, int n_terms, const catre_loss_cfg* cfg,
+                        float* dpose, float* dscale, int B, int M, int S1, void* stream) {
   REQUIRE(pose && scale && gt_rot && gt_trans && gt_scale && cfg && is_sym && best && counts && (upstream || up_prefix) &&
           dpose && dscale && B > 0 && S1 > 0);
   REQUIRE(!cfg->pm_on || (kps && cands && M > 0));
   REQUIRE(n_terms >= 0 && n_terms <= 6 && (!up_prefix || (terms && n_terms > 0)));
   unsigned order = 0;
+  LossUpPrefix upp;
   for (int k = 0; k < n_terms; ++k) {
     REQUIRE(terms[k] >= 0 && terms[k] < 6);
     order |= (unsigned)terms[k] << (4 * k);
+    if (up_prefix) upp.p[k] = up_prefix[k];
   }
   hipLaunchKernelGGL(k_loss_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, pose, scale, gt_rot, gt_trans, gt_scale, kps,
-                     cands, is_sym, best, upstream, *cfg, counts, dpose, dscale, B, M, S1, up_prefix, order, n_terms);
+                     cands, is_sym, best, upstream, *cfg, counts, dpose, dscale, B, M, S1, upp, order, up_prefix ? n_terms : 0);
   return check_launch();
 }
 

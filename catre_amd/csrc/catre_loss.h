@@ -266,6 +266,11 @@ __global__ __launch_bounds__(512) void k_loss_reduce(const float* __restrict__ p
   }
 }
 
+// upstream gradients of the running sums (one device scalar each, null = zero)
+struct LossUpPrefix {
+  const float* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
 // d(sum_i up[i] * losses[i]) / d(pose, scale);  up = the six upstream gradients (device)
 __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose, const float* __restrict__ scale,
                                                   const float* __restrict__ gt_rot, const float* __restrict__ gt_trans,
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
                                                   const int* __restrict__ best, const float* __restrict__ up_, LossCfg cfg,
                                                   const int* __restrict__ counts, float* __restrict__ dpose /*[B,3,4]*/,
                                                   float* __restrict__ dscale, int B, int M, int S1,
-                                                  const float* __restrict__ up_prefix = nullptr, unsigned term_order = 0,
+                                                  const LossUpPrefix up_prefix = LossUpPrefix{}, unsigned term_order = 0,
                                                   int n_terms = 0) {
   __shared__ float red[4];
   // effective upstream of loss i: its own (up_in, optional) plus that of every prefix sum it is part of (k >= its position)
@@ -283,10 +288,10 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ pose
     const float* up_in = up_;
 #pragma unroll
     for (int i = 0; i < 6; ++i) up[i] = up_in ? up_in[i] : 0.f;
-    if (up_prefix) {
+    {
       float tail = 0.f;
       for (int k = n_terms - 1; k >= 0; --k) {
-        tail += up_prefix[k];
+        if (up_prefix.p[k]) tail += up_prefix.p[k][0];
         const int t = (term_order >> (4 * k)) & 15u;
 #pragma unroll
         for (int i = 0; i < 6; ++i)

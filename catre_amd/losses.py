@@ -103,26 +103,30 @@ class _FusedLoss(torch.autograd.Function):
         ctx.save_for_backward(pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts)
         ctx.lcfg, ctx.dims, ctx.terms = lcfg, (B, M, S1), tuple(terms)
         ctx.set_materialize_grads(False)
-        losses, vis, prefix = buf[:6], buf[6:6 + N_VIS], buf[6 + N_VIS:]
+        losses, vis = buf[:6], buf[6:6 + N_VIS]
         ctx.mark_non_differentiable(vis)
-        return losses, vis, prefix
+        # the running sums as separate 0-dim outputs: the gradient of the one that gets used arrives alone (an unbind of
+        # one vector would zero-fill the other five and stack them)
+        return (losses, vis) + tuple(buf[6 + N_VIS + k] for k in range(n))
 
     @staticmethod
-    def backward(ctx, up, _up_vis, up_prefix):
-        if up is None and up_prefix is None:
+    def backward(ctx, up, _up_vis, *up_sums):
+        if up is None and all(u is None for u in up_sums):
             return (None,) * 12
         pose, scale, gt_rot, gt_trans, gt_scale, kps, cands, is_sym, best, counts = ctx.saved_tensors
         B, M, S1 = ctx.dims
         lib = hip.load()
         up = up.contiguous() if up is not None else None
-        up_prefix = up_prefix.contiguous() if up_prefix is not None else None
         n = len(ctx.terms)
         tarr = (ctypes.c_int32 * max(n, 1))(*ctx.terms)
+        ups = [u.reshape(1).float().contiguous() if u is not None else None for u in up_sums]   # (no-ops for fp32 scalars)
+        parr = (ctypes.c_void_p * max(n, 1))(*[u.data_ptr() if u is not None else None for u in ups])
         dpose, dscale = torch.empty_like(pose), torch.empty_like(scale)
         hip.check(lib.catre_loss_bwd_sums(hip.ptr(pose), hip.ptr(scale), hip.ptr(gt_rot), hip.ptr(gt_trans), hip.ptr(gt_scale),
                                           hip.ptr(kps), hip.ptr(cands), hip.ptr(is_sym), hip.ptr(best), hip.ptr(counts),
-                                          hip.ptr(up), hip.ptr(up_prefix), tarr, n, ctypes.byref(ctx.lcfg), hip.ptr(dpose),
-                                          hip.ptr(dscale), B, M, S1, hip.stream_ptr(pose.device)), "catre_loss_bwd_sums")
+                                          hip.ptr(up), parr if any(u is not None for u in ups) else None, tarr, n,
+                                          ctypes.byref(ctx.lcfg), hip.ptr(dpose), hip.ptr(dscale), B, M, S1,
+                                          hip.stream_ptr(pose.device)), "catre_loss_bwd_sums")
         return (dpose, dscale) + (None,) * 10
 
 
@@ -250,11 +254,11 @@ def catre_loss(cfg, out_rot, out_trans, out_scale, gt_rot, gt_trans, gt_scale, o
         keys += [("loss_trans_xy", 3), ("loss_trans_z", 4)] if lcfg.trans_split else [("loss_trans_LPnP", 3)]
     if lcfg.scale_on:
         keys.append(("loss_scale", 5))
-    losses, vis, prefix = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
+    losses, vis, *prefix = _FusedLoss.apply(hip.require_dev_f32(pose, "pose"), f32(out_scale), f32(gt_rot), f32(gt_trans), gs,
                                            f32(obj_kps), cands, valid, is_sym, lcfg, td, [i for _, i in keys])
     losses = losses.unbind(0)  # six 0-dim views; their backward is one stack instead of six zero-fill + index + add chains
     tok = object()
-    sums = [t.as_subclass(_LossTerm) for t in prefix.unbind(0)] if keys else []
+    sums = [t.as_subclass(_LossTerm) for t in prefix]
     for k, t in enumerate(sums):
         t._chain_tok, t._sum_pos = tok, k
     ld = {}

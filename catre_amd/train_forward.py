@@ -130,31 +130,39 @@ def _rot_head(g, pf_obj, p, prefix, B, N, M, x_cm=False):
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
         y3 = T.rot_l1_block(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
                             B, N, M)
-        return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
+        return _first_cols(T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P), rd)
     if T.rot_l1_tail_lp_ok(a, w("layers.3.weight"), w("layers.3.bias"), N, M):
         # autocast: the whole second half of the head as one node whose backward is one pass on the bf16 matrix pipe
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
-        return T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
-                                w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, N, M)[:, :rd]
+        o = T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"), wn, bn,
+                             w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, N, M)
+        return _first_cols(o, rd)
     y, part = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M)
     if part is not None and P % 64 == 0:
         # GroupNorm + GELU + neck + conv_p as one node: the [B*P,256] activation in between is never stored and the backward
         # needs no reduction pass over y (train_ops._NeckTail)
         wn, bn = neck_weight3(w("neck.0.weight"), w("neck.0.bias"))
-        return T.neck_tail(y, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
-                           p.get(f"{prefix}.conv_p.bias"), B, P, part)[:, :rd]
+        return _first_cols(T.neck_tail(y, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                           p.get(f"{prefix}.conv_p.bias"), B, P, part), rd)
     else:
         a = T.gn_points_gelu(y, w("layers.4.weight"), w("layers.4.bias"), B, P, part)
         y3 = neck_rows(a, w("neck.0.weight"), w("neck.0.bias"))              # [B*P,3] (columns >= rot_dim are zero)
-    return T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P)[:, :rd]
+    return _first_cols(T.weighted_point_sum(y3, w("conv_p.weight"), p.get(f"{prefix}.conv_p.bias"), B, P), rd)
 
 
 _ROT_PREFIX = ("rot_head.rot_head_x", "rot_head.rot_head_y")
 
 
+def _first_cols(o, rd):
+    """o[:, :rd] - the tensor itself when that is all of it (rot6d: rd = 3 of 3 columns; a slice node would cost a copy in
+    the backward)."""
+    return o if o.shape[1] == rd else o[:, :rd]
+
+
 def _rot_heads_lp(g, pf, p, B, N, M, x_cm):
     """Both RotHeads under autocast as ONE node (train_ops._RotHeadPairLP): per head the kernels of `_RotHeadLP`, and the two
     data gradients pointfeat receives from them are summed by the second head's backward kernel instead of by autograd."""
+    g = g if isinstance(g, (tuple, list)) else (g, g)   # one handle of the pooled feature per head (train_ops.hub)
     from .heads import neck_weight3
 
     heads = []
@@ -166,7 +174,7 @@ def _rot_heads_lp(g, pf, p, B, N, M, x_cm):
         heads.append((W0b, bias0, w("layers.1.weight"), w("layers.1.bias"), w("layers.3.weight"), w("layers.3.bias"),
                       w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias")))
     outs = T.rot_head_pair_lp(pf, heads[0], heads[1], B, N, M, x_cm)
-    return [o[:, :p[f"{pre}.neck.0.weight"].shape[0]] for pre, o in zip(_ROT_PREFIX, outs)]
+    return [_first_cols(o, p[f"{pre}.neck.0.weight"].shape[0]) for pre, o in zip(_ROT_PREFIX, outs)]
 
 
 def _rot_heads_shapes_ok_p(p, N, M):
@@ -192,6 +200,7 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
     """Both RotHeads in split mode: ONE fused forward launch chain (`catre_train_rot_fwd`, k_rot_l1_split<true>) computes what
     the per-head ops would - y0, a0 = gelu(GN0(y0)), y1 and the GroupNorm partials - and the per-head ops become graph nodes
     around those buffers (`pre=`); their backward is unchanged (split dgrad / wgrad GEMMs, fp32 GroupNorm / GELU passes)."""
+    g = g if isinstance(g, (tuple, list)) else (g, g)   # one handle of the pooled feature per head (train_ops.hub)
     from .heads import neck_weight3
 
     P = N + M
@@ -219,19 +228,21 @@ def _rot_heads_split(g, pf, pf_obj, p, rt, B, N, M):
         rd = w("neck.0.weight").shape[0]
         if T.knobs().split_l1_one_pass:
             # the second block + tail as one node: backward = conv_p, then ONE pass with hi + lo operands (k_rot_l1_bwd_sp)
-            out.append(T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"),
-                                        wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, N, M,
-                                        pre=(buf["y1"][h], buf["part1"][h]))[:, :rd])
+            o = T.rot_l1_tail_lp(a, w("layers.3.weight"), w("layers.3.bias"), w("layers.4.weight"), w("layers.4.bias"),
+                                 wn, bn, w("conv_p.weight"), p.get(f"{pre}.conv_p.bias"), B, N, M,
+                                 pre=(buf["y1"][h], buf["part1"][h]))
+            out.append(_first_cols(o, rd))
             continue
         y1, part1 = T.linear_gn_partials(a, w("layers.3.weight"), w("layers.3.bias"), B, N, M,
                                          pre=(buf["y1"][h], buf["part1"][h]))
-        out.append(T.neck_tail(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
-                               p.get(f"{pre}.conv_p.bias"), B, P, part1)[:, :rd])
+        out.append(_first_cols(T.neck_tail(y1, w("layers.4.weight"), w("layers.4.bias"), wn, bn, w("conv_p.weight"),
+                               p.get(f"{pre}.conv_p.bias"), B, P, part1), rd))
     return out
 
 
 def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
     """Both RotHeads (heads/conv_out_per_rot_head.py:126-140) with the fused forward (train_ops._RotHeads, fp32)."""
+    g = g if isinstance(g, (tuple, list)) else (g, g)   # one handle of the pooled feature per head (train_ops.hub)
     from .heads import neck_weight3
 
     heads = []
@@ -245,7 +256,7 @@ def _rot_heads_fused(g, pf, pf_obj, p, rt, B, N, M):
                       p.get(f"{pre}.conv_p.bias")))
     prm, packed = rt._train_packs(pf.device, 0)
     outs = T.rot_heads(pf.detach(), pf_obj, prm, packed, B, N, M, heads[0], heads[1])
-    return [o[:, :p[f"{pre}.neck.0.weight"].shape[0]] for pre, o in zip(_ROT_PREFIX, outs)]
+    return [_first_cols(o, p[f"{pre}.neck.0.weight"].shape[0]) for pre, o in zip(_ROT_PREFIX, outs)]
 
 
 def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_scales=None, rt=None):

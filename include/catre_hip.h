@@ -703,8 +703,9 @@ int catre_loss_bwd(const float* pose, const float* scale, const float* gt_rot, c
  * `losses = sum(loss_dict.values())`): one add kernel per term, and autograd's per-term bookkeeping on the way back.
  * catre_loss_fwd_sums also writes prefix[k] = ((0 + losses[terms[0]]) + losses[terms[1]]) + ... + losses[terms[k]] for
  * k < n_terms <= 6 (terms: HOST array of loss indices in the dict's order) - every intermediate that sum() builds, same
- * operations, same bits - and catre_loss_bwd_sums takes the upstream gradients of those prefix sums (up_prefix
- * [n_terms], device) next to the six per-loss ones; either may be NULL (= zeros).  catre_amd/losses.py hands the dict's
+ * operations, same bits - and catre_loss_bwd_sums takes the upstream gradients of those prefix sums (up_prefix: HOST array
+ * of n_terms device pointers to one float each, NULL entries = zero) next to the six per-loss ones (upstream [6], device);
+ * either argument may be NULL (= zeros).  catre_amd/losses.py hands the dict's
  * values out as tensors that answer `a + b` along that chain with the precomputed prefix. */
 int catre_loss_fwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                         const float* gt_scale, const float* kps, const float* cands, const unsigned char* valid,
@@ -713,9 +714,9 @@ int catre_loss_fwd_sums(const float* pose, const float* scale, const float* gt_r
                         int M, int S1, void* stream);
 int catre_loss_bwd_sums(const float* pose, const float* scale, const float* gt_rot, const float* gt_trans,
                         const float* gt_scale, const float* kps, const float* cands, const int32_t* is_sym,
-                        const int32_t* best, const int32_t* counts, const float* upstream, const float* up_prefix,
-                        const int32_t* terms, int n_terms, const catre_loss_cfg* cfg, float* dpose, float* dscale, int B,
-                        int M, int S1, void* stream);
+                        const int32_t* best, const int32_t* counts, const float* upstream,
+                        const float* const* up_prefix, const int32_t* terms, int n_terms, const catre_loss_cfg* cfg,
+                        float* dpose, float* dscale, int B, int M, int S1, void* stream);
 
 #ifdef __cplusplus
 }
