@@ -1955,7 +1955,7 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
   hipStream_t st = (hipStream_t)stream;
   // a NULL source is skipped, so a sub-module (e.g. PointNetfeat alone) can pack just its own layers
   const bool enc32 = sel & CATRE_PACK_F32_ENCODER, head32 = sel & CATRE_PACK_F32_HEADS, bf = sel & CATRE_PACK_BF16,
-             sp = sel & CATRE_PACK_SPLIT;
+             sp = sel & CATRE_PACK_SPLIT, tails = sel & CATRE_PACK_F32_TAILS;
   PackJobs jobs;
   jobs.n = 0;
   auto flush = [&]() {
@@ -2046,11 +2046,11 @@ int catre_pack_weights_sel(const float* const* prm, int N, int M, int ts_in, flo
     const int base = h ? CATRE_P_ROTY_L0_W : CATRE_P_ROTX_L0_W;
     frag(prm[base], PMW, 1024, 256, 64, L.rot_l0[h]);  // W0[:, 1024:1088]
     frag(prm[base + 4], 256, 0, 256, 256, L.rot_l1[h]);
-    if (prm[base + 10])
+    if (prm[base + 10] && tails)
       hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, prm[base + 10], N + M, packed + L.sumwp + h);
   }
   flush();
-  if (head32 && prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
+  if (head32 && tails && prm[CATRE_P_TS_L0_W] && prm[CATRE_P_TS_L1_W]) {
     int n = ts_in * 256;
     hipLaunchKernelGGL(k_pack_transpose, dim3((n + 255) / 256), dim3(256), 0, st, prm[CATRE_P_TS_L0_W], 256, ts_in,
                        packed + L.ts_w0t);

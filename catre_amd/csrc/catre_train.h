@@ -2183,13 +2183,13 @@ __global__ __launch_bounds__(256) void k_cloud_matmul_bwd_t(const float* __restr
 // out[r][:] = a[r][:] + b[r][:] + (r < Rc ? c[r][:] : 0), any of a / b / c null (= zeros): the gradient of a tensor with
 // several consumers, one of which reads only its first Rc rows (train_ops._Hub) - autograd's own route is a zero-fill and a
 // copy for the slice plus one add per further consumer
-__global__ void k_sum_rows(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
-                           float* __restrict__ out, size_t n, size_t nc) {
+__global__ void k_sum_rows(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int ldc,
+                           float* __restrict__ out, size_t n, size_t nc, int K) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = a ? a[i] : 0.f;
   if (b) v += b[i];
-  if (c && i < nc) v += c[i];
+  if (c && i < nc) v += c[(i / K) * ldc + (i % K)];
   out[i] = v;
 }
 

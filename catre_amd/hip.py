@@ -58,7 +58,7 @@ class CatreOpts(ctypes.Structure):
 
 
 DTYPE_F32, DTYPE_BF16, DTYPE_SPLIT = 0, 1, 2
-PACK_F32_ENCODER, PACK_F32_HEADS, PACK_BF16, PACK_SPLIT, PACK_ALL = 1, 2, 4, 8, 15
+PACK_F32_ENCODER, PACK_F32_HEADS, PACK_BF16, PACK_SPLIT, PACK_F32_TAILS, PACK_ALL = 1, 2, 4, 8, 16, 31
 ROT_6D, ROT_QUAT, ROT_LOG_QUAT, ROT_LIE_VEC = 0, 1, 2, 3
 ROT_DIMS = {ROT_6D: 6, ROT_QUAT: 4, ROT_LOG_QUAT: 3, ROT_LIE_VEC: 3}
 
@@ -160,7 +160,7 @@ _SIGS = {
     "catre_op_cloud_matmul": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_cloud_matmul_bwd_t": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "catre_op_relu_bwd": (_I, [_P, _P, _P, _SZ, _P]),
-    "catre_op_sum_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "catre_op_sum_rows": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "catre_op_gnp_gelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "catre_op_gnp_gelu_neck_bwd_ws_bytes": (_SZ, [_I, _I]),

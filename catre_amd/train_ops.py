@@ -488,9 +488,11 @@ class _Hub(torch.autograd.Function):
         ref = next(d for d in (da, db, dc) if d is not None)
         R, K = ctx.shape
         out = torch.empty(R, K, dtype=torch.float32, device=ref.device)
-        da, db, dc = (_c(d) if d is not None else None for d in (da, db, dc))
-        hip.check(hip.load().catre_op_sum_rows(hip.ptr(da), hip.ptr(db), hip.ptr(dc), hip.ptr(out), R, ctx.rc, K, _st(ref)),
-                  "catre_op_sum_rows")
+        da, db = (_c(d) if d is not None else None for d in (da, db))
+        if dc is not None and dc.stride(1) != 1:    # (a column slice of a wider gradient is read in place: any row pitch)
+            dc = _c(dc)
+        hip.check(hip.load().catre_op_sum_rows(hip.ptr(da), hip.ptr(db), hip.ptr(dc), dc.stride(0) if dc is not None else 0,
+                                               hip.ptr(out), R, ctx.rc, K, _st(ref)), "catre_op_sum_rows")
         return out, None
 
 

@@ -127,7 +127,16 @@ int catre_pack_weights(const float* const* params, int N, int M, int ts_in_dim,
 
 /* Same, restricted to the packs a caller needs (a training step that re-packs after every optimizer step only needs
  * the fp32 encoder image): OR of CATRE_PACK_*. */
-enum { CATRE_PACK_F32_ENCODER = 1, CATRE_PACK_F32_HEADS = 2, CATRE_PACK_BF16 = 4, CATRE_PACK_SPLIT = 8, CATRE_PACK_ALL = 15 };
+enum {
+  CATRE_PACK_F32_ENCODER = 1,
+  CATRE_PACK_F32_HEADS = 2,  /* the rotation heads' two linears as fp32 fragments */
+  CATRE_PACK_BF16 = 4,
+  CATRE_PACK_SPLIT = 8,
+  CATRE_PACK_F32_TAILS = 16, /* with _F32_HEADS: the ts head's transposed weights and the conv_p weight sums - read by the
+                                inference tail kernels only, so a training forward (which re-packs every iteration) leaves
+                                these four launches out */
+  CATRE_PACK_ALL = 31
+};
 int catre_pack_weights_sel(const float* const* params, int N, int M, int ts_in_dim, float* packed, size_t packed_floats,
                            int sel, void* stream);
 
@@ -380,11 +389,13 @@ int catre_op_cloud_matmul(const float* X, int ldx, const float* T, float* Y, int
                           int transpose, void* stream);
 int catre_op_cloud_matmul_bwd_t(const float* X, int ldx, const float* dY, int ldy, float* dT, int kd, int B, int N,
                                 int M, void* stream);
-/* out[R,K] = a + b + (c on its first Rc rows): a, b [R,K], c [Rc,K] contiguous, each optional (NULL = zeros) - the
+/* out[R,K] = a + b + (c on its first Rc rows): a, b [R,K] contiguous, c [Rc,K] with leading dimension ldc, each optional
+ * (NULL = zeros) - the
  * gradient of a tensor whose consumers include a row slice (the pooled feature: CATRE_disR_shared.py:69 feeds `[:B]` of it
  * to the ts head and all of it to both rotation heads), which autograd assembles from a zero-fill, a copy and an add per
  * further consumer */
-int catre_op_sum_rows(const float* a, const float* b, const float* c, float* out, int R, int Rc, int K, void* stream);
+int catre_op_sum_rows(const float* a, const float* b, const float* c, int ldc, float* out, int R, int Rc, int K,
+                      void* stream);
 int catre_op_relu_bwd(const float* dY, const float* Y, float* dX, size_t n, void* stream);
 int catre_op_gnp_gelu_fwd(const float* Y, const float* gamma, const float* beta, float* A, float* stat, int B, int P,
                           void* stream);
