@@ -423,21 +423,25 @@ template <int MB, int NB>
 __device__ __forceinline__ void argmax_tile_store(const f32x16 (&acc)[MB][NB], float* __restrict__ pmax,
                                                   int* __restrict__ pidx, int ch0, const float (&bl)[MB], int row0,
                                                   int lane) {
+  // Per accumulator: half a v_max3 for the maximum, then a compare + select that walks the points BACKWARDS looking for
+  // it (the last hit of the walk is the first occurrence: torch.max's choice) - 2.5 issue slots instead of the 4 of
+  // "add bias, compare, select value, select index" per accumulator.  The bias joins after the maximum: x -> fl(x + b) is
+  // monotonic, so max_r fl(v_r + b) == fl(max_r v_r + b) - the pooled value keeps its bits (and equals the inference
+  // kernels'); only a tie that the rounding of v_r + b would have created is now seen as the strict order of the v_r.
   const int n = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float m = -INFINITY;
+    float m = acc[mb][0][0];
+#pragma unroll
+    for (int i = 1; i + 1 < NB * 16; i += 2) m = fmaxf(fmaxf(m, acc[mb][i >> 4][i & 15]), acc[mb][(i + 1) >> 4][(i + 1) & 15]);
+    m = fmaxf(m, acc[mb][NB - 1][15]);
     int am = 0;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = NB - 1; nb >= 0; --nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {  // increasing point order inside a half-wave: strict > keeps the first
-        const float v = acc[mb][nb][r] + bl[mb];
-        if (v > m) {
-          m = v;
-          am = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        }
-      }
+      for (int r = 15; r >= 0; --r)  // decreasing point order inside a half-wave: the first occurrence is the last hit
+        am = acc[mb][nb][r] == m ? nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h : am;
+    m += bl[mb];
     const float mo = __shfl_xor(m, 32);
     const int ao = __shfl_xor(am, 32);
     if (mo > m || (mo == m && ao < am)) {
