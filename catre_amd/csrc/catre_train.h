@@ -4249,7 +4249,15 @@ __global__ __launch_bounds__(64) void k_ranger_rowmean(const RangerTensor* __res
   const int r = row - t.row_off;
   const float* g = t.g + (size_t)r * t.row_len;
   float s = 0.f;
-  for (int i = threadIdx.x; i < t.row_len; i += 64) s += ranger_clean(g[i], clean, lim);
+  int i = threadIdx.x;
+  for (; i + 192 < t.row_len; i += 256) {  // four loads requested together, added in the loop's order (same bits)
+    const float a = g[i], b = g[i + 64], c = g[i + 128], d = g[i + 192];
+    s += ranger_clean(a, clean, lim);
+    s += ranger_clean(b, clean, lim);
+    s += ranger_clean(c, clean, lim);
+    s += ranger_clean(d, clean, lim);
+  }
+  for (; i < t.row_len; i += 64) s += ranger_clean(g[i], clean, lim);
   s = wave_sum(s);
   if (threadIdx.x == 0) rowmean[row] = s / (float)t.row_len;
 }
@@ -4262,22 +4270,39 @@ __global__ __launch_bounds__(256) void k_ranger_update(const RangerTensor* __res
   const int2 c = chunks[blockIdx.x];
   const RangerTensor t = T[c.x];
   const int end = min(t.numel, c.y + RANGER_CHUNK);
-  for (int i = c.y + threadIdx.x; i < end; i += 256) {
-    float g = ranger_clean(t.g[i], clean, lim);
-    if (t.row_len > 0) g -= rowmean[t.row_off + i / t.row_len];
-    // omb = fp32(1 - beta) formed in double on the host like the reference's `1 - beta2` (1.f - 0.999f is off by 4.7e-5)
-    const float v = t.v[i] * beta2 + omb2 * g * g;
-    const float m = t.m[i] * beta1 + omb1 * g;
-    t.v[i] = v;
-    t.m[i] = m;
-    float p = t.p[i];
-    if (t.wd_lr != 0.f) p -= t.wd_lr * p;
-    p -= t.adaptive ? t.lr_step * (m / (sqrtf(v) + eps)) : t.lr_step * m;
-    if (t.lookahead) {
-      const float s = t.slow[i] + alpha * (p - t.slow[i]);
-      t.slow[i] = s;
-      p = s;
+  // four elements per thread and trip, every load of the trip requested before the first store (the tensors may alias as far
+  // as the compiler knows: as a plain loop each element waited for the previous one's stores - 16 dependent round trips)
+  for (int i0 = c.y + threadIdx.x; i0 < end; i0 += 1024) {
+    float g[4], v[4], m[4], p[4], sl[4], rm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + 256 * u, end - 1);
+      g[u] = t.g[i], v[u] = t.v[i], m[u] = t.m[i], p[u] = t.p[i];
+      sl[u] = t.lookahead ? t.slow[i] : 0.f;
+      rm[u] = t.row_len > 0 ? rowmean[t.row_off + i / t.row_len] : 0.f;
     }
-    t.p[i] = p;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < end) {
+        float gg = ranger_clean(g[u], clean, lim);
+        if (t.row_len > 0) gg -= rm[u];
+        // omb = fp32(1 - beta) formed in double on the host like the reference's `1 - beta2` (1.f - 0.999f is off by 4.7e-5)
+        const float vv = v[u] * beta2 + omb2 * gg * gg;
+        const float mm = m[u] * beta1 + omb1 * gg;
+        t.v[i] = vv;
+        t.m[i] = mm;
+        float pp = p[u];
+        if (t.wd_lr != 0.f) pp -= t.wd_lr * pp;
+        pp -= t.adaptive ? t.lr_step * (mm / (sqrtf(vv) + eps)) : t.lr_step * mm;
+        if (t.lookahead) {
+          const float s = sl[u] + alpha * (pp - sl[u]);
+          t.slow[i] = s;
+          pp = s;
+        }
+        t.p[i] = pp;
+      }
+    }
   }
 }
