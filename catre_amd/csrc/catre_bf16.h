@@ -64,6 +64,12 @@ __device__ __forceinline__ f32x4 ld_row4(const void* __restrict__ p, size_t i4) 
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i4);
   }
 }
+// four consecutive channels of a bf16 row as floats, through the caches (operand rows that several workgroups re-read:
+// the gathered rows of the row-sparse backward)
+__device__ __forceinline__ f32x4 ld_bf4(const void* __restrict__ p, size_t i4) {
+  const u32x2 v = reinterpret_cast<const u32x2*>(p)[i4];
+  return f32x4{bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+}
 template <bool HB>
 __device__ __forceinline__ void st_row4(void* __restrict__ p, size_t i4, const f32x4& v) {
   if constexpr (HB)
@@ -276,6 +282,26 @@ __device__ __forceinline__ void save_tile_rows_bf(const u32x4* __restrict__ img,
   }
 }
 
+// The same image as bf16 ROWS dst[row][C] in channel order (dst: the row buffer, C / 2 floats per row): half the bytes of
+// the fp32 form - the SAVE instances wait for these stores (k_trunk_bf2<true>: 1.5 GB of them as fp32 rows) - and nothing
+// is lost: the fp32 rows held the bf16-rounded values, and the backward kernels that read them (catre_op_maxlin_bwd_*_h,
+// catre_op_gemm_rows_nr / catre_op_gemm_tn_bias_nr with CATRE_ROWS_BF16) see the same numbers.  A thread takes a chunk
+// PAIR - 16 consecutive channels: [even.e0-3 | odd.e0-3 | even.e4-7 | odd.e4-7] - and stores 32 contiguous bytes.
+template <int C, int NT, int ROWS>
+__device__ __forceinline__ void save_tile_rows_bf16(const u32x4* __restrict__ img, float* __restrict__ dst, int valid, int tid) {
+  constexpr int CP = C / 8, PP = CP / 2;
+  static_assert((ROWS * PP) % NT == 0 || ROWS * PP < NT, "whole trips");
+#pragma unroll
+  for (int u = 0; u < (ROWS * PP + NT - 1) / NT; ++u) {
+    const int i = tid + NT * u, row = i / PP, q = i % PP;
+    if (i >= ROWS * PP || row >= valid) continue;
+    const u32x4 ev = img[bf_off<CP>(row, 2 * q)], od = img[bf_off<CP>(row, 2 * q + 1)];
+    u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + (size_t)row * C + 16 * q);
+    st_stream(d, u32x4{ev[0], ev[1], od[0], od[1]});
+    st_stream(d + 1, u32x4{ev[2], ev[3], od[2], od[3]});
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // a2: STN3d conv stack (pointnet.py:24-28), bf16 operands.  256 threads, 24 KiB LDS.
 // ------------------------------------------------------------------------------------------
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows_bf<64, 256, TP>(a1, sv.s1 + row0 * 64, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<64, 256, TP>(a1, sv.s1 + row0 * 32, ti.valid, tid);
   // conv3 128->1024 + max: wave owns m-blocks [8*wave, +8) in two passes of 4
   GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
   float bl[2][4];
@@ -317,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf(catre_points P, const float
     store_tile_bf<1, 2, true, 16>(acc, a2, wave, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows_bf<128, 256, TP>(a2, sv.s2 + row0 * 128, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<128, 256, TP>(a2, sv.s2 + row0 * 64, ti.valid, tid);
   float* out = pm + (size_t)blockIdx.x * PMW;
   float* pmax = SAVE ? sv.pmax + (size_t)blockIdx.x * 1024 : nullptr;
   int* pidx = SAVE ? sv.pidx + (size_t)blockIdx.x * 1024 : nullptr;
@@ -387,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows_bf<64, 256, TP>(f1, sv.s1 + row0 * 64, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<64, 256, TP>(f1, sv.s1 + row0 * 32, ti.valid, tid);
   GemmPipeB<4, 2, true, 16, 2, 1> g3a, g3b;
   float bl[2][4];
   g3a.prefetch(wpf3 + ((wave * 8) * 8) * 64 + lane, 8 * 64);
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf(catre_points P, const float
     store_tile_bf<1, 2, true, 16>(acc, f2, wave, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows_bf<128, 256, TP>(f2, sv.s2 + row0 * 128, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<128, 256, TP>(f2, sv.s2 + row0 * 64, ti.valid, tid);
   float* out = pm + (size_t)blockIdx.x * PMW;
   float* pmax = SAVE ? sv.pmax + (size_t)blockIdx.x * 1024 : nullptr;
   int* pidx = SAVE ? sv.pidx + (size_t)blockIdx.x * 1024 : nullptr;
@@ -757,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows_bf<64, 256, 2 * TP>(a1, sv.s1 + row0 * 64, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<64, 256, 2 * TP>(a1, sv.s1 + row0 * 32, ti.valid, tid);
   StnConv3Pipe g3[2];
   stn_conv3_prefetch(g3, wp3, wave, lane);
   {
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void k_stn3d_bf2(catre_points P, const floa
     store_tile_bf<1, 4, true, 16>(acc, a2, wave, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows_bf<128, 256, 2 * TP>(a2, sv.s2 + row0 * 128, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<128, 256, 2 * TP>(a2, sv.s2 + row0 * 64, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
   if constexpr (SAVE)
     stn_conv3_pair_bf<true>(g3, wp3, b3, a2, out, nullptr, wave, lane, sv.pmax + (size_t)tile0 * 1024,
@@ -819,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
   }
   __syncthreads();
   const size_t row0 = (ti.is_obs ? (size_t)ti.obj * N : (size_t)B * N + (size_t)ti.obj * M) + ti.p0;
-  if (SAVE) save_tile_rows_bf<64, 256, 2 * TP>(f1, sv.s1 + row0 * 64, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<64, 256, 2 * TP>(f1, sv.s1 + row0 * 32, ti.valid, tid);
   StnConv3Pipe g3[2];
   stn_conv3_prefetch(g3, wpf3, wave, lane);
   {
@@ -828,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void k_stnkd_bf2(catre_points P, const floa
     store_tile_bf<1, 4, true, 16>(acc, f2, wave, bv2, lane);
   }
   __syncthreads();
-  if (SAVE) save_tile_rows_bf<128, 256, 2 * TP>(f2, sv.s2 + row0 * 128, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<128, 256, 2 * TP>(f2, sv.s2 + row0 * 64, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
   if constexpr (SAVE)
     stn_conv3_pair_bf<true>(g3, wpf3, bf3, f2, out, nullptr, wave, lane, sv.pmax + (size_t)tile0 * 1024,
@@ -968,7 +994,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
   }
   __syncthreads();  // scratch / pf / h1 live inside a3, which conv3 overwrites next
   TRUNKB2_STAMP(3);
-  if (SAVE) save_tile_rows_bf<128, 512, 2 * TP>(a2, sv.s3 + srow0 * 128, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<128, 512, 2 * TP>(a2, sv.s3 + srow0 * 64, ti.valid, tid);
   {  // HBM stores of the pair's pointfeat rows and their maxima: issued here, a whole conv3 sweep before the next barrier
      // (which waits for their acknowledge), so that their 8 + 1 registers are free during the sweeps
     const size_t prow0 = ti.is_obs ? (size_t)ti.obj * N + ti.p0 : (size_t)B * N + (size_t)ti.obj * M + ti.p0;
@@ -1002,7 +1028,7 @@ __global__ __launch_bounds__(512) void k_trunk_bf2(catre_points P, const float* 
   TRUNKB2_STAMP(4);
   __syncthreads();
   TRUNKB2_STAMP(5);
-  if (SAVE) save_tile_rows_bf<512, 512, 2 * TP>(a3, sv.s4 + srow0 * 512, ti.valid, tid);
+  if (SAVE) save_tile_rows_bf16<512, 512, 2 * TP>(a3, sv.s4 + srow0 * 256, ti.valid, tid);
   float* out = pm + (size_t)tile0 * PMW;
   float* out2 = has2 ? out + PMW : nullptr;
   // SAVE: (max, arg-max row) of the PAIR into both tiles' rows of the per-tile tables - k_maxpool_tiles keeps the first

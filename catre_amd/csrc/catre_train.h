@@ -60,7 +60,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 
 // epilogue shared by the fp32 and bf16-operand row GEMMs: bias / ReLU / output mask -> Y, or (MAXP) the per-tile
 // max / arg-max over the 64 rows
-template <int MB, bool MAXP, bool YB = false>  // YB: Y holds bf16 rows (ldy in elements; full tiles only)
+template <int MB, bool MAXP, bool YB = false, bool MH = false>  // YB: Y holds bf16 rows (ldy in elements; full tiles only); MH: `mask` does (ldm in elements)
 __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const float* __restrict__ bias,
                                                    const float* __restrict__ mask, int ldm, float* __restrict__ Y,
                                                    int ldy, int R, int relu, int r0, int nblk, int wave, int lane,
@@ -116,7 +116,9 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
     const int ch = blk * 32 + n;
     const float bv = bias ? bias[ch] : 0.f;
     float* yo = Y + (size_t)(r0 + 4 * h) * ldy + ch;
-    const float* mo = mask ? mask + (mri >= 0 ? (size_t)0 : (size_t)(r0 + 4 * h) * ldm) + ch : nullptr;
+    const size_t mo0 = (mri >= 0 ? (size_t)0 : (size_t)(r0 + 4 * h) * ldm) + ch;  // element offset of the lane's first mask row
+    const float* mo = mask ? mask + mo0 : nullptr;
+    const short* moh = reinterpret_cast<const short*>(mask) + mo0;
     int lim = R - r0 - 4 * h;  // row (nb, r) of this half-wave exists iff its in-tile index < lim
     asm volatile("" : "+v"(lim));
     float s = 0.f;
@@ -130,7 +132,11 @@ __device__ __forceinline__ void gemm_rows_epilogue(f32x16 (&acc)[MB][2], const f
         size_t mrow = (size_t)row;
         if (mri >= 0) mrow = (size_t)__shfl(mri, 4 * h + row);
         if (full || row < lim) {
-          if (mo) t = mo[mrow * ldm] > 0.f ? t : 0.f;
+          if constexpr (MH) {
+            if (mo) t = moh[mrow * ldm] > 0 ? t : 0.f;  // (a bf16 is > 0 iff its bits, as int16, are)
+          } else {
+            if (mo) t = mo[mrow * ldm] > 0.f ? t : 0.f;
+          }
           if constexpr (!YB) yo[(size_t)row * ldy] = t;
           // bf16 rows: the GroupNorm partials below are those of the ROUNDED values - the tensor that is normalised and that
           // the backward re-reads (torch.autocast's GroupNorm sees the Conv1d's bf16 output too)
@@ -405,6 +411,7 @@ __global__ void k_op_pack_bf(const float* __restrict__ src, int ld, int J, int K
 
 // IO bit 0: X holds bf16 rows (ldx in elements, already the operand format: staged with one 16-byte copy per chunk);
 // bit 1: Y holds bf16 rows (full tiles, no masks) - the all-bf16 activations of train_ops._RotHeadLP;
+// bit 3: `mask` holds bf16 rows (ldm in elements) - the activation rows the autocast encoder forward saves;
 // bit 2 (with bit 0, K = 256): X is the INPUT of a GroupNorm(32,256) + GELU whose output is this GEMM's operand - a chunk of 8
 // channels is one GroupNorm group: the staging thread widens it, applies k_gnp_gelu_fwd's arithmetic with (mean, rstd) of
 // its object from xf_stat [B][32][2], rounds to bf16 into LDS and stores the same 16 bytes to xf_out (bf16 rows: the
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(512) void k_gemm_rows_bf(const float* __restrict__ 
   GemmPipeB<MB, 2, true, CP, (NKC >= 4 ? 2 : 1), 1> g;  // swapped: lane = channel (gemm_rows_epilogue)
   g.prefetch(Wp + ((size_t)wave * NKC) * 64 + lane, 8 * NKC * 64);
   g.run(acc, xs, lane);
-  gemm_rows_epilogue<MB, MAXP, (IO & 2) != 0>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0, nblk, wave, lane,
-                                              0, cb.gn_part, MAXP ? -1 : mri);
+  gemm_rows_epilogue<MB, MAXP, (IO & 2) != 0, (IO & 8) != 0>(acc, cloud_bias(bias, cb, r0, J), mask, ldm, Y, ldy, R, relu, r0,
+                                                             nblk, wave, lane, 0, cb.gn_part, MAXP ? -1 : mri);
 }
 
 // ---- split mode for the same row GEMMs: every operand hi + lo bf16, three products - fp32-grade results
@@ -906,7 +913,7 @@ __device__ __forceinline__ int tn_slot(int c, int chunk) {
   return (c >> 1) * 16 + 8 * ((c ^ (c >> 2)) & 1) + ((chunk ^ (c >> 1) ^ (c >> 4)) & 7);
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool XH = false>  // XH: X holds bf16 rows (ldx in elements) - the saved activations of the autocast encoder forward
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                        int ldx, float* __restrict__ part, int J, int K, int R,
                                                        int rows_per_split, float* __restrict__ colpart,
@@ -961,7 +968,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
             for (int q = 0; q < 4; ++q) vy[u][q] = m[q] > 0.f ? vy[u][q] : 0.f;
           }
         }
-        if (kc < K) vx[u] = *reinterpret_cast<const f32x4*>(X + (xrows ? (size_t)xi[u] : (size_t)gr) * ldx + kc);
+        if (kc < K) {
+          const size_t xo = (xrows ? (size_t)xi[u] : (size_t)gr) * ldx + kc;
+          if constexpr (XH) {
+            // the RAW 8 bytes (four bf16) ride in the first two words until stage(): a conversion here would wait for the
+            // load, and these loads are meant to fly during the MFMAs of the slab before
+            const u32x2 r = reinterpret_cast<const u32x2*>(X)[xo >> 2];
+            vx[u][0] = __uint_as_float(r[0]);
+            vx[u][1] = __uint_as_float(r[1]);
+          } else {
+            vx[u] = *reinterpret_cast<const f32x4*>(X + xo);
+          }
+        }
       }
     }
   };
@@ -995,7 +1013,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_lp(const float* __restrict__
       }
     }
     stage(vy, ys);
-    stage(vx, xs);
+    if constexpr (XH) {
+      // bf16 rows are the operand already: the eight rows' halves of channel q, paired as pack_bf8 pairs them
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u32x4 w;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const unsigned a = __float_as_uint(vx[2 * pr][q >> 1]), b = __float_as_uint(vx[2 * pr + 1][q >> 1]);
+          w[pr] = (q & 1) ? (a >> 16) | (b & 0xffff0000u) : (a & 0xffffu) | (b << 16);
+        }
+        xs[0][tn_slot(c4 * 4 + q, g)] = w;
+      }
+    } else {
+      stage(vx, xs);
+    }
     __syncthreads();
     if (rs + TN_ROWS < row_hi) {
       fetch(rs + TN_ROWS);  // in flight during the MFMAs below
@@ -1583,6 +1615,7 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w(const float* __restrict__ 
 // dependent global round trips whatever K is (150 us for K = 128 as for K = 512); here it is C / (8 CL) steps.
 // rowpos != nullptr: X holds COMPACT rows (the live rows of a row-sparse chain, recomputed by k_stn_recompute) - dense row r
 // sits at rowpos[r]; an arg-max row with dg == 0 is not live (rowpos < 0) and is read as row 0 (its product is an exact zero).
+template <bool XH = false>  // XH: X holds bf16 rows (ldx in elements)
 __global__ __launch_bounds__(256) void k_maxlin_bwd_w4(const float* __restrict__ dg, const int* __restrict__ idx,
                                                        const float* __restrict__ X, int ldx, float* __restrict__ dW,
                                                        float* __restrict__ db, int C, int J, int K,
@@ -1608,7 +1641,10 @@ __global__ __launch_bounds__(256) void k_maxlin_bwd_w4(const float* __restrict__
       }
       f32x4 xv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const f32x4*>(X + (size_t)row[u] * ldx + 4 * q);
+      for (int u = 0; u < 8; ++u) {
+        if constexpr (XH) xv[u] = ld_bf4(X, ((size_t)row[u] * ldx >> 2) + q);
+        else xv[u] = *reinterpret_cast<const f32x4*>(X + (size_t)row[u] * ldx + 4 * q);
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         sb += g[u];
@@ -1649,7 +1685,8 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
                                                            int ldx, int J, int K, int B, int N, int M,
                                                            const int* __restrict__ rowpos = nullptr,
                                                            const float* __restrict__ ymask = nullptr, int ldym = 0,
-                                                           int ymask_compact = 0 /*ymask holds the compact rows*/) {
+                                                           int ymask_compact = 0 /*ymask holds the compact rows*/,
+                                                           int ymask_bf16 = 0 /*ymask: bf16 rows, ldym in elements*/) {
   __shared__ int start[MLX_MAXN + 1];
   __shared__ int fill[MLX_MAXN];
   __shared__ int lst[1024];
@@ -1759,14 +1796,15 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
       }
     }
     if (ymask) {
-      const float* mr = ymask + (size_t)(ymask_compact ? rowpos[r0 + r] : r0 + r) * ldym;
+      const size_t mro = (size_t)(ymask_compact ? rowpos[r0 + r] : r0 + r) * ldym;
+      const float* mr = ymask + mro;
       if (q0 < nf4) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mr + q0 * 4);
+        const f32x4 m = ymask_bf16 ? ld_bf4(ymask, (mro >> 2) + q0) : *reinterpret_cast<const f32x4*>(mr + q0 * 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc0[u] = m[u] > 0.f ? acc0[u] : 0.f;
       }
       if (q1 < nf4) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mr + q1 * 4);
+        const f32x4 m = ymask_bf16 ? ld_bf4(ymask, (mro >> 2) + q1) : *reinterpret_cast<const f32x4*>(mr + q1 * 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc1[u] = m[u] > 0.f ? acc1[u] : 0.f;
       }

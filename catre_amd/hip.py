@@ -58,6 +58,7 @@ class CatreOpts(ctypes.Structure):
 
 
 DTYPE_F32, DTYPE_BF16, DTYPE_SPLIT = 0, 1, 2
+ROWS_BF16 = 0x100   # CATRE_ROWS_BF16
 PACK_F32_ENCODER, PACK_F32_HEADS, PACK_BF16, PACK_SPLIT, PACK_F32_TAILS, PACK_ALL = 1, 2, 4, 8, 16, 31
 ROT_6D, ROT_QUAT, ROT_LOG_QUAT, ROT_LIE_VEC = 0, 1, 2, 3
 ROT_DIMS = {ROT_6D: 6, ROT_QUAT: 4, ROT_LOG_QUAT: 3, ROT_LIE_VEC: 3}
@@ -95,6 +96,7 @@ _SIGS = {
     "catre_pack_weights_sel": (_I, [_P, _I, _I, _I, _P, _SZ, _I, _P]),
     "catre_op_rows_compact": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "catre_op_maxlin_bwd_x_compact": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_x_compact_h": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_x_compact_cm": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_w_c": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "catre_op_stn_recompute": (_I, [_I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -155,6 +157,7 @@ _SIGS = {
     "catre_op_maxpool_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "catre_op_maxpool_scatter": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_w": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "catre_op_maxlin_bwd_w_h": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_x": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "catre_op_maxlin_bwd_x_rows": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "catre_op_cloud_matmul": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

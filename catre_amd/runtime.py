@@ -233,16 +233,20 @@ class HipRuntime:
             )
 
     # ------------------------------------------------------------------ training forward on the fused encoder kernels
-    def train_encoder_buffers(self, B, N, M, device, stn_rows=True):
+    def train_encoder_buffers(self, B, N, M, device, stn_rows=True, mode=0):
         """stn_rows=False (fp32): the STN stacks' activation rows are not stored - their backward recomputes them on its
-        live rows (train_ops._PooledChain, catre_op_stn_recompute): 0.94 GB less at B = 256."""
+        live rows (train_ops._PooledChain, catre_op_stn_recompute): 0.94 GB less at B = 256.
+        mode 1 (the bf16-operand kernels): the rows of the three conv stacks behind their first layer (a1 / a2, f1 / f2,
+        c2 / c3) are bf16 - those kernels hold them as bf16 and the fp32 rows they used to write held the same values."""
         R, C = B * (N + M), 2 * B
         e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=device)
+        rdt = torch.bfloat16 if int(mode) == 1 else torch.float32
         buf = dict(
             g_stn=e(C, 1024), i_stn=e(C, 1024, dt=torch.int32), g_fstn=e(C, 1024), i_fstn=e(C, 1024, dt=torch.int32),
-            x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128), c3=e(R, 512), g=e(C, 1024), i=e(C, 1024, dt=torch.int32))
+            x1=e(R, 8), h1=e(R, 64), pf=e(R, 64), c2=e(R, 128, dt=rdt), c3=e(R, 512, dt=rdt), g=e(C, 1024),
+            i=e(C, 1024, dt=torch.int32))
         for k, w in (("a1", 64), ("a2", 128), ("f1", 64), ("f2", 128)):
-            buf[k] = e(R, w) if stn_rows else None
+            buf[k] = e(R, w, dt=rdt) if stn_rows else None
         return buf
 
     def _train_packs(self, device, mode):

@@ -54,13 +54,14 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0, obj
     layer.  Every layer op becomes a graph node around an output that exists already (``pre=``); the backward is the
     layer-wise one, unchanged.  N, M multiples of 64.  mode 0: the fp32 kernels; mode 2: the split kernels (rows hold hi + lo);
     mode 1 (autocast): the bf16-operand kernels -
-    the rows they save are the bf16-rounded activations, which is what the reduced-precision dgrad / wgrad kernels of the
-    backward make of their operands anyway."""
+    the rows they save behind each stack's first layer are bf16 ROWS (half the bytes; the values the reduced-precision dgrad /
+    wgrad kernels would round their operands to anyway), read in place by the row-sparse chains' backward - so mode 1
+    wants all three stacks to be chains (`fused_lp_ok`)."""
     w = lambda n: p[f"{prefix}.{n}"]
     dev = pts.device
     # fp32: the STN stacks store no activation rows (their row-sparse backward rebuilds them on its live rows)
     buf = rt.train_encoder_buffers(B, N, M, dev,
-                                   stn_rows=not (mode == 0 and T.knobs().stn_recompute and not pts.requires_grad))
+                                   stn_rows=not (mode == 0 and T.knobs().stn_recompute and not pts.requires_grad), mode=mode)
     rt.train_stn3d(desc, buf, B, N, M, dev, mode)
     trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M, pre=(buf["a1"], buf["a2"], buf["g_stn"], buf["i_stn"]))
     trans3 = trans.detach().reshape(-1, 9).contiguous()
@@ -83,6 +84,16 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0, obj
     h = T.linear(h, w("conv3.weight"), w("conv3.bias"), relu=True, pre=buf["c3"])
     g = T.linear_maxpool(h, w("conv4.weight"), w("conv4.bias"), False, B, N, M, pre=(buf["g"], buf["i"]))
     return g, pf, None
+
+
+def fused_lp_ok(pts, p, N, M, prefix="pcl_net"):
+    """The autocast fused encoder forward stores bf16 activation rows, which only the row-sparse chains read: every stack
+    must take that form (it does at N, M multiples of 64 up to 4096 points per cloud, for inputs without gradient)."""
+    w = lambda n: p[f"{prefix}.{n}"]
+    h1_like = torch.empty(0, 64, device=pts.device)
+    return (T.pooled_chain_ok(pts, w("stn.conv1.weight"), w("stn.conv2.weight"), w("stn.conv3.weight"), N, M)
+            and T.pooled_chain_ok(h1_like, w("fstn.conv1.weight"), w("fstn.conv2.weight"), w("fstn.conv3.weight"), N, M)
+            and T.pooled_chain_ok(h1_like, w("conv2.weight"), w("conv3.weight"), w("conv4.weight"), N, M))
 
 
 def pointnet_rows(pts, p, B, N, M, feature_transform=True, prefix="pcl_net"):
@@ -286,8 +297,11 @@ def forward_train(p, opts, x, tfd_kps, init_pose, init_scale, K_zoom=None, mean_
     elif rt is not None and T._amp() in (0, 1, 2) and opts.feature_transform and N % 64 == 0 and M % 64 == 0 \
             and N + M == rt.N + rt.M:
         pts = _cloud_major_rows(x, tfd_kps)
-        g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
-                                         obj_copy=not (fused_rot or lp_cm))
+        if T._amp() == 1 and not fused_lp_ok(pts, p, N, M):
+            (g, pf), hub = pointnet_rows(pts, p, B, N, M, True), None   # (e.g. a differentiable 3-d input: layer-wise ops)
+        else:
+            g, pf, hub = pointnet_rows_fused(pts, hip.points_desc(x, tfd_kps), rt, p, B, N, M, mode=T._amp(),
+                                             obj_copy=not (fused_rot or lp_cm))
         fused_rot = fused_rot and hub is not None
         lp_cm = lp_cm and hub is not None
     else:

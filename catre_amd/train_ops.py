@@ -636,10 +636,13 @@ def _dgrad_n(dy, w2, xmask, count, amp=0, mask=None, mask_rows=None):
     dx = torch.empty(cap, K, dtype=torch.float32, device=dev)
     if mask is not None:
         assert mask.shape[1] == K
+        # (bf16 rows: what the autocast encoder forward saves - only the bf16-operand kernel reads them)
+        rows_bf16 = hip.ROWS_BF16 if mask.dtype == torch.bfloat16 else 0
+        assert not rows_bf16 or amp == 1, "bf16 activation rows are read by the bf16-operand row GEMMs only"
         hip.check(lib.catre_op_gemm_rows_nr(hip.ptr(dy), dy.stride(0), hip.ptr(xmask),
                                             xmask.stride(0) if xmask is not None else 0, hip.ptr(wp), None, hip.ptr(mask),
                                             mask.stride(0), hip.ptr(mask_rows), hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count),
-                                            int(amp), _st(dy)), "catre_op_gemm_rows_nr")
+                                            int(amp) | rows_bf16, _st(dy)), "catre_op_gemm_rows_nr")
         return dx
     hip.check(lib.catre_op_gemm_rows_n(hip.ptr(dy), dy.stride(0), hip.ptr(xmask), xmask.stride(0) if xmask is not None else 0,
                                        hip.ptr(wp), None, None, 0, hip.ptr(dx), K, cap, K, J, 0, hip.ptr(count), int(amp),
@@ -658,11 +661,14 @@ def _wgrad_n(dy, x, ymask, count, amp=0, x_rows=None):
     dw, db = buf[: J * K].view(J, K), buf[J * K:]
     ws = _ws(lib.catre_op_gemm_tn_bias_ws_bytes(J, K, cap), dy.device)
     if x_rows is not None:
+        rows_bf16 = hip.ROWS_BF16 if x.dtype == torch.bfloat16 else 0
+        assert not rows_bf16 or amp == 1, "bf16 activation rows are read by the bf16-operand weight-gradient kernel only"
         hip.check(lib.catre_op_gemm_tn_bias_nr(hip.ptr(dy), dy.stride(0), hip.ptr(ymask),
                                                ymask.stride(0) if ymask is not None else 0, hip.ptr(x), x.stride(0),
                                                hip.ptr(x_rows), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws), ws.numel(),
-                                               hip.ptr(count), int(amp), _st(dy)), "catre_op_gemm_tn_bias_nr")
+                                               hip.ptr(count), int(amp) | rows_bf16, _st(dy)), "catre_op_gemm_tn_bias_nr")
         return dw, db
+    assert x.dtype == torch.float32
     hip.check(lib.catre_op_gemm_tn_bias_n(hip.ptr(dy), dy.stride(0), hip.ptr(ymask), ymask.stride(0) if ymask is not None else 0,
                                           hip.ptr(x), x.stride(0), hip.ptr(dw), hip.ptr(db), J, K, cap, 0, hip.ptr(ws),
                                           ws.numel(), hip.ptr(count), int(amp), _st(dy)), "catre_op_gemm_tn_bias_n")
@@ -717,15 +723,20 @@ def _pooled_chain_backward(ctx, dg, merge):
     # pooled layer: its own weight / bias gradient gathers the arg-max rows of y2 (unchanged)
     dw3 = torch.empty(J3, K3, dtype=torch.float32, device=dg.device)
     db3 = torch.empty(J3, dtype=torch.float32, device=dg.device)
-    hip.check(lib.catre_op_maxlin_bwd_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(y2), y2.stride(0), hip.ptr(dw3), hip.ptr(db3),
-                                        C, J3, K3, _st(dg)), "catre_op_maxlin_bwd_w")
+    # (y1 / y2 as bf16 rows: what the autocast encoder forward saves - the `_h` forms of the two pooled-layer kernels and
+    # the CATRE_ROWS_BF16 flag of the row GEMMs below read them in place)
+    hb = y2.dtype == torch.bfloat16
+    assert hb == (y1.dtype == torch.bfloat16)
+    fn_w, fn_x = ((lib.catre_op_maxlin_bwd_w_h, lib.catre_op_maxlin_bwd_x_compact_h) if hb
+                  else (lib.catre_op_maxlin_bwd_w, lib.catre_op_maxlin_bwd_x_compact))
+    hip.check(fn_w(hip.ptr(dg), hip.ptr(idx), hip.ptr(y2), y2.stride(0), hip.ptr(dw3), hip.ptr(db3), C, J3, K3, _st(dg)),
+              "catre_op_maxlin_bwd_w")
     rows, rowpos, count = _rows_compact(dg, idx, B, N, M)
     cap = rows.shape[0]
     # dy2 on the live rows, with y2's own ReLU applied on the way out
     dy2 = torch.empty(cap, K3, dtype=torch.float32, device=dg.device)
-    hip.check(lib.catre_op_maxlin_bwd_x_compact(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2),
-                                                y2.stride(0), hip.ptr(dy2), K3, J3, K3, B, N, M, _st(dg)),
-              "catre_op_maxlin_bwd_x_compact")
+    hip.check(fn_x(hip.ptr(dg), hip.ptr(idx), hip.ptr(w3m), K3, hip.ptr(rowpos), hip.ptr(y2), y2.stride(0), hip.ptr(dy2), K3,
+                   J3, K3, B, N, M, _st(dg)), "catre_op_maxlin_bwd_x_compact")
     amp = ctx.amp
     xk = _c(_pad_cols(x, 4))
     # no gathered copies of the saved activations: the weight-gradient GEMMs read the dense y1 / x through the live-row list,

@@ -110,6 +110,10 @@ enum { CATRE_ROT_6D = 0, CATRE_ROT_QUAT = 1, CATRE_ROT_LOG_QUAT = 2, CATRE_ROT_L
 /* CATRE_DTYPE_SPLIT: fp32 results from split-bf16 (hi + lo, three products) MFMAs on the layers holding 98 % of the FLOPs;
  * same parity bound as CATRE_DTYPE_F32 */
 enum { CATRE_DTYPE_F32 = 0, CATRE_DTYPE_BF16 = 1, CATRE_DTYPE_SPLIT = 2 };
+/* OR-ed into the compute_dtype of catre_op_gemm_rows_nr / catre_op_gemm_tn_bias_nr (with CATRE_DTYPE_BF16): the row-indexed
+ * dense tensor - `mask` / `X` - holds bf16 rows (leading dimension in ELEMENTS): the activation rows the autocast encoder
+ * forward saves (catre_train_*_fwd with CATRE_DTYPE_BF16) */
+enum { CATRE_ROWS_BF16 = 0x100 };
 
 /* ---- sizes ---------------------------------------------------------------------------- */
 
@@ -528,6 +532,13 @@ int catre_op_rows_compact(const float* dg, const int32_t* idx, int J, int B, int
 int catre_op_maxlin_bwd_x_compact(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
                                   const float* ymask, int ldym, float* dXc, int ldx, int J, int K, int B, int N, int M,
                                   void* stream);
+/* catre_op_maxlin_bwd_x_compact / catre_op_maxlin_bwd_w with the saved activation - the ReLU mask / the gathered operand -
+ * as bf16 rows (leading dimension in elements): the backward of the pooled layer behind the autocast encoder forward */
+int catre_op_maxlin_bwd_x_compact_h(const float* dg, const int32_t* idx, const float* W, int ldw, const int32_t* rowpos,
+                                    const void* ymask, int ldym, float* dXc, int ldx, int J, int K, int B, int N, int M,
+                                    void* stream);
+int catre_op_maxlin_bwd_w_h(const float* dg, const int32_t* idx, const void* X, int ldx, float* dW, float* db, int C, int J,
+                            int K, void* stream);
 /* Recompute instead of save (the STN stacks' row-sparse backward, fp32): catre_op_stn_recompute rebuilds
  * y1 = relu(conv1 x) [cap,64] and y2 = relu(conv2 y1) [cap,128] for the count[0] live rows as COMPACT rows with the forward
  * kernels' own device code (same bits), so catre_train_stn3d_fwd / _stnkd_fwd may be called without row buffers.
@@ -561,7 +572,8 @@ int catre_op_gemm_tn_bias_n(const float* dY, int ldy, const float* ymask, int ld
                             const int32_t* nrows_dev, int compute_dtype, void* stream);
 /* the two above with row indirection against DENSE tensors (no gathered copies of the saved activations in the row-sparse
  * backward): output row r of catre_op_gemm_rows_nr is masked with row mask_rows[r] of `mask`; catre_op_gemm_tn_bias_nr
- * contracts dY row r with row x_rows[r] of X.  Every compute_dtype; a null index array is the identity */
+ * contracts dY row r with row x_rows[r] of X.  Every compute_dtype; a null index array is the identity.
+ * compute_dtype = CATRE_DTYPE_BF16 | CATRE_ROWS_BF16: `mask` / `X` are bf16 rows (ldm / ldx in elements) */
 int catre_op_gemm_rows_nr(const float* X, int ldx, const float* xmask, int ldxm, const void* Wp, const float* bias,
                           const float* mask, int ldm, const int32_t* mask_rows, float* Y, int ldy, int R, int J, int K,
                           int relu, const int32_t* nrows_dev, int compute_dtype, void* stream);
@@ -578,8 +590,10 @@ int catre_op_gemm_tn_bias_nr(const float* dY, int ldy, const float* ymask, int l
  *          a3 = relu(conv3) [R,512]                                               (pointnet.py:98-116)
  * N and M multiples of 64; `workspace` as catre_workspace_bytes.  compute_dtype = CATRE_DTYPE_F32 (fp32 packs,
  * CATRE_PACK_F32_ENCODER, in `packed`) or CATRE_DTYPE_BF16 (what torch.autocast selects, engine.py:304: the bf16-operand
- * kernels, CATRE_PACK_BF16 packs; the saved rows then hold the bf16-rounded activations as fp32 - the reduced-precision
- * dgrad / wgrad ops round their operands the same way when they stage them; trans64 required) or CATRE_DTYPE_SPLIT (the
+ * kernels, CATRE_PACK_BF16 packs; a1 / a2, f1 / f2 and the trunk's a2 / a3 are then bf16 ROWS - [R,width] bf16, half the
+ * bytes, the values the reduced-precision dgrad / wgrad ops round their operands to anyway - which the row-sparse
+ * backward reads in place (catre_op_maxlin_bwd_w_h / _x_compact_h, CATRE_ROWS_BF16); x1, h1 and pf stay fp32 rows holding
+ * bf16-rounded values; trans64 required) or CATRE_DTYPE_SPLIT (the
  * split-bf16 kernels, CATRE_PACK_SPLIT | CATRE_PACK_F32_ENCODER packs - conv2 of the trunk stays an fp32 MFMA layer; the saved rows
  * hold hi + lo; trans64 required).
  * catre_train_stn3d_fwd / _stnkd_fwd, CATRE_DTYPE_F32 only: a1 = a2 = NULL (f1 = f2 = NULL) stores no activation rows - the

@@ -228,7 +228,7 @@ def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path(mode
     mi = {"bf16": 1, "split": 2}[mode]
     rel = 1e-2 if mode == "bf16" else 1e-4
     for m_ in (0, mi):
-        buf = rt.train_encoder_buffers(B, N, M, torch.device(DEV))
+        buf = rt.train_encoder_buffers(B, N, M, torch.device(DEV), mode=m_)   # bf16: the rows behind each stack's first layer are bf16
         for v in buf.values():
             v.fill_(0) if v.dtype == torch.int32 else v.fill_(float("nan"))
         rt.train_stn3d(desc, buf, B, N, M, torch.device(DEV), m_)
@@ -239,6 +239,9 @@ def test_autocast_fused_encoder_forward_matches_the_layerwise_autocast_path(mode
         torch.cuda.synchronize()
         bufs[m_] = buf
     got, ref = bufs[mi], bufs[0]
+    if mode == "bf16":
+        assert all(got[k].dtype == torch.bfloat16 for k in ("a1", "a2", "f1", "f2", "c2", "c3"))
+        got = {k: (v.float() if v.dtype == torch.bfloat16 else v) for k, v in got.items()}
     for k in ("a1", "x1", "h1", "pf"):   # inputs of the first reduced GEMMs: the fp32 values (bf16: rounded to bf16)
         want = ref[k].to(torch.bfloat16).float() if mode == "bf16" else ref[k]
         assert torch.isfinite(got[k]).all(), k
