@@ -440,7 +440,8 @@ __device__ __forceinline__ void argmax_tile_store(const f32x16 (&acc)[MB][NB], f
     for (int nb = NB - 1; nb >= 0; --nb)
 #pragma unroll
       for (int r = 15; r >= 0; --r)  // decreasing point order inside a half-wave: the first occurrence is the last hit
-        am = acc[mb][nb][r] == m ? nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h : am;
+        am = acc[mb][nb][r] == m ? nb * 32 + (r & 3) + 8 * (r >> 2) : am;  // (an inline constant; the half-wave's 4h joins once)
+    am += 4 * h;
     m += bl[mb];
     const float mo = __shfl_xor(m, 32);
     const int ao = __shfl_xor(am, 32);
