@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round-6 docs quote, collected on a GPU box from the build of this commit (run from the repo root), in
 # parts that each finish within a few minutes and write only small summaries:
-#   profiles/collect_r06.sh tests|bench|small|prof|train|pmc|pmctrain|bf16|sweep      -> gpurun_out/r06_*   (copy the summaries into profiles/)
+#   profiles/collect_r06.sh tests|bench|small|prof|train|launches|pmc|pmctrain|bf16|sweep      -> gpurun_out/r06_*   (copy the summaries into profiles/)
 o=gpurun_out
 part=${1:-all}
 want() { [ "$part" = all ] || [ "$part" = "$1" ]; }
@@ -33,6 +33,16 @@ if want train; then
   python profiles/gemm_probe.py 2>/dev/null | grep '^{' > $o/r06_gemm_probe.jsonl
   profiles/prof.sh $o/r06_train_bf16_kernel_stats.csv python $PWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1
   profiles/prof.sh $o/r06_train_split_kernel_stats.csv python $PWD/bench.py --mode train --dtype split --steps 3 --warmup 1
+fi
+if want launches; then   # what an iteration launches and from where, where the GPU idles, how far ahead the host runs
+  python profiles/train_launch_census.py 2>/dev/null | grep -v "^\[W\|Warning\|warn" > $o/r06_train_launch_census.txt
+  AMP=1 python profiles/train_launch_census.py 2>/dev/null | grep -v "^\[W\|Warning\|warn" > $o/r06_train_launch_census_amp.txt
+  PROF_TRACE="$PWD/$o/r06_train_trace.csv 1500" profiles/prof.sh /tmp/r06_tk.csv python $PWD/bench.py --mode train --steps 3 --warmup 1 > /dev/null
+  { echo "fp32:"; python profiles/gap_report.py $o/r06_train_trace.csv 8; } > $o/r06_train_gaps.txt
+  PROF_TRACE="$PWD/$o/r06_train_bf16_trace.csv 1500" profiles/prof.sh /tmp/r06_tk.csv python $PWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1 > /dev/null
+  { echo "autocast (under rocprofv3 the host, not the GPU, paces this mode - r06_train_host_time.jsonl has the unprofiled margins):"; python profiles/gap_report.py $o/r06_train_bf16_trace.csv 8; } >> $o/r06_train_gaps.txt
+  { python profiles/train_host_time.py 256; AMP=1 python profiles/train_host_time.py 256; python profiles/train_host_time.py 16; AMP=1 python profiles/train_host_time.py 16; } 2>/dev/null | grep '^{' > $o/r06_train_host_time.jsonl
+  rm -f $o/r06_train_trace.csv $o/r06_train_bf16_trace.csv /tmp/r06_tk.csv
 fi
 if want pmctrain; then   # counters for config 3 (MFMA busy, FETCH / WRITE per training kernel), fp32 and autocast
   profiles/pmc.sh /tmp/pmc_r06t --mode train > /dev/null 2>&1
