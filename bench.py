@@ -232,9 +232,12 @@ def cpu_baseline(cfg_fn, sd):
         for th in sorted({min(cores, t) for t in (4, 8, 16, 32, 64)}):
             torch.set_num_threads(th)
             O.refine_k(one, sd, cfg, n_iter=1)
-            t0 = time.perf_counter()
-            O.refine_k(one, sd, cfg, n_iter=2)
-            t = time.perf_counter() - t0
+            t = None
+            for _ in range(3):  # best of three: one 2-iteration trial per count let a noisy neighbour pick 32 threads (85 ms
+                t0 = time.perf_counter()  # per refine) where 16 take 35 ms
+                O.refine_k(one, sd, cfg, n_iter=2)
+                dt_ = time.perf_counter() - t0
+                t = dt_ if t is None or dt_ < t else t
             if b1_t is None or t < b1_t:
                 b1, b1_t = th, t
         torch.set_num_threads(b1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round-6 docs quote, collected on a GPU box from the build of this commit (run from the repo root), in
 # parts that each finish within a few minutes and write only small summaries:
-#   profiles/collect_r06.sh tests|bench|small|prof|train|launches|pmc|pmctrain|bf16|sweep      -> gpurun_out/r06_*   (copy the summaries into profiles/)
+#   profiles/collect_r06.sh tests|bench|small|prof|train|launches|ddp|pmc|pmctrain|bf16|sweep      -> gpurun_out/r06_*   (copy the summaries into profiles/)
 o=gpurun_out
 part=${1:-all}
 want() { [ "$part" = all ] || [ "$part" = "$1" ]; }
@@ -43,6 +43,11 @@ if want launches; then   # what an iteration launches and from where, where the 
   { echo "autocast (under rocprofv3 the host, not the GPU, paces this mode - r06_train_host_time.jsonl has the unprofiled margins):"; python profiles/gap_report.py $o/r06_train_bf16_trace.csv 8; } >> $o/r06_train_gaps.txt
   { python profiles/train_host_time.py 256; AMP=1 python profiles/train_host_time.py 256; python profiles/train_host_time.py 16; AMP=1 python profiles/train_host_time.py 16; } 2>/dev/null | grep '^{' > $o/r06_train_host_time.jsonl
   rm -f $o/r06_train_trace.csv $o/r06_train_bf16_trace.csv /tmp/r06_tk.csv
+fi
+if want ddp; then   # the reference's DDP wrap on a one-rank RCCL group: the default line's block on a second box, 4 MiB buckets + view, kernels
+  python bench.py > $o/r06_bench_ddp.json 2> /dev/null
+  python bench.py --mode train --ddp-world1 --bucket-cap-mb 4 --bucket-view --steps 4 --warmup 2 2>/dev/null | grep '^{' > $o/r06_train_ddp4.json
+  profiles/prof.sh $o/r06_train_ddp_kernel_stats.csv python $PWD/profiles/ddp_prof.py
 fi
 if want pmctrain; then   # counters for config 3 (MFMA busy, FETCH / WRITE per training kernel), fp32 and autocast
   profiles/pmc.sh /tmp/pmc_r06t --mode train > /dev/null 2>&1
