@@ -290,7 +290,23 @@ def check(status, what):
         raise CatreHipError(f"{what} failed: {msg} (status {status})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None):
+    """The current stream of `device` (a torch.device, an index or None = the current device) as a `void*`.  Through torch's
+    raw-stream accessor when it exists: `torch.cuda.current_stream()` builds a Stream object per call - 5 us, ~70 times per
+    training iteration."""
+    if _raw_stream is not None:
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            if isinstance(device, str):
+                device = torch.device(device)
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

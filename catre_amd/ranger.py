@@ -72,16 +72,28 @@ class Ranger(Optimizer):
         if len(groups_betas) != 1 or len(groups_eps) != 1:
             raise NotImplementedError("fused Ranger: betas / eps must be the same in every param group (lr, weight_decay, k may differ)")
         (beta1, beta2), eps = next(iter(groups_betas)), next(iter(groups_eps))
-        recs, dev = [], None
+        # One pass over the parameters fills plain lists; the pinned record table is then written column by column (a
+        # structured-array row assignment per tensor, two checker calls and a fresh rectification term per tensor were
+        # 0.65 ms of a 4 ms host iteration; this is 0.15).
+        f32 = torch.float32
+        ps, gs, sts = [], [], []
+        c_lr, c_wd, c_ad, c_look, c_rl, c_n = [], [], [], [], [], []
+        terms = {}
+        dev = None
         for group in self.param_groups:
+            lr, wd, k = group["lr"], group["weight_decay"], group["k"]
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if p.grad.is_sparse:
+                if g.is_sparse:
                     raise RuntimeError("Ranger optimizer does not support sparse gradients")
-                hip.require_dev_f32(p, "parameter")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                hip.require_dev_f32(g, "gradient")
+                if not (p.is_cuda and p.dtype is f32):
+                    hip.require_dev_f32(p, "parameter")   # raises with the library's message
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if not (g.is_cuda and g.dtype is f32):
+                    hip.require_dev_f32(g, "gradient")
                 if not p.is_contiguous():
                     raise ValueError("fused Ranger needs contiguous parameters")
                 dev = p.device
@@ -91,46 +103,59 @@ class Ranger(Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["slow_buffer"] = p.detach().clone(memory_format=torch.contiguous_format)
-                st["step"] += 1
-                size, adaptive = self._step_terms(st["step"], beta1, beta2)
+                step = st["step"] + 1
+                st["step"] = step
+                t = terms.get(step)
+                if t is None:
+                    t = terms[step] = self._step_terms(step, beta1, beta2)
                 gc = self.use_gc and p.dim() > self.gc_gradient_threshold
-                recs.append((p, g, st, size * group["lr"], group["weight_decay"] * group["lr"], adaptive,
-                             st["step"] % group["k"] == 0, (p.numel() // p.shape[0]) if gc else 0))
-        if not recs:
+                n = p.numel()
+                ps.append(p), gs.append(g), sts.append(st)
+                c_lr.append(t[0] * lr), c_wd.append(wd * lr), c_ad.append(int(t[1])), c_look.append(int(step % k == 0))
+                c_n.append(n), c_rl.append((n // p.shape[0]) if gc else 0)
+        if not ps:
             self._pending = None
             return False
-        key = tuple((r[0].data_ptr(), r[0].numel(), r[7]) for r in recs)
+        nrec = len(ps)
+        p_ptr = [p.data_ptr() for p in ps]
+        key = tuple(zip(p_ptr, c_n, c_rl))
         if self._layout is None or self._layout["key"] != key:
             chunks, row_tensor = [], []
-            for ti, r in enumerate(recs):
-                n = r[0].numel()
+            for ti in range(nrec):
+                n = c_n[ti]
                 chunks += [(ti, o) for o in range(0, n, _CHUNK)]
-                if r[7] > 0:
-                    row_tensor += [ti] * (n // r[7])
+                if c_rl[ti] > 0:
+                    row_tensor += [ti] * (n // c_rl[ti])
             # two pinned slots, used alternately: the host may fill one while the asynchronous upload of the other
             # is still queued behind earlier GPU work
-            hosts = [torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            hosts = [torch.empty(nrec * _REC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            row_off, off = [], 0
+            for ti in range(nrec):
+                row_off.append(off)
+                if c_rl[ti] > 0:
+                    off += c_n[ti] // c_rl[ti]
             self._layout = dict(
-                key=key, n_chunks=len(chunks), total_rows=len(row_tensor),
+                key=key, n_chunks=len(chunks), total_rows=len(row_tensor), row_off=row_off,
                 chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
                 rows=torch.tensor(row_tensor if row_tensor else [0], dtype=torch.int32).to(dev),
                 ws=torch.empty(max(len(row_tensor), 1), dtype=torch.float32, device=dev),
                 hosts=hosts, tables=[h.numpy().view(_REC) for h in hosts], events=[None, None], slot=0,
-                dev=torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev),
+                dev=torch.empty(nrec * _REC.itemsize, dtype=torch.uint8, device=dev),
             )
         L = self._layout
         L["slot"] ^= 1
         if wait and L["events"][L["slot"]] is not None:
             L["events"][L["slot"]].synchronize()  # its previous upload (two steps ago) has long been consumed
         table = L["tables"][L["slot"]]
-        row_off = 0
-        for i, (p, g, st, lr_step, wd_lr, adaptive, look, row_len) in enumerate(recs):
-            table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                        st["slow_buffer"].data_ptr(), p.numel(), row_len, row_off, lr_step, wd_lr, int(adaptive), int(look), 0)
-            if row_len > 0:
-                row_off += p.numel() // row_len
+        table["p"] = p_ptr
+        table["g"] = [g.data_ptr() for g in gs]
+        table["m"] = [st["exp_avg"].data_ptr() for st in sts]
+        table["v"] = [st["exp_avg_sq"].data_ptr() for st in sts]
+        table["slow"] = [st["slow_buffer"].data_ptr() for st in sts]
+        table["numel"], table["row_len"], table["row_off"] = c_n, c_rl, L["row_off"]
+        table["lr_step"], table["wd_lr"], table["adaptive"], table["lookahead"], table["pad"] = c_lr, c_wd, c_ad, c_look, 0
         # the (possibly copied-to-contiguous) gradients must outlive the launch
-        self._pending = dict(n=len(recs), beta1=beta1, beta2=beta2, eps=eps, device=dev, keep=[r[1] for r in recs])
+        self._pending = dict(n=nrec, beta1=beta1, beta2=beta2, eps=eps, device=dev, keep=gs)
         return True
 
     def upload_table(self):

@@ -152,7 +152,7 @@ class HipRuntime:
         # concurrently, profiles/multi_stream_probe.py) must not share intermediates; calls on one stream are ordered
         if self._ws is None:
             self._ws = {}
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        key = (device.index, hip.stream_ptr(device).value or 0)
         ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < need:
             if ws is None and len(self._ws) >= 16:
@@ -262,23 +262,24 @@ class HipRuntime:
         # (data_ptr, _version, epoch) fingerprint cannot see writes through `p.data` (EMA, third-party optimizers), and a
         # stale forward image next to a live-weight backward would give inconsistent gradients without any error.
         self._fingerprint = None
-        prm, packed = self._train_packs(device, mode)
+        prm, packed = packs = self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_stn3d_fwd(ctypes.byref(pts), prm, hip.ptr(packed), hip.ptr(buf["a1"]), hip.ptr(buf["a2"]),
                                             hip.ptr(buf["g_stn"]), hip.ptr(buf["i_stn"]), hip.ptr(ws), ws.numel(), B, N, M,
                                             int(mode), hip.stream_ptr(device)), "catre_train_stn3d_fwd")
+        return packs   # what the other two encoder kernels of the SAME forward may be handed (`packs=`: no second fingerprint)
 
-    def train_stnkd(self, pts, trans3, buf, B, N, M, device, mode=0):
+    def train_stnkd(self, pts, trans3, buf, B, N, M, device, mode=0, packs=None):
         lib = hip.load()
-        prm, packed = self._train_packs(device, mode)
+        prm, packed = packs if packs is not None else self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_stnkd_fwd(ctypes.byref(pts), hip.ptr(trans3), prm, hip.ptr(packed), hip.ptr(buf["f1"]),
                                             hip.ptr(buf["f2"]), hip.ptr(buf["g_fstn"]), hip.ptr(buf["i_fstn"]), hip.ptr(ws),
                                             ws.numel(), B, N, M, int(mode), hip.stream_ptr(device)), "catre_train_stnkd_fwd")
 
-    def train_trunk(self, pts, trans3, trans64, buf, B, N, M, device, mode=0):
+    def train_trunk(self, pts, trans3, trans64, buf, B, N, M, device, mode=0, packs=None):
         lib = hip.load()
-        prm, packed = self._train_packs(device, mode)
+        prm, packed = packs if packs is not None else self._train_packs(device, mode)
         ws = self.workspace(B, N, M, device)
         hip.check(lib.catre_train_trunk_fwd(ctypes.byref(pts), hip.ptr(trans3), hip.ptr(trans64), prm, hip.ptr(packed),
                                             hip.ptr(buf["x1"]), hip.ptr(buf["h1"]), hip.ptr(buf["pf"]), hip.ptr(buf["c2"]),

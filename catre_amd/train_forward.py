@@ -62,16 +62,16 @@ def pointnet_rows_fused(pts, desc, rt, p, B, N, M, prefix="pcl_net", mode=0, obj
     # fp32: the STN stacks store no activation rows (their row-sparse backward rebuilds them on its live rows)
     buf = rt.train_encoder_buffers(B, N, M, dev,
                                    stn_rows=not (mode == 0 and T.knobs().stn_recompute and not pts.requires_grad), mode=mode)
-    rt.train_stn3d(desc, buf, B, N, M, dev, mode)
+    packs = rt.train_stn3d(desc, buf, B, N, M, dev, mode)   # (params, packed image): re-packed here, shared by the three kernels
     trans = _stn(pts, p, f"{prefix}.stn", 3, B, N, M, pre=(buf["a1"], buf["a2"], buf["g_stn"], buf["i_stn"]))
     trans3 = trans.detach().reshape(-1, 9).contiguous()
     # x1 / h1 are written by the trunk kernel further down (same stream, before anything reads them)
     x1 = T.cloud_matmul(pts, trans, B, N, M, out_cols=8, pre=buf["x1"])
     h1, h1s = T.linear_fan2(x1, w("conv1.weight"), w("conv1.bias"), relu=True, pre=buf["h1"])  # two consumers, one backward pass
-    rt.train_stnkd(desc, trans3, buf, B, N, M, dev, mode)
+    rt.train_stnkd(desc, trans3, buf, B, N, M, dev, mode, packs=packs)
     trans_feat = _stn(h1s, p, f"{prefix}.fstn", 64, B, N, M, pre=(buf["f1"], buf["f2"], buf["g_fstn"], buf["i_fstn"]))
     trans64 = trans_feat.detach().reshape(-1, 4096).contiguous()
-    rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode)
+    rt.train_trunk(desc, trans3, trans64, buf, B, N, M, dev, mode, packs=packs)
     pf = T.cloud_matmul(h1, trans_feat, B, N, M, pre=buf["pf"])
     if T.pooled_chain_ok(pf, w("conv2.weight"), w("conv3.weight"), w("conv4.weight"), N, M):
         # the conv stack with its row-sparse backward AND pointfeat's two other consumers (max over points, the rotation

@@ -25,8 +25,7 @@ def _ws(nbytes, device):
     current stream, so reuse on one stream is ordered, and training iterations on different streams (or a captured
     ``GraphedTrainStep`` next to eager steps) never share split-K partials.  A buffer that is outgrown is dropped here
     only - whoever captured its address (``GraphedTrainStep``) keeps its own reference (``scratch_of``)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), hip.stream_ptr(device).value or 0)
     buf = _scratch.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         if buf is None and len(_scratch) >= 32:
