@@ -189,6 +189,66 @@ def test_small_linear_backward_in_one_launch(R, J, Kx, Kw, masked, mode):
                                Kw, 0, hip.stream_ptr(torch.device(DEV))) != 0, "db alone is refused"
 
 
+def test_hub_sums_the_consumers_of_a_tensor_in_one_launch():
+    """train_ops.hub (catre_op_sum_rows): t -> (t[:rc], t, t); the gradient of t is the sum of what its consumers send back,
+    equal to autograd's own route through a slice (zero-fill + copy) and two adds - for any subset of consumers that is used,
+    and for a slice gradient that arrives as a column slice of a wider tensor (read in place)."""
+    from catre_amd import train_ops as T
+
+    g = _gen(11)
+    R, rc, K = 37, 13, 70
+    base = torch.randn(R, K, generator=g)
+    wa, wb = torch.randn(R, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
+    wide = torch.randn(rc, K + 9, generator=g).to(DEV)   # the slice consumer's gradient: columns 4 .. 4 + K of a wider matrix
+    for use in ((1, 1, 1), (1, 0, 0), (0, 1, 1), (1, 1, 0), (0, 0, 1)):
+        t = base.clone().to(DEV).requires_grad_(True)
+        c, a, b = T.hub(t, rc)
+        assert torch.equal(c, t[:rc]) and torch.equal(a, t) and torch.equal(b, t)
+        tr = base.clone().to(DEV).requires_grad_(True)
+        loss, lossr = 0.0, 0.0
+        if use[0]:
+            pad = torch.zeros(rc, K + 9, device=DEV)
+            pad = torch.cat([pad[:, :4], c, pad[:, 4 + K:]], 1)       # c's gradient = wide[:, 4:4+K]: a strided view
+            loss = loss + (pad * wide).sum()
+            lossr = lossr + (tr[:rc] * wide[:, 4:4 + K]).sum()
+        if use[1]:
+            loss, lossr = loss + (a * wa).sum(), lossr + (tr * wa).sum()
+        if use[2]:
+            loss, lossr = loss + (b * wb).sum(), lossr + (tr * wb).sum()
+        loss.backward()
+        lossr.backward()
+        _cmp(t.grad, tr.grad.cpu(), f"hub {use}", atol=1e-6, rtol=1e-6)
+
+
+def test_conv_p_backward_also_gives_the_neck_bias_gradient():
+    """catre_op_wsum_bwd_n: dbn = column sums of dY3 taken as (sum_p w_p) (sum_b dout_b) in the launch that sums dbias;
+    dY3, dw and dbias are those of catre_op_wsum_bwd bit for bit."""
+    from catre_amd import hip
+
+    g = _gen(12)
+    B, P = 9, 192
+    dout, y3, w = torch.randn(B, 3, generator=g), torch.randn(B * P, 3, generator=g), torch.randn(P, generator=g)
+    dd, yd, wd = dout.to(DEV), y3.to(DEV), w.to(DEV)
+    lib, st = hip.load(), hip.stream_ptr(torch.device(DEV))
+    outs = []
+    for with_n in (False, True):
+        dy, dw, db, dbn = (torch.empty(B * P, 3, device=DEV), torch.empty(P, device=DEV), torch.empty(1, device=DEV),
+                           torch.full((3,), 7.0, device=DEV))
+        ws = torch.empty(B * P * 4, dtype=torch.uint8, device=DEV)
+        if with_n:
+            hip.check(lib.catre_op_wsum_bwd_n(hip.ptr(dd), hip.ptr(yd), hip.ptr(wd), hip.ptr(dy), hip.ptr(dw), hip.ptr(db),
+                                              hip.ptr(dbn), 0, hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd_n")
+        else:
+            hip.check(lib.catre_op_wsum_bwd(hip.ptr(dd), hip.ptr(yd), hip.ptr(wd), hip.ptr(dy), hip.ptr(dw), hip.ptr(db), 0,
+                                            hip.ptr(ws), ws.numel(), B, P, st), "catre_op_wsum_bwd")
+        outs.append((dy, dw, db, dbn))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    want_dy = (w.double().view(1, P, 1) * dout.double().view(B, 1, 3)).reshape(B * P, 3)
+    _cmp(outs[1][0], want_dy, "dY3")
+    _cmp(outs[1][3], want_dy.sum(0), "dbn", atol=2e-4, rtol=2e-5)
+
+
 def test_linear_identity_tail():
     from catre_amd import train_ops as T
 

@@ -436,3 +436,38 @@ def test_training_kernel_knobs_are_scoped_per_call_not_module_globals():
         T.train_kernels(dict(no_such_knob=True))
     for name in ("FUSED_LP_ROT", "LP_ROT_BF16_ROWS", "LP_ROT_FUSE_GN0", "SPLIT_L0_SP"):
         assert not hasattr(T, name)
+
+
+def test_loss_dict_sum_chain_returns_the_precomputed_running_sums():
+    """catre_amd.losses._LossTerm on plain CPU tensors (the mechanics need no GPU): `sum(dict.values())` walks the chain
+    0 + v0, prefix0 + v1, ... and gets the precomputed tensors back (attached to the same autograd graph); any other
+    arithmetic on the values is plain torch and gives plain tensors."""
+    import torch
+
+    from catre_amd.losses import _LossTerm
+
+    l = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], requires_grad=True)
+    order = [0, 2, 5]
+    pre = torch.cumsum(l[order], 0)
+    tok = object()
+    sums = [t.as_subclass(_LossTerm) for t in pre.unbind(0)]
+    for k, t in enumerate(sums):
+        t._chain_tok, t._sum_pos = tok, k
+    ld = {}
+    for k, (name, i) in enumerate(zip("abc", order)):
+        t = l.unbind(0)[i].as_subclass(_LossTerm)
+        t._chain_tok, t._term_pos, t._next_sum = tok, k, sums[k]
+        ld[name] = t
+    tot = sum(ld.values())
+    assert tot is sums[2] and float(tot.detach()) == 10.0
+    tot.backward()
+    assert l.grad.tolist() == [1.0, 0.0, 1.0, 0.0, 0.0, 1.0]
+    assert ld["c"] + (ld["b"] + (ld["a"] + 0)) is sums[2]                 # either operand order
+    assert type(ld["a"] + ld["c"]) is torch.Tensor and float((ld["a"] + ld["c"]).detach()) == 7.0   # off the chain
+    assert type(ld["b"] * 2) is torch.Tensor and type(torch.stack(list(ld.values()))) is torch.Tensor
+    assert type(1 + ld["a"]) is torch.Tensor and type(sums[0] + ld["c"]) is torch.Tensor              # not the next step
+    other = object()
+    foreign = l.unbind(0)[1].as_subclass(_LossTerm)
+    foreign._chain_tok, foreign._term_pos, foreign._next_sum = other, 1, sums[1]
+    assert type(sums[0] + foreign) is torch.Tensor                                                    # another dict's term
+    assert {k: round(float(v.detach()), 6) for k, v in ld.items()} == {"a": 1.0, "b": 3.0, "c": 6.0}
