@@ -207,6 +207,40 @@ def test_autocast_iteration_with_bf16_rows_tracks_the_fp32_iteration():
     assert checked >= 20
 
 
+def test_autocast_iteration_with_differentiable_points_takes_the_layerwise_encoder():
+    """The autocast fused encoder forward saves bf16 activation rows that only the row-sparse chains read; with a
+    differentiable 3-d input the first STN stack is not a chain (train_forward.fused_lp_ok), so the whole encoder runs
+    layer-wise: the parameter gradients track the default autocast iteration's and the points get a finite gradient."""
+    from test_hip_train import _train_setup, _iteration
+
+    B, N, M = 4, 128, 128
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 35, 1)
+
+    def run(diff_points):
+        kk = dict(kw)
+        if diff_points:
+            kk["x"] = kk["x"].clone().requires_grad_(True)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ld = _iteration(model, kk, sym)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return ld, grads, (kk["x"].grad if diff_points else None)
+
+    l0, g0, _ = run(False)
+    l1, g1, gx = run(True)
+    assert gx is not None and torch.isfinite(gx).all() and float(gx.abs().max()) > 0
+    for k in l0:
+        assert abs(float(l1[k]) - float(l0[k])) <= 3e-2 * abs(float(l0[k])) + 1e-3, (k, float(l1[k]), float(l0[k]))
+    checked = 0
+    for k, g in g0.items():
+        if g.numel() < 4096 or float(g.norm()) < 1e-8:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), g1[k].reshape(-1), dim=0))
+        assert cos >= 0.97, (k, cos)
+        checked += 1
+    assert checked >= 20
+
+
 def test_groupnorm0_inside_the_second_linears_staging_changes_nothing():
     """catre_op_gn_gelu_gemm_rows_h (GroupNorm-0 + GELU applied while the 256 -> 256 GEMM stages its operand) against the
     separate pass + GEMM: the head's output and every gradient bit for bit."""
