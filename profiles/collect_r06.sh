@@ -39,8 +39,10 @@ if want launches; then   # what an iteration launches and from where, where the 
   AMP=1 python profiles/train_launch_census.py 2>/dev/null | grep -v "^\[W\|Warning\|warn" > $o/r06_train_launch_census_amp.txt
   PROF_TRACE="$PWD/$o/r06_train_trace.csv 1500" profiles/prof.sh /tmp/r06_tk.csv python $PWD/bench.py --mode train --steps 3 --warmup 1 > /dev/null
   { echo "fp32:"; python profiles/gap_report.py $o/r06_train_trace.csv 8; } > $o/r06_train_gaps.txt
+  python profiles/iteration_stats.py $o/r06_train_trace.csv $o/r06_train_iter_kernel_stats.csv > $o/r06_train_iter_counts.txt
   PROF_TRACE="$PWD/$o/r06_train_bf16_trace.csv 1500" profiles/prof.sh /tmp/r06_tk.csv python $PWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1 > /dev/null
   { echo "autocast (under rocprofv3 the host, not the GPU, paces this mode - r06_train_host_time.jsonl has the unprofiled margins):"; python profiles/gap_report.py $o/r06_train_bf16_trace.csv 8; } >> $o/r06_train_gaps.txt
+  python profiles/iteration_stats.py $o/r06_train_bf16_trace.csv $o/r06_train_bf16_iter_kernel_stats.csv >> $o/r06_train_iter_counts.txt
   { python profiles/train_host_time.py 256; AMP=1 python profiles/train_host_time.py 256; python profiles/train_host_time.py 16; AMP=1 python profiles/train_host_time.py 16; } 2>/dev/null | grep '^{' > $o/r06_train_host_time.jsonl
   rm -f $o/r06_train_trace.csv $o/r06_train_bf16_trace.csv /tmp/r06_tk.csv
 fi
