@@ -501,6 +501,29 @@ def test_summing_the_loss_dict_takes_the_precomputed_chain(variant):
     assert torch.equal(part.detach().as_subclass(torch.Tensor), (vals[0].as_subclass(torch.Tensor) + vals[1].as_subclass(torch.Tensor)).detach())
 
 
+def test_inference_after_a_training_forward_repacks_the_tail_images():
+    """A training forward packs without the inference tails' images (CATRE_PACK_F32_TAILS: the ts head's transposed weights
+    and the conv_p sums are read by the inference tail kernels only); an inference call on the same model right after - same
+    weights, so the same fingerprint - must still get them: R, t, s equal, bit for bit, to a fresh model's."""
+    from catre_amd.CATRE_disR_shared import build_model_optimizer
+
+    B, N, M = 5, 128, 128
+    cfg, sd, kw, sym, ((model, opt),) = _train_setup(B, N, M, 41, 1)
+    fresh, _ = build_model_optimizer(cfg, is_test=True)
+    fresh.load_state_dict(sd)
+    fresh.eval()
+    args = (kw["x"], kw["tfd_kps"])
+    ikw = dict(init_pose=kw["init_pose"], init_scale=kw["init_scale"], K_zoom=kw["K_zoom"], mean_scales=kw["mean_scales"])
+    with torch.no_grad():
+        want = fresh(*args, **ikw)
+    _iteration(model, kw, sym)             # training forward + backward: packs the encoder / head images only
+    model.eval()
+    with torch.no_grad():
+        got = model(*args, **ikw)          # no optimizer step in between: the weights are the ones just packed
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
 @pytest.mark.parametrize("amp", [False, True])
 def test_graphed_train_step_replays_the_eager_iteration(amp):
     """GraphedTrainStep (forward + loss + backward + fused Ranger step in one HIP graph) against the eager loop on
