@@ -131,6 +131,7 @@ class _FusedLoss(torch.autograd.Function):
 
 
 _ADDS = (torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.add)
+_IADDS = (torch.Tensor.add_, torch.Tensor.__iadd__)   # `acc += v` arrives as add_
 
 
 class _LossTerm(torch.Tensor):
@@ -138,17 +139,22 @@ class _LossTerm(torch.Tensor):
     python's ``sum(loss_dict.values())`` (engine.py:318): ``0 + v0``, then ``+ v1`` ...  - one device add per term, and
     autograd's per-term bookkeeping on the way back (ten small launches per iteration).  The loss kernels already hold every
     intermediate of that chain (``prefix[k]``, the same additions in the same order: same bits), so an add that continues
-    the chain - ``0 + v0``, ``prefix[k] + v(k+1)``, either operand order - returns the precomputed tensor, attached to the
-    same autograd node.  Every other use of these tensors is plain torch."""
+    the chain - ``0 + v0``, ``prefix[k] + v(k+1)``, either operand order, also written ``acc += v`` - returns the precomputed
+    tensor, attached to the same autograd node.  Every other use of these tensors is plain torch."""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        if func in _ADDS and len(args) == 2 and not kwargs:
+        if (func in _ADDS or func in _IADDS) and len(args) == 2 and not kwargs:
             hit = _chain_next(args[0], args[1])
             if hit is None:
                 hit = _chain_next(args[1], args[0])
             if hit is not None:
                 return hit
+        if func in _IADDS and isinstance(args[0], _LossTerm):
+            # `acc += v` off the chain, acc being one of these tensors (the loop form of the sum leaves a running sum in
+            # acc): they are views of the loss node's output buffer, which autograd does not let anybody modify in place -
+            # the statement rebinds acc anyway, so the out-of-place sum is what it gets
+            func = torch.Tensor.add
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 

@@ -482,8 +482,23 @@ def test_summing_the_loss_dict_takes_the_precomputed_chain(variant):
             acc = acc + v.as_subclass(torch.Tensor)
         return acc
 
+    def loop_form(ld):
+        acc = 0
+        for v in ld.values():
+            acc += v              # (arrives as add_ on a view of the loss node's buffer: answered out of place)
+        return acc
+
     ld, tot, grads = run(lambda ld: sum(ld.values()))
     ld2, tot2, grads2 = run(plain_chain)
+    ld3, tot3, grads3 = run(loop_form)
+    assert torch.equal(tot3.detach().as_subclass(torch.Tensor), tot2.detach())
+    for a, b in zip(grads3, grads2):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    w = {k: 1.0 + 0.5 * i for i, k in enumerate(ld3)}
+    off = 0
+    for k, v in ld3.items():
+        off += w[k] * v           # a weighted loop: plain torch
+    assert type(off) is torch.Tensor
     assert isinstance(tot, _LossTerm) and type(tot2) is torch.Tensor
     assert tot.grad_fn is not None and "Add" not in type(tot.grad_fn).__name__      # no add kernel ran
     assert torch.equal(tot.detach().as_subclass(torch.Tensor), tot2.detach())

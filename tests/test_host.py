@@ -463,6 +463,14 @@ def test_loss_dict_sum_chain_returns_the_precomputed_running_sums():
     tot.backward()
     assert l.grad.tolist() == [1.0, 0.0, 1.0, 0.0, 0.0, 1.0]
     assert ld["c"] + (ld["b"] + (ld["a"] + 0)) is sums[2]                 # either operand order
+    acc = 0
+    for v in ld.values():
+        acc += v                                                           # the loop form of the same sum
+    assert acc is sums[2]
+    acc = 0
+    acc += ld["a"]
+    acc += ld["c"]                                                         # off the chain: a plain out-of-place sum
+    assert type(acc) is torch.Tensor and float(acc.detach()) == 7.0 and float(sums[0].detach()) == 1.0
     assert type(ld["a"] + ld["c"]) is torch.Tensor and float((ld["a"] + ld["c"]).detach()) == 7.0   # off the chain
     assert type(ld["b"] * 2) is torch.Tensor and type(torch.stack(list(ld.values()))) is torch.Tensor
     assert type(1 + ld["a"]) is torch.Tensor and type(sums[0] + ld["c"]) is torch.Tensor              # not the next step
