@@ -155,8 +155,20 @@ class _LossTerm(torch.Tensor):
             # acc): they are views of the loss node's output buffer, which autograd does not let anybody modify in place -
             # the statement rebinds acc anyway, so the out-of-place sum is what it gets
             func = torch.Tensor.add
+        # everything else: plain torch on plain tensors (aliases on the same autograd graph) - code that asks
+        # `type(t) is Tensor` (Tensor.__format__ behind f"{loss:.4f}") sees what it saw before
         with torch._C.DisableTorchFunctionSubclass():
-            return func(*args, **(kwargs or {}))
+            return func(*_plain(args), **_plain(kwargs or {}))
+
+
+def _plain(x):
+    if isinstance(x, _LossTerm):
+        return x.as_subclass(torch.Tensor)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_plain(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    return x
 
 
 def _chain_next(acc, term):

@@ -479,3 +479,6 @@ def test_loss_dict_sum_chain_returns_the_precomputed_running_sums():
     foreign._chain_tok, foreign._term_pos, foreign._next_sum = other, 1, sums[1]
     assert type(sums[0] + foreign) is torch.Tensor                                                    # another dict's term
     assert {k: round(float(v.detach()), 6) for k, v in ld.items()} == {"a": 1.0, "b": 3.0, "c": 6.0}
+    # what logging code does with loss values: torch's own `type(t) is Tensor` paths see plain tensors
+    assert f"{sums[2].detach():.3f}" == "10.000" and "{:.2f}".format(ld["b"].detach()) == "3.00" and ld["c"].item() == 6.0
+    assert bool(torch.isfinite(tot)) and max(ld.values()) is ld["c"]
