@@ -249,6 +249,41 @@ def test_conv_p_backward_also_gives_the_neck_bias_gradient():
     _cmp(outs[1][3], want_dy.sum(0), "dbn", atol=2e-4, rtol=2e-5)
 
 
+def test_new_training_entry_points_refuse_bad_arguments():
+    """Error behaviour of the round's entry points: a status, not a launch (no fallback, nothing written)."""
+    import ctypes
+
+    from catre_amd import hip
+
+    lib, st = hip.load(), hip.stream_ptr(torch.device(DEV))
+    a = torch.zeros(64, 64, device=DEV)
+    p = hip.ptr
+    # fc_bwd: 2048 rows or more belong to the tiled kernels; a leading dimension under the width; no output at all
+    assert lib.catre_op_fc_bwd(p(a), 64, None, p(a), 64, p(a), 64, p(a), p(a), None, 2048, 64, 64, 64, 0, st) != 0
+    assert lib.catre_op_fc_bwd(p(a), 32, None, p(a), 64, p(a), 64, p(a), p(a), None, 64, 64, 64, 64, 0, st) != 0
+    assert lib.catre_op_fc_bwd(p(a), 64, None, p(a), 64, p(a), 64, None, None, None, 64, 64, 64, 64, 0, st) != 0
+    assert lib.catre_op_fc_bwd(p(a), 64, None, p(a), 64, p(a), 64, p(a), p(a), None, 64, 64, 64, 64, 7, st) != 0   # dtype
+    # sum_rows: the slice cannot be longer than the tensor, its pitch not under the width
+    assert lib.catre_op_sum_rows(p(a), None, p(a), 64, p(a), 32, 33, 64, st) != 0
+    assert lib.catre_op_sum_rows(p(a), None, p(a), 32, p(a), 32, 16, 64, st) != 0
+    # bf16-row flag: only with the bf16-operand kernels
+    cnt = torch.ones(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    assert lib.catre_op_gemm_tn_bias_nr(p(a), 64, None, 0, p(a), 64, None, p(a), None, 64, 64, 64, 0, p(ws), ws.numel(), p(cnt),
+                                        hip.ROWS_BF16 | 0, st) != 0
+    assert lib.catre_op_gemm_rows_nr(p(a), 64, None, 0, p(a), None, p(a), 64, None, p(a), 64, 64, 64, 64, 0, p(cnt),
+                                     hip.ROWS_BF16 | 2, st) != 0
+    # loss sums: more than six terms, a term index out of range
+    terms = (ctypes.c_int32 * 7)(0, 1, 2, 3, 4, 5, 0)
+    z = torch.zeros(64, device=DEV)
+    args = [p(z)] * 15
+    assert lib.catre_loss_fwd_sums(*args, terms, 7, p(z), 2, 4, 1, st) != 0
+    bad = (ctypes.c_int32 * 1)(9)
+    assert lib.catre_loss_fwd_sums(*args, bad, 1, p(z), 2, 4, 1, st) != 0
+    torch.cuda.synchronize()
+    assert float(a.abs().max()) == 0.0 and float(z.abs().max()) == 0.0
+
+
 def test_linear_identity_tail():
     from catre_amd import train_ops as T
 
