@@ -1821,8 +1821,8 @@ __global__ __launch_bounds__(512) void k_maxlin_bwd_x_rows(const float* __restri
 // These kernels build the ascending list of live rows and a dense -> compact map on the device (no host sync: the
 // count stays in `count[0]`, the row GEMMs read it - Rdev above), so that dgrad / wgrad run on the compacted rows only.
 //   k_rows_count   : per cloud, how many distinct rows are the arg-max of a channel with dg != 0
-//   k_rows_scan    : exclusive scan over the clouds' counts -> base[c]; count[0] = total
-//   k_rows_fill    : rows[base[c] + rank] = r (ascending), rowpos[r] = base[c] + rank or -1
+//   k_rows_fill    : base[c] = the counts of the clouds in front of c, summed by the workgroup itself (no scan launch);
+//                    rows[base[c] + rank] = r (ascending), rowpos[r] = base[c] + rank or -1; the last cloud writes count[0]
 // One workgroup per cloud, flags in LDS (clouds of <= MLX_MAXN points).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rows_flag_scan(const float* __restrict__ g, const int* __restrict__ ix, int J, int r0, int n,
@@ -1869,41 +1869,26 @@ __global__ __launch_bounds__(512) void k_rows_count(const float* __restrict__ dg
   if (threadIdx.x == 0) cnt[c] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_rows_scan(const int* __restrict__ cnt, int C, int* __restrict__ base /*[C]*/,
-                                                    int* __restrict__ count /*[1]*/) {
-  __shared__ int sums[1024];
-  const int tid = threadIdx.x, per = (C + 1023) / 1024, lo = min(C, tid * per), hi = min(C, lo + per);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += cnt[i];
-  sums[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < 1024; ++t) {
-      const int v = sums[t];
-      sums[t] = run;
-      run += v;
-    }
-    count[0] = run;
-  }
-  __syncthreads();
-  int run = sums[tid];
-  for (int i = lo; i < hi; ++i) {
-    base[i] = run;
-    run += cnt[i];
-  }
-}
-
+// (the cloud's base - the live rows of all clouds in front of it - is summed here from the per-cloud counts, 2 KB per
+// workgroup: the single-workgroup scan launch that sat between count and fill is gone; the last cloud also writes the total)
 __global__ __launch_bounds__(512) void k_rows_fill(const float* __restrict__ dg, const int* __restrict__ idx, int J, int B,
-                                                   int N, int M, const int* __restrict__ base, int* __restrict__ rows,
-                                                   int* __restrict__ rowpos) {
+                                                   int N, int M, const int* __restrict__ cnt, int C, int* __restrict__ rows,
+                                                   int* __restrict__ rowpos, int* __restrict__ count) {
   __shared__ int flag[MLX_MAXN + 1];
   __shared__ int part[256];
+  __shared__ int bsum[8];
   const int c = blockIdx.x, tid = threadIdx.x;
   int r0, n;
   cloud_rows(c, B, N, M, r0, n);
-  rows_flag_scan(dg + (size_t)c * J, idx + (size_t)c * J, J, r0, n, flag, part, tid);
-  const int b = base[c];
+  int mine = 0;
+  for (int i = tid; i < c; i += 512) mine += cnt[i];  // requested before the flag scan's own loads
+  const int total = rows_flag_scan(dg + (size_t)c * J, idx + (size_t)c * J, J, r0, n, flag, part, tid);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((tid & 63) == 0) bsum[tid >> 6] = mine;
+  __syncthreads();
+  const int b = ((bsum[0] + bsum[1]) + (bsum[2] + bsum[3])) + ((bsum[4] + bsum[5]) + (bsum[6] + bsum[7]));
+  if (c == C - 1 && tid == 0) count[0] = b + total;
   for (int i = tid; i < n; i += 512) {
     const int rk = flag[i];
     rowpos[r0 + i] = rk < 0 ? -1 : b + rk;
