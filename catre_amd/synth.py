@@ -176,6 +176,18 @@ def make_inputs(B, N=1024, M=1024, seed=0, prior=None, dtype=torch.float32):
     return out
 
 
+def y_axis_symmetries(n):
+    """n-1 rotations about the y axis by multiples of 2 pi / n, float32 [n-1,3,3]: the symmetry transformations of the NOCS
+    y-symmetric categories (bottle / bowl / can, ref/nocs.py:138-158; shape of lib/pysixd/misc.py:220-231) as synthetic
+    `sym_info` entries for benches and probes."""
+    import numpy as np
+
+    a = 2.0 * np.pi * np.arange(1, n, dtype=np.float64) / n
+    out = np.zeros((n - 1, 3, 3), dtype=np.float32)
+    out[:, 0, 0], out[:, 0, 2], out[:, 1, 1], out[:, 2, 0], out[:, 2, 2] = np.cos(a), np.sin(a), 1.0, -np.sin(a), np.cos(a)
+    return out
+
+
 def make_depth_scene(H=120, W=160, n_inst=5, seed=0):
     """A synthetic depth frame for the point-cloud preparation: a tilted background plane with
     ``n_inst`` ellipsoidal blobs in front of it, zero-depth holes, per-instance masks and poses.  The instances cover

@@ -1,3 +1,5 @@
+"""Probe (a parity CHECK, like the tests: the oracle is only the checker here): autocast gradients of sampled objects at full
+size against the rounding oracle - the development form of tests/test_hip_amp_pin.py's full-size test."""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from catre_amd import synth

@@ -1,7 +1,8 @@
 """Parity statistics beyond the goldens: S seeded batches (B objects, N=M=1024, K iterations) through the HIP path in each
 compute mode against the oracle (torch CPU fp32 restatement of the reference, pinned to the reference's own outputs by
 tests/golden) on the same inputs and recipe weights (a fresh weight salt per seed).  Prints one JSON line per mode with
-the worst and median absolute deviation of (R, t, s) after every iteration.
+the worst and median absolute deviation of (R, t, s) after every iteration.  (A parity CHECK like the tests: the oracle
+is only the checker here, nothing measured or shipped runs through it.)
 
 usage: parity_sweep.py [S=24] [B=4] [K=4]"""
 import json, logging, os, sys

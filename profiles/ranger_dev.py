@@ -1,4 +1,5 @@
-"""Probe: worst deviation of the fused Ranger step from the reference class's golden run (tests/golden/ranger_steps.npz)."""
+"""Probe: worst deviation of the fused Ranger step from the reference class's golden run (tests/golden/ranger_steps.npz).
+(A parity CHECK like the tests: the oracle is only the checker here.)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

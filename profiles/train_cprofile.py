@@ -8,7 +8,7 @@ from catre_amd import synth
 from catre_amd.batching import batch_updater_test
 from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 from catre_amd.config import default_cfg
-from oracle.catre_oracle import y_axis_symmetries
+from catre_amd.synth import y_axis_symmetries
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 AMP = os.environ.get("AMP") == "1"

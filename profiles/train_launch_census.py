@@ -9,7 +9,7 @@ from catre_amd import hip, synth
 from catre_amd.batching import batch_updater_test
 from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 from catre_amd.config import default_cfg
-from oracle.catre_oracle import y_axis_symmetries
+from catre_amd.synth import y_axis_symmetries
 from torch.profiler import profile, ProfilerActivity
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -7,7 +7,7 @@ from catre_amd import synth
 from catre_amd.batching import batch_updater_test
 from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 from catre_amd.config import default_cfg
-from oracle.catre_oracle import y_axis_symmetries
+from catre_amd.synth import y_axis_symmetries
 for (B, N, M) in ((8, 2048, 1024), (3, 64, 192), (33, 128, 64), (1, 1024, 1024), (5, 4096, 64)):
     for amp in (False, True):
         cfg = default_cfg(num_pcl=N, num_kps=M, device="cuda:0")

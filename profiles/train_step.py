@@ -7,7 +7,7 @@ from catre_amd import synth
 from catre_amd.batching import batch_updater_test
 from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 from catre_amd.config import default_cfg
-from oracle.catre_oracle import y_axis_symmetries
+from catre_amd.synth import y_axis_symmetries
 
 def run(B, N=1024, M=1024, reps=3):
     cfg = default_cfg(num_pcl=N, num_kps=M, device="cuda:0")

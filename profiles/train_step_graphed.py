@@ -9,7 +9,7 @@ from catre_amd.batching import batch_updater_test
 from catre_amd.CATRE_disR_shared import build_model_optimizer, expected_state_shapes
 from catre_amd.config import default_cfg
 from catre_amd.graphed import GraphedTrainStep
-from oracle.catre_oracle import y_axis_symmetries
+from catre_amd.synth import y_axis_symmetries
 AMP = os.environ.get("AMP", "0") == "1"
 
 def run(B, N=1024, M=1024, reps=10):
